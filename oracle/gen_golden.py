@@ -1,0 +1,220 @@
+"""Generates tests/golden/*.npz from the REFERENCE's own code (TEST INFRASTRUCTURE ONLY).
+
+Run in the build container only (the reference tree is not on the GPU box):
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+For every curve function on the hot path the reference
+implementation is imported in place (``oracle/ref_import.py``), run on small seeded inputs and
+its inputs/outputs are stored as arrays.  While generating, the CPU restatement in
+``oracle/torch_ref.py`` is checked against the same outputs (bit-exact for integer results), so a
+fixture is only written if the oracle already agrees with the reference.
+The fixtures hold data only: no reference source text.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import torch_ref as R                      # noqa: E402
+from oracle.ref_import import load_reference           # noqa: E402
+from curvecloudnet_amd.synth import make_batch         # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def curve_case(case_id, lens_per_cloud, step=0.0035):
+    """Packed batch with explicit curve lengths per cloud (covers length 1, 2, k//2, k, >k, ...)."""
+    from curvecloudnet_amd.synth import make_cloud
+    clouds = [make_cloud(100 * case_id + i, lengths=l, step=step) for i, l in enumerate(lens_per_cloud)]
+    pos = torch.cat([c.pos for c in clouds])
+    p2c = torch.cat([c.curve_idxs for c in clouds])
+    batch = torch.cat([torch.full((c.pos.size(0),), i, dtype=torch.long) for i, c in enumerate(clouds)])
+    x = torch.cat([c.x for c in clouds])
+    return x, pos, batch, p2c
+
+
+CASES = {
+    # name: curve lengths per cloud
+    "one_cloud": [[1, 2, 5, 7, 3, 12, 1, 1, 30, 2]],
+    "three_clouds": [[4, 1, 9, 2, 2, 17, 6, 1], [1, 1, 3, 25, 8, 2, 11, 5, 1], [13, 2, 7, 1, 40, 3, 5, 9, 1]],
+    "single_points": [[1, 1, 1, 1], [1, 2, 1]],
+    "long_curves": [[60, 90, 33], [120, 5]],
+}
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def eq(a, b, what):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    if a.shape != b.shape or not bool((a == b).all()):
+        raise SystemExit("oracle != reference for %s" % what)
+
+
+def close(a, b, what, tol=1e-5):
+    err = float((torch.as_tensor(a) - torch.as_tensor(b)).abs().max()) if torch.as_tensor(a).numel() else 0.0
+    if not err <= tol:
+        raise SystemExit("oracle != reference for %s (max err %g)" % (what, err))
+
+
+def main():
+    fc, po, fo = load_reference()
+    os.makedirs(OUT, exist_ok=True)
+
+    # ---------------- A1 / A2 / A12: index algebra ----------------
+    blob = {}
+    for ci, (name, lens) in enumerate(CASES.items()):
+        x, pos, batch, p2c = curve_case(ci, lens)
+        glob = po.curveidx_local2global(p2c.clone(), batch.clone())
+        blob[name + ".batch"], blob[name + ".p2c"] = np_(batch), np_(p2c)
+        blob[name + ".cloud_ptr"] = np_(po.batch2ptr(batch, with_ends=True))
+        blob[name + ".cloud_ptr_interior"] = np_(po.batch2ptr(batch))
+        blob[name + ".glob"] = np_(glob)
+        blob[name + ".curve_ptr_interior"] = np_(po.batch2ptr(glob))
+        blob[name + ".curve_ptr"] = np_(po.batch2ptr(glob, with_ends=True))
+        eq(R.segment_starts(batch, True), blob[name + ".cloud_ptr"], "segment_starts")
+        eq(R.curve_ids_global(p2c, batch), glob, "curve_ids_global")
+        eq(R.segment_starts(glob), blob[name + ".curve_ptr_interior"], "segment_starts(glob)")
+        feats = torch.cat([x, pos], dim=1)
+        padded, mask, lens_b, offs = po.dense2padded_pyg(feats, batch)
+        blob[name + ".feats"] = np_(feats)
+        blob[name + ".padded"], blob[name + ".mask"] = np_(padded), np_(mask)
+        blob[name + ".lengths"], blob[name + ".offsets"] = np_(lens_b), np_(offs)
+        o = R.padded_layout(feats, batch)
+        eq(o[0], padded, "padded"); eq(o[1], mask, "mask"); eq(o[2], lens_b, "lengths"); eq(o[3], offs, "offsets")
+    np.savez_compressed(os.path.join(OUT, "index_algebra.npz"), **blob)
+
+    # ---------------- A3: feature diffs (+ gradient) ----------------
+    blob = {}
+    for ci, (name, lens) in enumerate(CASES.items()):
+        _, pos, batch, p2c = curve_case(ci, lens)
+        g = torch.Generator().manual_seed(7 + ci)
+        x = torch.randn(pos.size(0), 5, generator=g).requires_grad_(True)
+        cot = torch.randn(pos.size(0), 5, generator=g)
+        d = fc.compute_feature_diffs(x, p2c, batch)
+        (gx,) = torch.autograd.grad((d * cot).sum(), x)
+        blob[name + ".x"], blob[name + ".p2c"], blob[name + ".batch"] = np_(x), np_(p2c), np_(batch)
+        blob[name + ".cot"], blob[name + ".diff"], blob[name + ".grad_x"] = np_(cot), np_(d), np_(gx)
+        x2 = x.detach().clone().requires_grad_(True)
+        d2 = R.feature_diffs(x2, p2c, batch)
+        eq(d2, d, "feature_diffs")
+        close(torch.autograd.grad((d2 * cot).sum(), x2)[0], gx, "feature_diffs grad", 1e-6)
+    np.savez_compressed(os.path.join(OUT, "feature_diffs.npz"), **blob)
+
+    # ---------------- A4-A6: curve convolutions ----------------
+    blob = {}
+    conv_cfgs = [
+        ("v1_k5_diff_xyz", "v1", [4, 8, 6], 5, True, True, "three_clouds"),
+        ("v1_k7_plain", "v1", [3, 6], 7, True, False, "one_cloud"),
+        ("v1_k5_single", "v1", [4, 5, 5], 5, True, True, "single_points"),
+        ("v2_k5_diff_xyz", "v2", [4, 8, 8, 6], 5, True, True, "three_clouds"),
+        ("v2_k5_one", "v2", [4, 6, 6], 5, True, True, "one_cloud"),
+        ("v2_k7_nodiff", "v2", [1, 4, 4], 7, False, False, "long_curves"),
+    ]
+    for tag, ver, dims, k, with_xyz, with_diff, case in conv_cfgs:
+        ci = list(CASES).index(case)
+        x, pos, batch, p2c = curve_case(ci, CASES[case])
+        torch.manual_seed(11 + len(tag))
+        cls = fc.SymmetricCurve1DConvFastV1 if ver == "v1" else fc.SymmetricCurve1DConvV2
+        mine = R.SymmetricCurve1DConvFastV1 if ver == "v1" else R.SymmetricCurve1DConvV2
+        ref = cls(dims, k, with_xyz=with_xyz, with_diff=with_diff)
+        for nm in ref.norm_modules:
+            nm.weight.data.uniform_(0.5, 1.5)
+            nm.bias.data.uniform_(-0.3, 0.3)
+        c_in = dims[0] - (3 if with_xyz else 0)
+        feats = torch.randn(pos.size(0), c_in).requires_grad_(True)
+        state0 = {n: v.clone() for n, v in ref.state_dict().items()}
+        ref.train()
+        y = ref(feats, pos, batch, p2c)[0]
+        cot = torch.randn_like(y)
+        params = list(ref.parameters())
+        grads = torch.autograd.grad((y * cot).sum(), [feats] + params)
+        state1 = {n: v.clone() for n, v in ref.state_dict().items()}
+        ref.eval()
+        y_eval = ref(feats, pos, batch, p2c)[0]
+        blob[tag + ".feats"], blob[tag + ".pos"] = np_(feats), np_(pos)
+        blob[tag + ".batch"], blob[tag + ".p2c"] = np_(batch), np_(p2c)
+        blob[tag + ".cot"], blob[tag + ".y_train"], blob[tag + ".y_eval"] = np_(cot), np_(y), np_(y_eval)
+        blob[tag + ".grad_feats"] = np_(grads[0])
+        for (n, _), gval in zip(ref.named_parameters(), grads[1:]):
+            blob[tag + ".grad." + n] = np_(gval)
+        for n, v in state0.items():
+            blob[tag + ".state0." + n] = np_(v)
+        for n, v in state1.items():
+            blob[tag + ".state1." + n] = np_(v)
+        blob[tag + ".meta"] = np.array([int(ver[1]), k, int(with_xyz), int(with_diff)] + dims, dtype=np.int64)
+        # oracle check
+        m = mine(dims, k, with_xyz=with_xyz, with_diff=with_diff)
+        m.load_state_dict(state0, strict=True)
+        m.train()
+        f2 = feats.detach().clone().requires_grad_(True)
+        y2 = m(f2, pos, batch, p2c)[0]
+        close(y2, y, tag + " train fwd")
+        g2 = torch.autograd.grad((y2 * cot).sum(), [f2] + list(m.parameters()))
+        for a, b_ in zip(g2, grads):
+            close(a, b_, tag + " grads", 2e-4)
+        m.eval()
+        close(m(f2, pos, batch, p2c)[0], y_eval, tag + " eval fwd")
+        for n, v in m.state_dict().items():
+            close(v.float(), state1[n].float(), tag + " state " + n)
+    np.savez_compressed(os.path.join(OUT, "curve_conv.npz"), **blob)
+
+    # ---------------- A7: CurveFPS ----------------
+    blob = {}
+    for ci, (name, lens) in enumerate(CASES.items()):
+        for step, spacing in ((0.0035, 0.007), (0.004, 0.03)):
+            _, pos, batch, p2c = curve_case(ci, lens, step=step)
+            torch.manual_seed(100 + ci)
+            u = torch.rand(1)
+            torch.manual_seed(100 + ci)               # the reference draws the same value itself
+            idx = fo.CurveFPS(spacing)(pos.clone(), batch.clone(), p2c.clone())
+            key = "%s.s%g" % (name, spacing)
+            blob[key + ".pos"], blob[key + ".batch"], blob[key + ".p2c"] = np_(pos), np_(batch), np_(p2c)
+            blob[key + ".u"], blob[key + ".spacing"], blob[key + ".idx"] = np_(u), np.float64(spacing), np_(idx)
+            eq(R.curve_fps(pos, batch, p2c, spacing, u), idx, "curve_fps " + key)
+    np.savez_compressed(os.path.join(OUT, "curve_fps.npz"), **blob)
+
+    # ---------------- A8 / A9: curve grouping + interpolation ----------------
+    blob = {}
+    for ci, (name, lens) in enumerate(CASES.items()):
+        _, pos, batch, p2c = curve_case(ci, lens)
+        u = torch.tensor([0.37 + 0.1 * ci])
+        idx = R.curve_fps(pos, batch, p2c, 0.007, u)
+        for radius in (0.02, 0.006):
+            row, col = po.radius_1d_group_subset(pos, idx, p2c, batch, radius)
+            key = "%s.r%g" % (name, radius)
+            blob[key + ".row"], blob[key + ".col"] = np_(row), np_(col)
+            r2, c2 = R.curve_radius_group(pos, idx, p2c, batch, radius)
+            eq(r2, row, "radius group row " + key); eq(c2, col, "radius group col " + key)
+        blob[name + ".pos"], blob[name + ".batch"], blob[name + ".p2c"] = np_(pos), np_(batch), np_(p2c)
+        blob[name + ".idx"] = np_(idx)
+        for k in (3, 1):
+            row, col = po.knn_1d_group_superset(pos, idx, p2c, batch, k)
+            blob["%s.k%d.row" % (name, k)], blob["%s.k%d.col" % (name, k)] = np_(row), np_(col)
+            r2, c2 = R.curve_knn_superset(pos, idx, p2c, batch, k)
+            eq(r2, row, "superset row"); eq(c2, col, "superset col")
+        g = torch.Generator().manual_seed(5 + ci)
+        xs = torch.randn(idx.numel(), 6, generator=g).requires_grad_(True)
+        cot = torch.randn(pos.size(0), 6, generator=g)
+        y = po.knn_interpolate_1D_pytorch3d(xs, idx, pos, batch, p2c, 3)
+        (gx,) = torch.autograd.grad((y * cot).sum(), xs)
+        blob[name + ".interp_x"], blob[name + ".interp_cot"] = np_(xs), np_(cot)
+        blob[name + ".interp_y"], blob[name + ".interp_grad_x"] = np_(y), np_(gx)
+        xs2 = xs.detach().clone().requires_grad_(True)
+        y2 = R.curve_interpolate(xs2, idx, pos, batch, p2c, 3)
+        close(y2, y, "curve_interpolate", 1e-5)
+        close(torch.autograd.grad((y2 * cot).sum(), xs2)[0], gx, "curve_interpolate grad", 1e-5)
+    np.savez_compressed(os.path.join(OUT, "curve_group.npz"), **blob)
+    print("golden vectors written to", OUT)
+    for f in sorted(os.listdir(OUT)):
+        print("  %-24s %7.1f KB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,849 @@
+"""CPU oracle: a plain PyTorch-CPU / numpy restatement of the CurveCloudNet hot path.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).  Every function cites the reference
+``file:line`` (relative to the upstream tree) whose behaviour it restates.  The integer /
+index functions are pinned bit-for-bit against the reference's own code by
+``oracle/gen_golden.py`` (golden vectors in ``tests/golden``, checked by
+``tests/test_oracle_golden.py``); floating point outputs are pinned to 1e-5 there.
+
+Parity status: curve functions (A1-A9 of SURVEY.md section 8a) are PINNED by golden vectors made
+from the imported reference.  FRNN (``frnn_grid_points``), PyG ``MLP``/``softmax`` and
+torch_scatter are third-party packages that are NOT vendored in the reference tree (empty
+submodule, version pin unrecoverable): for those this file restates the published semantics
+ and parity is UNPINNED -- anchored only on the reference's call sites.
+
+Arithmetic conventions that the HIP kernels reproduce exactly (measured on torch 2.10 CPU):
+  * ``norm3(d) = sqrt(fma(dz,dz, fma(dy,dy, dx*dx)))``  (what ``torch.linalg.norm`` does on CPU)
+  * ``cumsum`` over float32 accumulates in float64 and rounds every output to float32
+  * ``index_add_`` / scatter-add over float32 adds sequentially in index order
+  * FRNN squared distance ``d2 = fma(dz,dz, fma(dy,dy, dx*dx))``, neighbour iff ``d2 < r*r``,
+    order (d2, index) ascending  (tie order is unspecified upstream)
+"""
+import copy
+import ctypes
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# --------------------------------------------------------------------------------------
+# A1 / A2 : segment pointers and curve-id globalisation
+# --------------------------------------------------------------------------------------
+
+
+def segment_starts(ids, with_ends=False):
+    """Start offset of every run of a sorted id vector (ref point_ops.py:47-54 ``batch2ptr``).
+
+    Interior starts only (``R-1`` entries) unless ``with_ends`` (then ``[0, ..., N]``)."""
+    ids = ids.long()
+    step = ids[1:] - ids[:-1]
+    if bool((step < 0).any()):
+        raise AssertionError("ids must be sorted")
+    starts = torch.nonzero(step > 0).flatten() + 1
+    if with_ends:
+        n = torch.tensor([ids.numel()], dtype=starts.dtype)
+        starts = torch.cat([torch.zeros(1, dtype=starts.dtype), starts, n])
+    return starts
+
+
+def curve_ids_global(point2curveidx, batch):
+    """Per-cloud curve ids -> batch-global ids (ref point_ops.py:20-44).
+
+    A single-cloud batch returns the input object untouched (quirk Q8)."""
+    bounds = segment_starts(batch, with_ends=True)
+    n_clouds = bounds.numel() - 1
+    if n_clouds == 1:
+        return point2curveidx
+    last_pt = bounds[1:-1] - 1                       # last point of clouds 0..B-2
+    curves_in_cloud = point2curveidx[last_pt] + 1
+    offs = torch.cat([torch.zeros(1, dtype=curves_in_cloud.dtype), torch.cumsum(curves_in_cloud, 0)])
+    return point2curveidx + offs[batch]
+
+
+def curve_start_of_point(glob):
+    """Index of the first point of the curve each point lies on (ref fps_ops.py:24-25)."""
+    first = torch.cat([torch.zeros(1, dtype=torch.long), segment_starts(glob)])
+    return first[glob]
+
+
+# --------------------------------------------------------------------------------------
+# A3 : per-point absolute feature differences along the curve
+# --------------------------------------------------------------------------------------
+
+
+def feature_diffs(x, point2curveidx, batch):
+    """|mean of the in-curve forward/backward finite differences| (ref fast_conv1d.py:190-205)."""
+    g = curve_ids_global(point2curveidx, batch)
+    linked = (g[1:] == g[:-1])
+    step = torch.where(linked[:, None], x[1:] - x[:-1], torch.zeros((), dtype=x.dtype))
+    zrow = torch.zeros((1, x.size(1)), dtype=x.dtype)
+    zflag = torch.zeros(1, dtype=x.dtype)
+    ahead = torch.cat([step, zrow], 0)               # edge i -> i+1
+    behind = torch.cat([zrow, step], 0)              # edge i-1 -> i
+    n_edges = torch.cat([linked.to(x.dtype), zflag]) + torch.cat([zflag, linked.to(x.dtype)])
+    return torch.abs((ahead + behind) / torch.clamp(n_edges, min=1)[:, None])
+
+
+# --------------------------------------------------------------------------------------
+# A4-A6 : symmetric curve convolution
+# --------------------------------------------------------------------------------------
+
+
+class SymmetricConv1d(nn.Module):
+    """Conv weights store the centre tap and one side; the other side mirrors it
+    (ref fast_conv1d.py:148-187).  Parameter names/shapes match the reference's ``_ConvNd``."""
+
+    def __init__(self, in_channels, out_channels, half_taps, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, half_taps))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        # same initialisation as torch's _ConvNd.reset_parameters
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = in_channels * half_taps
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def full_weight(self):
+        w = self.weight
+        if w.size(2) > 1:
+            w = torch.cat([torch.flip(w[:, :, 1:], dims=[2]), w], dim=2)
+        return w
+
+    def forward(self, seq):                           # seq: (L, C_in) one zero-padded sequence
+        w = self.full_weight()
+        y = F.conv1d(seq.t().unsqueeze(0), w, self.bias, stride=1, padding=w.size(2) // 2)
+        return y.squeeze(0).t()
+
+
+def _conv_layers(feat_dims, kernel_size, bias, diff_first_only, with_diff):
+    convs, norms = [], []
+    for i in range(1, len(feat_dims)):
+        doubled = with_diff and (i == 1 or not diff_first_only)
+        cin = feat_dims[i - 1] * 2 if doubled else feat_dims[i - 1]
+        convs.append(SymmetricConv1d(cin, feat_dims[i], kernel_size // 2 + 1, bias=bias))
+        norms.append(nn.BatchNorm1d(feat_dims[i]))
+    return nn.ModuleList(convs), nn.ModuleList(norms)
+
+
+def _separator_layout(glob, n_points, pad, with_ends):
+    """Row index of every real point inside the zero-separated sequence, and its length
+    (ref fast_conv1d.py:48-61 / 115-126)."""
+    starts = segment_starts(glob, with_ends=with_ends)
+    n_sep = starts.numel()
+    n_rows = n_points + n_sep * pad
+    is_real = torch.ones(n_rows, dtype=torch.bool)
+    if pad > 0 and n_sep > 0:
+        sep = (starts[:, None] + torch.arange(n_sep * pad).view(n_sep, pad)).flatten()
+        is_real[sep] = False
+    return torch.nonzero(is_real).flatten(), n_rows
+
+
+class SymmetricCurve1DConvFastV1(nn.Module):
+    """ref fast_conv1d.py:78-145: per layer diff-concat, separators of k//2 zero rows between
+    curves, conv, BN over the real rows only, LeakyReLU."""
+
+    def __init__(self, feat_dims=(64, 64, 128), kernel_size=5, bias=True, with_xyz=False, with_diff=False):
+        super().__init__()
+        self.kernel_size, self.feat_dims = kernel_size, feat_dims
+        self.with_xyz, self.with_diff = with_xyz, with_diff
+        self.conv_modules, self.norm_modules = _conv_layers(feat_dims, kernel_size, bias, False, with_diff)
+
+    def forward(self, x, pos, batch, point2curveidx, **kwargs):
+        g = curve_ids_global(point2curveidx, batch)
+        if self.with_xyz:
+            x = pos if x is None else torch.cat([x, pos], dim=1)
+        rows, n_rows = _separator_layout(g, x.size(0), self.kernel_size // 2 if self.kernel_size > 1 else 0, False)
+        for conv, norm in zip(self.conv_modules, self.norm_modules):
+            if self.with_diff:
+                x = torch.cat([x, feature_diffs(x, point2curveidx, batch)], dim=1)
+            seq = torch.zeros((n_rows, x.size(1)), dtype=x.dtype).index_copy(0, rows, x)
+            x = conv(seq)[rows]
+            x = F.leaky_relu(norm(x))
+        return x, pos, batch, point2curveidx
+
+
+class SymmetricCurve1DConvV2(nn.Module):
+    """ref fast_conv1d.py:11-75: diff once, separators of (k//2)*n_layers rows between curves AND
+    at both ends, conv+BN+LeakyReLU on the whole padded sequence (quirk Q2), gather once."""
+
+    def __init__(self, feat_dims=(64, 64, 128), kernel_size=5, bias=True, with_xyz=False, with_diff=False):
+        super().__init__()
+        self.kernel_size, self.feat_dims = kernel_size, feat_dims
+        self.with_xyz, self.with_diff = with_xyz, with_diff
+        self.conv_modules, self.norm_modules = _conv_layers(feat_dims, kernel_size, bias, True, with_diff)
+
+    def forward(self, x, pos, batch, point2curveidx, **kwargs):
+        g = curve_ids_global(point2curveidx, batch)
+        if self.with_xyz:
+            x = pos if x is None else torch.cat([x, pos], dim=1)
+        pad = (self.kernel_size // 2) * (len(self.feat_dims) - 1) if self.kernel_size > 1 else 0
+        rows, n_rows = _separator_layout(g, x.size(0), pad, True)
+        if self.with_diff:
+            x = torch.cat([x, feature_diffs(x, point2curveidx, batch)], dim=1)
+        seq = torch.zeros((n_rows, x.size(1)), dtype=x.dtype).index_copy(0, rows, x)
+        for conv, norm in zip(self.conv_modules, self.norm_modules):
+            seq = F.leaky_relu(norm(conv(seq)))
+        return seq[rows], pos, batch, point2curveidx
+
+
+# --------------------------------------------------------------------------------------
+# A7 : arclength sub-sampling along curves
+# --------------------------------------------------------------------------------------
+
+
+def _edge_lengths(pos, glob):
+    step = pos[1:] - pos[:-1]
+    length = torch.linalg.norm(step, dim=-1)
+    return torch.where(glob[1:] == glob[:-1], length, torch.zeros((), dtype=length.dtype))
+
+
+def curve_fps(pos, batch, point2curveidx, spacing, u):
+    """Keep one point per ``spacing`` of arclength on each curve (ref fps_ops.py:16-39).
+
+    ``u`` is the reference's ``torch.rand(1)`` draw (float32 tensor of shape (1,)), injected so the
+    result is reproducible (quirk Q10)."""
+    g = curve_ids_global(point2curveidx, batch)
+    start = curve_start_of_point(g)
+    run = torch.cat([torch.zeros(1, dtype=pos.dtype), torch.cumsum(_edge_lengths(pos, g), dim=0)])
+    arclen = run - run[start]
+    arclen = arclen + ((start * 117 * u) % spacing)
+    bucket = torch.round(arclen / spacing)
+    keep = torch.cat([torch.ones(1, dtype=torch.bool), bucket[1:] != bucket[:-1]])
+    keep[start] = True
+    return torch.nonzero(keep).flatten()
+
+
+# --------------------------------------------------------------------------------------
+# A8 : radius grouping along a curve (queries are a subset of the points)
+# --------------------------------------------------------------------------------------
+
+
+def _alternating_offsets(reach):
+    """0, -1, +1, -2, +2, ... , -reach, +reach  (ref point_ops.py:170-171)."""
+    mag = torch.arange(1, reach + 1)
+    return torch.cat([torch.zeros(1, dtype=torch.long), torch.stack([-mag, mag], dim=1).flatten()])
+
+
+def curve_hop_budget(pos, glob, radius):
+    """Per-curve neighbour budget ceil(radius / mean edge), mean = length / #points, inf -> 1
+    (ref point_ops.py:149-162).  Returns (budget float32 (Q,), points-per-curve float32 (Q,))."""
+    n_curves = int(glob.max().item()) + 1
+    length = torch.zeros(n_curves, dtype=pos.dtype).index_add_(0, glob[1:], _edge_lengths(pos, glob))
+    count = torch.zeros(n_curves, dtype=pos.dtype).index_add_(0, glob, torch.ones(glob.numel(), dtype=pos.dtype))
+    budget = torch.ceil(radius / (length / count))
+    budget[torch.isinf(budget)] = 1
+    return budget, count
+
+
+def curve_radius_group(pos, idx, point2curveidx, batch, radius):
+    """Edges (row = query number, col = point index) from every sampled point ``idx[q]`` to its
+    nearest points along the same curve (ref point_ops.py:143-193).
+
+    Reproduces quirk Q3: the per-curve budget table is indexed with the *local* curve id."""
+    g = curve_ids_global(point2curveidx, batch)
+    budget, count = curve_hop_budget(pos, g, radius)
+    reach = int(min(budget.max().item(), count.max().item()))
+    offs = _alternating_offsets(reach)
+    cand = idx[:, None] + offs[None, :]
+    inside = (cand >= 0) & (cand < pos.size(0))
+    cand = torch.where(inside, cand, torch.zeros((), dtype=cand.dtype))
+    ok = inside & (g[cand] == g[idx][:, None])
+    allowed = budget[point2curveidx[idx].long()]
+    ok = ok & (torch.cumsum(ok, dim=1) <= allowed[:, None])
+    q = torch.arange(idx.numel())[:, None].expand_as(cand)
+    return q[ok], cand[ok]
+
+
+# --------------------------------------------------------------------------------------
+# A9 : every point -> k nearest sampled points on its own curve, and the interpolation
+# --------------------------------------------------------------------------------------
+
+
+def curve_knn_superset(pos, idx, point2curveidx, batch, k):
+    """(row = point index, col = position inside ``idx``) (ref point_ops.py:196-260)."""
+    g = curve_ids_global(point2curveidx, batch)
+    n, m = pos.size(0), idx.numel()
+    taken = torch.zeros(n, dtype=torch.bool)
+    taken[idx] = True
+    upto = torch.cumsum(taken, dim=0)                 # number of samples at positions <= i
+    offs = _alternating_offsets(k + 1)
+    cand = upto[:, None] + offs[None, :]
+    inside = (cand >= 0) & (cand < m)
+    cand = torch.where(inside, cand, torch.zeros((), dtype=cand.dtype))
+    cand_pt = idx[cand]
+    ok = inside & (g[cand_pt] == g[:, None])
+    dist = torch.linalg.norm(pos[cand_pt] - pos[:, None, :], dim=-1)
+    dist = torch.where(ok, dist, torch.full((), 100.0, dtype=dist.dtype))
+    order = torch.argsort(dist, dim=1)
+    cand = torch.gather(cand, 1, order)
+    ok = torch.gather(ok, 1, order)
+    ok = ok & (torch.cumsum(ok, dim=1) <= k)
+    if not bool(ok.any(dim=1).all()):
+        raise AssertionError("a point has no sampled neighbour on its curve")
+    rows = torch.arange(n)[:, None].expand_as(cand)
+    return rows[ok], cand[ok]
+
+
+def curve_interpolate(x, idx, pos_y, batch_y, point2curveidx_y, k):
+    """Inverse-squared-distance interpolation along curves (ref point_ops.py:344-355)."""
+    pos_x = pos_y[idx]
+    with torch.no_grad():
+        y_idx, x_idx = curve_knn_superset(pos_y, idx, point2curveidx_y, batch_y, k)
+        d = torch.linalg.norm(pos_x[x_idx] - pos_y[y_idx], dim=-1, keepdim=True) ** 2
+        w = 1.0 / torch.clamp(d, min=1e-16)
+    n = pos_y.size(0)
+    num = torch.zeros((n, x.size(1)), dtype=x.dtype).index_add(0, y_idx, x[x_idx] * w)
+    den = torch.zeros((n, 1), dtype=x.dtype).index_add(0, y_idx, w)
+    return num / den
+
+
+# --------------------------------------------------------------------------------------
+# A12 : packed <-> padded layouts
+# --------------------------------------------------------------------------------------
+
+
+def to_batch_padded(t, batch):
+    """(N, ...) + sorted cloud ids -> zero padded (B, Nmax, ...) + bool mask (ref point_ops.py:358-381)."""
+    bounds = segment_starts(batch, with_ends=True)
+    lens = bounds[1:] - bounds[:-1]
+    n_clouds, n_max = lens.numel(), int(lens.max().item())
+    if n_clouds == 1:
+        return t.unsqueeze(0), torch.ones((1, t.size(0)), dtype=torch.bool)
+    local = torch.arange(batch.numel()) - bounds[batch]
+    out = torch.zeros((n_clouds, n_max) + tuple(t.shape[1:]), dtype=t.dtype)
+    mask = torch.zeros((n_clouds, n_max), dtype=torch.bool)
+    out = out.index_put((batch, local), t)
+    mask[batch, local] = True
+    return out, mask
+
+
+def padded_layout(t, batch):
+    """ref point_ops.py:264-284 ``dense2padded_pyg``: (padded, mask, lengths, offsets)."""
+    padded, mask = to_batch_padded(t, batch)
+    lens = mask.sum(dim=-1)
+    return padded, mask, lens, torch.cumsum(lens, 0)[:-1]
+
+
+# --------------------------------------------------------------------------------------
+# A11 : fixed-radius kNN (FRNN semantics), exhaustive search
+# --------------------------------------------------------------------------------------
+
+_BRUTE = None
+
+
+def _brute_lib():
+    global _BRUTE
+    if _BRUTE is None:
+        path = os.path.join(_HERE, "libccn_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/libccn_oracle.so missing: run `make -C oracle` (or __graft_entry__.build())")
+        lib = ctypes.CDLL(path)
+        lib.ccn_oracle_frnn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 4 + [ctypes.c_void_p] * 3
+        lib.ccn_oracle_frnn.restype = None
+        lib.ccn_oracle_knn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 4 + [ctypes.c_void_p] * 2
+        lib.ccn_oracle_knn.restype = None
+        _BRUTE = lib
+    return _BRUTE
+
+
+def frnn_bruteforce(points1, points2, lengths1, lengths2, K, r, return_dists=False):
+    """Semantics of ``frnn.frnn_grid_points`` as used at ref point_ops.py:459 (third-party, not
+    vendored): for each query the <=K nearest points2 with d2 < r*r, ascending
+    by (d2, index); int64 indices padded with -1; rows >= lengths1 are -1."""
+    p1 = np.ascontiguousarray(points1.detach().numpy(), dtype=np.float32)
+    p2 = np.ascontiguousarray(points2.detach().numpy(), dtype=np.float32)
+    B, P1, _ = p1.shape
+    P2 = p2.shape[1]
+    l1 = np.ascontiguousarray(lengths1.numpy(), dtype=np.int64)
+    l2 = np.ascontiguousarray(lengths2.numpy(), dtype=np.int64)
+    if isinstance(r, (int, float)):
+        rr = np.full(B, r, dtype=np.float32)
+    else:
+        rr = np.ascontiguousarray(torch.as_tensor(r, dtype=torch.float32).expand(B).numpy(), dtype=np.float32)
+    idx = np.full((B, P1, K), -1, dtype=np.int64)
+    d2 = np.full((B, P1, K), -1.0, dtype=np.float32)
+    _brute_lib().ccn_oracle_frnn(p1.ctypes.data, p2.ctypes.data, l1.ctypes.data, l2.ctypes.data,
+                                 B, P1, P2, K, rr.ctypes.data, idx.ctypes.data, d2.ctypes.data)
+    if return_dists:
+        return torch.from_numpy(idx), torch.from_numpy(d2)
+    return torch.from_numpy(idx)
+
+
+def knn_bruteforce(points1, points2, lengths1, lengths2, K):
+    """Exact kNN with pytorch3d ``knn_points`` semantics (ref point_ops.py:91): ascending by
+    (d2, index), -1 where a cloud has fewer than K points."""
+    p1 = np.ascontiguousarray(points1.detach().numpy(), dtype=np.float32)
+    p2 = np.ascontiguousarray(points2.detach().numpy(), dtype=np.float32)
+    B, P1, _ = p1.shape
+    P2 = p2.shape[1]
+    l1 = np.ascontiguousarray(lengths1.numpy(), dtype=np.int64)
+    l2 = np.ascontiguousarray(lengths2.numpy(), dtype=np.int64)
+    idx = np.full((B, P1, K), -1, dtype=np.int64)
+    d2 = np.full((B, P1, K), -1.0, dtype=np.float32)
+    _brute_lib().ccn_oracle_knn(p1.ctypes.data, p2.ctypes.data, l1.ctypes.data, l2.ctypes.data,
+                                B, P1, P2, K, idx.ctypes.data, d2.ctypes.data)
+    return torch.from_numpy(idx)
+
+
+def group_fixed_radius(p1, p2, batch1, batch2, knn, radius, return_dense=False):
+    """ref point_ops.py:73-111 ``knn_ball_group_pytorch3d`` (operation="knn", accel_knn=True)."""
+    if radius is None:
+        radius = 0.25                                  # quirk Q7
+    q_pad, mask1, len1, off1 = padded_layout(p1, batch1)
+    s_pad, mask2, len2, off2 = padded_layout(p2, batch2)
+    nbr = frnn_bruteforce(q_pad, s_pad, len1, len2, knn, radius)
+    if return_dense:
+        return nbr, len2, mask1
+    keep = (nbr != -1) & mask1[:, :, None]
+    col = nbr.clone()
+    col[1:] += off2.view(-1, 1, 1)
+    qid = torch.arange(nbr.size(1)).view(1, -1, 1).expand_as(nbr).clone()
+    qid[1:] += off1.view(-1, 1, 1)
+    return qid[keep], col[keep]
+
+
+# --------------------------------------------------------------------------------------
+# A16 : the MLP block (PyG 2.3.0 ``MLP`` semantics)
+# --------------------------------------------------------------------------------------
+
+
+class _Norm(nn.Module):
+    """PyG ``BatchNorm`` wrapper: the real BatchNorm1d lives in ``.module`` (state-dict key)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.module = nn.BatchNorm1d(channels)
+
+    def forward(self, x):
+        return self.module(x)
+
+
+class MLP(nn.Module):
+    """lin -> batch-norm -> act -> dropout per hidden layer; the last layer is a bare Linear when
+    ``plain_last`` (ref base.py:32,64,90-125; mlp.py:13)."""
+
+    def __init__(self, channel_list, dropout=0.0, act="relu", norm="batch_norm", plain_last=True, bias=True, **kwargs):
+        super().__init__()
+        assert norm == "batch_norm"
+        self.channel_list, self.plain_last, self.dropout = list(channel_list), plain_last, dropout
+        self.act = {"relu": F.relu, "leaky_relu": F.leaky_relu}[act]
+        self.lins = nn.ModuleList(nn.Linear(a, b, bias=bias) for a, b in zip(channel_list[:-1], channel_list[1:]))
+        normed = channel_list[1:-1] if plain_last else channel_list[1:]
+        self.norms = nn.ModuleList(_Norm(c) for c in normed)
+
+    def forward(self, x):
+        for lin, norm in zip(self.lins, self.norms):
+            x = F.dropout(self.act(norm(lin(x))), p=self.dropout, training=self.training)
+        if self.plain_last:
+            x = F.dropout(self.lins[-1](x), p=self.dropout, training=self.training)
+        return x
+
+
+# --------------------------------------------------------------------------------------
+# A13 : PointNetConv2 on a bipartite edge list whose rows are grouped by destination
+# --------------------------------------------------------------------------------------
+
+
+def _segment_dense(values, dst, n_dst):
+    """Edges sorted by destination -> (n_dst, Dmax, C) zero padded view + validity mask."""
+    counts = torch.bincount(dst, minlength=n_dst)
+    first = torch.cumsum(counts, 0) - counts
+    slot = torch.arange(dst.numel()) - first[dst]
+    dmax = int(counts.max().item()) if dst.numel() else 0
+    dense = torch.zeros((n_dst, dmax) + tuple(values.shape[1:]), dtype=values.dtype)
+    dense = dense.index_put((dst, slot), values)
+    valid = torch.zeros((n_dst, dmax), dtype=torch.bool)
+    valid[dst, slot] = True
+    return dense, valid
+
+
+def segment_softmax(src, dst, n_dst):
+    """PyG ``softmax(src, index)``: exp(src - segment max) / (segment sum + 1e-16) per channel."""
+    top = torch.full((n_dst, src.size(1)), float("-inf"), dtype=src.dtype)
+    top = top.scatter_reduce(0, dst[:, None].expand_as(src), src.detach(), reduce="amax", include_self=True)
+    e = (src - top[dst]).exp()
+    tot = torch.zeros((n_dst, src.size(1)), dtype=src.dtype).index_add(0, dst, e) + 1e-16
+    return e / tot[dst]
+
+
+class PointNetConv2(nn.Module):
+    """ref point_conv.py:12-93 with PyG 2.3.0 bipartite ``propagate`` semantics:
+    x_j = x_src[edge[0]], pos_j = pos_src[edge[0]], pos_i = pos_dst[edge[1]], aggregate over edge[1]."""
+
+    def __init__(self, local_nn, attend_nn=None, global_nn=None, aggr_type="max", normalize_radius=None):
+        super().__init__()
+        assert aggr_type in ("max", "attend", "mean", "weighted-sum")
+        self.local_nn, self.attend_nn, self.global_nn = local_nn, attend_nn, global_nn
+        self.aggr_type, self.normalize_radius = aggr_type, normalize_radius
+
+    def forward(self, x_src, pos_src, pos_dst, src, dst):
+        n_dst = pos_dst.size(0)
+        rel = pos_src[src] - pos_dst[dst]
+        if self.normalize_radius is not None:
+            rel = rel / self.normalize_radius
+        msg = rel if x_src is None else torch.cat([x_src[src], rel], dim=1)
+        if self.local_nn is not None:
+            msg = self.local_nn(msg)
+        if self.aggr_type == "max":
+            dense, valid = _segment_dense(msg, dst, n_dst)
+            dense = torch.where(valid[:, :, None], dense, torch.full((), float("-inf"), dtype=msg.dtype))
+            out = dense.max(dim=1)[0]
+            out = torch.where(valid.any(dim=1)[:, None], out, torch.zeros((), dtype=msg.dtype))
+        elif self.aggr_type == "mean":
+            cnt = torch.bincount(dst, minlength=n_dst).clamp(min=1).to(msg.dtype)
+            out = torch.zeros((n_dst, msg.size(1)), dtype=msg.dtype).index_add(0, dst, msg) / cnt[:, None]
+        elif self.aggr_type == "weighted-sum":
+            w = torch.sigmoid(self.attend_nn(msg))
+            out = torch.zeros((n_dst, msg.size(1)), dtype=msg.dtype).index_add(0, dst, msg * w)
+        else:
+            w = segment_softmax(self.attend_nn(msg), dst, n_dst)
+            out = torch.zeros((n_dst, msg.size(1)), dtype=msg.dtype).index_add(0, dst, msg * w)
+        if self.global_nn is not None:
+            out = self.global_nn(out)
+        return out
+
+
+# --------------------------------------------------------------------------------------
+# A7 users / A10 / A14 / A15 / A17 : step modules (same constructor + call surface as the reference)
+# --------------------------------------------------------------------------------------
+
+
+def _draw_u():
+    return torch.rand(1)
+
+
+class CurveFPS(nn.Module):
+    def __init__(self, arclen_spacing=0.3):
+        super().__init__()
+        self.arclen_spacing = arclen_spacing
+
+    def forward(self, pos, batch, point2curveidx, u=None):
+        return curve_fps(pos, batch, point2curveidx, self.arclen_spacing, _draw_u() if u is None else u)
+
+
+def farthest_point_indices(pos, batch, ratio, start=None):
+    """ref point_ops.py:57-70 with pytorch3d ``sample_farthest_points`` semantics (App. C):
+    per cloud ceil(len*ratio) samples, first = ``start[b]`` (the reference draws it at random),
+    then repeatedly the point with the largest distance to the chosen set; sorted global indices."""
+    bounds = segment_starts(batch, with_ends=True)
+    out = []
+    for b in range(bounds.numel() - 1):
+        lo, hi = int(bounds[b]), int(bounds[b + 1])
+        p = pos[lo:hi]
+        n_keep = int(math.ceil((hi - lo) * ratio))
+        cur = int(start[b]) if start is not None else int(torch.randint(hi - lo, (1,)))
+        d = torch.full((hi - lo,), float("inf"), dtype=pos.dtype)
+        chosen = []
+        for _ in range(n_keep):
+            chosen.append(cur)
+            diff = p - p[cur]
+            d = torch.minimum(d, (diff * diff).sum(-1))
+            cur = int(torch.argmax(d))
+        out.append(torch.tensor(chosen, dtype=torch.long) + lo)
+    return torch.sort(torch.cat(out))[0]
+
+
+class SAModule(nn.Module):
+    """ref pointnet2.py:33-78."""
+
+    def __init__(self, ratio, r, nn, k, curve_fps_arclen=None, voxel_size=None, downsample_type="random",
+                 attend_nn=None, aggr_type="max", normalize_radius=False, use_fast_knn=True, **kwargs):
+        super().__init__()
+        assert downsample_type in ("curve-fps", "random", "fps", "voxel")
+        self.ratio, self.r, self.knn = ratio, r, k
+        self.downsample_type, self.use_fast_knn = downsample_type, use_fast_knn
+        self.curve_fps_arclen, self.voxel_size = curve_fps_arclen, voxel_size
+        self.conv = PointNetConv2(nn, attend_nn=attend_nn, aggr_type=aggr_type,
+                                  normalize_radius=r if normalize_radius else None)
+
+    def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
+        if "sample_idx" in kwargs and kwargs["sample_idx"] is not None:
+            idx = kwargs["sample_idx"]
+        elif self.downsample_type == "random":
+            idx = torch.sort(torch.randperm(pos.size(0))[: int(pos.size(0) * self.ratio)])[0]
+        elif self.downsample_type == "curve-fps":
+            idx = curve_fps(pos, batch, point2curveidx, self.curve_fps_arclen, _draw_u())
+        elif self.downsample_type == "fps":
+            idx = farthest_point_indices(pos, batch, self.ratio)
+        else:
+            raise NotImplementedError("voxel down-sampling is a 'next' row (SURVEY.md section 8f)")
+        if not self.use_fast_knn:
+            raise NotImplementedError("ball_query grouping is a 'next' row (SURVEY.md section 8f)")
+        row, col = group_fixed_radius(pos[idx], pos, batch[idx], batch, self.knn, self.r)
+        x = self.conv(x, pos, pos[idx], col, row)
+        p2c = None if point2curveidx is None else point2curveidx[idx]
+        return x, pos[idx], batch[idx], p2c
+
+
+class CurveSAModule(nn.Module):
+    """ref pointnet2.py:146-181."""
+
+    def __init__(self, ratio, r, nn, curve_fps_arclen=None, use_curve_fps=False, global_nn=None, attend_nn=None,
+                 with_xyz=False, aggr_type="max", normalize_radius=False, **kwargs):
+        super().__init__()
+        self.ratio, self.r, self.curve_fps_arclen = ratio, r, curve_fps_arclen
+        self.use_curve_fps, self.with_xyz = use_curve_fps, with_xyz
+        self.conv = PointNetConv2(nn, attend_nn=attend_nn, global_nn=global_nn, aggr_type=aggr_type,
+                                  normalize_radius=r if normalize_radius else None)
+
+    def forward(self, x, pos, batch, point2curveidx, **kwargs):
+        if self.with_xyz:
+            x = pos[:, :3] if x is None else torch.cat([x, pos[:, :3]], dim=1)
+        if "sample_idx" in kwargs and kwargs["sample_idx"] is not None:
+            idx = kwargs["sample_idx"]
+        elif self.use_curve_fps:
+            idx = curve_fps(pos, batch, point2curveidx, self.curve_fps_arclen, _draw_u())
+        else:
+            idx = farthest_point_indices(pos, batch, self.ratio)
+        row, col = curve_radius_group(pos, idx, point2curveidx, batch, self.r)
+        x = self.conv(x, pos, pos[idx], col, row)
+        return x, pos[idx], batch[idx], point2curveidx[idx], None, idx
+
+
+def knn_interpolate(x, pos_x, pos_y, batch_x, batch_y, k):
+    """ref point_ops.py:293-341 (exact kNN, inverse squared distance weights)."""
+    with torch.no_grad():
+        q_pad, mask1, len1, off1 = padded_layout(pos_y, batch_y)
+        s_pad, mask2, len2, off2 = padded_layout(pos_x, batch_x)
+        nbr = knn_bruteforce(q_pad, s_pad, len1, len2, k)
+        keep = (nbr != -1) & mask1[:, :, None]
+        col = nbr.clone()
+        col[1:] += off2.view(-1, 1, 1)
+        qid = torch.arange(nbr.size(1)).view(1, -1, 1).expand_as(nbr).clone()
+        qid[1:] += off1.view(-1, 1, 1)
+        y_idx, x_idx = qid[keep], col[keep]
+        diff = pos_x[x_idx] - pos_y[y_idx]
+        w = 1.0 / torch.clamp((diff * diff).sum(dim=-1, keepdim=True), min=1e-16)
+    n = pos_y.size(0)
+    num = torch.zeros((n, x.size(1)), dtype=x.dtype).index_add(0, y_idx, x[x_idx] * w)
+    den = torch.zeros((n, 1), dtype=x.dtype).index_add(0, y_idx, w)
+    return num / den
+
+
+def _fp_concat(x, x_skip, pos_skip, with_xyz):
+    parts = [x]
+    if x_skip is not None:
+        parts.append(x_skip)
+    if with_xyz:
+        parts.append(pos_skip[:, :3])
+    return torch.cat(parts, dim=1)
+
+
+class FPModule(nn.Module):
+    """ref pointnet2.py:119-143."""
+
+    def __init__(self, k, nn, with_xyz=False):
+        super().__init__()
+        self.k, self.nn, self.with_xyz = k, nn, with_xyz
+
+    def forward(self, x, pos, batch, x_skip, pos_skip, batch_skip, point2curveidx=None, point2curveidx_skip=None, **kwargs):
+        x = knn_interpolate(x, pos, pos_skip, batch, batch_skip, self.k)
+        return self.nn(_fp_concat(x, x_skip, pos_skip, self.with_xyz)), pos_skip, batch_skip, point2curveidx_skip
+
+
+class CurveFPModule(FPModule):
+    """ref pointnet2.py:184-205."""
+
+    def forward(self, x, idx, x_skip, pos_skip, batch_skip, point2curveidx_skip=None, **kwargs):
+        x = curve_interpolate(x, idx, pos_skip, batch_skip, point2curveidx_skip, self.k)
+        return self.nn(_fp_concat(x, x_skip, pos_skip, self.with_xyz)), pos_skip, batch_skip, point2curveidx_skip
+
+
+class SGCNNLayer(nn.Module):
+    """ref dgcnn.py:130-266, dense FRNN path ``forward_fast`` (quirk Q4: the MLP and its batch
+    statistics run over all B*Nmax*(K+1) rows, masking afterwards)."""
+
+    def __init__(self, nn, k, aggr="max", r=1.0, num_workers=1, with_xyz=False, attend_nn=None, aggr_type="max",
+                 use_sparse_feat_agg=False, **kwargs):
+        super().__init__()
+        assert aggr_type in ("max", "attend", "mean", "weighted-sum")
+        self.nn, self.k, self.r, self.with_xyz = nn, k, r, with_xyz
+        self.attend_nn, self.aggr_type, self.use_sparse_feat_agg = attend_nn, aggr_type, use_sparse_feat_agg
+
+    def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
+        if self.with_xyz:
+            x = pos if x is None else torch.cat([x, pos], dim=1)
+        if self.use_sparse_feat_agg:
+            raise NotImplementedError("sparse aggregation is a 'next' row (SURVEY.md section 8f)")
+        nbr, len2, mask1 = group_fixed_radius(pos, pos, batch, batch, self.k, self.r, return_dense=True)
+        B, N = nbr.shape[:2]
+        me = torch.arange(N).view(1, N, 1).expand(B, N, 1)
+        nbr = torch.cat([me, nbr], dim=2)
+        xp = to_batch_padded(x, batch)[0]
+        gathered = torch.gather(xp[:, :, None, :].expand(-1, -1, nbr.size(2), -1), 1,
+                                nbr.clamp(min=0)[..., None].expand(-1, -1, -1, xp.size(-1)))
+        gathered = torch.where((nbr >= 0)[..., None], gathered, torch.zeros((), dtype=x.dtype))
+        edge = torch.cat([gathered, gathered[:, :, 0:1, :] - gathered], dim=-1)
+        f = self.nn(edge.reshape(-1, edge.size(-1))).view(B, N, self.k + 1, -1)
+        mask = (nbr != -1) & mask1[:, :, None]
+        if self.aggr_type == "max":
+            f = torch.where(mask[..., None], f, torch.full((), -1e2, dtype=f.dtype)).max(dim=2)[0]
+        elif self.aggr_type == "mean":
+            f = torch.where(mask[..., None], f, torch.zeros((), dtype=f.dtype)).sum(dim=2) / mask.sum(dim=2)[..., None]
+        elif self.aggr_type == "weighted-sum":
+            a = torch.sigmoid(self.attend_nn(f.reshape(B * N * (self.k + 1), -1)).view(B, N, self.k + 1, -1))
+            a = torch.where(mask[..., None], a, torch.zeros((), dtype=f.dtype))
+            a = a / torch.clamp(a.sum(dim=2, keepdim=True), min=1e-3)
+            f = (f * a).sum(dim=2)
+        else:
+            a = self.attend_nn(f.reshape(B * N * (self.k + 1), -1)).view(B, N, self.k + 1, -1)
+            a = torch.where(mask[..., None], a, torch.full((), -5e2, dtype=f.dtype))
+            f = (f * F.softmax(a, dim=2)).sum(dim=2)
+        return f[mask1], pos, batch, point2curveidx
+
+
+class SharedMLP(nn.Module):
+    """ref mlp.py:5-22."""
+
+    def __init__(self, dims, use_bias=False, with_xyz=False, act="leaky_relu", **kwargs):
+        super().__init__()
+        self.mlp = MLP(dims, dropout=kwargs.get("dropout", 0.0), norm=kwargs.get("norm", "batch_norm"),
+                       plain_last=kwargs.get("plain_last", True), act=act, bias=use_bias)
+        self.with_xyz = with_xyz
+
+    def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
+        if self.with_xyz:
+            x = pos if x is None else torch.cat([x, pos], dim=1)
+        return self.mlp(x), pos, batch, point2curveidx
+
+
+class SkipConnect(nn.Module):
+    """ref skip_connect.py:6-14."""
+
+    def __init__(self, nn, num_skips=1):
+        super().__init__()
+        self.num_skips, self.nn = num_skips, nn
+
+    def forward(self, xs, pos, batch, point2curveidx=None, **kwargs):
+        return self.nn(torch.cat(xs, dim=1)), pos, batch, point2curveidx
+
+
+# --------------------------------------------------------------------------------------
+# A18 : model assembly from the reference's config dict
+# --------------------------------------------------------------------------------------
+
+_DOWN = ("sa", "sa-geo", "sa-global", "pt-transition-down")
+
+
+class ModelBase(nn.Module):
+    """ref base.py:16-215 (step table, dimension inference, skip-state machine, final MLP)."""
+
+    def __init__(self, in_dim, n_out, steps, feat_dims, out_mlp=dict(), **kwargs):
+        super().__init__()
+        self.in_dim, self.n_out = in_dim, n_out
+        self.use_bias = kwargs.get("use_bias", False)
+        self.version = kwargs.get("version", 2.0)
+        self.step_names = list(steps)
+        self.skip_connect_state_store = list(kwargs.get("skip_connect_state_store", []))
+        self.steps = nn.ModuleList()
+        for i, name in enumerate(steps):
+            kw = dict(kwargs)
+            if isinstance(name, dict):
+                kw.update(name)
+                name = kw.pop("step_name")
+                self.step_names[i] = name
+            kw["with_xyz"] = kw.get("with_xyz", False)
+            self.steps.append(self._make(i, name, self._dims(i, name, feat_dims, in_dim, kw["with_xyz"]), **kw))
+        tail = {"dropout": 0.5, "norm": "batch_norm", "plain_last": True}
+        spec = copy.deepcopy(out_mlp)
+        if isinstance(spec, dict):
+            hidden = spec.pop("dims") or []
+            tail.update(spec)
+        else:
+            hidden = spec
+        dims = [feat_dims[-1][-1]] + list(hidden) + [n_out]
+        if tail.pop("with_seg_category", False):
+            dims[0] += 64
+            self.lin_categorical = MLP([16, 64, 64])
+        self.mlp = nn.Identity() if tail.pop("identity", False) else MLP(dims, bias=self.use_bias, **tail)
+
+    @staticmethod
+    def _dims(i, name, feat_dims, in_dim, xyz):
+        prev = in_dim if i == 0 else feat_dims[i - 1][-1]
+        if name in ("dgcnn", "sgcnn"):
+            head = [in_dim * 2] if i == 0 else [2 * (prev + 3 * xyz)]
+        elif name in ("sa", "sa-global", "sa-geo"):
+            head = [in_dim + 3 * xyz] if i == 0 else [prev + 3 + 3 * xyz]
+        elif name in ("skip-connect", "fp", "fp-geo") and i != 0:
+            head = []
+        elif name in ("mlp", "conv1d-fast-v1", "conv1d-fast-v2") or i == 0:
+            head = [in_dim] if i == 0 else [prev + 3 * xyz]
+        else:
+            raise NotImplementedError("No Module Named >> %s" % name)
+        return head + list(feat_dims[i])
+
+    def _attend(self, dims, kw, halve):
+        if kw.get("aggr_type") not in ("attend", "weighted-sum"):
+            return None
+        c = dims[-1]
+        mid = c // 2 if (halve and self.version == 2.0) else c
+        return MLP([c, mid, c], act="leaky_relu", bias=self.use_bias)
+
+    def _make(self, i, name, dims, **kw):
+        b = self.use_bias
+        if name == "sa":
+            return SAModule(kw["ratios"][i], kw["radii"][i], MLP(dims, bias=b), attend_nn=self._attend(dims, kw, True),
+                            k=kw["knn"][i], **kw)
+        if name == "sgcnn":
+            return SGCNNLayer(MLP(dims, bias=b), kw["knn"][i], r=kw["radii"][i], attend_nn=self._attend(dims, kw, False), **kw)
+        if name == "sa-geo":
+            return CurveSAModule(kw["ratios"][i], kw["radii"][i], MLP(dims, act="leaky_relu", bias=b),
+                                 attend_nn=self._attend(dims, kw, False), **kw)
+        if name == "conv1d-fast-v1":
+            return SymmetricCurve1DConvFastV1(dims, kw["kernel_sizes"][i], with_xyz=kw["with_xyz"], with_diff=kw.get("with_diff", False))
+        if name == "conv1d-fast-v2":
+            return SymmetricCurve1DConvV2(dims, kw["kernel_sizes"][i], with_xyz=kw["with_xyz"], with_diff=kw.get("with_diff", False))
+        if name == "skip-connect":
+            return SkipConnect(MLP(dims, act="leaky_relu", bias=b), kw["num_skips"][i])
+        if name == "fp":
+            return FPModule(kw["knn"][i], MLP(dims, bias=b), with_xyz=kw["with_xyz"])
+        if name == "fp-geo":
+            return CurveFPModule(kw["knn"][i], MLP(dims, act="leaky_relu", bias=b), with_xyz=kw["with_xyz"])
+        if name == "mlp":
+            return SharedMLP(dims, **kw)
+        raise NotImplementedError("Have not implemented step %s yet!" % name)
+
+    def forward(self, data, **kwargs):
+        x, pos, batch, p2c = data.x, data.pos, data.batch, data.curve_idxs
+        if hasattr(data, "labels"):
+            kwargs["shapenet-categories"] = data.labels
+        hist = {"x": [x], "pos": [pos], "batch": [batch], "p2c": [p2c], "idx": []}
+        keep_prop, keep_down = [], []
+        cloud_of_point = batch
+        for i, (name, step) in enumerate(zip(self.step_names, self.steps)):
+            if name in ("fp", "fp-geo"):
+                j = keep_down.pop()
+                skip_x = hist["x"][j] if hist["x"][j] is not None else hist["pos"][j]
+                if name == "fp":
+                    out = step(x, pos, batch, skip_x, hist["pos"][j], hist["batch"][j], p2c, hist["p2c"][j], **kwargs)
+                else:
+                    out = step(x, hist["idx"][j], skip_x, hist["pos"][j], hist["batch"][j], hist["p2c"][j], **kwargs)
+            elif name == "skip-connect":
+                take = keep_prop[-step.num_skips:]
+                del keep_prop[-step.num_skips:]
+                xs = [x] + [hist["x"][j] if hist["x"][j] is not None else hist["pos"][j] for j in take]
+                out = step(xs, pos, batch, p2c, **kwargs)
+            else:
+                out = step(x, pos, batch, p2c, **kwargs)
+            x, pos, batch, p2c = out[:4]
+            hist["x"].append(x); hist["pos"].append(pos); hist["batch"].append(batch); hist["p2c"].append(p2c)
+            hist["idx"].append(out[5] if len(out) > 5 else None)
+            if name in self.skip_connect_state_store:
+                keep_prop.append(i)
+            if name in _DOWN:
+                keep_down.append(i)
+        if "shapenet-categories" in kwargs and hasattr(self, "lin_categorical"):
+            cats = self.lin_categorical(F.one_hot(kwargs["shapenet-categories"], num_classes=16).float())
+            x = torch.cat([x, cats[cloud_of_point]], dim=1)
+        return self.mlp(x)
+
+
+def segmentation_loss(logits, target):
+    """Mean negative log-likelihood over points (ref src/run/kitti_seg.py:184-192)."""
+    return F.nll_loss(F.log_softmax(logits, dim=-1), target)
