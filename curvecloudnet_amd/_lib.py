@@ -1,0 +1,94 @@
+"""ctypes binding of ``libccn_hip.so`` (the C-ABI in ``include/ccn_hip.h``).
+
+The prototypes are read from the header itself, so the header is the single source of truth for
+the boundary.  There is NO fallback: if the shared library is missing, or an op is called without
+a GPU tensor, this raises.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libccn_hip.so")
+HEADER_PATH = os.path.join(_ROOT, "include", "ccn_hip.h")
+
+_CTYPES = {
+    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
+}
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [argtypes])} for every function the header declares."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)
+    protos = {}
+    for m in re.finditer(r"([\w\s\*]+?)\b(ccn_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "*" in ret:
+            restype = ctypes.c_char_p if "char" in ret else ctypes.c_void_p
+        else:
+            restype = _CTYPES[ret.replace("const", "").strip()]
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_CTYPES[a.replace("const", "").split()[0]])
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "curvecloudnet_amd: %s is missing -- build it with `make -C curvecloudnet_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in parse_header().items():
+            fn = getattr(handle, name)       # AttributeError if the header declares a missing symbol
+            fn.restype, fn.argtypes = restype, argtypes
+        if handle.ccn_abi_version() != 1:
+            raise RuntimeError("libccn_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("libccn_hip %s failed (%d): %s" % (what, rc, lib().ccn_last_error().decode()))
+
+
+def call(name, *args):
+    """Invoke ``ccn_<name>`` on the current torch stream (appended as the last argument)."""
+    fn = getattr(lib(), "ccn_" + name)
+    check(fn(*args, stream()), name)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("curvecloudnet_amd ops run on the GPU only (got a %s tensor); there is no CPU path"
+                               % t.device)
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

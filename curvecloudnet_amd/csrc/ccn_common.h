@@ -1,0 +1,71 @@
+// Shared helpers for libccn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/ccn_hip.h"
+
+// ---- error reporting (never throws; negative return + ccn_last_error()) ----
+void ccn_set_error(const char* fmt, ...);
+
+#define CCN_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      ccn_set_error(__VA_ARGS__);       \
+      return CCN_ERR_ARG;               \
+    }                                   \
+  } while (0)
+
+#define CCN_LAUNCH_OK(name)                                               \
+  do {                                                                    \
+    hipError_t e__ = hipGetLastError();                                   \
+    if (e__ != hipSuccess) {                                              \
+      ccn_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return CCN_ERR_LAUNCH;                                              \
+    }                                                                     \
+  } while (0)
+
+#define CCN_HIP(call, name)                                             \
+  do {                                                                  \
+    hipError_t e__ = (call);                                            \
+    if (e__ != hipSuccess) {                                            \
+      ccn_set_error("%s: %s", name, hipGetErrorString(e__));            \
+      return CCN_ERR_LAUNCH;                                            \
+    }                                                                   \
+  } while (0)
+
+// ---- workspace carving: 256-byte aligned bump allocator over a caller-owned buffer ----
+struct CcnArena {
+  char* base;
+  size_t cap;
+  size_t used;
+  __host__ CcnArena(void* p, size_t n) : base((char*)p), cap(n), used(0) {}
+  template <typename T>
+  __host__ T* take(size_t count) {
+    size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    if (base == nullptr || used + bytes > cap) {
+      used = cap + 1;  // poison
+      return nullptr;
+    }
+    T* r = (T*)(base + used);
+    used += bytes;
+    return r;
+  }
+  __host__ bool ok() const { return used <= cap; }
+};
+static inline size_t ccn_align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+static inline int ccn_blocks(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
+
+// ---- device-wide scans (ccn_scan.hip) ----
+// exclusive/inclusive prefix sums over n elements; `scratch` needs ccn_scan_scratch_bytes(n) bytes.
+size_t ccn_scan_scratch_bytes(int64_t n);
+int ccn_scan_i32(const int32_t* in, int32_t* out, int64_t n, bool inclusive, int32_t* total_out, void* scratch,
+                 hipStream_t s);
+int ccn_scan_f64(const double* in, double* out, int64_t n, bool inclusive, void* scratch, hipStream_t s);
+
+// exact distance arithmetic shared by every index kernel and by oracle/frnn_bruteforce.c
+__device__ __forceinline__ float ccn_sqdist3(float dx, float dy, float dz) {
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}

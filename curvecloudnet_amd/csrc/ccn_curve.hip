@@ -1,0 +1,719 @@
+// Curve index algebra and the curve-local float kernels.
+// Built with -ffp-contract=off: every float expression below is evaluated exactly as written so
+// that integer results (sample indices, edge lists) are bit-identical to the CPU oracle.
+#include "ccn_common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+// ------------------------------------------------------------------ A1: segment pointers
+__global__ void run_flags_kernel(const int64_t* __restrict__ ids, int64_t n, int32_t* __restrict__ flag,
+                                 unsigned long long* __restrict__ meta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int f = 1;
+  if (i > 0) {
+    const int64_t a = ids[i - 1], b = ids[i];
+    f = b != a;
+    if (b < a) atomicAdd(&meta[1], 1ULL);
+  }
+  flag[i] = f;
+}
+
+// rank = inclusive scan of flags; element i starts run rank[i]-1 when flag[i]
+__global__ void run_starts_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ rank, int64_t n,
+                                  int64_t* __restrict__ starts, int32_t* __restrict__ run_of,
+                                  int64_t* __restrict__ meta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t r = rank[i] - 1;
+  if (flag[i]) starts[r] = i;
+  if (run_of) run_of[i] = r;
+  if (i == n - 1) {
+    starts[r + 1] = n;
+    meta[0] = r + 1;
+  }
+}
+
+// ------------------------------------------------------------------ A2: topology
+__global__ void cloud_ptr_kernel(const int64_t* __restrict__ batch, int64_t n, int64_t num_clouds,
+                                 int64_t* __restrict__ cloud_ptr, unsigned long long* __restrict__ meta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t b = batch[i];
+  if (b < 0 || b >= num_clouds) {
+    atomicAdd(&meta[1], 1ULL);
+    return;
+  }
+  if (i == 0) {
+    if (b != 0) atomicAdd(&meta[1], 1ULL);
+    cloud_ptr[0] = 0;
+  } else {
+    const int64_t a = batch[i - 1];
+    if (b < a || b > a + 1) atomicAdd(&meta[1], 1ULL);  // unsorted, or a cloud id without points
+    if (b != a) cloud_ptr[b] = i;
+  }
+  if (i == n - 1) {
+    if (b != num_clouds - 1) atomicAdd(&meta[1], 1ULL);
+    cloud_ptr[num_clouds] = n;
+  }
+}
+
+// one thread: per-cloud curve-id offsets (exclusive running sum of "last local id + 1") and the longest cloud
+__global__ void cloud_offsets_kernel(const int64_t* __restrict__ p2c, const int64_t* __restrict__ cloud_ptr,
+                                     int64_t num_clouds, int64_t* __restrict__ curve_off, int64_t* __restrict__ meta) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int64_t run = 0, longest = 0;
+  for (int64_t b = 0; b < num_clouds; ++b) {
+    curve_off[b] = run;
+    const int64_t lo = cloud_ptr[b], hi = cloud_ptr[b + 1];
+    if (hi > lo) run += p2c[hi - 1] + 1;
+    if (hi - lo > longest) longest = hi - lo;
+  }
+  meta[2] = longest;
+  meta[3] = 0;
+}
+
+__global__ void glob_flags_kernel(const int64_t* __restrict__ batch, const int64_t* __restrict__ p2c,
+                                  const int64_t* __restrict__ curve_off, int64_t n, int64_t num_clouds,
+                                  int64_t* __restrict__ glob, int32_t* __restrict__ flag,
+                                  unsigned long long* __restrict__ meta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t b = batch[i];
+  b = b < 0 ? 0 : (b >= num_clouds ? num_clouds - 1 : b);
+  const int64_t g = p2c[i] + curve_off[b];
+  glob[i] = g;
+  int f = 1;
+  if (i > 0) {
+    int64_t pb = batch[i - 1];
+    pb = pb < 0 ? 0 : (pb >= num_clouds ? num_clouds - 1 : pb);
+    const int64_t pg = p2c[i - 1] + curve_off[pb];
+    f = g != pg;
+    if (g < pg) atomicAdd(&meta[1], 1ULL);
+  }
+  flag[i] = f;
+}
+
+__global__ void curve_ptr_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ rank, int64_t n,
+                                 int32_t* __restrict__ cid, int32_t* __restrict__ curve_ptr,
+                                 int64_t* __restrict__ meta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t r = rank[i] - 1;
+  cid[i] = r;
+  if (flag[i]) curve_ptr[r] = (int32_t)i;
+  if (i == n - 1) {
+    curve_ptr[r + 1] = (int32_t)n;
+    meta[0] = r + 1;
+  }
+}
+
+// ------------------------------------------------------------------ A3: feature differences
+// v_i = (a_i + b_i) / max(1, nlinks), a_i = x[i+1]-x[i] if linked, b_i = x[i]-x[i-1] if linked
+__device__ __forceinline__ float diff_raw(const float* __restrict__ x, int64_t ldx, int64_t i, int64_t c, bool lp,
+                                          bool ln) {
+  const float xi = x[i * ldx + c];
+  const float a = ln ? x[(i + 1) * ldx + c] - xi : 0.0f;
+  const float b = lp ? xi - x[(i - 1) * ldx + c] : 0.0f;
+  const float cnt = (float)((int)lp + (int)ln);
+  return (a + b) / (cnt < 1.0f ? 1.0f : cnt);
+}
+
+__global__ void diff_concat_fwd_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ cid,
+                                       int64_t n, int64_t C, float* __restrict__ out, int64_t ldo) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * C) return;
+  const int64_t i = t / C, c = t - i * C;
+  const int32_t me = cid[i];
+  const bool lp = i > 0 && cid[i - 1] == me, ln = i + 1 < n && cid[i + 1] == me;
+  out[i * ldo + c] = x[i * ldx + c];
+  out[i * ldo + C + c] = fabsf(diff_raw(x, ldx, i, c, lp, ln));
+}
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+__global__ void diff_concat_bwd_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ cid,
+                                       int64_t n, int64_t C, const float* __restrict__ g, int64_t ldg,
+                                       float* __restrict__ dx, int64_t lddx) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * C) return;
+  const int64_t j = t / C, c = t - j * C;
+  const int32_t me = cid[j];
+  const bool l_m2 = j > 1 && cid[j - 2] == me && cid[j - 1] == me;  // link (j-2, j-1)
+  const bool l_m1 = j > 0 && cid[j - 1] == me;                      // link (j-1, j)
+  const bool l_p0 = j + 1 < n && cid[j + 1] == me;                  // link (j, j+1)
+  const bool l_p1 = j + 2 < n && cid[j + 2] == me && l_p0;          // link (j+1, j+2)
+  float acc = g[j * ldg + c];
+  // s_i = sign(v_i) * gd_i / cnt_i
+  if (l_m1) {  // point j-1: ahead edge touches x[j] with +1
+    const float cnt = (float)((int)l_m2 + 1);
+    acc += sgn(diff_raw(x, ldx, j - 1, c, l_m2, true)) * g[(j - 1) * ldg + C + c] / cnt;
+  }
+  {
+    const int k = (int)l_m1 + (int)l_p0;
+    if (k > 0) {
+      const float coef = (float)((int)l_m1 - (int)l_p0);
+      if (coef != 0.0f) acc += coef * sgn(diff_raw(x, ldx, j, c, l_m1, l_p0)) * g[j * ldg + C + c] / (float)k;
+    }
+  }
+  if (l_p0) {  // point j+1: behind edge touches x[j] with -1
+    const float cnt = (float)((int)l_p1 + 1);
+    acc -= sgn(diff_raw(x, ldx, j + 1, c, true, l_p1)) * g[(j + 1) * ldg + C + c] / cnt;
+  }
+  dx[j * lddx + c] = acc;
+}
+
+// ------------------------------------------------------------------ A4: shifted rows
+__global__ void im2col_fwd_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ seg,
+                                  int64_t rows, int64_t C, int64_t taps, float* __restrict__ col) {
+  const int64_t width = taps * C;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * width) return;
+  const int64_t i = t / width, rem = t - i * width;
+  const int64_t tap = rem / C, c = rem - tap * C;
+  const int64_t j = i + tap - taps / 2;
+  float v = 0.0f;
+  if (j >= 0 && j < rows && (seg == nullptr || seg[j] == seg[i])) v = x[j * ldx + c];
+  col[t] = v;
+}
+
+__global__ void im2col_bwd_kernel(const float* __restrict__ dcol, const int32_t* __restrict__ seg, int64_t rows,
+                                  int64_t C, int64_t taps, float* __restrict__ dx, int64_t lddx) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * C) return;
+  const int64_t j = t / C, c = t - j * C;
+  const int64_t width = taps * C;
+  float acc = 0.0f;
+  for (int64_t tap = 0; tap < taps; ++tap) {
+    const int64_t i = j - tap + taps / 2;  // output row whose tap `tap` read x[j]
+    if (i >= 0 && i < rows && (seg == nullptr || seg[i] == seg[j])) acc += dcol[i * width + tap * C + c];
+  }
+  dx[j * lddx + c] = acc;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, int64_t lds_, const int64_t* __restrict__ index,
+                                   int64_t m, int64_t C, float* __restrict__ dst, int64_t ldd) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m * C) return;
+  const int64_t r = t / C, c = t - r * C;
+  dst[r * ldd + c] = src[index[r] * lds_ + c];
+}
+
+__global__ void scatter_rows_kernel(const float* __restrict__ src, int64_t lds_, const int64_t* __restrict__ index,
+                                    int64_t m, int64_t C, float* __restrict__ dst, int64_t ldd, int accumulate) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m * C) return;
+  const int64_t r = t / C, c = t - r * C;
+  const float v = src[r * lds_ + c];
+  float* p = dst + index[r] * ldd + c;
+  if (accumulate)
+    atomicAdd(p, v);
+  else
+    *p = v;
+}
+
+// ------------------------------------------------------------------ shared curve helpers
+__device__ __forceinline__ float edge_len(const float* __restrict__ pos, int64_t i) {  // |pos[i+1] - pos[i]|
+  const float dx = pos[3 * (i + 1)] - pos[3 * i];
+  const float dy = pos[3 * (i + 1) + 1] - pos[3 * i + 1];
+  const float dz = pos[3 * (i + 1) + 2] - pos[3 * i + 2];
+  return __fsqrt_rn(ccn_sqdist3(dx, dy, dz));
+}
+
+// ------------------------------------------------------------------ A7: CurveFPS
+// step[i] = length of the in-curve edge ending at point i (0 for curve starts), as float64
+__global__ void fps_steps_kernel(const float* __restrict__ pos, const int32_t* __restrict__ cid, int64_t n,
+                                 double* __restrict__ step) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double v = 0.0;
+  if (i > 0 && cid[i - 1] == cid[i]) v = (double)edge_len(pos, i - 1);
+  step[i] = v;
+}
+
+__device__ __forceinline__ float fps_bucket(const double* __restrict__ run, int64_t i, int32_t start, float spacing,
+                                            float u) {
+  // torch: cumsum accumulates in float64 and rounds each output to float32
+  float arclen = (float)run[i] - (float)run[start];
+  const float scaled = __ll2float_rn((long long)start * 117LL) * u;
+  float phase = fmodf(scaled, spacing);
+  if (phase != 0.0f && ((spacing < 0.0f) != (phase < 0.0f))) phase += spacing;  // python-style remainder
+  arclen = arclen + phase;
+  return rintf(__fdiv_rn(arclen, spacing));
+}
+
+__global__ void fps_keep_kernel(const double* __restrict__ run, const int32_t* __restrict__ cid,
+                                const int32_t* __restrict__ curve_ptr, int64_t n, float spacing, float u,
+                                int32_t* __restrict__ keep) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t start = curve_ptr[cid[i]];
+  int k = 1;
+  if (i > 0 && i != start) {
+    const float b1 = fps_bucket(run, i, start, spacing, u);
+    const float b0 = fps_bucket(run, i - 1, curve_ptr[cid[i - 1]], spacing, u);
+    k = (b1 - b0) != 0.0f;
+  }
+  keep[i] = k;
+}
+
+__global__ void compact_kernel(const int32_t* __restrict__ keep, const int32_t* __restrict__ rank_excl, int64_t n,
+                               int64_t* __restrict__ out, int64_t* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (keep[i]) out[rank_excl[i]] = i;
+  if (i == n - 1) *count = (int64_t)rank_excl[i] + keep[i];
+}
+
+// ------------------------------------------------------------------ A8: radius group along curves
+__global__ void curve_budget_kernel(const float* __restrict__ pos, const int32_t* __restrict__ curve_ptr, int64_t Q,
+                                    float radius, float* __restrict__ budget, unsigned int* __restrict__ maxbits) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Q) return;
+  const int32_t lo = curve_ptr[c], hi = curve_ptr[c + 1];
+  float len = 0.0f;  // sequential float32 sum in point order (index_add_ semantics)
+  for (int32_t i = lo; i + 1 < hi; ++i) len += edge_len(pos, i);
+  const float cnt = (float)(hi - lo);
+  const float mean_edge = __fdiv_rn(len, cnt);
+  // the reference writes `radius / tensor`, which torch evaluates as reciprocal(tensor) * radius
+  float b = ceilf(__frcp_rn(mean_edge) * radius);
+  if (isinf(b)) b = 1.0f;
+  budget[c] = b;
+  // positive floats order like their bit patterns
+  atomicMax(&maxbits[0], __float_as_uint(b > 0.0f ? b : 0.0f));
+  atomicMax(&maxbits[1], __float_as_uint(cnt));
+}
+
+__global__ void curve_reach_kernel(const unsigned int* __restrict__ maxbits, float* __restrict__ budget, int64_t Q) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) budget[Q] = fminf(__uint_as_float(maxbits[0]), __uint_as_float(maxbits[1]));
+}
+
+// walk 0,-1,+1,-2,+2,... inside [lo,hi) up to `reach`; accept while fewer than `allow` accepted.
+template <bool FILL>
+__device__ __forceinline__ int group_walk(int64_t centre, int32_t lo, int32_t hi, int reach, float allow, int64_t q,
+                                          int64_t* __restrict__ row, int64_t* __restrict__ col) {
+  int taken = 0;
+  if ((float)(taken + 1) <= allow) {
+    if (FILL) { row[taken] = q; col[taken] = centre; }
+    ++taken;
+  } else {
+    return 0;
+  }
+  for (int m = 1; m <= reach; ++m) {
+    const int64_t left = centre - m, right = centre + m;
+    if (left >= lo) {
+      if ((float)(taken + 1) <= allow) {
+        if (FILL) { row[taken] = q; col[taken] = left; }
+        ++taken;
+      } else {
+        break;
+      }
+    }
+    if (right < hi) {
+      if ((float)(taken + 1) <= allow) {
+        if (FILL) { row[taken] = q; col[taken] = right; }
+        ++taken;
+      } else {
+        break;
+      }
+    }
+    if (left < lo && right >= hi) break;
+  }
+  return taken;
+}
+
+template <bool FILL>
+__global__ void group_subset_kernel(const int32_t* __restrict__ cid, const int32_t* __restrict__ curve_ptr,
+                                    const int64_t* __restrict__ p2c, int64_t Q, const int64_t* __restrict__ idx,
+                                    int64_t M, const float* __restrict__ budget, int32_t* __restrict__ counts,
+                                    const int32_t* __restrict__ offsets, int64_t* __restrict__ row,
+                                    int64_t* __restrict__ col) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= M) return;
+  const int64_t centre = idx[q];
+  const int32_t c = cid[centre];
+  int64_t local = p2c[centre];  // quirk Q3: LOCAL id indexes the global table
+  local = local < 0 ? 0 : (local >= Q ? Q - 1 : local);
+  const float allow = budget[local];
+  const int reach = (int)budget[Q];
+  if (FILL) {
+    const int32_t o = offsets[q];
+    group_walk<true>(centre, curve_ptr[c], curve_ptr[c + 1], reach, allow, q, row + o, col + o);
+  } else {
+    counts[q] = group_walk<false>(centre, curve_ptr[c], curve_ptr[c + 1], reach, allow, q, nullptr, nullptr);
+  }
+}
+
+// ------------------------------------------------------------------ A9: k nearest sampled points on the curve
+__global__ void mark_samples_kernel(const int64_t* __restrict__ idx, int64_t M, int32_t* __restrict__ taken) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < M) taken[idx[m]] = 1;
+}
+
+constexpr int SUP_MAXK = 8;  // supports k <= 8 (2k+3 <= 19 candidates)
+
+__global__ void group_superset_kernel(const float* __restrict__ pos, const int32_t* __restrict__ cid, int64_t n,
+                                      const int64_t* __restrict__ idx, int64_t M, int k,
+                                      const int32_t* __restrict__ upto, int64_t* __restrict__ nbr,
+                                      float* __restrict__ weight) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+  const int32_t me = cid[i];
+  const int64_t base = upto[i];
+  float bd[SUP_MAXK];
+  int64_t bi[SUP_MAXK];
+#pragma unroll
+  for (int t = 0; t < SUP_MAXK; ++t) {
+    bd[t] = __builtin_inff();
+    bi[t] = -1;
+  }
+  const int ncand = 2 * k + 3;
+  for (int s = 0; s < ncand; ++s) {
+    // candidate order 0,-1,+1,-2,+2,...; equal distances keep this order (stable insertion)
+    const int mag = (s + 1) >> 1;
+    const int64_t cand = base + ((s & 1) ? -mag : mag);
+    if (cand < 0 || cand >= M) continue;
+    const int64_t p = idx[cand];
+    if (cid[p] != me) continue;
+    float cd = __fsqrt_rn(ccn_sqdist3(pos[3 * p] - px, pos[3 * p + 1] - py, pos[3 * p + 2] - pz));
+    int64_t ci = cand;
+#pragma unroll
+    for (int t = 0; t < SUP_MAXK; ++t) {  // static indices only: the lists stay in registers
+      if (t < k) {
+        const bool sw = cd < bd[t];
+        const float td = bd[t];
+        const int64_t ti = bi[t];
+        bd[t] = sw ? cd : td;
+        bi[t] = sw ? ci : ti;
+        cd = sw ? td : cd;
+        ci = sw ? ti : ci;
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < SUP_MAXK; ++t) {
+    if (t < k) {
+      const bool ok = bi[t] >= 0;
+      nbr[i * k + t] = bi[t];
+      float w = 0.0f;
+      if (ok) {
+        const float d2 = bd[t] * bd[t];
+        w = __frcp_rn(d2 < 1e-16f ? 1e-16f : d2);
+      }
+      weight[i * k + t] = w;
+    }
+  }
+}
+
+__global__ void interp_fwd_kernel(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ nbr,
+                                  const float* __restrict__ weight, int64_t n, int k, int64_t C,
+                                  float* __restrict__ y, int64_t ldy) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * C) return;
+  const int64_t i = t / C, c = t - i * C;
+  float num = 0.0f, den = 0.0f;
+  for (int s = 0; s < k; ++s) {
+    const int64_t m = nbr[i * k + s];
+    if (m < 0) break;
+    const float w = weight[i * k + s];
+    num += x[m * ldx + c] * w;
+    den += w;
+  }
+  y[i * ldy + c] = num / den;
+}
+
+__global__ void interp_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const int64_t* __restrict__ nbr,
+                                  const float* __restrict__ weight, int64_t n, int k, int64_t C,
+                                  float* __restrict__ dx, int64_t lddx) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * C) return;
+  const int64_t i = t / C, c = t - i * C;
+  float den = 0.0f;
+  for (int s = 0; s < k; ++s) {
+    if (nbr[i * k + s] < 0) break;
+    den += weight[i * k + s];
+  }
+  const float g = dy[i * lddy + c] / den;
+  for (int s = 0; s < k; ++s) {
+    const int64_t m = nbr[i * k + s];
+    if (m < 0) break;
+    atomicAdd(&dx[m * lddx + c], g * weight[i * k + s]);
+  }
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" {
+
+size_t ccn_exclusive_scan_workspace_bytes(int64_t n) { return ccn_scan_scratch_bytes(n + 1) + 256; }
+
+namespace {
+__global__ void widen_total_kernel(const int32_t* __restrict__ offsets, int64_t n, int64_t* __restrict__ total64) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *total64 = offsets[n];
+}
+__global__ void zero_tail_kernel(int32_t* p) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *p = 0;
+}
+}  // namespace
+
+int ccn_exclusive_scan_i32(const int32_t* counts, int64_t n, int32_t* offsets, int64_t* total64, void* ws,
+                           size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(n >= 0 && offsets != nullptr, "exclusive_scan: bad arguments");
+  CCN_REQUIRE(ws_bytes >= ccn_exclusive_scan_workspace_bytes(n), "exclusive_scan: workspace too small");
+  // offsets[n] = total: scan n elements exclusively, total lands in offsets[n]
+  if (n == 0) {
+    hipLaunchKernelGGL(zero_tail_kernel, dim3(1), dim3(64), 0, s, offsets);
+  } else {
+    int rc = ccn_scan_i32(counts, offsets, n, false, offsets + n, ws, s);
+    if (rc) return rc;
+  }
+  if (total64) hipLaunchKernelGGL(widen_total_kernel, dim3(1), dim3(64), 0, s, offsets, n, total64);
+  CCN_LAUNCH_OK("exclusive_scan");
+  return CCN_OK;
+}
+
+size_t ccn_segment_ptr_workspace_bytes(int64_t n) {
+  return 2 * ccn_align256((size_t)(n + 1) * 4) + ccn_scan_scratch_bytes(n) + 256;
+}
+
+int ccn_segment_ptr(const int64_t* ids, int64_t n, int64_t* starts, int32_t* run_of, int64_t* meta, void* ws,
+                    size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(n >= 0 && starts && meta, "segment_ptr: bad arguments");
+  CCN_REQUIRE(ws_bytes >= ccn_segment_ptr_workspace_bytes(n), "segment_ptr: workspace too small");
+  CCN_HIP(hipMemsetAsync(meta, 0, 2 * sizeof(int64_t), s), "segment_ptr");
+  CCN_HIP(hipMemsetAsync(starts, 0, sizeof(int64_t), s), "segment_ptr");
+  if (n == 0) return CCN_OK;
+  CcnArena a(ws, ws_bytes);
+  int32_t* flag = a.take<int32_t>(n + 1);
+  int32_t* rank = a.take<int32_t>(n + 1);
+  void* scratch = a.take<char>(ccn_scan_scratch_bytes(n));
+  CCN_REQUIRE(a.ok(), "segment_ptr: workspace carve failed");
+  const int nb = ccn_blocks(n, TPB);
+  hipLaunchKernelGGL(run_flags_kernel, dim3(nb), dim3(TPB), 0, s, ids, n, flag, (unsigned long long*)meta);
+  int rc = ccn_scan_i32(flag, rank, n, true, nullptr, scratch, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(run_starts_kernel, dim3(nb), dim3(TPB), 0, s, flag, rank, n, starts, run_of, meta);
+  CCN_LAUNCH_OK("segment_ptr");
+  return CCN_OK;
+}
+
+size_t ccn_curve_topology_workspace_bytes(int64_t n, int64_t num_clouds) {
+  return 2 * ccn_align256((size_t)(n + 1) * 4) + ccn_align256((size_t)(num_clouds + 1) * 8) +
+         ccn_scan_scratch_bytes(n) + 512;
+}
+
+int ccn_curve_topology(const int64_t* batch, const int64_t* p2c, int64_t n, int64_t num_clouds, int64_t* glob,
+                       int32_t* cid, int32_t* curve_ptr, int64_t* cloud_ptr, int64_t* meta, void* ws,
+                       size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(n > 0 && num_clouds > 0, "curve_topology: empty input (n=%lld, clouds=%lld)", (long long)n,
+              (long long)num_clouds);
+  CCN_REQUIRE(batch && p2c && glob && cid && curve_ptr && cloud_ptr && meta, "curve_topology: null pointer");
+  CCN_REQUIRE(n < 2147483647LL, "curve_topology: more than 2^31-1 points");
+  CCN_REQUIRE(ws_bytes >= ccn_curve_topology_workspace_bytes(n, num_clouds), "curve_topology: workspace too small");
+  CcnArena a(ws, ws_bytes);
+  int32_t* flag = a.take<int32_t>(n + 1);
+  int32_t* rank = a.take<int32_t>(n + 1);
+  int64_t* curve_off = a.take<int64_t>(num_clouds + 1);
+  void* scratch = a.take<char>(ccn_scan_scratch_bytes(n));
+  CCN_REQUIRE(a.ok(), "curve_topology: workspace carve failed");
+  CCN_HIP(hipMemsetAsync(meta, 0, 4 * sizeof(int64_t), s), "curve_topology");
+  CCN_HIP(hipMemsetAsync(cloud_ptr, 0, (num_clouds + 1) * sizeof(int64_t), s), "curve_topology");
+  const int nb = ccn_blocks(n, TPB);
+  hipLaunchKernelGGL(cloud_ptr_kernel, dim3(nb), dim3(TPB), 0, s, batch, n, num_clouds, cloud_ptr,
+                     (unsigned long long*)meta);
+  hipLaunchKernelGGL(cloud_offsets_kernel, dim3(1), dim3(64), 0, s, p2c, cloud_ptr, num_clouds, curve_off, meta);
+  hipLaunchKernelGGL(glob_flags_kernel, dim3(nb), dim3(TPB), 0, s, batch, p2c, curve_off, n, num_clouds, glob, flag,
+                     (unsigned long long*)meta);
+  int rc = ccn_scan_i32(flag, rank, n, true, nullptr, scratch, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(curve_ptr_kernel, dim3(nb), dim3(TPB), 0, s, flag, rank, n, cid, curve_ptr, meta);
+  CCN_LAUNCH_OK("curve_topology");
+  return CCN_OK;
+}
+
+int ccn_diff_concat_fwd(const float* x, int64_t ldx, const int32_t* cid, int64_t n, int64_t C, float* out,
+                        int64_t ldo, void* stream) {
+  CCN_REQUIRE(x && cid && out && ldx >= C && ldo >= 2 * C, "diff_concat_fwd: bad arguments");
+  if (n * C == 0) return CCN_OK;
+  hipLaunchKernelGGL(diff_concat_fwd_kernel, dim3(ccn_blocks(n * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, x, ldx,
+                     cid, n, C, out, ldo);
+  CCN_LAUNCH_OK("diff_concat_fwd");
+  return CCN_OK;
+}
+
+int ccn_diff_concat_bwd(const float* x, int64_t ldx, const int32_t* cid, int64_t n, int64_t C, const float* g,
+                        int64_t ldg, float* dx, int64_t lddx, void* stream) {
+  CCN_REQUIRE(x && cid && g && dx && ldx >= C && ldg >= 2 * C && lddx >= C, "diff_concat_bwd: bad arguments");
+  if (n * C == 0) return CCN_OK;
+  hipLaunchKernelGGL(diff_concat_bwd_kernel, dim3(ccn_blocks(n * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, x, ldx,
+                     cid, n, C, g, ldg, dx, lddx);
+  CCN_LAUNCH_OK("diff_concat_bwd");
+  return CCN_OK;
+}
+
+int ccn_im2col_fwd(const float* x, int64_t ldx, const int32_t* seg, int64_t rows, int64_t C, int64_t taps, float* col,
+                   void* stream) {
+  CCN_REQUIRE(x && col && ldx >= C && taps >= 1 && (taps & 1), "im2col_fwd: bad arguments");
+  if (rows * C == 0) return CCN_OK;
+  hipLaunchKernelGGL(im2col_fwd_kernel, dim3(ccn_blocks(rows * taps * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, x,
+                     ldx, seg, rows, C, taps, col);
+  CCN_LAUNCH_OK("im2col_fwd");
+  return CCN_OK;
+}
+
+int ccn_im2col_bwd(const float* dcol, const int32_t* seg, int64_t rows, int64_t C, int64_t taps, float* dx,
+                   int64_t lddx, void* stream) {
+  CCN_REQUIRE(dcol && dx && lddx >= C && taps >= 1 && (taps & 1), "im2col_bwd: bad arguments");
+  if (rows * C == 0) return CCN_OK;
+  hipLaunchKernelGGL(im2col_bwd_kernel, dim3(ccn_blocks(rows * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, dcol, seg,
+                     rows, C, taps, dx, lddx);
+  CCN_LAUNCH_OK("im2col_bwd");
+  return CCN_OK;
+}
+
+int ccn_gather_rows(const float* src, int64_t lds_, const int64_t* index, int64_t m, int64_t C, float* dst,
+                    int64_t ldd, void* stream) {
+  CCN_REQUIRE(src && index && dst && lds_ >= C && ldd >= C, "gather_rows: bad arguments");
+  if (m * C == 0) return CCN_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ccn_blocks(m * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, src, lds_,
+                     index, m, C, dst, ldd);
+  CCN_LAUNCH_OK("gather_rows");
+  return CCN_OK;
+}
+
+int ccn_scatter_rows(const float* src, int64_t lds_, const int64_t* index, int64_t m, int64_t C, float* dst,
+                     int64_t ldd, int accumulate, void* stream) {
+  CCN_REQUIRE(src && index && dst && lds_ >= C && ldd >= C, "scatter_rows: bad arguments");
+  if (m * C == 0) return CCN_OK;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(ccn_blocks(m * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, src, lds_,
+                     index, m, C, dst, ldd, accumulate);
+  CCN_LAUNCH_OK("scatter_rows");
+  return CCN_OK;
+}
+
+size_t ccn_curve_fps_workspace_bytes(int64_t n) {
+  return 2 * ccn_align256((size_t)(n + 1) * 8) + 2 * ccn_align256((size_t)(n + 1) * 4) + ccn_scan_scratch_bytes(n) +
+         512;
+}
+
+int ccn_curve_fps(const float* pos, const int32_t* cid, const int32_t* curve_ptr, int64_t n, float spacing, float u,
+                  int64_t* idx_out, int64_t* count_out, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(pos && cid && curve_ptr && idx_out && count_out && n > 0, "curve_fps: bad arguments");
+  CCN_REQUIRE(spacing > 0.0f, "curve_fps: arclength spacing must be positive");
+  CCN_REQUIRE(ws_bytes >= ccn_curve_fps_workspace_bytes(n), "curve_fps: workspace too small");
+  CcnArena a(ws, ws_bytes);
+  double* step = a.take<double>(n + 1);
+  double* run = a.take<double>(n + 1);
+  int32_t* keep = a.take<int32_t>(n + 1);
+  int32_t* rank = a.take<int32_t>(n + 1);
+  void* scratch = a.take<char>(ccn_scan_scratch_bytes(n));
+  CCN_REQUIRE(a.ok(), "curve_fps: workspace carve failed");
+  const int nb = ccn_blocks(n, TPB);
+  hipLaunchKernelGGL(fps_steps_kernel, dim3(nb), dim3(TPB), 0, s, pos, cid, n, step);
+  int rc = ccn_scan_f64(step, run, n, true, scratch, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fps_keep_kernel, dim3(nb), dim3(TPB), 0, s, run, cid, curve_ptr, n, spacing, u, keep);
+  rc = ccn_scan_i32(keep, rank, n, false, nullptr, scratch, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(TPB), 0, s, keep, rank, n, idx_out, count_out);
+  CCN_LAUNCH_OK("curve_fps");
+  return CCN_OK;
+}
+
+size_t ccn_curve_group_subset_workspace_bytes(int64_t n, int64_t Q, int64_t M) {
+  (void)n;
+  (void)Q;
+  return ccn_align256((size_t)(M + 1) * 4) + ccn_scan_scratch_bytes(M + 1) + 1024;
+}
+
+int ccn_curve_group_subset_count(const float* pos, const int32_t* cid, const int32_t* curve_ptr, const int64_t* p2c,
+                                 int64_t n, int64_t Q, const int64_t* idx, int64_t M, float radius, float* budget,
+                                 int32_t* offsets, int64_t* total, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(pos && cid && curve_ptr && p2c && idx && budget && offsets && total, "group_subset_count: null pointer");
+  CCN_REQUIRE(n > 0 && Q > 0 && M > 0, "group_subset_count: empty input");
+  CCN_REQUIRE(ws_bytes >= ccn_curve_group_subset_workspace_bytes(n, Q, M), "group_subset_count: workspace too small");
+  CcnArena a(ws, ws_bytes);
+  int32_t* counts = a.take<int32_t>(M + 1);
+  unsigned int* maxbits = a.take<unsigned int>(2);
+  void* scratch = a.take<char>(ccn_scan_scratch_bytes(M + 1));
+  CCN_REQUIRE(a.ok(), "group_subset_count: workspace carve failed");
+  CCN_HIP(hipMemsetAsync(maxbits, 0, 2 * sizeof(unsigned int), s), "group_subset_count");
+  hipLaunchKernelGGL(curve_budget_kernel, dim3(ccn_blocks(Q, TPB)), dim3(TPB), 0, s, pos, curve_ptr, Q, radius, budget,
+                     maxbits);
+  hipLaunchKernelGGL(curve_reach_kernel, dim3(1), dim3(64), 0, s, maxbits, budget, Q);
+  hipLaunchKernelGGL(group_subset_kernel<false>, dim3(ccn_blocks(M, TPB)), dim3(TPB), 0, s, cid, curve_ptr, p2c, Q, idx,
+                     M, budget, counts, (const int32_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr);
+  int rc = ccn_scan_i32(counts, offsets, M, false, offsets + M, scratch, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(widen_total_kernel, dim3(1), dim3(64), 0, s, offsets, M, total);
+  CCN_LAUNCH_OK("group_subset_count");
+  return CCN_OK;
+}
+
+int ccn_curve_group_subset_fill(const int32_t* cid, const int32_t* curve_ptr, const int64_t* p2c, int64_t n,
+                                int64_t Q, const int64_t* idx, int64_t M, const float* budget,
+                                const int32_t* offsets, int64_t* row, int64_t* col, void* stream) {
+  (void)n;
+  CCN_REQUIRE(cid && curve_ptr && p2c && idx && budget && offsets && row && col, "group_subset_fill: null pointer");
+  if (M == 0) return CCN_OK;
+  hipLaunchKernelGGL(group_subset_kernel<true>, dim3(ccn_blocks(M, TPB)), dim3(TPB), 0, (hipStream_t)stream, cid,
+                     curve_ptr, p2c, Q, idx, M, budget, (int32_t*)nullptr, offsets, row, col);
+  CCN_LAUNCH_OK("group_subset_fill");
+  return CCN_OK;
+}
+
+size_t ccn_curve_group_superset_workspace_bytes(int64_t n) {
+  return 2 * ccn_align256((size_t)(n + 1) * 4) + ccn_scan_scratch_bytes(n) + 512;
+}
+
+int ccn_curve_group_superset(const float* pos, const int32_t* cid, int64_t n, const int64_t* idx, int64_t M, int64_t k,
+                             int64_t* nbr, float* weight, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(pos && cid && idx && nbr && weight && n > 0 && M > 0, "group_superset: bad arguments");
+  CCN_REQUIRE(k >= 1 && k <= SUP_MAXK, "group_superset: k must be in [1, %d]", SUP_MAXK);
+  CCN_REQUIRE(ws_bytes >= ccn_curve_group_superset_workspace_bytes(n), "group_superset: workspace too small");
+  CcnArena a(ws, ws_bytes);
+  int32_t* taken = a.take<int32_t>(n + 1);
+  int32_t* upto = a.take<int32_t>(n + 1);
+  void* scratch = a.take<char>(ccn_scan_scratch_bytes(n));
+  CCN_REQUIRE(a.ok(), "group_superset: workspace carve failed");
+  CCN_HIP(hipMemsetAsync(taken, 0, (size_t)n * 4, s), "group_superset");
+  hipLaunchKernelGGL(mark_samples_kernel, dim3(ccn_blocks(M, TPB)), dim3(TPB), 0, s, idx, M, taken);
+  int rc = ccn_scan_i32(taken, upto, n, true, nullptr, scratch, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(group_superset_kernel, dim3(ccn_blocks(n, TPB)), dim3(TPB), 0, s, pos, cid, n, idx, M, (int)k,
+                     upto, nbr, weight);
+  CCN_LAUNCH_OK("group_superset");
+  return CCN_OK;
+}
+
+int ccn_interp_fwd(const float* x, int64_t ldx, const int64_t* nbr, const float* weight, int64_t n, int64_t k,
+                   int64_t C, float* y, int64_t ldy, void* stream) {
+  CCN_REQUIRE(x && nbr && weight && y && ldx >= C && ldy >= C && k >= 1, "interp_fwd: bad arguments");
+  if (n * C == 0) return CCN_OK;
+  hipLaunchKernelGGL(interp_fwd_kernel, dim3(ccn_blocks(n * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, x, ldx, nbr,
+                     weight, n, (int)k, C, y, ldy);
+  CCN_LAUNCH_OK("interp_fwd");
+  return CCN_OK;
+}
+
+int ccn_interp_bwd(const float* dy, int64_t lddy, const int64_t* nbr, const float* weight, int64_t n, int64_t k,
+                   int64_t C, float* dx, int64_t lddx, void* stream) {
+  CCN_REQUIRE(dy && nbr && weight && dx && lddy >= C && lddx >= C && k >= 1, "interp_bwd: bad arguments");
+  if (n * C == 0) return CCN_OK;
+  hipLaunchKernelGGL(interp_bwd_kernel, dim3(ccn_blocks(n * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, lddy, nbr,
+                     weight, n, (int)k, C, dx, lddx);
+  CCN_LAUNCH_OK("interp_bwd");
+  return CCN_OK;
+}
+
+}  // extern "C"

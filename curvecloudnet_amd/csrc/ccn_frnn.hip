@@ -1,0 +1,253 @@
+// Fixed-radius k-nearest-neighbour search on a hashed uniform grid:
+// replaces third_party/FRNN (frnn.frnn_grid_points, called at src/models/utils/point_ops.py:459).
+//
+// Layout in HBM (all inside the caller-owned `grid` buffer, see ccn_frnn_grid_bytes):
+//   cell_start  int32 [B*T + 1]   exclusive prefix of bucket populations, T = pow2 >= 2*P2 buckets per cloud
+//   cell_fill   int32 [B*T]       bucket populations (build) / scatter cursors
+//   sorted_pts  float4[B*P2]      (x, y, z, original index) grouped by bucket -> coalesced candidate reads
+//   sorted_cell int4  [B*P2]      integer cell of every sorted point (exact-cell filter: hash collisions and
+//                                 two neighbour cells sharing a bucket can never produce a duplicate)
+// The grid only prunes: a candidate is accepted iff d2 = fma(dz,dz,fma(dy,dy,dx*dx)) < r*r, and the K best
+// are kept ordered by (d2, original index), exactly the exhaustive oracle (oracle/frnn_bruteforce.c).
+// Cell edge = 1.001 r, so every point within r of a query lies in the 27 cells around the query's cell
+// even after float rounding of the cell coordinate (valid while |coordinate| / r < 1e4).
+// Built with -ffp-contract=off.
+#include "ccn_common.h"
+
+namespace {
+
+constexpr int BUILD_TPB = 256;
+constexpr int QUERY_TPB = 128;
+
+struct GridView {
+  int32_t* cell_start;
+  int32_t* cell_fill;
+  float4* sorted_pts;
+  int4* sorted_cell;
+  void* scan_scratch;
+  int64_t T;
+};
+
+__host__ int64_t table_size(int64_t P2) {
+  int64_t t = 256;
+  while (t < 2 * P2) t <<= 1;
+  return t;
+}
+
+__host__ size_t grid_bytes(int64_t B, int64_t P2) {
+  const int64_t T = table_size(P2);
+  return ccn_align256((size_t)(B * T + 1) * 4) + ccn_align256((size_t)(B * T) * 4) +
+         ccn_align256((size_t)(B * P2) * 16) * 2 + ccn_scan_scratch_bytes(B * T + 1) + 1024;
+}
+
+__host__ bool carve(void* grid, size_t bytes, int64_t B, int64_t P2, GridView* g) {
+  CcnArena a(grid, bytes);
+  g->T = table_size(P2);
+  g->cell_start = a.take<int32_t>(B * g->T + 1);
+  g->cell_fill = a.take<int32_t>(B * g->T);
+  g->sorted_pts = a.take<float4>(B * P2);
+  g->sorted_cell = a.take<int4>(B * P2);
+  g->scan_scratch = a.take<char>(ccn_scan_scratch_bytes(B * g->T + 1));
+  return a.ok();
+}
+
+__device__ __forceinline__ int3 cell_of(float x, float y, float z, float inv_cell) {
+  return make_int3(__float2int_rd(x * inv_cell), __float2int_rd(y * inv_cell), __float2int_rd(z * inv_cell));
+}
+
+__device__ __forceinline__ uint32_t bucket_of(int cx, int cy, int cz, uint32_t mask) {
+  return (((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u) ^ ((uint32_t)cz * 83492791u)) & mask;
+}
+
+__device__ __forceinline__ float inv_cell_of(float r) { return __frcp_rn(r * 1.001f); }
+
+template <bool SCATTER>
+__global__ __launch_bounds__(BUILD_TPB) void grid_insert_kernel(const float* __restrict__ pts,
+                                                                const int64_t* __restrict__ lengths,
+                                                                const float* __restrict__ radius, int64_t P2,
+                                                                int64_t T, const int32_t* __restrict__ cell_start,
+                                                                int32_t* __restrict__ cell_fill,
+                                                                float4* __restrict__ sorted_pts,
+                                                                int4* __restrict__ sorted_cell) {
+  const int64_t b = blockIdx.y;
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= lengths[b]) return;
+  const float* p = pts + (b * P2 + j) * 3;
+  const float x = p[0], y = p[1], z = p[2];
+  const int3 c = cell_of(x, y, z, inv_cell_of(radius[b]));
+  const int64_t slot = b * T + bucket_of(c.x, c.y, c.z, (uint32_t)(T - 1));
+  if (!SCATTER) {
+    atomicAdd(&cell_fill[slot], 1);
+  } else {
+    const int32_t at = cell_start[slot] + atomicAdd(&cell_fill[slot], 1);
+    sorted_pts[at] = make_float4(x, y, z, __int_as_float((int)j));
+    sorted_cell[at] = make_int4(c.x, c.y, c.z, 0);
+  }
+}
+
+// one thread per query; its running top-K lives in LDS as column `threadIdx.x` of [K][QUERY_TPB] arrays,
+// so every access is bank-conflict free whatever slot each lane is working on.
+__global__ __launch_bounds__(QUERY_TPB) void grid_query_kernel(
+    const float* __restrict__ q_pts, const int64_t* __restrict__ lengths1, const float* __restrict__ radius,
+    int64_t P1, int K, int64_t T, const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted_pts,
+    const int4* __restrict__ sorted_cell, int64_t* __restrict__ idx_out, float* __restrict__ dist_out,
+    int32_t* __restrict__ count_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float* best_d = (float*)lds_raw;                       // [K][QUERY_TPB]
+  int* best_i = (int*)(lds_raw + (size_t)K * QUERY_TPB * 4);  // [K][QUERY_TPB]
+  const int tid = threadIdx.x;
+  const int64_t b = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + tid;
+  if (i >= P1) return;
+  int64_t* out_i = idx_out + (b * P1 + i) * K;
+  float* out_d = dist_out ? dist_out + (b * P1 + i) * K : nullptr;
+  int have = 0;
+  if (i < lengths1[b]) {
+    const float* q = q_pts + (b * P1 + i) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const float r = radius[b];
+    const float r2 = r * r;
+    const int3 cq = cell_of(qx, qy, qz, inv_cell_of(r));
+    const uint32_t mask = (uint32_t)(T - 1);
+    const int32_t* starts = cell_start + b * T;
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int cx = cq.x + dx, cy = cq.y + dy, cz = cq.z + dz;
+          const uint32_t h = bucket_of(cx, cy, cz, mask);
+          const int32_t lo = starts[h], hi = starts[h + 1];
+          for (int32_t s = lo; s < hi; ++s) {
+            const int4 c = sorted_cell[s];
+            if (c.x != cx || c.y != cy || c.z != cz) continue;
+            const float4 p = sorted_pts[s];
+            const float d2 = ccn_sqdist3(p.x - qx, p.y - qy, p.z - qz);
+            if (!(d2 < r2)) continue;
+            const int j = __float_as_int(p.w);
+            if (have == K) {
+              const float wd = best_d[(K - 1) * QUERY_TPB + tid];
+              if (!(d2 < wd || (d2 == wd && j < best_i[(K - 1) * QUERY_TPB + tid]))) continue;
+            }
+            int slot = have < K ? have : K - 1;
+            while (slot > 0) {
+              const float pd = best_d[(slot - 1) * QUERY_TPB + tid];
+              const int pi = best_i[(slot - 1) * QUERY_TPB + tid];
+              if (!(pd > d2 || (pd == d2 && pi > j))) break;
+              best_d[slot * QUERY_TPB + tid] = pd;
+              best_i[slot * QUERY_TPB + tid] = pi;
+              --slot;
+            }
+            best_d[slot * QUERY_TPB + tid] = d2;
+            best_i[slot * QUERY_TPB + tid] = j;
+            if (have < K) ++have;
+          }
+        }
+  }
+  for (int s = 0; s < K; ++s) {
+    const bool ok = s < have;
+    out_i[s] = ok ? (int64_t)best_i[s * QUERY_TPB + tid] : -1;
+    if (out_d) out_d[s] = ok ? best_d[s * QUERY_TPB + tid] : -1.0f;
+  }
+  if (count_out) count_out[b * P1 + i] = have;
+}
+
+// ------------------------------------------------------------------ dense idx -> CSR edge list
+__global__ void dense_count_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ cloud_ptr1, int64_t P1,
+                                   int64_t K, int32_t* __restrict__ counts) {
+  const int64_t b = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t len = cloud_ptr1[b + 1] - cloud_ptr1[b];
+  if (i >= len || i >= P1) return;
+  const int64_t* row = idx + (b * P1 + i) * K;
+  int c = 0;
+  for (int64_t s = 0; s < K; ++s) c += row[s] != -1;
+  counts[cloud_ptr1[b] + i] = c;
+}
+
+__global__ void dense_fill_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ cloud_ptr1,
+                                  const int64_t* __restrict__ cloud_ptr2, int64_t P1, int64_t K,
+                                  const int32_t* __restrict__ offsets, int64_t* __restrict__ row_out,
+                                  int64_t* __restrict__ col_out) {
+  const int64_t b = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t len = cloud_ptr1[b + 1] - cloud_ptr1[b];
+  if (i >= len || i >= P1) return;
+  const int64_t* row = idx + (b * P1 + i) * K;
+  const int64_t q = cloud_ptr1[b] + i;
+  int32_t at = offsets[q];
+  const int64_t base2 = cloud_ptr2[b];
+  for (int64_t s = 0; s < K; ++s) {
+    const int64_t j = row[s];
+    if (j != -1) {
+      row_out[at] = q;
+      col_out[at] = base2 + j;
+      ++at;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ccn_frnn_grid_bytes(int64_t B, int64_t P2) { return grid_bytes(B < 1 ? 1 : B, P2 < 1 ? 1 : P2); }
+
+int ccn_frnn_grid_build(const float* points2, const int64_t* lengths2, const float* r, int64_t B, int64_t P2,
+                        void* grid, size_t bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(points2 && lengths2 && r && grid, "frnn_grid_build: null pointer");
+  CCN_REQUIRE(B > 0 && P2 > 0 && B < 65536, "frnn_grid_build: bad batch/points (B=%lld, P2=%lld)", (long long)B,
+              (long long)P2);
+  CCN_REQUIRE(B * P2 < 2147483647LL, "frnn_grid_build: B*P2 exceeds int32");
+  CCN_REQUIRE(bytes >= grid_bytes(B, P2), "frnn_grid_build: grid buffer too small");
+  GridView g;
+  CCN_REQUIRE(carve(grid, bytes, B, P2, &g), "frnn_grid_build: carve failed");
+  const int64_t cells = B * g.T;
+  CCN_HIP(hipMemsetAsync(g.cell_fill, 0, (size_t)cells * 4, s), "frnn_grid_build");
+  dim3 gridDim_(ccn_blocks(P2, BUILD_TPB), (unsigned)B);
+  hipLaunchKernelGGL(grid_insert_kernel<false>, gridDim_, dim3(BUILD_TPB), 0, s, points2, lengths2, r, P2, g.T,
+                     (const int32_t*)nullptr, g.cell_fill, (float4*)nullptr, (int4*)nullptr);
+  int rc = ccn_scan_i32(g.cell_fill, g.cell_start, cells, false, g.cell_start + cells, g.scan_scratch, s);
+  if (rc) return rc;
+  CCN_HIP(hipMemsetAsync(g.cell_fill, 0, (size_t)cells * 4, s), "frnn_grid_build");
+  hipLaunchKernelGGL(grid_insert_kernel<true>, gridDim_, dim3(BUILD_TPB), 0, s, points2, lengths2, r, P2, g.T,
+                     g.cell_start, g.cell_fill, g.sorted_pts, g.sorted_cell);
+  CCN_LAUNCH_OK("frnn_grid_build");
+  return CCN_OK;
+}
+
+int ccn_frnn_query(const float* points1, const int64_t* lengths1, const float* r, int64_t B, int64_t P1, int64_t K,
+                   const void* grid, int64_t P2, int64_t* idx, float* dist2, int32_t* count, void* stream) {
+  CCN_REQUIRE(points1 && lengths1 && r && grid && idx, "frnn_query: null pointer");
+  CCN_REQUIRE(B > 0 && P1 > 0 && P2 > 0 && B < 65536, "frnn_query: bad sizes");
+  CCN_REQUIRE(K >= 1 && K <= 128, "frnn_query: K must be in [1, 128] (got %lld)", (long long)K);
+  GridView g;
+  CCN_REQUIRE(carve(const_cast<void*>(grid), grid_bytes(B, P2), B, P2, &g), "frnn_query: carve failed");
+  const size_t lds = (size_t)K * QUERY_TPB * 8;
+  dim3 gridDim_(ccn_blocks(P1, QUERY_TPB), (unsigned)B);
+  hipLaunchKernelGGL(grid_query_kernel, gridDim_, dim3(QUERY_TPB), lds, (hipStream_t)stream, points1, lengths1, r, P1,
+                     (int)K, g.T, g.cell_start, g.sorted_pts, g.sorted_cell, idx, dist2, count);
+  CCN_LAUNCH_OK("frnn_query");
+  return CCN_OK;
+}
+
+int ccn_dense_to_csr_count(const int64_t* idx, const int64_t* cloud_ptr1, int64_t B, int64_t P1, int64_t K,
+                           int32_t* counts, void* stream) {
+  CCN_REQUIRE(idx && cloud_ptr1 && counts && B > 0 && P1 > 0 && K > 0 && B < 65536, "dense_to_csr_count: bad arguments");
+  dim3 gridDim_(ccn_blocks(P1, 256), (unsigned)B);
+  hipLaunchKernelGGL(dense_count_kernel, gridDim_, dim3(256), 0, (hipStream_t)stream, idx, cloud_ptr1, P1, K, counts);
+  CCN_LAUNCH_OK("dense_to_csr_count");
+  return CCN_OK;
+}
+
+int ccn_dense_to_csr_fill(const int64_t* idx, const int64_t* cloud_ptr1, const int64_t* cloud_ptr2, int64_t B,
+                          int64_t P1, int64_t K, const int32_t* offsets, int64_t* row, int64_t* col, void* stream) {
+  CCN_REQUIRE(idx && cloud_ptr1 && cloud_ptr2 && offsets && row && col && B > 0 && P1 > 0 && K > 0 && B < 65536,
+              "dense_to_csr_fill: bad arguments");
+  dim3 gridDim_(ccn_blocks(P1, 256), (unsigned)B);
+  hipLaunchKernelGGL(dense_fill_kernel, gridDim_, dim3(256), 0, (hipStream_t)stream, idx, cloud_ptr1, cloud_ptr2, P1,
+                     K, offsets, row, col);
+  CCN_LAUNCH_OK("dense_to_csr_fill");
+  return CCN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,566 @@
+// fp32 MFMA GEMMs for the per-point / per-edge MLP stack and the
+// BatchNorm / activation kernels around them.
+//
+// One kernel template serves forward (Y = A W^T), data-gradient (dX = dY W) and weight-gradient
+// (dW += dY^T X, split over the row dimension with fp32 atomics): the operands differ only in which
+// index is contiguous in memory.
+//   KC operand: element (row r, k) at p[r*ld + k]   -> LDS tile [rows][BK+4], fragments by ds_read_b128
+//   MC operand: element (row r, k) at p[k*ld + r]   -> LDS tile [BK][rows+4], fragments by ds_read_b32
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).  Lane l = (i = l&31, h = l>>5) supplies A[i][k] and
+// B[k][i] for k = 8q + 4h + s of the current 32-wide K slice (q = 0..3 picks a float4, s its element):
+// the K index is permuted identically for A and B, which leaves the contraction unchanged and lets a
+// lane fetch four MFMA steps with one 16-byte LDS read.
+// Workgroup = 4 waves; WM waves along M (32 rows each), 4/WM along N.
+#include "ccn_common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 32;
+constexpr int KC_LD = BK + 4;  // 144-byte rows: 16-byte aligned, conflict-free ds_read_b128
+constexpr int GEMM_TPB = 256;
+
+enum Layout { KC = 0, MC = 1 };
+enum Epilogue { EPI_STORE = 0, EPI_ATOMIC = 1 };
+
+template <int ROWS, int LAY>
+struct Tile {
+  static constexpr int FLOATS = LAY == KC ? ROWS * KC_LD : BK * (ROWS + 4);
+  static constexpr int VEC4 = ROWS * BK / 4;           // float4 slots in the tile
+  static constexpr int PER_THREAD = VEC4 / GEMM_TPB;   // >= 1 for ROWS >= 32
+};
+
+// global -> registers for one K slice of one operand
+template <int ROWS, int LAY>
+__device__ __forceinline__ void tile_load(const float* __restrict__ p, int64_t ld, int64_t row0, int64_t nrows,
+                                          int64_t k0, int64_t kend, bool vec_ok,
+                                          float4 (&regs)[Tile<ROWS, LAY>::PER_THREAD]) {
+#pragma unroll
+  for (int it = 0; it < Tile<ROWS, LAY>::PER_THREAD; ++it) {
+    const int slot = threadIdx.x + it * GEMM_TPB;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (LAY == KC) {
+      const int r = slot >> 3, kq = slot & 7;
+      const int64_t row = row0 + r, k = k0 + kq * 4;
+      if (row < nrows && k < kend) {
+        const float* src = p + row * ld + k;
+        if (vec_ok && k + 4 <= kend) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (k + 1 < kend) v.y = src[1];
+          if (k + 2 < kend) v.z = src[2];
+          if (k + 3 < kend) v.w = src[3];
+        }
+      }
+    } else {
+      constexpr int Q = ROWS / 4;
+      const int kk = slot / Q, rq = slot - kk * Q;
+      const int64_t k = k0 + kk, row = row0 + rq * 4;
+      if (k < kend && row < nrows) {
+        const float* src = p + k * ld + row;
+        if (vec_ok && row + 4 <= nrows) {
+          v = *reinterpret_cast<const float4*>(src);
+        } else {
+          v.x = src[0];
+          if (row + 1 < nrows) v.y = src[1];
+          if (row + 2 < nrows) v.z = src[2];
+          if (row + 3 < nrows) v.w = src[3];
+        }
+      }
+    }
+    regs[it] = v;
+  }
+}
+
+template <int ROWS, int LAY>
+__device__ __forceinline__ void tile_store(float* __restrict__ lds,
+                                           const float4 (&regs)[Tile<ROWS, LAY>::PER_THREAD]) {
+#pragma unroll
+  for (int it = 0; it < Tile<ROWS, LAY>::PER_THREAD; ++it) {
+    const int slot = threadIdx.x + it * GEMM_TPB;
+    if (LAY == KC) {
+      const int r = slot >> 3, kq = slot & 7;
+      *reinterpret_cast<float4*>(lds + r * KC_LD + kq * 4) = regs[it];
+    } else {
+      constexpr int Q = ROWS / 4;
+      const int kk = slot / Q, rq = slot - kk * Q;
+      *reinterpret_cast<float4*>(lds + kk * (ROWS + 4) + rq * 4) = regs[it];
+    }
+  }
+}
+
+// four MFMA steps' worth of one operand for lane (i, h), K group q
+template <int ROWS, int LAY>
+__device__ __forceinline__ float4 frag_read(const float* __restrict__ lds, int r, int q, int h) {
+  if (LAY == KC) {
+    return *reinterpret_cast<const float4*>(lds + r * KC_LD + 8 * q + 4 * h);
+  } else {
+    const float* base = lds + (8 * q + 4 * h) * (ROWS + 4) + r;
+    return make_float4(base[0], base[ROWS + 4], base[2 * (ROWS + 4)], base[3 * (ROWS + 4)]);
+  }
+}
+
+// C[M x N] (+)= A[M x K] * B[K x N]; K range split over blockIdx.z
+template <int BM, int BN, int WM, int ALAY, int BLAY, int EPI>
+__global__ __launch_bounds__(GEMM_TPB) void gemm_kernel(const float* __restrict__ A, int64_t lda,
+                                                        const float* __restrict__ B, int64_t ldb,
+                                                        const float* __restrict__ bias, float* __restrict__ C,
+                                                        int64_t ldc, int64_t M, int64_t N, int64_t K, int64_t kchunk,
+                                                        int a_vec, int b_vec, double* __restrict__ colstats) {
+  constexpr int WN = 4 / WM;
+  constexpr int WCOLS = BN / WN;  // columns per wave
+  constexpr int NT = WCOLS / 32;  // 32x32 MFMA tiles per wave along N
+  static_assert(BM == 32 * WM && NT >= 1, "tile shape");
+  __shared__ __attribute__((aligned(16))) float As[Tile<BM, ALAY>::FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[Tile<BN, BLAY>::FLOATS];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int i = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  float4 ra[Tile<BM, ALAY>::PER_THREAD], rb[Tile<BN, BLAY>::PER_THREAD];
+  if (kbeg < kend) {
+    tile_load<BM, ALAY>(A, lda, m0, M, kbeg, kend, a_vec != 0, ra);
+    tile_load<BN, BLAY>(B, ldb, n0, N, kbeg, kend, b_vec != 0, rb);
+  }
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    tile_store<BM, ALAY>(As, ra);
+    tile_store<BN, BLAY>(Bs, rb);
+    __syncthreads();
+    if (k0 + BK < kend) {  // next slice in flight while this one is multiplied
+      tile_load<BM, ALAY>(A, lda, m0, M, k0 + BK, kend, a_vec != 0, ra);
+      tile_load<BN, BLAY>(B, ldb, n0, N, k0 + BK, kend, b_vec != 0, rb);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 a4 = frag_read<BM, ALAY>(As, wm * 32 + i, q, h);
+      float4 b4[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b4[t] = frag_read<BN, BLAY>(Bs, wn * WCOLS + t * 32 + i, q, h);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[t].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[t].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[t].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[t].w, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  double* stat_lds = reinterpret_cast<double*>(As);  // [WM][BN][2] doubles, reused after the last barrier
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ncol_local = wn * WCOLS + t * 32 + i;
+    const int64_t n = n0 + ncol_local;
+    const float bv = (EPI == EPI_STORE && bias != nullptr && n < N) ? bias[n] : 0.f;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m < M && n < N) {
+        const float v = acc[t][r] + bv;
+        if (EPI == EPI_STORE) {
+          C[m * ldc + n] = v;
+          if (colstats != nullptr) {
+            s1 += (double)v;
+            s2 += (double)v * (double)v;
+          }
+        } else {
+          atomicAdd(&C[m * ldc + n], v);
+        }
+      }
+    }
+    if (EPI == EPI_STORE && colstats != nullptr) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) {
+        stat_lds[(wm * BN + ncol_local) * 2] = s1;
+        stat_lds[(wm * BN + ncol_local) * 2 + 1] = s2;
+      }
+    }
+  }
+  if (EPI == EPI_STORE && colstats != nullptr) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < BN; c += GEMM_TPB) {
+      const int64_t n = n0 + c;
+      if (n < N) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          s1 += stat_lds[(w * BN + c) * 2];
+          s2 += stat_lds[(w * BN + c) * 2 + 1];
+        }
+        double* dst = colstats + (int64_t)blockIdx.x * 2 * N;  // one partial row per M tile (deterministic)
+        dst[n] = s1;
+        dst[N + n] = s2;
+      }
+    }
+  }
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <int BM, int BN, int WM, int ALAY, int BLAY, int EPI>
+int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
+                int64_t M, int64_t N, int64_t K, int64_t ksplit, double* colstats, hipStream_t s) {
+  const int64_t gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
+  int64_t kchunk = (K + ksplit - 1) / ksplit;
+  kchunk = (kchunk + BK - 1) / BK * BK;
+  const int64_t gz = (K + kchunk - 1) / kchunk;
+  const int a_vec = aligned16(A) && (lda % 4 == 0);
+  const int b_vec = aligned16(B) && (ldb % 4 == 0);
+  if (gm > 2147483647LL || gn > 65535 || gz > 65535) {
+    ccn_set_error("gemm: grid too large");
+    return CCN_ERR_ARG;
+  }
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, ALAY, BLAY, EPI>), dim3((unsigned)gm, (unsigned)gn, (unsigned)gz),
+                     dim3(GEMM_TPB), 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, kchunk, a_vec, b_vec, colstats);
+  return CCN_OK;
+}
+
+// ------------------------------------------------------------------ column reductions (BatchNorm)
+constexpr int RED_ROWS = 128;  // rows per workgroup == GEMM BM, so both produce ceil(rows/128) partial rows
+
+__device__ __forceinline__ float act_fwd(float z, int act, float slope) {
+  if (act == CCN_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (act == CCN_ACT_LEAKY) return z > 0.f ? z : z * slope;
+  return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act, float slope) {
+  if (act == CCN_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == CCN_ACT_LEAKY) return z > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+// MODE 0: (sum x, 0)   MODE 1: (sum g, sum g*xhat) with g = dZ * act'(y*scale+shift)
+template <int MODE>
+__global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ X, int64_t ldx,
+                                                          const float* __restrict__ Y, int64_t ldy, int64_t rows,
+                                                          int64_t C, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, int act, float slope,
+                                                          double* __restrict__ partial) {
+  __shared__ double red[4][64][2];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS;
+  const int64_t r1 = r0 + RED_ROWS < rows ? r0 + RED_ROWS : rows;
+  for (int64_t c0 = 0; c0 < C; c0 += 64) {
+    const int64_t c = c0 + cx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+      float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
+      if (MODE == 1) {
+        sc = scale[c];
+        sh = shift[c];
+        mu = mean[c];
+        rs = rstd[c];
+      }
+      for (int64_t r = r0 + ry; r < r1; r += 4) {
+        const float xv = X[r * ldx + c];
+        if (MODE == 0) {
+          s1 += (double)xv;
+        } else {
+          const float y = Y[r * ldy + c];
+          const float g = xv * act_grad(y * sc + sh, act, slope);
+          s1 += (double)g;
+          s2 += (double)(g * ((y - mu) * rs));
+        }
+      }
+    }
+    red[ry][cx][0] = s1;
+    red[ry][cx][1] = s2;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a += red[w][cx][0];
+        b += red[w][cx][1];
+      }
+      partial[(int64_t)blockIdx.x * 2 * C + c] = a;
+      partial[(int64_t)blockIdx.x * 2 * C + C + c] = b;
+    }
+    __syncthreads();
+  }
+}
+
+// sums[w] = sum_p partial[p][w], w < width; one workgroup per 64 columns
+__global__ __launch_bounds__(256) void col_final_kernel(const double* __restrict__ partial, int64_t nparts,
+                                                        int64_t width, double* __restrict__ sums) {
+  __shared__ double red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t w = (int64_t)blockIdx.x * 64 + cx;
+  double s = 0.0;
+  if (w < width)
+    for (int64_t p = ry; p < nparts; p += 4) s += partial[p * width + w];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && w < width) sums[w] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t rows, int64_t C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+                                   float* __restrict__ save_rstd) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double n = (double)rows;
+  const double mean = sums[c] / n;
+  double var = sums[C + c] / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  const float sc = g * rstd;
+  scale[c] = sc;
+  shift[c] = b - (float)mean * sc;
+  save_mean[c] = (float)mean;
+  save_rstd[c] = rstd;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) {
+    const double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      float eps, int64_t C, float* __restrict__ scale, float* __restrict__ shift,
+                                      float* __restrict__ save_mean, float* __restrict__ save_rstd) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float rstd = 1.0f / sqrtf(running_var[c] + eps);
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * rstd;
+  shift[c] = b - running_mean[c] * g * rstd;
+  save_mean[c] = running_mean[c];
+  save_rstd[c] = rstd;
+}
+
+__global__ void bn_act_fwd_kernel(const float* __restrict__ Y, int64_t ldy, int64_t rows, int64_t C,
+                                  const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                  float slope, float* __restrict__ Z, int64_t ldz) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * C) return;
+  const int64_t r = t / C, c = t - r * C;
+  Z[r * ldz + c] = act_fwd(Y[r * ldy + c] * scale[c] + shift[c], act, slope);
+}
+
+__global__ void bn_act_fwd_vec_kernel(const float4* __restrict__ Y, int64_t ldy4, int64_t rows, int64_t C4,
+                                      const float4* __restrict__ scale, const float4* __restrict__ shift, int act,
+                                      float slope, float4* __restrict__ Z, int64_t ldz4) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * C4) return;
+  const int64_t r = t / C4, c = t - r * C4;
+  const float4 y = Y[r * ldy4 + c], sc = scale[c], sh = shift[c];
+  float4 z;
+  z.x = act_fwd(y.x * sc.x + sh.x, act, slope);
+  z.y = act_fwd(y.y * sc.y + sh.y, act, slope);
+  z.z = act_fwd(y.z * sc.z + sh.z, act, slope);
+  z.w = act_fwd(y.w * sc.w + sh.w, act, slope);
+  Z[r * ldz4 + c] = z;
+}
+
+__global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ Y,
+                                        int64_t ldy, int64_t rows, int64_t C, const float* __restrict__ scale,
+                                        const float* __restrict__ shift, const float* __restrict__ mean,
+                                        const float* __restrict__ rstd, int act, float slope,
+                                        const double* __restrict__ sums, int training, float* __restrict__ dY,
+                                        int64_t lddy, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * C) return;
+  const int64_t r = t / C, c = t - r * C;
+  const float y = Y[r * ldy + c];
+  const float sc = scale[c];
+  const float g = dZ[r * lddz + c] * act_grad(y * sc + shift[c], act, slope);
+  float out;
+  if (training) {
+    const float inv_n = 1.0f / (float)rows;
+    const float xhat = (y - mean[c]) * rstd[c];
+    out = sc * (g - (float)sums[c] * inv_n - xhat * ((float)sums[C + c] * inv_n));
+  } else {
+    out = sc * g;
+  }
+  dY[r * lddy + c] = out;
+  if (r == 0) {
+    if (dgamma) dgamma[c] = (float)sums[C + c];
+    if (dbeta) dbeta[c] = (float)sums[c];
+  }
+}
+
+__global__ void colsum_out_kernel(const double* __restrict__ sums, int64_t C, float* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) out[c] = (float)sums[c];
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t ccn_stats_rows(int64_t rows) { return (rows + RED_ROWS - 1) / RED_ROWS; }
+
+int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                int64_t M, int64_t N, int64_t K, double* colstats, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(A && W && Y, "gemm_nt: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, "gemm_nt: bad sizes M=%lld N=%lld K=%lld",
+              (long long)M, (long long)N, (long long)K);
+  if (M == 0) return CCN_OK;
+  int rc;
+  if (N <= 32)
+    rc = launch_gemm<128, 32, 4, KC, KC, EPI_STORE>(A, lda, W, ldw, bias, Y, ldy, M, N, K, 1, colstats, s);
+  else if (N <= 64)
+    rc = launch_gemm<128, 64, 4, KC, KC, EPI_STORE>(A, lda, W, ldw, bias, Y, ldy, M, N, K, 1, colstats, s);
+  else
+    rc = launch_gemm<128, 128, 4, KC, KC, EPI_STORE>(A, lda, W, ldw, bias, Y, ldy, M, N, K, 1, colstats, s);
+  if (rc) return rc;
+  CCN_LAUNCH_OK("gemm_nt");
+  return CCN_OK;
+}
+
+int ccn_gemm_nn(const float* dY, int64_t lddy, const float* W, int64_t ldw, float* dX, int64_t lddx, int64_t M,
+                int64_t N, int64_t K, void* stream) {
+  // dX[M x K] = dY[M x N] * W[N x K]: contraction over N (the layer's output channels)
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(dY && W && dX, "gemm_nn: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldw >= K && lddx >= K, "gemm_nn: bad sizes");
+  if (M == 0) return CCN_OK;
+  int rc;
+  if (K <= 32)
+    rc = launch_gemm<128, 32, 4, KC, MC, EPI_STORE>(dY, lddy, W, ldw, nullptr, dX, lddx, M, K, N, 1, nullptr, s);
+  else if (K <= 64)
+    rc = launch_gemm<128, 64, 4, KC, MC, EPI_STORE>(dY, lddy, W, ldw, nullptr, dX, lddx, M, K, N, 1, nullptr, s);
+  else
+    rc = launch_gemm<128, 128, 4, KC, MC, EPI_STORE>(dY, lddy, W, ldw, nullptr, dX, lddx, M, K, N, 1, nullptr, s);
+  if (rc) return rc;
+  CCN_LAUNCH_OK("gemm_nn");
+  return CCN_OK;
+}
+
+int ccn_gemm_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                int64_t N, int64_t K, void* stream) {
+  // dW[N x K] += dY[M x N]^T * X[M x K]: contraction over the M rows, split across workgroups
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(dY && X && dW, "gemm_tn: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "gemm_tn: bad sizes");
+  if (M == 0) return CCN_OK;
+  const int64_t tiles = ((N + 63) / 64) * ((K + 127) / 128);
+  int64_t ksplit = (2048 + tiles - 1) / tiles;  // aim at ~2048 workgroups
+  const int64_t max_split = (M + 4 * BK - 1) / (4 * BK);
+  if (ksplit > max_split) ksplit = max_split;
+  if (ksplit < 1) ksplit = 1;
+  int rc;
+  if (N <= 32) {
+    rc = launch_gemm<32, 128, 1, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s);
+  } else {
+    if (K <= 64)
+      rc = launch_gemm<64, 64, 2, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s);
+    else
+      rc = launch_gemm<64, 128, 2, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s);
+  }
+  if (rc) return rc;
+  CCN_LAUNCH_OK("gemm_tn");
+  return CCN_OK;
+}
+
+int ccn_bn_finalize(const double* colstats, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                    float* save_mean, float* save_rstd, void* stream) {
+  // colstats: [ccn_stats_rows(rows)][2*C] partial rows followed by 2*C doubles of scratch for the totals
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(colstats && scale && shift && save_mean && save_rstd && rows > 0 && C > 0, "bn_finalize: bad arguments");
+  const int64_t nparts = ccn_stats_rows(rows);
+  double* sums = const_cast<double*>(colstats) + nparts * 2 * C;
+  hipLaunchKernelGGL(col_final_kernel, dim3(ccn_blocks(2 * C, 64)), dim3(256), 0, s, colstats, nparts, 2 * C, sums);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ccn_blocks(C, 128)), dim3(128), 0, s, sums, rows, C, gamma, beta, eps,
+                     momentum, running_mean, running_var, scale, shift, save_mean, save_rstd);
+  CCN_LAUNCH_OK("bn_finalize");
+  return CCN_OK;
+}
+
+int ccn_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, int64_t C, float* scale, float* shift, float* save_mean, float* save_rstd,
+                       void* stream) {
+  CCN_REQUIRE(running_mean && running_var && scale && shift && save_mean && save_rstd && C > 0,
+              "bn_eval_params: bad arguments");
+  hipLaunchKernelGGL(bn_eval_params_kernel, dim3(ccn_blocks(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma, beta,
+                     running_mean, running_var, eps, C, scale, shift, save_mean, save_rstd);
+  CCN_LAUNCH_OK("bn_eval_params");
+  return CCN_OK;
+}
+
+int ccn_bn_act_fwd(const float* Y, int64_t ldy, int64_t rows, int64_t C, const float* scale, const float* shift,
+                   int act, float slope, float* Z, int64_t ldz, void* stream) {
+  CCN_REQUIRE(Y && Z && scale && shift && ldy >= C && ldz >= C, "bn_act_fwd: bad arguments");
+  if (rows * C == 0) return CCN_OK;
+  const bool vec = (C % 4 == 0) && (ldy % 4 == 0) && (ldz % 4 == 0) && aligned16(Y) && aligned16(Z) &&
+                   aligned16(scale) && aligned16(shift);
+  if (vec)
+    hipLaunchKernelGGL(bn_act_fwd_vec_kernel, dim3(ccn_blocks(rows * C / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)Y, ldy / 4, rows, C / 4, (const float4*)scale, (const float4*)shift, act, slope,
+                       (float4*)Z, ldz / 4);
+  else
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ccn_blocks(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, Y, ldy,
+                       rows, C, scale, shift, act, slope, Z, ldz);
+  CCN_LAUNCH_OK("bn_act_fwd");
+  return CCN_OK;
+}
+
+int ccn_bn_act_bwd_reduce(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C,
+                          const float* scale, const float* shift, const float* mean, const float* rstd, int act,
+                          float slope, double* sums, void* stream) {
+  // sums: 2*C totals followed by [ccn_stats_rows(rows)][2*C] doubles of scratch
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(dZ && Y && scale && shift && mean && rstd && sums && rows > 0 && C > 0, "bn_act_bwd_reduce: bad arguments");
+  const int64_t nparts = ccn_stats_rows(rows);
+  double* partial = sums + 2 * C;
+  hipLaunchKernelGGL(col_partial_kernel<1>, dim3((unsigned)nparts), dim3(256), 0, s, dZ, lddz, Y, ldy, rows, C, scale,
+                     shift, mean, rstd, act, slope, partial);
+  hipLaunchKernelGGL(col_final_kernel, dim3(ccn_blocks(2 * C, 64)), dim3(256), 0, s, partial, nparts, 2 * C, sums);
+  CCN_LAUNCH_OK("bn_act_bwd_reduce");
+  return CCN_OK;
+}
+
+int ccn_bn_act_bwd_apply(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C,
+                         const float* scale, const float* shift, const float* mean, const float* rstd, int act,
+                         float slope, const double* sums, int training, float* dY, int64_t lddy, float* dgamma,
+                         float* dbeta, void* stream) {
+  CCN_REQUIRE(dZ && Y && scale && shift && mean && rstd && sums && dY && rows > 0 && C > 0,
+              "bn_act_bwd_apply: bad arguments");
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ccn_blocks(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, dZ,
+                     lddz, Y, ldy, rows, C, scale, shift, mean, rstd, act, slope, sums, training, dY, lddy, dgamma,
+                     dbeta);
+  CCN_LAUNCH_OK("bn_act_bwd_apply");
+  return CCN_OK;
+}
+
+int ccn_colsum(const float* X, int64_t ldx, int64_t rows, int64_t C, double* acc, float* out, void* stream) {
+  // acc: 2*C totals followed by [ccn_stats_rows(rows)][2*C] doubles of scratch
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(X && acc && out && rows > 0 && C > 0 && ldx >= C, "colsum: bad arguments");
+  const int64_t nparts = ccn_stats_rows(rows);
+  double* partial = acc + 2 * C;
+  hipLaunchKernelGGL(col_partial_kernel<0>, dim3((unsigned)nparts), dim3(256), 0, s, X, ldx, (const float*)nullptr,
+                     (int64_t)0, rows, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, 0, 0.f, partial);
+  hipLaunchKernelGGL(col_final_kernel, dim3(ccn_blocks(2 * C, 64)), dim3(256), 0, s, partial, nparts, 2 * C, acc);
+  hipLaunchKernelGGL(colsum_out_kernel, dim3(ccn_blocks(C, 128)), dim3(128), 0, s, acc, C, out);
+  CCN_LAUNCH_OK("colsum");
+  return CCN_OK;
+}
+
+}  // extern "C"

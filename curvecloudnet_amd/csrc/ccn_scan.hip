@@ -1,0 +1,147 @@
+// Device-wide prefix sums (reduce-then-scan, three launches) + error plumbing.
+// Used for: run/segment ranking (A1/A2), CSR edge offsets (A8), stream compaction (A7),
+// the float64 arclength running sum (A7) and the hash-grid cell offsets (A11).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "ccn_common.h"
+
+static thread_local char g_err[512] = "";
+
+void ccn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* ccn_last_error(void) { return g_err; }
+extern "C" int ccn_abi_version(void) { return CCN_ABI_VERSION; }
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_ITEMS;  // elements per workgroup
+
+template <typename T>
+__device__ __forceinline__ T wave_inclusive(T v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    T t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// inclusive scan of one value per thread across the 256-thread workgroup; returns the
+// inclusive value, *block_total = sum of all.
+template <typename T>
+__device__ __forceinline__ T block_inclusive(T v, T* lds /*4*/, T* block_total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T inc = wave_inclusive(v, lane);
+  if (lane == 63) lds[wave] = inc;
+  __syncthreads();
+  T add = 0;
+  T tot = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+    T x = lds[w];
+    if (w < wave) add += x;
+    tot += x;
+  }
+  __syncthreads();
+  *block_total = tot;
+  return inc + add;
+}
+
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_chunk_sums(const T* __restrict__ in, T* __restrict__ partial,
+                                                                int64_t n) {
+  __shared__ T lds[4];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+  T s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j)
+    if (base + j < n) s += in[base + j];
+  T tot;
+  block_inclusive(s, lds, &tot);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// single workgroup: exclusive scan of the chunk sums in place; partial[nb] = grand total
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_partials(T* __restrict__ partial, int64_t nb) {
+  __shared__ T lds[4];
+  __shared__ T carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nb; base += SCAN_THREADS) {
+    const int64_t i = base + threadIdx.x;
+    T v = i < nb ? partial[i] : (T)0;
+    T tot;
+    T inc = block_inclusive(v, lds, &tot);
+    T carry = carry_s;
+    if (i < nb) partial[i] = carry + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[nb] = carry_s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_apply(const T* in, T* out,
+                                                           const T* __restrict__ partial, int64_t n, int inclusive,
+                                                           T* __restrict__ total_out, int64_t nb) {
+  __shared__ T lds[4];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+  T v[SCAN_ITEMS];
+  T s = 0;
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    v[j] = base + j < n ? in[base + j] : (T)0;
+    s += v[j];
+  }
+  T tot;
+  T inc = block_inclusive(s, lds, &tot);
+  T run = partial[blockIdx.x] + inc - s;  // exclusive prefix of this thread's first item
+#pragma unroll
+  for (int j = 0; j < SCAN_ITEMS; ++j) {
+    if (base + j < n) out[base + j] = inclusive ? run + v[j] : run;
+    run += v[j];
+  }
+  if (total_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *total_out = partial[nb];
+}
+
+template <typename T>
+int scan_impl(const T* in, T* out, int64_t n, bool inclusive, T* total_out, void* scratch, hipStream_t s) {
+  if (n <= 0) {
+    if (total_out) CCN_HIP(hipMemsetAsync(total_out, 0, sizeof(T), s), "scan");
+    return CCN_OK;
+  }
+  const int64_t nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  T* partial = (T*)scratch;
+  hipLaunchKernelGGL(scan_chunk_sums<T>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, partial, n);
+  hipLaunchKernelGGL(scan_partials<T>, dim3(1), dim3(SCAN_THREADS), 0, s, partial, nb);
+  hipLaunchKernelGGL(scan_apply<T>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, out, partial, n,
+                     inclusive ? 1 : 0, total_out, nb);
+  CCN_LAUNCH_OK("scan");
+  return CCN_OK;
+}
+
+}  // namespace
+
+size_t ccn_scan_scratch_bytes(int64_t n) {
+  const int64_t nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+  return ccn_align256((size_t)(nb + 2) * sizeof(double));
+}
+
+int ccn_scan_i32(const int32_t* in, int32_t* out, int64_t n, bool inclusive, int32_t* total_out, void* scratch,
+                 hipStream_t s) {
+  return scan_impl<int32_t>(in, out, n, inclusive, total_out, scratch, s);
+}
+
+int ccn_scan_f64(const double* in, double* out, int64_t n, bool inclusive, void* scratch, hipStream_t s) {
+  return scan_impl<double>(in, out, n, inclusive, (double*)nullptr, scratch, s);
+}

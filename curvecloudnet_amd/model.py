@@ -1,0 +1,169 @@
+"""``ModelBase``: assembles the step modules from the reference's config dict (same ``model:``
+section of the YAMLs, same state-dict keys) and runs its skip-connection state machine
+(ref src/models/base.py:16-215).
+"""
+import copy
+
+import torch
+import torch.nn.functional as F
+import yaml
+
+from .nn import MLP
+from .steps import (CurveFPModule, CurveSAModule, ForwardContext, FPModule, SAModule, SGCNNLayer, SharedMLP,
+                    SkipConnect, SymmetricCurve1DConvFastV1, SymmetricCurve1DConvV2)
+
+_DOWNSAMPLING_STEPS = ("sa", "sa-geo", "sa-global", "pt-transition-down")
+
+
+class ModelBase(torch.nn.Module):
+    def __init__(self, in_dim, n_out, steps=("conv1d", "dgcnn", "conv1d", "sa", "sa", "sa-global"),
+                 feat_dims=((32, 32, 64), (64, 128), (128, 128), (128, 128, 256), (256, 512, 1024), (1024,)),
+                 out_mlp=dict(), **kwargs):
+        super().__init__()
+        self.in_dim, self.n_out = in_dim, n_out
+        self.use_bias = kwargs.get("use_bias", False)
+        self.version = kwargs.get("version", 2.0)
+        self.mlp_func = MLP
+        self.step_names = list(steps)
+        self.skip_connect_state_store = list(kwargs.get("skip_connect_state_store", []))
+
+        self.steps = torch.nn.ModuleList()
+        for i, step_name in enumerate(steps):
+            step_kwargs = kwargs.copy()
+            if isinstance(step_name, dict):
+                step_kwargs = {**step_kwargs, **step_name}
+                step_name = step_kwargs.pop("step_name")
+                self.step_names[i] = step_name
+            step_kwargs["with_xyz"] = step_kwargs.get("with_xyz", False)
+            dims = self._get_input_dim(i, step_name, feat_dims, in_dim, step_kwargs["with_xyz"])
+            self.steps.append(self.add_step(i, step_name, dims, **step_kwargs))
+
+        final_mlp_kwargs = {"dropout": 0.5, "norm": "batch_norm", "plain_last": True}
+        spec = copy.deepcopy(out_mlp)
+        if isinstance(spec, dict):
+            hidden = spec.pop("dims", None) or []
+            final_mlp_kwargs.update(spec)
+        else:
+            hidden = spec
+        dims = [feat_dims[-1][-1]] + list(hidden) + [n_out]
+        if final_mlp_kwargs.pop("with_seg_category", False):
+            dims[0] += 64
+            self.lin_categorical = self.mlp_func([16, 64, 64])
+        if final_mlp_kwargs.pop("identity", False):
+            self.mlp = torch.nn.Identity()
+        else:
+            self.mlp = self.mlp_func(dims, bias=self.use_bias, **final_mlp_kwargs)
+
+    # ---- ref base.py:66-84
+    def _get_input_dim(self, step_idx, step_name, feat_dims, in_dim, with_xyz):
+        prev = in_dim if step_idx == 0 else feat_dims[step_idx - 1][-1]
+        if step_name in ("dgcnn", "sgcnn"):
+            head = [in_dim * 2] if step_idx == 0 else [2 * (prev + 3 * with_xyz)]
+        elif step_name in ("sa", "sa-global", "sa-geo"):
+            head = [in_dim + 3 * with_xyz] if step_idx == 0 else [prev + 3 + 3 * with_xyz]
+        elif step_idx == 0:
+            head = [in_dim]
+        elif step_name in ("skip-connect", "fp", "fp-geo"):
+            head = []
+        elif step_name in ("mlp", "conv1d-fast-v1", "conv1d-fast-v2"):
+            head = [prev + 3 * with_xyz]
+        else:
+            raise NotImplementedError("No Module Named >> %s" % step_name)
+        return head + list(feat_dims[step_idx])
+
+    def _attend_nn(self, dims, kwargs, halve_v2):
+        if kwargs.get("aggr_type") not in ("attend", "weighted-sum"):
+            return None
+        c = dims[-1]
+        mid = c // 2 if (halve_v2 and self.version == 2.0) else c
+        return self.mlp_func([c, mid, c], act="leaky_relu", bias=self.use_bias)
+
+    # ---- ref base.py:86-131
+    def add_step(self, step_idx, step_name, dims, **kwargs):
+        b = self.use_bias
+        if step_name == "sa":
+            return SAModule(kwargs["ratios"][step_idx], kwargs["radii"][step_idx], self.mlp_func(dims, bias=b),
+                            attend_nn=self._attend_nn(dims, kwargs, True), k=kwargs["knn"][step_idx], **kwargs)
+        if step_name == "sgcnn":
+            return SGCNNLayer(self.mlp_func(dims, bias=b), kwargs["knn"][step_idx], r=kwargs["radii"][step_idx],
+                              attend_nn=self._attend_nn(dims, kwargs, False), **kwargs)
+        if step_name == "sa-geo":
+            return CurveSAModule(kwargs["ratios"][step_idx], kwargs["radii"][step_idx],
+                                 self.mlp_func(dims, act="leaky_relu", bias=b),
+                                 attend_nn=self._attend_nn(dims, kwargs, False), **kwargs)
+        if step_name == "conv1d-fast-v1":
+            return SymmetricCurve1DConvFastV1(dims, kwargs["kernel_sizes"][step_idx], with_xyz=kwargs["with_xyz"],
+                                              with_diff=kwargs.get("with_diff", False))
+        if step_name == "conv1d-fast-v2":
+            return SymmetricCurve1DConvV2(dims, kwargs["kernel_sizes"][step_idx], with_xyz=kwargs["with_xyz"],
+                                          with_diff=kwargs.get("with_diff", False))
+        if step_name == "skip-connect":
+            return SkipConnect(self.mlp_func(dims, act="leaky_relu", bias=b), kwargs["num_skips"][step_idx])
+        if step_name == "fp":
+            return FPModule(kwargs["knn"][step_idx], self.mlp_func(dims, bias=b), with_xyz=kwargs["with_xyz"])
+        if step_name == "fp-geo":
+            return CurveFPModule(kwargs["knn"][step_idx], self.mlp_func(dims, act="leaky_relu", bias=b),
+                                 with_xyz=kwargs["with_xyz"])
+        if step_name == "mlp":
+            return SharedMLP(dims, **kwargs)
+        if step_name in ("sa-global", "dgcnn", "dgcnn-rad"):
+            raise NotImplementedError("step %r is outside the hot path built so far (SURVEY.md section 8f)" % step_name)
+        raise NotImplementedError("Have not implemented step %s yet!" % step_name)
+
+    # ---- ref base.py:133-209
+    def forward(self, data, **kwargs):
+        x, pos, batch, p2c = data.x, data.pos, data.batch, data.curve_idxs
+        if hasattr(data, "labels"):
+            kwargs["shapenet-categories"] = data.labels
+        num_clouds = getattr(data, "num_clouds", None) or getattr(data, "num_graphs", None)
+        kwargs["_ccn_ctx"] = ForwardContext(num_clouds)
+        hist = {"x": [x], "pos": [pos], "batch": [batch], "p2c": [p2c], "idx": []}
+        proportional, downsampled = [], []
+        cloud_of_point = batch
+        for i, (name, step) in enumerate(zip(self.step_names, self.steps)):
+            if name in ("fp", "fp-geo"):
+                j = downsampled.pop()
+                x_skip = hist["x"][j] if hist["x"][j] is not None else hist["pos"][j]
+                if name == "fp":
+                    out = step(x, pos, batch, x_skip, hist["pos"][j], hist["batch"][j], p2c, hist["p2c"][j], **kwargs)
+                else:
+                    out = step(x, hist["idx"][j], x_skip, hist["pos"][j], hist["batch"][j], hist["p2c"][j], **kwargs)
+            elif name == "skip-connect":
+                take = proportional[-step.num_skips:]
+                del proportional[-step.num_skips:]
+                xs = [x] + [hist["x"][j] if hist["x"][j] is not None else hist["pos"][j] for j in take]
+                out = step(xs, pos, batch, p2c, **kwargs)
+            else:
+                out = step(x, pos, batch, p2c, **kwargs)
+            x, pos, batch, p2c = out[:4]
+            hist["x"].append(x)
+            hist["pos"].append(pos)
+            hist["batch"].append(batch)
+            hist["p2c"].append(p2c)
+            hist["idx"].append(out[5] if len(out) > 5 else None)
+            if name in self.skip_connect_state_store:
+                proportional.append(i)
+            if name in _DOWNSAMPLING_STEPS:
+                downsampled.append(i)
+        if "shapenet-categories" in kwargs and hasattr(self, "lin_categorical"):
+            cats = F.one_hot(kwargs["shapenet-categories"], num_classes=16).float()
+            x = torch.cat([x, self.lin_categorical(cats)[cloud_of_point]], dim=1)
+        return self.mlp(x)
+
+
+def load_model_config(path):
+    """The ``model:`` section of a reference YAML (ref src/utils/load_utils.py:17-27)."""
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    return cfg["model"] if "model" in cfg else cfg
+
+
+def build_model(model_cfg, in_dim, n_out):
+    """ref src/utils/load_utils.py:17-27 ``load_model``: ModelBase(in_dim, out_dim, **config['model'])."""
+    cfg = {k: v for k, v in copy.deepcopy(model_cfg).items() if k != "type"}
+    return ModelBase(in_dim, n_out, **cfg)
+
+
+def segmentation_loss(logits, target):
+    """Harness counterpart of ref src/run/kitti_seg.py:184-192 (mean NLL over points)."""
+    return F.nll_loss(F.log_softmax(logits, dim=-1), target)

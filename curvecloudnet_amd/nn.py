@@ -1,0 +1,59 @@
+"""MLP block with the state-dict layout of ``torch_geometric.nn.MLP`` (PyG 2.3.0), which the
+reference instantiates everywhere (src/models/base.py:7,32,64,90-125; src/models/modules/mlp.py:13).
+
+Keys: ``lins.{j}.weight (out,in)``, ``lins.{j}.bias``, ``norms.{j}.module.{weight,bias,running_mean,
+running_var,num_batches_tracked}`` -- reference checkpoints load with ``strict=True``.
+``torch.nn.Linear`` / ``torch.nn.BatchNorm1d`` are used as parameter containers only (same
+initialisation as PyG); their ``forward`` is never called: every layer runs as
+``ops.linear_bn_act`` (MFMA GEMM with BatchNorm statistics in the epilogue + fused scale/shift/act).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class BatchNorm(nn.Module):
+    """PyG's BatchNorm wrapper: the real ``BatchNorm1d`` sits in ``.module``."""
+
+    def __init__(self, channels, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.module = nn.BatchNorm1d(channels, eps=eps, momentum=momentum)
+
+
+class MLP(nn.Module):
+    def __init__(self, channel_list, dropout=0.0, act="relu", norm="batch_norm", plain_last=True, bias=True, **kwargs):
+        super().__init__()
+        if norm != "batch_norm":
+            raise NotImplementedError("only batch_norm is used by the reference configs")
+        if act not in ("relu", "leaky_relu"):
+            raise NotImplementedError("activation %r" % (act,))
+        self.channel_list = list(channel_list)
+        self.act, self.plain_last, self.dropout = act, plain_last, float(dropout)
+        self.lins = nn.ModuleList(nn.Linear(a, b, bias=bias) for a, b in zip(channel_list[:-1], channel_list[1:]))
+        normed = channel_list[1:-1] if plain_last else channel_list[1:]
+        self.norms = nn.ModuleList(BatchNorm(c) for c in normed)
+
+    @property
+    def in_channels(self):
+        return self.channel_list[0]
+
+    @property
+    def out_channels(self):
+        return self.channel_list[-1]
+
+    def forward(self, x):
+        for lin, norm in zip(self.lins, self.norms):
+            x = ops.linear_bn_act(x, lin.weight, lin.bias, norm.module, self.training, self.act)
+            if self.dropout > 0.0:
+                x = F.dropout(x, p=self.dropout, training=self.training)
+        if self.plain_last:
+            last = self.lins[-1]
+            x = ops.linear_bn_act(x, last.weight, last.bias, None, self.training, None)
+            if self.dropout > 0.0:
+                x = F.dropout(x, p=self.dropout, training=self.training)
+        return x
+
+    def __repr__(self):
+        return "MLP(%s)" % ", ".join(str(c) for c in self.channel_list)

@@ -1,0 +1,581 @@
+"""Host-side operators: thin wrappers + ``torch.autograd.Function`` classes over the HIP C-ABI.
+
+PyTorch supplies device memory, streams and autograd bookkeeping only; every arithmetic step on
+the hot path is a ``ccn_*`` kernel launch.  Reference call sites are cited per operator.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import call, lib, ptr, require_gpu, workspace
+
+ACT = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2}
+LEAKY_SLOPE = 0.01  # torch.nn.LeakyReLU default, the only slope the reference uses
+
+
+def _mat(t):
+    """contiguous float32 2-D tensor"""
+    require_gpu(t)
+    if t.dtype != torch.float32:
+        raise TypeError("expected float32, got %s" % t.dtype)
+    return t.contiguous()
+
+
+def _i64(t):
+    require_gpu(t)
+    return t.to(torch.int64).contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# A1 / A2: segment pointers and curve topology
+# --------------------------------------------------------------------------------------
+
+def batch2ptr(batch, with_ends=False):
+    """ref src/models/utils/point_ops.py:47-54 (same name, arguments and result)."""
+    ids = _i64(batch)
+    n = ids.numel()
+    dev = ids.device
+    starts = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    meta = torch.empty(2, dtype=torch.int64, device=dev)
+    nbytes = lib().ccn_segment_ptr_workspace_bytes(n)
+    ws = workspace(nbytes, dev)
+    call("segment_ptr", ptr(ids), n, ptr(starts), None, ptr(meta), ptr(ws), ws.numel())
+    runs, bad = (int(v) for v in meta.tolist())           # host sync, as torch.where in the reference
+    if bad:
+        raise AssertionError("batch2ptr: ids are not sorted")   # reference: assert at point_ops.py:49
+    if n == 0:
+        return starts[:0] if not with_ends else torch.zeros(2, dtype=torch.int64, device=dev)
+    return starts[: runs + 1] if with_ends else starts[1:runs]
+
+
+class CurveTopology:
+    """Curve / cloud CSR tables of one resolution level (built once, shared by every step at
+    that level).  ``glob`` is exactly ``curveidx_local2global`` (ref point_ops.py:20-44)."""
+
+    def __init__(self, batch, point2curveidx, num_clouds=None):
+        batch, p2c = _i64(batch), _i64(point2curveidx)
+        n, dev = batch.numel(), batch.device
+        if n == 0:
+            raise ValueError("empty point cloud")
+        if num_clouds is None:
+            num_clouds = int(batch[-1].item()) + 1
+        self.n, self.num_clouds, self.batch, self.p2c = n, num_clouds, batch, p2c
+        self.glob = torch.empty(n, dtype=torch.int64, device=dev)
+        self.cid = torch.empty(n, dtype=torch.int32, device=dev)
+        curve_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        self.cloud_ptr = torch.empty(num_clouds + 1, dtype=torch.int64, device=dev)
+        meta = torch.empty(4, dtype=torch.int64, device=dev)
+        ws = workspace(lib().ccn_curve_topology_workspace_bytes(n, num_clouds), dev)
+        call("curve_topology", ptr(batch), ptr(p2c), n, num_clouds, ptr(self.glob), ptr(self.cid), ptr(curve_ptr),
+             ptr(self.cloud_ptr), ptr(meta), ptr(ws), ws.numel())
+        q, bad, longest, _ = (int(v) for v in meta.tolist())
+        if bad:
+            raise AssertionError("batch / curve ids are not sorted (or cloud ids are not 0..B-1)")
+        self.num_curves, self.max_cloud = q, longest
+        self.curve_ptr = curve_ptr[: q + 1]
+        self.lengths = self.cloud_ptr[1:] - self.cloud_ptr[:-1]
+        if num_clouds == 1:
+            self.glob = p2c                                   # quirk Q8: identity for one cloud
+
+
+def curveidx_local2global(point2curveidx, batch):
+    """ref point_ops.py:20-44."""
+    return CurveTopology(batch, point2curveidx).glob
+
+
+# --------------------------------------------------------------------------------------
+# generic row gather / scatter (x[idx], x_padded[valid] = x)
+# --------------------------------------------------------------------------------------
+
+class GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, index, unique):
+        src, index = _mat(src), _i64(index)
+        out = torch.empty((index.numel(), src.size(1)), dtype=src.dtype, device=src.device)
+        call("gather_rows", ptr(src), src.size(1), ptr(index), index.numel(), src.size(1), ptr(out), out.size(1))
+        ctx.save_for_backward(index)
+        ctx.rows, ctx.unique = src.size(0), unique
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        g = _mat(g)
+        dsrc = torch.zeros((ctx.rows, g.size(1)), dtype=g.dtype, device=g.device)
+        call("scatter_rows", ptr(g), g.size(1), ptr(index), index.numel(), g.size(1), ptr(dsrc), g.size(1),
+             0 if ctx.unique else 1)
+        return dsrc, None, None
+
+
+def gather_rows(src, index, unique=True):
+    return GatherRows.apply(src, index, unique)
+
+
+class ScatterRows(torch.autograd.Function):
+    """out = zeros(rows, C); out[index] = src  (index entries unique)."""
+
+    @staticmethod
+    def forward(ctx, src, index, rows):
+        src, index = _mat(src), _i64(index)
+        out = torch.zeros((rows, src.size(1)), dtype=src.dtype, device=src.device)
+        call("scatter_rows", ptr(src), src.size(1), ptr(index), index.numel(), src.size(1), ptr(out), out.size(1), 0)
+        ctx.save_for_backward(index)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        g = _mat(g)
+        d = torch.empty((index.numel(), g.size(1)), dtype=g.dtype, device=g.device)
+        call("gather_rows", ptr(g), g.size(1), ptr(index), index.numel(), g.size(1), ptr(d), g.size(1))
+        return d, None, None
+
+
+# --------------------------------------------------------------------------------------
+# A3: feature differences fused with the concat
+# --------------------------------------------------------------------------------------
+
+class DiffConcat(torch.autograd.Function):
+    """cat([x, compute_feature_diffs(x)], dim=1)  (ref fast_conv1d.py:190-205 with :66 / :133)."""
+
+    @staticmethod
+    def forward(ctx, x, cid):
+        x = _mat(x)
+        n, c = x.shape
+        out = torch.empty((n, 2 * c), dtype=x.dtype, device=x.device)
+        call("diff_concat_fwd", ptr(x), c, ptr(cid), n, c, ptr(out), 2 * c)
+        ctx.save_for_backward(x, cid)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, cid = ctx.saved_tensors
+        g = _mat(g)
+        n, c = x.shape
+        dx = torch.empty_like(x)
+        call("diff_concat_bwd", ptr(x), c, ptr(cid), n, c, ptr(g), 2 * c, ptr(dx), c)
+        return dx, None
+
+
+def compute_feature_diffs(x, topo):
+    return DiffConcat.apply(x, topo.cid)[:, x.size(1):]
+
+
+# --------------------------------------------------------------------------------------
+# A4: shifted-row matrix of the symmetric convolution
+# --------------------------------------------------------------------------------------
+
+class Im2Col(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, seg, taps):
+        x = _mat(x)
+        rows, c = x.shape
+        col = torch.empty((rows, taps * c), dtype=x.dtype, device=x.device)
+        call("im2col_fwd", ptr(x), c, ptr(seg), rows, c, taps, ptr(col))
+        ctx.seg, ctx.taps, ctx.c = seg, taps, c
+        return col
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _mat(g)
+        rows = g.size(0)
+        dx = torch.empty((rows, ctx.c), dtype=g.dtype, device=g.device)
+        call("im2col_bwd", ptr(g), ptr(ctx.seg), rows, ctx.c, ctx.taps, ptr(dx), ctx.c)
+        return dx, None, None
+
+
+# --------------------------------------------------------------------------------------
+# A16: Linear (+ BatchNorm + activation) layer
+# --------------------------------------------------------------------------------------
+
+def _stats_buffer(rows, c, device):
+    parts = lib().ccn_stats_rows(rows)
+    return torch.empty((parts + 1) * 2 * c, dtype=torch.float64, device=device)
+
+
+class LinearBNAct(torch.autograd.Function):
+    """y = act(BN(x W^T + b)) with batch statistics taken in the GEMM epilogue.
+
+    One layer of torch_geometric.nn.MLP as the reference uses it (src/models/base.py:32,64,90-125;
+    mlp.py:13) and, with the shifted-row matrix as input, one conv+BN+LeakyReLU layer of
+    fast_conv1d.py:71-73 / :140-143.  ``gamma is None`` = plain Linear (MLP's last layer)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum):
+        x, weight = _mat(x), _mat(weight)
+        m, k = x.shape
+        n = weight.size(0)
+        if weight.size(1) != k:
+            raise ValueError("linear: input has %d channels, weight expects %d" % (k, weight.size(1)))
+        dev = x.device
+        y = torch.empty((m, n), dtype=torch.float32, device=dev)
+        has_bn = gamma is not None
+        ctx.has_bn, ctx.act, ctx.training, ctx.has_bias = has_bn, ACT[act], bool(training), bias is not None
+        if not has_bn:
+            call("gemm_nt", ptr(x), k, ptr(weight), k, ptr(bias), ptr(y), n, m, n, k, None)
+            ctx.save_for_backward(x, weight)
+            return y
+        par = torch.empty((4, n), dtype=torch.float32, device=dev)      # scale, shift, mean, rstd
+        if training:
+            if m < 2:
+                raise ValueError("Expected more than 1 value per channel when training")
+            stats = _stats_buffer(m, n, dev)
+            call("gemm_nt", ptr(x), k, ptr(weight), k, ptr(bias), ptr(y), n, m, n, k, ptr(stats))
+            call("bn_finalize", ptr(stats), m, n, ptr(gamma), ptr(beta), float(eps), float(momentum),
+                 ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        else:
+            call("gemm_nt", ptr(x), k, ptr(weight), k, ptr(bias), ptr(y), n, m, n, k, None)
+            call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), n,
+                 ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        z = torch.empty_like(y)
+        call("bn_act_fwd", ptr(y), n, m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), n)
+        ctx.save_for_backward(x, weight, y, par)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _mat(g)
+        dev = g.device
+        if ctx.has_bn:
+            x, weight, y, par = ctx.saved_tensors
+            m, n = y.shape
+            sums = _stats_buffer(m, n, dev)
+            call("bn_act_bwd_reduce", ptr(g), n, ptr(y), n, m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]),
+                 ctx.act, LEAKY_SLOPE, ptr(sums))
+            dy = torch.empty_like(y)
+            dgb = torch.empty((2, n), dtype=torch.float32, device=dev)
+            call("bn_act_bwd_apply", ptr(g), n, ptr(y), n, m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]),
+                 ctx.act, LEAKY_SLOPE, ptr(sums), 1 if ctx.training else 0, ptr(dy), n, ptr(dgb[0]), ptr(dgb[1]))
+            dgamma, dbeta = dgb[0], dgb[1]
+        else:
+            x, weight = ctx.saved_tensors
+            dy, dgamma, dbeta = g, None, None
+            m, n = dy.shape
+        k = x.size(1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((m, k), dtype=torch.float32, device=dev)
+            call("gemm_nn", ptr(dy), n, ptr(weight), k, ptr(dx), k, m, n, k)
+        dw = torch.zeros((n, k), dtype=torch.float32, device=dev)
+        call("gemm_tn", ptr(dy), n, ptr(x), k, ptr(dw), k, m, n, k)
+        db = None
+        if ctx.has_bias:
+            acc = _stats_buffer(m, n, dev)
+            db = torch.empty(n, dtype=torch.float32, device=dev)
+            call("colsum", ptr(dy), n, m, n, ptr(acc), ptr(db))
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None
+
+
+def linear_bn_act(x, weight, bias, bn, training, act):
+    """bn: a torch.nn.BatchNorm1d used as parameter/buffer container, or None."""
+    if bn is None:
+        return LinearBNAct.apply(x, weight, bias, None, None, None, None, False, None, 0.0, 0.0)
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    use_batch_stats = training or not bn.track_running_stats
+    return LinearBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats,
+                             act, bn.eps, bn.momentum if bn.momentum is not None else 0.1)
+
+
+# --------------------------------------------------------------------------------------
+# A7: CurveFPS
+# --------------------------------------------------------------------------------------
+
+def curve_fps(pos, topo, spacing, u):
+    """ref src/models/modules/fps_ops.py:16-39; ``u`` = the reference's torch.rand(1) draw."""
+    pos = _mat(pos)
+    n, dev = pos.size(0), pos.device
+    idx = torch.empty(n, dtype=torch.int64, device=dev)
+    count = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = workspace(lib().ccn_curve_fps_workspace_bytes(n), dev)
+    call("curve_fps", ptr(pos), ptr(topo.cid), ptr(topo.curve_ptr), n, float(spacing), float(u), ptr(idx), ptr(count),
+         ptr(ws), ws.numel())
+    return idx[: int(count.item())]
+
+
+# --------------------------------------------------------------------------------------
+# A8: radius grouping along curves -> CSR edge list
+# --------------------------------------------------------------------------------------
+
+class EdgeList:
+    """Edges grouped by destination: ``row`` (destination / query number, non-decreasing),
+    ``col`` (source point), ``offsets`` int32 (num_dst + 1)."""
+
+    def __init__(self, row, col, offsets, num_dst):
+        self.row, self.col, self.offsets, self.num_dst = row, col, offsets, num_dst
+        self.num_edges = row.numel()
+
+
+def radius_1d_group_subset(pos, idx, topo, radius):
+    """ref point_ops.py:143-193 (quirk Q3 included); returns an EdgeList (row, col as the reference)."""
+    pos, idx = _mat(pos), _i64(idx)
+    n, m, q, dev = pos.size(0), idx.numel(), topo.num_curves, pos.device
+    budget = torch.empty(q + 1, dtype=torch.float32, device=dev)
+    offsets = torch.empty(m + 1, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = workspace(lib().ccn_curve_group_subset_workspace_bytes(n, q, m), dev)
+    call("curve_group_subset_count", ptr(pos), ptr(topo.cid), ptr(topo.curve_ptr), ptr(topo.p2c), n, q, ptr(idx), m,
+         float(radius), ptr(budget), ptr(offsets), ptr(total), ptr(ws), ws.numel())
+    e = int(total.item())
+    row = torch.empty(e, dtype=torch.int64, device=dev)
+    col = torch.empty(e, dtype=torch.int64, device=dev)
+    call("curve_group_subset_fill", ptr(topo.cid), ptr(topo.curve_ptr), ptr(topo.p2c), n, q, ptr(idx), m, ptr(budget),
+         ptr(offsets), ptr(row), ptr(col))
+    return EdgeList(row, col, offsets, m)
+
+
+# --------------------------------------------------------------------------------------
+# A9: curve interpolation
+# --------------------------------------------------------------------------------------
+
+def knn_1d_group_superset_dense(pos, idx, topo, k):
+    """ref point_ops.py:196-260 in fixed-width form: (nbr (n,k) int64 -1 padded, weight (n,k))."""
+    pos, idx = _mat(pos), _i64(idx)
+    n, dev = pos.size(0), pos.device
+    nbr = torch.empty((n, k), dtype=torch.int64, device=dev)
+    w = torch.empty((n, k), dtype=torch.float32, device=dev)
+    ws = workspace(lib().ccn_curve_group_superset_workspace_bytes(n), dev)
+    call("curve_group_superset", ptr(pos), ptr(topo.cid), n, ptr(idx), idx.numel(), k, ptr(nbr), ptr(w), ptr(ws),
+         ws.numel())
+    return nbr, w
+
+
+def knn_1d_group_superset(pos, idx, topo, k):
+    """Same (row, col) edge list as the reference function (host-side flatten of the dense form)."""
+    nbr, _ = knn_1d_group_superset_dense(pos, idx, topo, k)
+    keep = nbr >= 0
+    rows = torch.arange(nbr.size(0), device=nbr.device)[:, None].expand_as(nbr)
+    return rows[keep], nbr[keep]
+
+
+class CurveInterp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nbr, w):
+        x = _mat(x)
+        n, k = nbr.shape
+        c = x.size(1)
+        y = torch.empty((n, c), dtype=x.dtype, device=x.device)
+        call("interp_fwd", ptr(x), c, ptr(nbr), ptr(w), n, k, c, ptr(y), c)
+        ctx.save_for_backward(nbr, w)
+        ctx.m = x.size(0)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        nbr, w = ctx.saved_tensors
+        g = _mat(g)
+        n, k = nbr.shape
+        c = g.size(1)
+        dx = torch.zeros((ctx.m, c), dtype=g.dtype, device=g.device)
+        call("interp_bwd", ptr(g), c, ptr(nbr), ptr(w), n, k, c, ptr(dx), c)
+        return dx, None, None
+
+
+def knn_interpolate_1D(x, idx, pos_y, topo_y, k):
+    """ref point_ops.py:344-355."""
+    nbr, w = knn_1d_group_superset_dense(pos_y, idx, topo_y, k)
+    return CurveInterp.apply(x, nbr, w)
+
+
+# --------------------------------------------------------------------------------------
+# A11 / A12: fixed-radius kNN and layouts
+# --------------------------------------------------------------------------------------
+
+def fast_knn(points1, points2, lengths1, lengths2, K, r, return_dists=False):
+    """Drop-in for ref point_ops.py:431-461 (frnn.frnn_grid_points): (B,P1,K) int64, -1 padded."""
+    if points1.shape[0] != points2.shape[0]:
+        raise ValueError("points1 and points2 must have the same batch  dimension")
+    if points1.shape[2] != points2.shape[2]:
+        raise ValueError("dimension mismatch: points1 of dimension %d while points2 of dimension %d"
+                         % (points1.shape[2], points2.shape[2]))
+    if not points1.is_cuda or not points2.is_cuda:
+        raise TypeError("for now only cuda version is supported")
+    if points1.shape[2] != 3:
+        raise ValueError("only 3-D points are supported")
+    p1, p2 = _mat(points1), _mat(points2)
+    b, n1, n2, dev = p1.size(0), p1.size(1), p2.size(1), p1.device
+    if isinstance(r, (float, int)):
+        r = torch.full((b,), float(r), dtype=torch.float32)
+    r = r.to(torch.float32)
+    if r.numel() == 1:
+        r = r.expand(b)
+    if r.numel() != b:
+        raise ValueError("r must hold one radius or one per cloud")
+    r = r.contiguous().to(dev)
+    l1, l2 = _i64(lengths1.to(dev)), _i64(lengths2.to(dev))
+    idx = torch.empty((b, n1, K), dtype=torch.int64, device=dev)
+    d2 = torch.empty((b, n1, K), dtype=torch.float32, device=dev) if return_dists else None
+    nbytes = lib().ccn_frnn_grid_bytes(b, n2)
+    grid = workspace(nbytes, dev)
+    call("frnn_grid_build", ptr(p2), ptr(l2), ptr(r), b, n2, ptr(grid), grid.numel())
+    call("frnn_query", ptr(p1), ptr(l1), ptr(r), b, n1, K, ptr(grid), n2, ptr(idx), ptr(d2), None)
+    return (idx, d2) if return_dists else idx
+
+
+def to_batch_padded(t, topo):
+    """ref point_ops.py:358-381 using the level's cloud table: (B, Nmax, ...) zero padded + mask."""
+    b, nmax = topo.num_clouds, topo.max_cloud
+    if b == 1:
+        return t.unsqueeze(0), torch.ones((1, t.size(0)), dtype=torch.bool, device=t.device)
+    local = torch.arange(topo.n, device=t.device) - topo.cloud_ptr[topo.batch]
+    out = torch.zeros((b, nmax) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    out[topo.batch, local] = t
+    mask = torch.zeros((b, nmax), dtype=torch.bool, device=t.device)
+    mask[topo.batch, local] = True
+    return out, mask
+
+
+def frnn_edges(pos_q, topo_q, pos_s, topo_s, k, radius):
+    """ref point_ops.py:73-111 (operation="knn", accel_knn=True): EdgeList of (query, point)."""
+    if radius is None:
+        print("Not setting radius for Fast-KNN!")          # quirk Q7
+        radius = 0.25
+    qp, _ = to_batch_padded(pos_q, topo_q)
+    sp, _ = to_batch_padded(pos_s, topo_s)
+    nbr = fast_knn(qp, sp, topo_q.lengths, topo_s.lengths, k, radius)
+    b, p1, dev = nbr.size(0), nbr.size(1), nbr.device
+    m = topo_q.n
+    counts = torch.empty(m + 1, dtype=torch.int32, device=dev)
+    call("dense_to_csr_count", ptr(nbr), ptr(topo_q.cloud_ptr), b, p1, k, ptr(counts))
+    offsets = torch.empty(m + 1, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = workspace(lib().ccn_exclusive_scan_workspace_bytes(m), dev)
+    call("exclusive_scan_i32", ptr(counts), m, ptr(offsets), ptr(total), ptr(ws), ws.numel())
+    e = int(total.item())
+    row = torch.empty(e, dtype=torch.int64, device=dev)
+    col = torch.empty(e, dtype=torch.int64, device=dev)
+    call("dense_to_csr_fill", ptr(nbr), ptr(topo_q.cloud_ptr), ptr(topo_s.cloud_ptr), b, p1, k, ptr(offsets), ptr(row),
+         ptr(col))
+    return EdgeList(row, col, offsets, m)
+
+
+# --------------------------------------------------------------------------------------
+# A13: PointNetConv2 message + aggregation
+# --------------------------------------------------------------------------------------
+
+class MessageBuild(torch.autograd.Function):
+    """cat([x_j, (pos_j - pos_i) / r])  (ref point_conv.py:60-69)."""
+
+    @staticmethod
+    def forward(ctx, x_src, pos_src, pos_dst, src, dst, radius):
+        c = 0 if x_src is None else x_src.size(1)
+        if x_src is not None:
+            x_src = _mat(x_src)
+        pos_src, pos_dst = _mat(pos_src), _mat(pos_dst)
+        e = src.numel()
+        msg = torch.empty((e, c + 3), dtype=torch.float32, device=pos_src.device)
+        call("msg_build_fwd", ptr(x_src), c, ptr(pos_src), ptr(pos_dst), ptr(src), ptr(dst), e, c,
+             float(radius) if radius is not None else 0.0, ptr(msg))
+        ctx.save_for_backward(src)
+        ctx.c, ctx.n_src = c, (0 if x_src is None else x_src.size(0))
+        return msg
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.c == 0:
+            return None, None, None, None, None, None
+        (src,) = ctx.saved_tensors
+        g = _mat(g)
+        dx = torch.zeros((ctx.n_src, ctx.c), dtype=torch.float32, device=g.device)
+        call("msg_build_bwd", ptr(g), ptr(src), src.numel(), ctx.c, ptr(dx), ctx.c)
+        return dx, None, None, None, None, None
+
+
+class SegSoftmaxAgg(torch.autograd.Function):
+    """scatter_add(msg * softmax_per_destination(att))  (ref point_conv.py:89-93)."""
+
+    @staticmethod
+    def forward(ctx, msg, att, offsets, num_dst):
+        msg, att = _mat(msg), _mat(att)
+        c = msg.size(1)
+        out = torch.empty((num_dst, c), dtype=torch.float32, device=msg.device)
+        call("seg_softmax_agg_fwd", ptr(msg), ptr(att), ptr(offsets), num_dst, c, ptr(out), c)
+        ctx.save_for_backward(msg, att, offsets)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        msg, att, offsets = ctx.saved_tensors
+        g = _mat(g)
+        m, c = g.shape
+        dmsg, datt = torch.empty_like(msg), torch.empty_like(att)
+        call("seg_softmax_agg_bwd", ptr(msg), ptr(att), ptr(offsets), m, c, ptr(g), c, ptr(dmsg), ptr(datt))
+        return dmsg, datt, None, None
+
+
+class SegMax(torch.autograd.Function):
+    """scatter_max over destinations (ref point_conv.py:81-82)."""
+
+    @staticmethod
+    def forward(ctx, msg, offsets, num_dst):
+        msg = _mat(msg)
+        c = msg.size(1)
+        out = torch.empty((num_dst, c), dtype=torch.float32, device=msg.device)
+        arg = torch.empty((num_dst, c), dtype=torch.int32, device=msg.device)
+        call("seg_max_fwd", ptr(msg), ptr(offsets), num_dst, c, ptr(out), c, ptr(arg))
+        ctx.save_for_backward(arg, offsets)
+        ctx.e = msg.size(0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, offsets = ctx.saved_tensors
+        g = _mat(g)
+        m, c = g.shape
+        dmsg = torch.empty((ctx.e, c), dtype=torch.float32, device=g.device)
+        call("seg_max_bwd", ptr(g), c, ptr(arg), ptr(offsets), m, c, ptr(dmsg))
+        return dmsg, None, None
+
+
+# --------------------------------------------------------------------------------------
+# A15: dense SGCNN gather / masked max
+# --------------------------------------------------------------------------------------
+
+class SGGather(torch.autograd.Function):
+    """frnn_gather + [f_j, f_self - f_j] over all B*Nmax*(K+1) rows (ref dgcnn.py:166-174)."""
+
+    @staticmethod
+    def forward(ctx, x, nbr, cloud_ptr):
+        x = _mat(x)
+        b, nmax, k = nbr.shape
+        c = x.size(1)
+        feat = torch.empty((b * nmax * (k + 1), 2 * c), dtype=torch.float32, device=x.device)
+        call("sg_gather_fwd", ptr(x), c, ptr(nbr), ptr(cloud_ptr), b, nmax, k, c, ptr(feat))
+        ctx.save_for_backward(nbr, cloud_ptr)
+        ctx.n, ctx.c = x.size(0), c
+        return feat
+
+    @staticmethod
+    def backward(ctx, g):
+        nbr, cloud_ptr = ctx.saved_tensors
+        g = _mat(g)
+        b, nmax, k = nbr.shape
+        dx = torch.empty((ctx.n, ctx.c), dtype=torch.float32, device=g.device)
+        call("sg_gather_bwd", ptr(g), ptr(nbr), ptr(cloud_ptr), b, nmax, k, ctx.c, ptr(dx), ctx.c)
+        return dx, None, None
+
+
+class SGMax(torch.autograd.Function):
+    """masked max over the K+1 slots, packed output rows (ref dgcnn.py:181,187-189,206)."""
+
+    @staticmethod
+    def forward(ctx, f, nbr, cloud_ptr, n):
+        f = _mat(f)
+        b, nmax, k = nbr.shape
+        c = f.size(1)
+        out = torch.empty((n, c), dtype=torch.float32, device=f.device)
+        arg = torch.empty((n, c), dtype=torch.int32, device=f.device)
+        call("sg_max_fwd", ptr(f), ptr(nbr), ptr(cloud_ptr), b, nmax, k, c, ptr(out), c, ptr(arg))
+        ctx.save_for_backward(arg, cloud_ptr)
+        ctx.shape = (b, nmax, k, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, cloud_ptr = ctx.saved_tensors
+        g = _mat(g)
+        b, nmax, k, c = ctx.shape
+        df = torch.empty((b * nmax * (k + 1), c), dtype=torch.float32, device=g.device)
+        call("sg_max_bwd", ptr(g), c, ptr(arg), ptr(cloud_ptr), b, nmax, k, c, ptr(df))
+        return df, None, None, None

@@ -1,0 +1,108 @@
+"""Data parallelism over the 8 GPUs of one node: one process per GPU, whole clouds sharded across
+ranks, and ONE kind of collective -- a bucketed all-reduce (RCCL over xGMI; backend "nccl" is RCCL
+on ROCm) of the gradients, launched from autograd hooks so it overlaps the rest of backward.
+
+The reference has no distributed code at all; this is the new functionality of
+section 8(e).  BatchNorm statistics stay per rank (a rank's result equals the reference run on
+that rank's sub-batch).  Works with the gloo backend on CPU tensors too (used by the tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_process_group_from_env(backend=None):
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def shard_clouds(cloud_ids, rank, world):
+    """Whole clouds are the unit of work: rank r takes every world-th cloud (independent objects,
+    no data-path collective)."""
+    return list(cloud_ids)[rank::world]
+
+
+class GradientAllReduce:
+    """Flat fp32 gradient buckets (~25 MB: a handful of large messages per step so that every xGMI
+    link carries traffic and launch latency is amortised), all-reduced as soon as every gradient of
+    a bucket has been produced.
+
+    ``param.grad`` tensors are VIEWS into the bucket buffers, so there is no pack/unpack copy; use
+    ``zero_grad()`` of this object (or ``set_to_none=False``) between steps.
+    """
+
+    def __init__(self, module, bucket_bytes=25 * 1024 * 1024, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        params = [p for p in module.parameters() if p.requires_grad]
+        self.buckets = []          # (flat buffer, [params])
+        self._bucket_of = {}
+        cur, cur_bytes = [], 0
+        for p in reversed(params):  # backward produces gradients roughly in reverse registration order
+            cur.append(p)
+            cur_bytes += p.numel() * p.element_size()
+            if cur_bytes >= bucket_bytes:
+                self._close(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            self._close(cur)
+        self._pending = [0] * len(self.buckets)
+        self._handles = []
+        if self.world > 1:
+            for p in params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _close(self, plist):
+        flat = torch.zeros(sum(p.numel() for p in plist), dtype=plist[0].dtype, device=plist[0].device)
+        off = 0
+        for p in plist:
+            p.grad = flat[off: off + p.numel()].view_as(p)
+            off += p.numel()
+            self._bucket_of[p] = len(self.buckets)
+        self.buckets.append((flat, list(plist)))
+
+    def _on_grad(self, p):
+        b = self._bucket_of[p]
+        self._pending[b] += 1
+        if self._pending[b] == len(self.buckets[b][1]):
+            self._handles.append(dist.all_reduce(self.buckets[b][0], op=dist.ReduceOp.SUM, group=self.group,
+                                                 async_op=True))
+
+    def finish(self):
+        """Call after ``loss.backward()``: waits for the collectives and averages over ranks."""
+        if self.world > 1:
+            # buckets whose parameters did not all receive a gradient this step are reduced here
+            for b, (flat, plist) in enumerate(self.buckets):
+                if self._pending[b] != len(plist):
+                    self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for h in self._handles:
+                h.wait()
+            for flat, _ in self.buckets:
+                flat.div_(self.world)
+        self._handles = []
+        self._pending = [0] * len(self.buckets)
+
+    def zero_grad(self):
+        for flat, plist in self.buckets:
+            flat.zero_()
+            off = 0
+            for p in plist:        # re-attach in case an optimizer replaced .grad
+                if p.grad is None or p.grad.data_ptr() != flat[off: off + p.numel()].data_ptr():
+                    p.grad = flat[off: off + p.numel()].view_as(p)
+                off += p.numel()
+
+    @property
+    def num_bytes(self):
+        return sum(f.numel() * f.element_size() for f, _ in self.buckets)

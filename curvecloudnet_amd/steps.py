@@ -1,0 +1,336 @@
+"""Step modules: the reference's ``nn.Module`` operator surface (same class names, constructor
+arguments, call signatures, return tuples and state-dict keys), computing through the HIP kernels.
+
+Reference files mirrored: src/models/modules/{fast_conv1d,pointnet2,point_conv,dgcnn,fps_ops,mlp,
+skip_connect}.py.  A step receives ``(x, pos, batch, point2curveidx, **kwargs)``; ``ModelBase`` adds a
+per-forward ``ForwardContext`` under ``kwargs['_ccn_ctx']`` so that the curve/cloud CSR tables of a
+resolution level are built once and shared by every step at that level.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .nn import MLP
+
+
+class ForwardContext:
+    """Caches ``CurveTopology`` objects for the (batch, curve-id) tensor pairs seen in one forward."""
+
+    def __init__(self, num_clouds=None):
+        self.num_clouds = num_clouds
+        self._topo = {}
+
+    def topology(self, batch, p2c):
+        if p2c is None:
+            p2c = torch.zeros_like(batch)
+        key = (batch.data_ptr(), p2c.data_ptr(), batch.numel())
+        hit = self._topo.get(key)
+        if hit is None:
+            hit = (ops.CurveTopology(batch, p2c, self.num_clouds), batch, p2c)   # tensors kept alive with the entry
+            self._topo[key] = hit
+        return hit[0]
+
+
+def _topology(batch, p2c, kwargs):
+    ctx = kwargs.get("_ccn_ctx")
+    if ctx is None:
+        return ops.CurveTopology(batch, p2c if p2c is not None else torch.zeros_like(batch))
+    return ctx.topology(batch, p2c)
+
+
+def _with_xyz(x, pos, flag):
+    if not flag:
+        return x
+    return pos if x is None else torch.cat([x, pos], dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# curve convolutions (ref fast_conv1d.py)
+# --------------------------------------------------------------------------------------
+
+class SymmetricConv1d(nn.Module):
+    """Parameter holder with the reference's shapes: weight (C_out, C_in, k//2+1), bias (C_out)
+    (ref fast_conv1d.py:148-187; initialised like torch's ``_ConvNd``)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = in_channels * kernel_size
+            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def gemm_weight(self):
+        """(C_out, taps*C_in) matrix matching the shifted-row layout [tap][channel]; the mirrored taps
+        share storage with the stored half, so autograd folds their gradients (ref :176-178)."""
+        w = self.weight
+        if w.size(2) > 1:
+            w = torch.cat([torch.flip(w[:, :, 1:], dims=[2]), w], dim=2)
+        return w.permute(0, 2, 1).reshape(w.size(0), -1)
+
+
+def _conv_stack(feat_dims, kernel_size, bias, with_diff, diff_every_layer):
+    convs, norms = [], []
+    for i in range(1, len(feat_dims)):
+        doubled = with_diff and (diff_every_layer or i == 1)
+        cin = feat_dims[i - 1] * 2 if doubled else feat_dims[i - 1]
+        convs.append(SymmetricConv1d(cin, feat_dims[i], kernel_size // 2 + 1, bias=bias))
+        norms.append(nn.BatchNorm1d(feat_dims[i]))
+    return nn.ModuleList(convs), nn.ModuleList(norms)
+
+
+def _conv_bn_act(x, seg, taps, conv, norm, training):
+    col = ops.Im2Col.apply(x, seg, taps)
+    return ops.linear_bn_act(col, conv.gemm_weight(), conv.bias, norm, training, "leaky_relu")
+
+
+class SymmetricCurve1DConvFastV1(nn.Module):
+    """ref fast_conv1d.py:78-145.  The zero separators of k//2 rows between curves (quirk Q1) are
+    equivalent to a per-curve zero-padded convolution, which is what the shifted-row kernel builds
+    directly on the packed rows; BatchNorm sees the N real rows."""
+
+    def __init__(self, feat_dims=(64, 64, 128), kernel_size=5, bias=True, device=None, dtype=None, with_xyz=False,
+                 with_diff=False):
+        super().__init__()
+        self.kernel_size, self.feat_dims = kernel_size, feat_dims
+        self.with_xyz, self.with_diff = with_xyz, with_diff
+        self.conv_modules, self.norm_modules = _conv_stack(feat_dims, kernel_size, bias, with_diff, True)
+
+    def forward(self, x, pos, batch, point2curveidx, **kwargs):
+        topo = _topology(batch, point2curveidx, kwargs)
+        x = _with_xyz(x, pos, self.with_xyz)
+        for conv, norm in zip(self.conv_modules, self.norm_modules):
+            if self.with_diff:
+                x = ops.DiffConcat.apply(x, topo.cid)
+            x = _conv_bn_act(x, topo.cid, self.kernel_size, conv, norm, self.training)
+        return x, pos, batch, point2curveidx
+
+
+class SymmetricCurve1DConvV2(nn.Module):
+    """ref fast_conv1d.py:11-75.  Quirk Q2 is kept literally: the points are scattered into one
+    sequence with (k//2)*n_layers zero rows between curves and at both ends, and conv + BatchNorm +
+    LeakyReLU run over ALL rows of that sequence (the separators enter the batch statistics)."""
+
+    def __init__(self, feat_dims=(64, 64, 128), kernel_size=5, bias=True, device=None, dtype=None, with_xyz=False,
+                 with_diff=False):
+        super().__init__()
+        self.kernel_size, self.feat_dims = kernel_size, feat_dims
+        self.with_xyz, self.with_diff = with_xyz, with_diff
+        self.conv_modules, self.norm_modules = _conv_stack(feat_dims, kernel_size, bias, with_diff, False)
+
+    def forward(self, x, pos, batch, point2curveidx, **kwargs):
+        topo = _topology(batch, point2curveidx, kwargs)
+        x = _with_xyz(x, pos, self.with_xyz)
+        pad = (self.kernel_size // 2) * (len(self.feat_dims) - 1) if self.kernel_size > 1 else 0
+        rows = torch.arange(topo.n, device=pos.device) + pad * (topo.cid.long() + 1)
+        n_rows = topo.n + (topo.num_curves + 1) * pad
+        if self.with_diff:
+            x = ops.DiffConcat.apply(x, topo.cid)
+        seq = ops.ScatterRows.apply(x, rows, n_rows)
+        for conv, norm in zip(self.conv_modules, self.norm_modules):
+            seq = _conv_bn_act(seq, None, self.kernel_size, conv, norm, self.training)
+        return ops.gather_rows(seq, rows), pos, batch, point2curveidx
+
+
+# --------------------------------------------------------------------------------------
+# samplers (ref fps_ops.py)
+# --------------------------------------------------------------------------------------
+
+class CurveFPS(nn.Module):
+    """ref fps_ops.py:7-39.  The random phase is drawn exactly like the reference does
+    (``torch.rand(1)`` on the CPU generator), so seeding torch reproduces its samples."""
+
+    def __init__(self, arclen_spacing=0.3):
+        super().__init__()
+        self.arclen_spacing = arclen_spacing
+
+    def forward(self, pos, batch, point2curveidx, u=None, **kwargs):
+        topo = _topology(batch, point2curveidx, kwargs)
+        if u is None:
+            u = torch.rand(1)
+        return ops.curve_fps(pos, topo, self.arclen_spacing, float(u))
+
+
+# --------------------------------------------------------------------------------------
+# PointNetConv2 (ref point_conv.py)
+# --------------------------------------------------------------------------------------
+
+class PointNetConv2(nn.Module):
+    """ref point_conv.py:12-93 on an edge list grouped by destination (``ops.EdgeList``)."""
+
+    def __init__(self, local_nn=None, global_nn=None, attend_nn=None, add_self_loops=True, aggr_type="max",
+                 normalize_radius=None, **kwargs):
+        super().__init__()
+        assert aggr_type in ["max", "attend", "mean", "weighted-sum"]
+        if add_self_loops:
+            raise NotImplementedError("the reference always passes add_self_loops=False")
+        if aggr_type in ("mean", "weighted-sum"):
+            raise NotImplementedError("aggr_type %r is not used by any reference config" % aggr_type)
+        self.local_nn, self.global_nn, self.attend_nn = local_nn, global_nn, attend_nn
+        self.aggr_type, self.normalize_radius = aggr_type, normalize_radius
+
+    def forward(self, x, pos, edges):
+        x_src = x[0] if isinstance(x, tuple) else x
+        pos_src, pos_dst = pos if isinstance(pos, tuple) else (pos, pos)
+        msg = ops.MessageBuild.apply(x_src, pos_src, pos_dst, edges.col, edges.row, self.normalize_radius)
+        if self.local_nn is not None:
+            msg = self.local_nn(msg)
+        if self.aggr_type == "max":
+            out = ops.SegMax.apply(msg, edges.offsets, edges.num_dst)
+        else:
+            out = ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst)
+        if self.global_nn is not None:
+            out = self.global_nn(out)
+        return out
+
+
+# --------------------------------------------------------------------------------------
+# set abstraction / feature propagation (ref pointnet2.py)
+# --------------------------------------------------------------------------------------
+
+class SAModule(nn.Module):
+    """ref pointnet2.py:33-78 (FRNN grouping path, ``use_fast_knn=True``)."""
+
+    def __init__(self, ratio, r, nn, k, curve_fps_arclen=None, voxel_size=None, downsample_type="random",
+                 attend_nn=None, aggr_type="max", normalize_radius=False, use_fast_knn=True, **kwargs):
+        super().__init__()
+        self.ratio, self.r, self.knn = ratio, r, k
+        self.downsample_type, self.use_fast_knn = downsample_type, use_fast_knn
+        assert self.downsample_type in ["curve-fps", "random", "fps", "voxel"]
+        self.curve_fps_arclen, self.voxel_size = curve_fps_arclen, voxel_size
+        self.normalize_radius = r if normalize_radius else None
+        self.conv = PointNetConv2(nn, add_self_loops=False, aggr_type=aggr_type, attend_nn=attend_nn,
+                                  normalize_radius=self.normalize_radius)
+
+    def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
+        topo = _topology(batch, point2curveidx, kwargs)
+        if self.downsample_type == "random":
+            idx = torch.sort(torch.randperm(pos.size(0))[: int(pos.size(0) * self.ratio)])[0].to(pos.device)
+        elif self.downsample_type == "curve-fps":
+            idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
+        else:
+            raise NotImplementedError("downsample_type=%r is a 'next' row (SURVEY.md section 8f)" % self.downsample_type)
+        if not self.use_fast_knn:
+            raise NotImplementedError("ball_query grouping (use_fast_knn=False) is a 'next' row (SURVEY.md section 8f)")
+        pos_q, batch_q = pos[idx], batch[idx]
+        p2c_q = None if point2curveidx is None else point2curveidx[idx]
+        topo_q = _topology(batch_q, p2c_q, kwargs)
+        edges = ops.frnn_edges(pos_q, topo_q, pos, topo, self.knn, self.r)
+        x = self.conv((x, None), (pos, pos_q), edges)
+        return x, pos_q, batch_q, p2c_q
+
+
+class CurveSAModule(nn.Module):
+    """ref pointnet2.py:146-181: CurveFPS -> radius grouping along curves -> PointNetConv2."""
+
+    def __init__(self, ratio, r, nn, curve_fps_arclen=None, use_curve_fps=False, global_nn=None, attend_nn=None,
+                 with_xyz=False, aggr_type="max", normalize_radius=False, **kwargs):
+        super().__init__()
+        self.ratio, self.r, self.curve_fps_arclen = ratio, r, curve_fps_arclen
+        self.use_curve_fps, self.with_xyz = use_curve_fps, with_xyz
+        self.normalize_radius = r if normalize_radius else None
+        self.conv = PointNetConv2(nn, add_self_loops=False, global_nn=global_nn, aggr_type=aggr_type,
+                                  attend_nn=attend_nn, normalize_radius=self.normalize_radius)
+
+    def forward(self, x, pos, batch, point2curveidx, **kwargs):
+        topo = _topology(batch, point2curveidx, kwargs)
+        x = _with_xyz(x, pos[:, :3], self.with_xyz)
+        if not self.use_curve_fps:
+            raise NotImplementedError("farthest point sampling is a 'next' row (SURVEY.md section 8f)")
+        idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
+        edges = ops.radius_1d_group_subset(pos, idx, topo, self.r)
+        pos_q = pos[idx]
+        x = self.conv((x, None), (pos, pos_q), edges)
+        return x, pos_q, batch[idx], point2curveidx[idx], None, idx
+
+
+def _fp_concat(x, x_skip, pos_skip, with_xyz):
+    parts = [x]
+    if x_skip is not None:
+        parts.append(x_skip)
+    if with_xyz:
+        parts.append(pos_skip[:, :3])
+    return torch.cat(parts, dim=1) if len(parts) > 1 else x
+
+
+class FPModule(nn.Module):
+    """ref pointnet2.py:119-143 (exact 3-NN interpolation; 'next' row)."""
+
+    def __init__(self, k, nn, with_xyz=False):
+        super().__init__()
+        self.k, self.nn, self.with_xyz = k, nn, with_xyz
+
+    def forward(self, x, pos, batch, x_skip, pos_skip, batch_skip, point2curveidx=None, point2curveidx_skip=None,
+                **kwargs):
+        raise NotImplementedError("FPModule (pytorch3d knn_points interpolation) is a 'next' row (SURVEY.md section 8f)")
+
+
+class CurveFPModule(FPModule):
+    """ref pointnet2.py:184-205: interpolate along curves from the sampled points, concat skip, MLP."""
+
+    def forward(self, x, idx, x_skip, pos_skip, batch_skip, point2curveidx_skip=None, **kwargs):
+        topo = _topology(batch_skip, point2curveidx_skip, kwargs)
+        x = ops.knn_interpolate_1D(x, idx, pos_skip, topo, self.k)
+        x = self.nn(_fp_concat(x, x_skip, pos_skip, self.with_xyz))
+        return x, pos_skip, batch_skip, point2curveidx_skip
+
+
+# --------------------------------------------------------------------------------------
+# static edge conv (ref dgcnn.py)
+# --------------------------------------------------------------------------------------
+
+class SGCNNLayer(nn.Module):
+    """ref dgcnn.py:130-266, dense FRNN path ``forward_fast`` (quirk Q4 kept: the MLP and its batch
+    statistics run over all B*Nmax*(K+1) rows)."""
+
+    def __init__(self, nn, k, aggr="max", r=1.0, num_workers=1, with_xyz=False, attend_nn=None, aggr_type="max",
+                 use_sparse_feat_agg=False, use_fast_knn=True, **kwargs):
+        super().__init__()
+        assert aggr_type in ["max", "attend", "mean", "weighted-sum"]
+        self.nn, self.k, self.r, self.with_xyz = nn, k, r, with_xyz
+        self.attend_nn, self.aggr_type = attend_nn, aggr_type
+        self.use_fast_knn, self.use_sparse_feat_agg = use_fast_knn, use_sparse_feat_agg
+
+    def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
+        if self.use_sparse_feat_agg or not self.use_fast_knn:
+            raise NotImplementedError("sparse aggregation / exact kNN is a 'next' row (SURVEY.md section 8f)")
+        if self.aggr_type != "max":
+            raise NotImplementedError("dense SGCNN with aggr_type=%r is not used by the FRNN configs" % self.aggr_type)
+        topo = _topology(batch, point2curveidx, kwargs)
+        x = _with_xyz(x, pos, self.with_xyz)
+        padded, _ = ops.to_batch_padded(pos, topo)
+        radius = 0.25 if self.r is None else self.r
+        nbr = ops.fast_knn(padded, padded, topo.lengths, topo.lengths, self.k, radius)
+        feat = ops.SGGather.apply(x, nbr, topo.cloud_ptr)
+        feat = self.nn(feat)
+        out = ops.SGMax.apply(feat, nbr, topo.cloud_ptr, topo.n)
+        return out, pos, batch, point2curveidx
+
+
+# --------------------------------------------------------------------------------------
+# per-point MLP steps (ref mlp.py, skip_connect.py)
+# --------------------------------------------------------------------------------------
+
+class SharedMLP(nn.Module):
+    def __init__(self, dims, use_bias=False, with_xyz=False, act="leaky_relu", **kwargs):
+        super().__init__()
+        self.mlp = MLP(dims, dropout=kwargs.get("dropout", 0.0), norm=kwargs.get("norm", "batch_norm"),
+                       plain_last=kwargs.get("plain_last", True), act=act, bias=use_bias)
+        self.with_xyz = with_xyz
+
+    def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
+        return self.mlp(_with_xyz(x, pos, self.with_xyz)), pos, batch, point2curveidx
+
+
+class SkipConnect(nn.Module):
+    def __init__(self, nn, num_skips=1):
+        super().__init__()
+        self.num_skips, self.nn = num_skips, nn
+
+    def forward(self, xs, pos, batch, point2curveidx=None, **kwargs):
+        return self.nn(torch.cat(xs, dim=1)), pos, batch, point2curveidx

@@ -1,0 +1,199 @@
+/* libccn_hip.so -- C ABI of the MI355X (gfx950) CurveCloudNet hot-path kernels.
+ *
+ * This is the drop-in boundary.  The reference reaches its native code
+ * through Python extension packages; every entry point below names the reference call site
+ * (path:line under the upstream tree) whose arithmetic it replaces.  A maintainer binds these
+ * with ctypes exactly as curvecloudnet_amd/_lib.py does (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked host;
+ *   - the caller (the PyTorch caching allocator) owns inputs, outputs and workspaces; the library
+ *     allocates nothing and keeps no device state between calls;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never synchronises
+ *     the host, and is therefore hipGraph-capturable;
+ *   - return value: 0 on success, negative CCN_ERR_* otherwise; ccn_last_error() gives the text
+ *     (thread local).  Nothing throws.
+ *   - feature matrices are row-major float32 with an explicit leading dimension (elements);
+ *   - index tensors that the reference exposes as int64 stay int64; internal tables are int32.
+ */
+#ifndef CCN_HIP_H
+#define CCN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCN_ABI_VERSION 1
+
+#define CCN_OK 0
+#define CCN_ERR_ARG (-1)
+#define CCN_ERR_LAUNCH (-2)
+#define CCN_ERR_WORKSPACE (-3)
+
+#define CCN_ACT_NONE 0
+#define CCN_ACT_RELU 1
+#define CCN_ACT_LEAKY 2
+
+const char* ccn_last_error(void);
+int ccn_abi_version(void);
+
+/* generic exclusive prefix sum over int32 (CSR offsets from counts); out has n+1 entries, out[n] = total,
+ * which is also written to total64 (device, nullable). */
+size_t ccn_exclusive_scan_workspace_bytes(int64_t n);
+int ccn_exclusive_scan_i32(const int32_t* counts, int64_t n, int32_t* offsets, int64_t* total64, void* ws,
+                           size_t ws_bytes, void* stream);
+
+/* ---- A1: src/models/utils/point_ops.py:47-54 batch2ptr ------------------------------------------
+ * ids: sorted int64 (n).  starts: capacity n+1, receives [0, s_1, ..., s_{R-1}, n] (the reference's
+ * with_ends form; the interior form is starts[1:R]).  run_of (nullable): dense run number of every
+ * element.  meta (device int64[2]): {R, number of descending neighbours (reference asserts == 0)}. */
+size_t ccn_segment_ptr_workspace_bytes(int64_t n);
+int ccn_segment_ptr(const int64_t* ids, int64_t n, int64_t* starts, int32_t* run_of, int64_t* meta, void* ws,
+                    size_t ws_bytes, void* stream);
+
+/* ---- A2: point_ops.py:20-44 curveidx_local2global (+ the CSR tables every curve kernel uses) ----
+ * batch, p2c: int64 (n), batch ids must be 0..num_clouds-1 and sorted, p2c sorted inside a cloud.
+ * glob: int64 (n) global curve id.  cid: int32 (n) dense curve number.  curve_ptr: int32, capacity n+1,
+ * first Q+1 entries valid.  cloud_ptr: int64 (num_clouds+1).
+ * meta (device int64[4]): {Q, ordering violations, longest cloud, 0}. */
+size_t ccn_curve_topology_workspace_bytes(int64_t n, int64_t num_clouds);
+int ccn_curve_topology(const int64_t* batch, const int64_t* p2c, int64_t n, int64_t num_clouds, int64_t* glob,
+                       int32_t* cid, int32_t* curve_ptr, int64_t* cloud_ptr, int64_t* meta, void* ws,
+                       size_t ws_bytes, void* stream);
+
+/* ---- A3: src/models/modules/fast_conv1d.py:190-205 compute_feature_diffs (fused with the concat
+ * of fast_conv1d.py:66 / :133): out[:, 0:C] = x, out[:, C:2C] = |mean in-curve finite difference|. */
+int ccn_diff_concat_fwd(const float* x, int64_t ldx, const int32_t* cid, int64_t n, int64_t C, float* out,
+                        int64_t ldo, void* stream);
+int ccn_diff_concat_bwd(const float* x, int64_t ldx, const int32_t* cid, int64_t n, int64_t C, const float* g,
+                        int64_t ldg, float* dx, int64_t lddx, void* stream);
+
+/* ---- A4: fast_conv1d.py:173-184 (F.conv1d 'same', zero pad) as shifted-row matrix ---------------
+ * col[i, t*C + c] = x[i + t - taps/2, c] if that row exists and lies in the same segment, else 0.
+ * seg == NULL: the whole buffer is one sequence (V2's padded buffer, fast_conv1d.py:67-72). */
+int ccn_im2col_fwd(const float* x, int64_t ldx, const int32_t* seg, int64_t rows, int64_t C, int64_t taps,
+                   float* col, void* stream);
+int ccn_im2col_bwd(const float* dcol, const int32_t* seg, int64_t rows, int64_t C, int64_t taps, float* dx,
+                   int64_t lddx, void* stream);
+
+/* row gather / scatter (fast_conv1d.py:136-141 x_padded[valid] = x ; x = x_padded[valid]; x[idx]) */
+int ccn_gather_rows(const float* src, int64_t lds, const int64_t* index, int64_t m, int64_t C, float* dst,
+                    int64_t ldd, void* stream);
+int ccn_scatter_rows(const float* src, int64_t lds, const int64_t* index, int64_t m, int64_t C, float* dst,
+                     int64_t ldd, int accumulate, void* stream);
+
+/* ---- A7: src/models/modules/fps_ops.py:16-39 CurveFPS -------------------------------------------
+ * u is the reference's torch.rand(1) draw.  idx_out: capacity n (sorted point indices), count_out: device int64. */
+size_t ccn_curve_fps_workspace_bytes(int64_t n);
+int ccn_curve_fps(const float* pos, const int32_t* cid, const int32_t* curve_ptr, int64_t n, float spacing, float u,
+                  int64_t* idx_out, int64_t* count_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- A8: point_ops.py:143-193 radius_1d_group_subset ---------------------------------------------
+ * count: budget (float, Q+1; [Q] = candidate reach), offsets (int32, M+1), total (device int64).
+ * fill: row/col int64 (total).  p2c is the LOCAL curve id (quirk Q3 of SURVEY.md is reproduced). */
+size_t ccn_curve_group_subset_workspace_bytes(int64_t n, int64_t Q, int64_t M);
+int ccn_curve_group_subset_count(const float* pos, const int32_t* cid, const int32_t* curve_ptr, const int64_t* p2c,
+                                 int64_t n, int64_t Q, const int64_t* idx, int64_t M, float radius, float* budget,
+                                 int32_t* offsets, int64_t* total, void* ws, size_t ws_bytes, void* stream);
+int ccn_curve_group_subset_fill(const int32_t* cid, const int32_t* curve_ptr, const int64_t* p2c, int64_t n,
+                                int64_t Q, const int64_t* idx, int64_t M, const float* budget,
+                                const int32_t* offsets, int64_t* row, int64_t* col, void* stream);
+
+/* ---- A9: point_ops.py:196-260 knn_1d_group_superset + :344-355 knn_interpolate_1D ----------------
+ * nbr: int64 (n, k) position inside idx of the k nearest sampled points on the same curve, ascending
+ * distance, -1 padded; weight: float (n, k) = 1 / max(d^2, 1e-16), 0 where padded. */
+size_t ccn_curve_group_superset_workspace_bytes(int64_t n);
+int ccn_curve_group_superset(const float* pos, const int32_t* cid, int64_t n, const int64_t* idx, int64_t M,
+                             int64_t k, int64_t* nbr, float* weight, void* ws, size_t ws_bytes, void* stream);
+int ccn_interp_fwd(const float* x, int64_t ldx, const int64_t* nbr, const float* weight, int64_t n, int64_t k,
+                   int64_t C, float* y, int64_t ldy, void* stream);
+int ccn_interp_bwd(const float* dy, int64_t lddy, const int64_t* nbr, const float* weight, int64_t n, int64_t k,
+                   int64_t C, float* dx, int64_t lddx, void* stream);
+
+/* ---- A11: point_ops.py:459 frnn.frnn_grid_points (third_party/FRNN: grid build + radius query) ---
+ * points: (B, P, 3) float32 zero padded, lengths int64 (B), r float32 (B).  idx: (B, P1, K) int64, the
+ * <=K nearest points2 with d2 < r*r ascending by (d2, index), -1 padded; rows >= lengths1 are -1.
+ * dist2 (nullable) same shape float32, -1 padded.  count (nullable): (B, P1) int32 neighbours found. */
+size_t ccn_frnn_grid_bytes(int64_t B, int64_t P2);
+int ccn_frnn_grid_build(const float* points2, const int64_t* lengths2, const float* r, int64_t B, int64_t P2,
+                        void* grid, size_t grid_bytes, void* stream);
+int ccn_frnn_query(const float* points1, const int64_t* lengths1, const float* r, int64_t B, int64_t P1, int64_t K,
+                   const void* grid, int64_t P2, int64_t* idx, float* dist2, int32_t* count, void* stream);
+
+/* ---- A12: point_ops.py:98-111 / :287-290 dense (B,P1,K) idx -> flat (row, col) edge list ----------
+ * counts: int32 per packed query (cloud_ptr1[b] + i).  fill writes row = packed query, col = packed point. */
+int ccn_dense_to_csr_count(const int64_t* idx, const int64_t* cloud_ptr1, int64_t B, int64_t P1, int64_t K,
+                           int32_t* counts, void* stream);
+int ccn_dense_to_csr_fill(const int64_t* idx, const int64_t* cloud_ptr1, const int64_t* cloud_ptr2, int64_t B,
+                          int64_t P1, int64_t K, const int32_t* offsets, int64_t* row, int64_t* col, void* stream);
+
+/* ---- A16: torch_geometric.nn.MLP layers as used at src/models/base.py:32,64,90-125 ---------------
+ * fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32).  colstats (nullable): double[(ccn_stats_rows(M)+1) * 2*N];
+ * gemm_nt writes one partial row {column sums, column sums of squares} of Y per 128-row tile
+ * (deterministic, no atomics); ccn_bn_finalize reduces them (using the last 2*N doubles as scratch)
+ * into the BatchNorm batch statistics (torch.nn.BatchNorm1d inside PyG MLP; fast_conv1d.py:30,73). */
+int64_t ccn_stats_rows(int64_t rows); /* partial-statistics rows a reduction over `rows` rows produces (= ceil(rows/128)) */
+int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                int64_t M, int64_t N, int64_t K, double* colstats, void* stream); /* Y = A W^T + b */
+int ccn_gemm_nn(const float* dY, int64_t lddy, const float* W, int64_t ldw, float* dX, int64_t lddx, int64_t M,
+                int64_t N, int64_t K, void* stream);                              /* dX = dY W      */
+int ccn_gemm_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                int64_t N, int64_t K, void* stream); /* dW += dY^T X (dW pre-zeroed by caller) */
+
+int ccn_bn_finalize(const double* colstats, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                    float* save_mean, float* save_rstd, void* stream);
+int ccn_bn_eval_params(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, int64_t C, float* scale, float* shift, float* save_mean, float* save_rstd,
+                       void* stream);
+int ccn_bn_act_fwd(const float* Y, int64_t ldy, int64_t rows, int64_t C, const float* scale, const float* shift,
+                   int act, float slope, float* Z, int64_t ldz, void* stream);
+int ccn_bn_act_bwd_reduce(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C,
+                          const float* scale, const float* shift, const float* mean, const float* rstd, int act,
+                          float slope, double* sums, void* stream);
+int ccn_bn_act_bwd_apply(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C,
+                         const float* scale, const float* shift, const float* mean, const float* rstd, int act,
+                         float slope, const double* sums, int training, float* dY, int64_t lddy, float* dgamma,
+                         float* dbeta, void* stream);
+int ccn_colsum(const float* X, int64_t ldx, int64_t rows, int64_t C, double* acc, float* out, void* stream);
+
+/* ---- A15: src/models/modules/dgcnn.py:158-207 StaticEdgeConv.forward_fast ------------------------
+ * idx is the FRNN output (B, Nmax, K); the self-loop column of dgcnn.py:166-168 is implicit (slot 0).
+ * feat row (b, i, s) = [g, x_i - g], g = x[neighbour] or 0 (frnn_gather, dgcnn.py:172-173).
+ * x is PACKED (N, C) with cloud_ptr (B+1); rows i >= len_b are the zero padding rows of quirk Q4. */
+int ccn_sg_gather_fwd(const float* x, int64_t ldx, const int64_t* idx, const int64_t* cloud_ptr, int64_t B,
+                      int64_t Nmax, int64_t K, int64_t C, float* feat, void* stream);
+int ccn_sg_gather_bwd(const float* dfeat, const int64_t* idx, const int64_t* cloud_ptr, int64_t B, int64_t Nmax,
+                      int64_t K, int64_t C, float* dx, int64_t lddx, void* stream);
+/* masked max over the K+1 slots (dgcnn.py:187-189, fill -1e2) written to PACKED rows (dgcnn.py:206). */
+int ccn_sg_max_fwd(const float* f, const int64_t* idx, const int64_t* cloud_ptr, int64_t B, int64_t Nmax, int64_t K,
+                   int64_t C, float* out, int64_t ldo, int32_t* arg, void* stream);
+int ccn_sg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const int64_t* cloud_ptr, int64_t B,
+                   int64_t Nmax, int64_t K, int64_t C, float* df, void* stream);
+
+/* ---- A13: src/models/modules/point_conv.py:60-93 PointNetConv2 message + aggregate ----------------
+ * msg[e] = [x_src[src[e]], (pos_src[src[e]] - pos_dst[dst[e]]) / radius]   (radius <= 0: no division). */
+int ccn_msg_build_fwd(const float* x_src, int64_t ldx, const float* pos_src, const float* pos_dst,
+                      const int64_t* src, const int64_t* dst, int64_t E, int64_t C, float radius, float* msg,
+                      void* stream);
+int ccn_msg_build_bwd(const float* dmsg, const int64_t* src, int64_t E, int64_t C, float* dx, int64_t lddx,
+                      void* stream);
+/* edges grouped by destination: offsets int32 (M+1).  softmax over each group per channel (PyG softmax,
+ * +1e-16 in the denominator), weighted sum (point_conv.py:89-93). */
+int ccn_seg_softmax_agg_fwd(const float* msg, const float* att, const int32_t* offsets, int64_t M, int64_t C,
+                            float* out, int64_t ldo, void* stream);
+int ccn_seg_softmax_agg_bwd(const float* msg, const float* att, const int32_t* offsets, int64_t M, int64_t C,
+                            const float* dout, int64_t lddo, float* dmsg, float* datt, void* stream);
+/* scatter_max (point_conv.py:81-82): empty groups give 0. */
+int ccn_seg_max_fwd(const float* msg, const int32_t* offsets, int64_t M, int64_t C, float* out, int64_t ldo,
+                    int32_t* arg, void* stream);
+int ccn_seg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const int32_t* offsets, int64_t M,
+                    int64_t C, float* dmsg, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCN_HIP_H */

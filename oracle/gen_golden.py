@@ -128,17 +128,21 @@ def main():
             nm.weight.data.uniform_(0.5, 1.5)
             nm.bias.data.uniform_(-0.3, 0.3)
         c_in = dims[0] - (3 if with_xyz else 0)
-        feats = torch.randn(pos.size(0), c_in).requires_grad_(True)
+        feats = torch.randn(pos.size(0), c_in).requires_grad_(True) if c_in > 0 else None   # None: x = pos
         state0 = {n: v.clone() for n, v in ref.state_dict().items()}
         ref.train()
         y = ref(feats, pos, batch, p2c)[0]
         cot = torch.randn_like(y)
         params = list(ref.parameters())
-        grads = torch.autograd.grad((y * cot).sum(), [feats] + params)
+        lead = [feats] if feats is not None else []
+        grads = torch.autograd.grad((y * cot).sum(), lead + params)
+        if feats is None:
+            grads = (torch.zeros(pos.size(0), 0),) + tuple(grads)
         state1 = {n: v.clone() for n, v in ref.state_dict().items()}
         ref.eval()
         y_eval = ref(feats, pos, batch, p2c)[0]
-        blob[tag + ".feats"], blob[tag + ".pos"] = np_(feats), np_(pos)
+        blob[tag + ".feats"] = np_(feats) if feats is not None else np.zeros((pos.size(0), 0), np.float32)
+        blob[tag + ".pos"] = np_(pos)
         blob[tag + ".batch"], blob[tag + ".p2c"] = np_(batch), np_(p2c)
         blob[tag + ".cot"], blob[tag + ".y_train"], blob[tag + ".y_eval"] = np_(cot), np_(y), np_(y_eval)
         blob[tag + ".grad_feats"] = np_(grads[0])
@@ -153,11 +157,11 @@ def main():
         m = mine(dims, k, with_xyz=with_xyz, with_diff=with_diff)
         m.load_state_dict(state0, strict=True)
         m.train()
-        f2 = feats.detach().clone().requires_grad_(True)
+        f2 = feats.detach().clone().requires_grad_(True) if feats is not None else None
         y2 = m(f2, pos, batch, p2c)[0]
         close(y2, y, tag + " train fwd")
-        g2 = torch.autograd.grad((y2 * cot).sum(), [f2] + list(m.parameters()))
-        for a, b_ in zip(g2, grads):
+        g2 = torch.autograd.grad((y2 * cot).sum(), ([f2] if f2 is not None else []) + list(m.parameters()))
+        for a, b_ in zip(g2, grads if feats is not None else grads[1:]):
             close(a, b_, tag + " grads", 2e-4)
         m.eval()
         close(m(f2, pos, batch, p2c)[0], y_eval, tag + " eval fwd")

@@ -1,0 +1,253 @@
+"""GPU parity, floating point: HIP kernels vs golden vectors (from the reference), the CPU oracle
+and plain torch fp32 references.  Tolerance: 1e-4 absolute on O(1) features (north star), scaled by
+the magnitude of the reference for gradients."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import CASES, golden, maxdiff, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-4
+
+
+def _ops():
+    from curvecloudnet_amd import ops
+    return ops
+
+
+def _close(a, b, tol=TOL, what=""):
+    scale = max(1.0, float(b.detach().abs().max()) if b.numel() else 1.0)
+    err = maxdiff(a, b)
+    assert err <= tol * scale, "%s: max |diff| %.3g (scale %.3g)" % (what, err, scale)
+
+
+# ---------------------------------------------------------------- A3
+@pytest.mark.parametrize("case", CASES)
+def test_feature_diffs_golden(case):
+    ops = _ops()
+    g = golden("feature_diffs")
+    x = t(g[case + ".x"], DEV).requires_grad_(True)
+    topo = ops.CurveTopology(t(g[case + ".batch"], DEV), t(g[case + ".p2c"], DEV))
+    out = ops.DiffConcat.apply(x, topo.cid)
+    assert torch.equal(out[:, :5].detach().cpu(), t(g[case + ".x"]))
+    _close(out[:, 5:], t(g[case + ".diff"]), 1e-6, "diff")
+    (gx,) = torch.autograd.grad((out[:, 5:] * t(g[case + ".cot"], DEV)).sum(), x)
+    _close(gx, t(g[case + ".grad_x"]), 1e-5, "diff grad")
+
+
+# ---------------------------------------------------------------- A16: GEMMs and the fused layer
+@pytest.mark.parametrize("M,K,N", [(1, 3, 2), (127, 6, 20), (128, 32, 32), (1000, 134, 64), (333, 259, 128),
+                                   (4097, 64, 192), (70, 515, 300)])
+def test_linear_plain_fwd_bwd(M, K, N):
+    ops = _ops()
+    gen = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen)
+    cot = torch.randn(M, N, generator=gen)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.linear(xr, wr, br)
+    gr = torch.autograd.grad((yr * cot).sum(), [xr, wr, br])
+    xd, wd, bd = (v.to(DEV).requires_grad_(True) for v in (x, w, b))
+    y = ops.linear_bn_act(xd, wd, bd, None, False, None)
+    g = torch.autograd.grad((y * cot.to(DEV)).sum(), [xd, wd, bd])
+    _close(y, yr, 2e-5, "y")
+    for a, r, name in zip(g, gr, ("dx", "dw", "db")):
+        _close(a, r, 5e-5, name)
+
+
+@pytest.mark.parametrize("M,K,N,act,bias", [(500, 38, 64, "leaky_relu", False), (2000, 134, 64, "relu", False),
+                                             (129, 16, 40, "relu", True), (4100, 64, 256, "leaky_relu", True)])
+@pytest.mark.parametrize("training", [True, False])
+def test_linear_bn_act_vs_torch(M, K, N, act, bias, training):
+    ops = _ops()
+    gen = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=gen) + 0.3
+    cot = torch.randn(M, N, generator=gen)
+    lin = torch.nn.Linear(K, N, bias=bias)
+    bn = torch.nn.BatchNorm1d(N)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.uniform_(-0.3, 0.3)
+    bn.running_mean.uniform_(-0.2, 0.2)
+    bn.running_var.uniform_(0.5, 1.5)
+    lin_d, bn_d = torch.nn.Linear(K, N, bias=bias), torch.nn.BatchNorm1d(N)
+    lin_d.load_state_dict(lin.state_dict())
+    bn_d.load_state_dict(bn.state_dict())
+    lin_d, bn_d = lin_d.to(DEV), bn_d.to(DEV)
+    bn.train(training)
+    fn = F.relu if act == "relu" else F.leaky_relu
+    xr = x.clone().requires_grad_(True)
+    yr = fn(bn(lin(xr)))
+    params_r = [xr, lin.weight, bn.weight, bn.bias] + ([lin.bias] if bias else [])
+    gr = torch.autograd.grad((yr * cot).sum(), params_r)
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.linear_bn_act(xd, lin_d.weight, lin_d.bias, bn_d, training, act)
+    params_d = [xd, lin_d.weight, bn_d.weight, bn_d.bias] + ([lin_d.bias] if bias else [])
+    g = torch.autograd.grad((y * cot.to(DEV)).sum(), params_d)
+    _close(y, yr, TOL, "y")
+    for a, r, name in zip(g, gr, ("dx", "dw", "dgamma", "dbeta", "db")):
+        _close(a, r, 2e-4, name)
+    _close(bn_d.running_mean, bn.running_mean, 1e-5, "running_mean")
+    _close(bn_d.running_var, bn.running_var, 1e-5, "running_var")
+    assert int(bn_d.num_batches_tracked) == int(bn.num_batches_tracked)
+
+
+def test_mlp_state_dict_and_forward_match_oracle():
+    from oracle import torch_ref as R
+    from curvecloudnet_amd.nn import MLP
+    torch.manual_seed(3)
+    ref = R.MLP([19, 32, 48, 10], act="leaky_relu", plain_last=True, bias=True)
+    mine = MLP([19, 32, 48, 10], act="leaky_relu", plain_last=True, bias=True)
+    assert list(ref.state_dict().keys()) == list(mine.state_dict().keys())
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine = mine.to(DEV)
+    x = torch.randn(777, 19)
+    for mode in (True, False):
+        ref.train(mode)
+        mine.train(mode)
+        _close(mine(x.to(DEV)), ref(x), TOL, "mlp train=%s" % mode)
+    for k, v in ref.state_dict().items():
+        _close(mine.state_dict()[k].float(), v.float(), 1e-5, k)
+
+
+# ---------------------------------------------------------------- A4-A6: curve convolutions vs the reference
+def _conv_tags():
+    g = golden("curve_conv")
+    return sorted({k.split(".")[0] for k in g.files})
+
+
+@pytest.mark.parametrize("tag", ["v1_k5_diff_xyz", "v1_k7_plain", "v1_k5_single", "v2_k5_diff_xyz", "v2_k5_one",
+                                 "v2_k7_nodiff"])
+def test_curve_conv_golden(tag):
+    from curvecloudnet_amd import steps
+    g = golden("curve_conv")
+    assert tag in _conv_tags()
+    meta = g[tag + ".meta"].tolist()
+    ver, k, with_xyz, with_diff, dims = meta[0], meta[1], bool(meta[2]), bool(meta[3]), meta[4:]
+    cls = steps.SymmetricCurve1DConvFastV1 if ver == 1 else steps.SymmetricCurve1DConvV2
+    mod = cls(dims, k, with_xyz=with_xyz, with_diff=with_diff)
+    state0 = {n[len(tag) + 8:]: t(g[n]) for n in g.files if n.startswith(tag + ".state0.")}
+    mod.load_state_dict(state0, strict=True)
+    mod = mod.to(DEV).train()
+    feats = t(g[tag + ".feats"], DEV).requires_grad_(True) if g[tag + ".feats"].shape[1] else None   # None: x = pos
+    pos, batch, p2c = t(g[tag + ".pos"], DEV), t(g[tag + ".batch"], DEV), t(g[tag + ".p2c"], DEV)
+    y = mod(feats, pos, batch, p2c)[0]
+    _close(y, t(g[tag + ".y_train"]), TOL, "train fwd")
+    names = [n for n, _ in mod.named_parameters()]
+    lead = [feats] if feats is not None else []
+    grads = torch.autograd.grad((y * t(g[tag + ".cot"], DEV)).sum(), lead + list(mod.parameters()))
+    if feats is not None:
+        _close(grads[0], t(g[tag + ".grad_feats"]), 3e-4, "grad feats")
+    for n, gv in zip(names, grads[len(lead):]):
+        _close(gv, t(g[tag + ".grad." + n]), 3e-4, "grad " + n)
+    for n, v in mod.state_dict().items():
+        _close(v.float(), t(g[tag + ".state1." + n]).float(), 1e-5, "state " + n)
+    mod.eval()
+    _close(mod(feats, pos, batch, p2c)[0], t(g[tag + ".y_eval"]), TOL, "eval fwd")
+
+
+# ---------------------------------------------------------------- A9: interpolation
+@pytest.mark.parametrize("case", CASES)
+def test_curve_interpolate_golden(case):
+    ops = _ops()
+    g = golden("curve_group")
+    pos, batch, p2c = t(g[case + ".pos"], DEV), t(g[case + ".batch"], DEV), t(g[case + ".p2c"], DEV)
+    topo = ops.CurveTopology(batch, p2c)
+    x = t(g[case + ".interp_x"], DEV).requires_grad_(True)
+    y = ops.knn_interpolate_1D(x, t(g[case + ".idx"], DEV), pos, topo, 3)
+    _close(y, t(g[case + ".interp_y"]), 2e-5, "interp")
+    (gx,) = torch.autograd.grad((y * t(g[case + ".interp_cot"], DEV)).sum(), x)
+    _close(gx, t(g[case + ".interp_grad_x"]), 5e-5, "interp grad")
+
+
+# ---------------------------------------------------------------- A13-A15: step modules vs the oracle modules
+def _pair(make_ref, make_mine):
+    torch.manual_seed(1)
+    ref = make_ref()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.2, 0.2)
+    mine = make_mine()
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    return ref.train(), mine.to(DEV).train()
+
+
+def _run_pair(ref, mine, args_cpu, seed, n_out_check=1):
+    args_dev = [a.to(DEV) if torch.is_tensor(a) else a for a in args_cpu]
+    xr = args_cpu[0].clone().requires_grad_(True)
+    xd = args_dev[0].clone().requires_grad_(True)
+    torch.manual_seed(seed)
+    out_r = ref(xr, *args_cpu[1:])
+    torch.manual_seed(seed)
+    out_d = mine(xd, *args_dev[1:])
+    _close(out_d[0], out_r[0], TOL, "forward")
+    for a, b in zip(out_d[1:4], out_r[1:4]):
+        if torch.is_tensor(b):
+            assert torch.equal(a.cpu(), b)
+    cot = torch.randn(out_r[0].shape, generator=torch.Generator().manual_seed(2))
+    gr = torch.autograd.grad((out_r[0] * cot).sum(), [xr] + list(ref.parameters()))
+    gd = torch.autograd.grad((out_d[0] * cot.to(DEV)).sum(), [xd] + list(mine.parameters()))
+    names = ["x"] + [n for n, _ in ref.named_parameters()]
+    for a, b, n in zip(gd, gr, names):
+        _close(a, b, 3e-4, "grad " + n)
+    return out_r, out_d
+
+
+@pytest.mark.parametrize("ids", [[0], [1, 2, 3]])
+def test_sgcnn_layer_vs_oracle(ids):
+    from oracle import torch_ref as R
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch(ids, n_curves=60)
+    c = 13
+    ref, mine = _pair(lambda: R.SGCNNLayer(R.MLP([2 * (c + 3), 32, 24], bias=False), 8, r=0.03, with_xyz=True),
+                      lambda: steps.SGCNNLayer(MLP([2 * (c + 3), 32, 24], bias=False), 8, r=0.03, with_xyz=True))
+    x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4))
+    _run_pair(ref, mine, [x, d.pos, d.batch, d.curve_idxs], seed=0)
+
+
+@pytest.mark.parametrize("aggr", ["attend", "max"])
+def test_sa_module_vs_oracle(aggr):
+    from oracle import torch_ref as R
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([5, 6], n_curves=80)
+    c = 10
+    kw = dict(curve_fps_arclen=0.012, downsample_type="curve-fps", aggr_type=aggr, normalize_radius=True)
+
+    def mk(mod, mlp):
+        att = mlp([24, 12, 24], act="leaky_relu", bias=False) if aggr == "attend" else None
+        return mod(None, 0.05, mlp([c + 3, 32, 24], bias=False), 16, attend_nn=att, **kw)
+    ref, mine = _pair(lambda: mk(R.SAModule, R.MLP), lambda: mk(steps.SAModule, MLP))
+    x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4))
+    out_r, out_d = _run_pair(ref, mine, [x, d.pos, d.batch, d.curve_idxs], seed=11)
+    assert out_r[0].size(0) < x.size(0)
+
+
+def test_curve_sa_and_fp_modules_vs_oracle():
+    from oracle import torch_ref as R
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([9, 10, 11], n_curves=70)
+    c = 7
+
+    def mk(mod, mlp):
+        return mod(None, 0.02, mlp([c + 6, 24, 40], act="leaky_relu", bias=False), curve_fps_arclen=0.007,
+                   use_curve_fps=True, attend_nn=mlp([40, 40, 40], act="leaky_relu", bias=False), with_xyz=True,
+                   aggr_type="attend", normalize_radius=True)
+    ref, mine = _pair(lambda: mk(R.CurveSAModule, R.MLP), lambda: mk(steps.CurveSAModule, MLP))
+    x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4))
+    out_r, out_d = _run_pair(ref, mine, [x, d.pos, d.batch, d.curve_idxs], seed=21)
+    assert torch.equal(out_d[5].cpu(), out_r[5])                       # the sampled indices
+    # fp-geo back to the full resolution
+    idx = out_r[5]
+    ref_fp, mine_fp = _pair(lambda: R.CurveFPModule(3, R.MLP([40 + c + 3, 32, 16], act="leaky_relu", bias=False), with_xyz=True),
+                            lambda: steps.CurveFPModule(3, MLP([40 + c + 3, 32, 16], act="leaky_relu", bias=False), with_xyz=True))
+    xs = out_r[0].detach()
+    _run_pair(ref_fp, mine_fp, [xs, idx, x, d.pos, d.batch, d.curve_idxs], seed=0)

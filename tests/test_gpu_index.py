@@ -1,0 +1,215 @@
+"""GPU parity, integer results: HIP kernels (through the C-ABI) vs the CPU oracle and the golden
+vectors made from the reference.  Everything here must be BIT-EXACT."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import CASES, golden, t
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _ops():
+    from curvecloudnet_amd import ops
+    return ops
+
+
+def _synth(ids, **kw):
+    from curvecloudnet_amd.synth import make_batch
+    return make_batch(ids, **kw)
+
+
+# ---------------------------------------------------------------- A1 / A2
+@pytest.mark.parametrize("case", CASES)
+def test_segment_ptr_and_topology_golden(case):
+    ops = _ops()
+    g = golden("index_algebra")
+    batch, p2c = t(g[case + ".batch"], DEV), t(g[case + ".p2c"], DEV)
+    assert torch.equal(ops.batch2ptr(batch, with_ends=True).cpu(), t(g[case + ".cloud_ptr"]))
+    assert torch.equal(ops.batch2ptr(batch).cpu(), t(g[case + ".cloud_ptr_interior"]))
+    topo = ops.CurveTopology(batch, p2c)
+    assert torch.equal(topo.glob.cpu(), t(g[case + ".glob"]))
+    assert torch.equal(topo.curve_ptr.cpu().long(), t(g[case + ".curve_ptr"]))
+    assert torch.equal(topo.cloud_ptr.cpu(), t(g[case + ".cloud_ptr"]))
+    assert torch.equal(ops.batch2ptr(topo.glob).cpu(), t(g[case + ".curve_ptr_interior"]))
+    assert torch.equal(ops.curveidx_local2global(p2c, batch).cpu(), t(g[case + ".glob"]))
+    feats = t(g[case + ".feats"], DEV)
+    padded, mask = ops.to_batch_padded(feats, topo)
+    assert torch.equal(padded.cpu(), t(g[case + ".padded"]))
+    assert torch.equal(mask.cpu(), t(g[case + ".mask"]))
+    assert torch.equal(topo.lengths.cpu(), t(g[case + ".lengths"]))
+
+
+def test_segment_ptr_rejects_unsorted_and_handles_edges():
+    ops = _ops()
+    with pytest.raises(AssertionError):
+        ops.batch2ptr(torch.tensor([0, 1, 0, 2], device=DEV))
+    one = ops.batch2ptr(torch.tensor([5], device=DEV), with_ends=True)
+    assert one.tolist() == [0, 1]
+    assert ops.batch2ptr(torch.tensor([3, 3, 3], device=DEV)).numel() == 0
+    big = torch.sort(torch.randint(0, 5000, (300001,), generator=torch.Generator().manual_seed(1)))[0]
+    from oracle import torch_ref as R
+    assert torch.equal(ops.batch2ptr(big.to(DEV), with_ends=True).cpu(), R.segment_starts(big, True))
+    with pytest.raises(AssertionError):
+        ops.CurveTopology(torch.tensor([0, 0, 2, 2], device=DEV), torch.tensor([0, 1, 0, 1], device=DEV), 3)
+
+
+def test_topology_large_matches_oracle():
+    ops = _ops()
+    from oracle import torch_ref as R
+    d = _synth([3, 4, 5], n_curves=700)
+    topo = ops.CurveTopology(d.batch.to(DEV), d.curve_idxs.to(DEV))
+    glob = R.curve_ids_global(d.curve_idxs, d.batch)
+    assert torch.equal(topo.glob.cpu(), glob)
+    assert torch.equal(topo.curve_ptr.cpu().long(), R.segment_starts(glob, True))
+    assert torch.equal(topo.cid.cpu().long(), glob)           # synthetic ids are dense
+    assert topo.num_curves == 2100 and topo.num_clouds == 3
+
+
+# ---------------------------------------------------------------- A7
+def test_curve_fps_golden():
+    ops = _ops()
+    g = golden("curve_fps")
+    keys = sorted({k.rsplit(".", 1)[0] for k in g.files})
+    assert len(keys) == 8
+    for key in keys:
+        pos, batch, p2c = t(g[key + ".pos"], DEV), t(g[key + ".batch"], DEV), t(g[key + ".p2c"], DEV)
+        topo = ops.CurveTopology(batch, p2c)
+        idx = ops.curve_fps(pos, topo, float(g[key + ".spacing"]), float(g[key + ".u"][0]))
+        assert torch.equal(idx.cpu(), t(g[key + ".idx"])), key
+
+
+@pytest.mark.parametrize("ids,spacing", [([0], 0.007), ([1, 2, 3], 0.007), ([4, 5], 0.02), ([6], 0.03)])
+def test_curve_fps_matches_oracle(ids, spacing):
+    ops = _ops()
+    from oracle import torch_ref as R
+    d = _synth(ids, n_curves=600)
+    u = torch.rand(1, generator=torch.Generator().manual_seed(9))
+    want = R.curve_fps(d.pos, d.batch, d.curve_idxs, spacing, u)
+    topo = ops.CurveTopology(d.batch.to(DEV), d.curve_idxs.to(DEV))
+    got = ops.curve_fps(d.pos.to(DEV), topo, spacing, float(u))
+    assert torch.equal(got.cpu(), want)
+
+
+# ---------------------------------------------------------------- A8 / A9
+@pytest.mark.parametrize("case", CASES)
+def test_curve_groups_golden(case):
+    ops = _ops()
+    g = golden("curve_group")
+    pos, batch, p2c = t(g[case + ".pos"], DEV), t(g[case + ".batch"], DEV), t(g[case + ".p2c"], DEV)
+    idx = t(g[case + ".idx"], DEV)
+    topo = ops.CurveTopology(batch, p2c)
+    for radius in (0.02, 0.006):
+        e = ops.radius_1d_group_subset(pos, idx, topo, radius)
+        key = "%s.r%g" % (case, radius)
+        assert torch.equal(e.row.cpu(), t(g[key + ".row"])), key
+        assert torch.equal(e.col.cpu(), t(g[key + ".col"])), key
+        counts = torch.bincount(e.row, minlength=idx.numel())
+        assert torch.equal((e.offsets[1:] - e.offsets[:-1]).long(), counts)
+    for k in (3, 1):
+        row, col = ops.knn_1d_group_superset(pos, idx, topo, k)
+        assert torch.equal(row.cpu(), t(g["%s.k%d.row" % (case, k)]))
+        assert torch.equal(col.cpu(), t(g["%s.k%d.col" % (case, k)]))
+
+
+@pytest.mark.parametrize("ids", [[0], [1, 2, 3]])
+def test_curve_groups_match_oracle(ids):
+    ops = _ops()
+    from oracle import torch_ref as R
+    d = _synth(ids, n_curves=500)
+    u = torch.tensor([0.41])
+    idx = R.curve_fps(d.pos, d.batch, d.curve_idxs, 0.007, u)
+    topo = ops.CurveTopology(d.batch.to(DEV), d.curve_idxs.to(DEV))
+    pos = d.pos.to(DEV)
+    for radius in (0.02, 0.05):
+        want = R.curve_radius_group(d.pos, idx, d.curve_idxs, d.batch, radius)
+        e = ops.radius_1d_group_subset(pos, idx.to(DEV), topo, radius)
+        assert torch.equal(e.row.cpu(), want[0]) and torch.equal(e.col.cpu(), want[1])
+    want = R.curve_knn_superset(d.pos, idx, d.curve_idxs, d.batch, 3)
+    row, col = ops.knn_1d_group_superset(pos, idx.to(DEV), topo, 3)
+    assert torch.equal(row.cpu(), want[0]) and torch.equal(col.cpu(), want[1])
+
+
+# ---------------------------------------------------------------- A11
+def _frnn_case(B, P1, P2, K, r, seed, ragged=True, same=False):
+    gen = torch.Generator().manual_seed(seed)
+    p2 = torch.rand(B, P2, 3, generator=gen) * torch.tensor([2.0, 2.0, 0.4])
+    p1 = p2[:, :P1].clone() if same else torch.rand(B, P1, 3, generator=gen) * torch.tensor([2.0, 2.0, 0.4])
+    if ragged:
+        l1 = torch.randint(max(1, P1 // 2), P1 + 1, (B,), generator=gen)
+        l2 = torch.randint(max(1, P2 // 2), P2 + 1, (B,), generator=gen)
+        l1[0], l2[0] = P1, P2
+    else:
+        l1, l2 = torch.full((B,), P1), torch.full((B,), P2)
+    if same:
+        l1 = torch.minimum(l1, l2)
+    return p1, p2, l1, l2
+
+
+@pytest.mark.parametrize("B,P1,P2,K,r", [(1, 500, 500, 8, 0.15), (3, 257, 1000, 20, 0.2), (2, 1000, 300, 32, 0.5),
+                                          (4, 64, 64, 5, 0.05), (1, 3000, 3000, 20, 0.08), (2, 100, 100, 40, 3.0)])
+def test_frnn_bit_exact_vs_bruteforce(B, P1, P2, K, r):
+    ops = _ops()
+    from oracle import torch_ref as R
+    p1, p2, l1, l2 = _frnn_case(B, P1, P2, K, r, seed=B * 1000 + P1)
+    want, want_d = R.frnn_bruteforce(p1, p2, l1, l2, K, r, return_dists=True)
+    got, got_d = ops.fast_knn(p1.to(DEV), p2.to(DEV), l1.to(DEV), l2.to(DEV), K, r, return_dists=True)
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(got_d.cpu(), want_d)            # same fma chain => identical distances
+
+
+def test_frnn_per_cloud_radius_empty_and_lattice():
+    ops = _ops()
+    from oracle import torch_ref as R
+    # per-cloud radii, one cloud with a single point, K larger than any neighbourhood
+    p1, p2, l1, l2 = _frnn_case(3, 200, 200, 50, 0.1, seed=5, same=True)
+    l1[1], l2[1] = 1, 1
+    r = torch.tensor([0.05, 0.3, 0.12])
+    want = R.frnn_bruteforce(p1, p2, l1, l2, 50, r)
+    got = ops.fast_knn(p1.to(DEV), p2.to(DEV), l1.to(DEV), l2.to(DEV), 50, r)
+    assert torch.equal(got.cpu(), want)
+    assert (got[1, 1:] == -1).all() and got[1, 0, 0] == 0
+    # lattice: many exactly equal distances -> ties resolved by index on both sides, r between shells
+    ax = torch.arange(6, dtype=torch.float32) * 0.25
+    lat = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(1, -1, 3)
+    n = torch.tensor([lat.size(1)])
+    for rad in (0.3, 0.36, 0.26):
+        want = R.frnn_bruteforce(lat, lat, n, n, 27, rad)
+        got = ops.fast_knn(lat.to(DEV), lat.to(DEV), n.to(DEV), n.to(DEV), 27, rad)
+        assert torch.equal(got.cpu(), want), rad
+    # argument errors mirror the reference's (point_ops.py:432-440)
+    with pytest.raises(ValueError):
+        ops.fast_knn(p1[:2].to(DEV), p2.to(DEV), l1, l2, 4, 0.1)
+    with pytest.raises(TypeError):
+        ops.fast_knn(p1, p2, l1, l2, 4, 0.1)
+
+
+def test_frnn_on_curve_clouds_full_size():
+    """BASELINE-size cloud (2048 curves, ~50k points): bit match against the exhaustive oracle."""
+    ops = _ops()
+    from oracle import torch_ref as R
+    d = _synth([0])
+    n = torch.tensor([d.pos.size(0)])
+    p = d.pos.unsqueeze(0)
+    for K, r in ((20, 0.04), (32, 0.1)):
+        want = R.frnn_bruteforce(p, p, n, n, K, r)
+        got = ops.fast_knn(p.to(DEV), p.to(DEV), n.to(DEV), n.to(DEV), K, r)
+        assert torch.equal(got.cpu(), want)
+        # size-independent properties: self is the nearest neighbour; rows sorted by distance
+        assert torch.equal(got[0, :, 0].cpu(), torch.arange(n.item()))
+
+
+def test_frnn_edges_match_oracle_flat_lists():
+    ops = _ops()
+    from oracle import torch_ref as R
+    d = _synth([7, 8], n_curves=300)
+    u = torch.tensor([0.3])
+    idx = R.curve_fps(d.pos, d.batch, d.curve_idxs, 0.01, u)
+    want = R.group_fixed_radius(d.pos[idx], d.pos, d.batch[idx], d.batch, 16, 0.05)
+    pos, batch, p2c = d.pos.to(DEV), d.batch.to(DEV), d.curve_idxs.to(DEV)
+    topo = ops.CurveTopology(batch, p2c)
+    idxd = idx.to(DEV)
+    topo_q = ops.CurveTopology(batch[idxd], p2c[idxd])
+    e = ops.frnn_edges(pos[idxd], topo_q, pos, topo, 16, 0.05)
+    assert torch.equal(e.row.cpu(), want[0]) and torch.equal(e.col.cpu(), want[1])

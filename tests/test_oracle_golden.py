@@ -1,0 +1,120 @@
+"""CPU: the oracle restatement against the golden vectors generated from the reference's own code
+(oracle/gen_golden.py).  Integer results bit-exact, floats to 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as R
+from tests.util import CASES, golden, t
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_index_algebra(case):
+    g = golden("index_algebra")
+    batch, p2c = t(g[case + ".batch"]), t(g[case + ".p2c"])
+    assert torch.equal(R.segment_starts(batch, True), t(g[case + ".cloud_ptr"]))
+    assert torch.equal(R.segment_starts(batch), t(g[case + ".cloud_ptr_interior"]))
+    glob = R.curve_ids_global(p2c, batch)
+    assert torch.equal(glob, t(g[case + ".glob"]))
+    assert torch.equal(R.segment_starts(glob, True), t(g[case + ".curve_ptr"]))
+    padded, mask, lens, offs = R.padded_layout(t(g[case + ".feats"]), batch)
+    assert torch.equal(padded, t(g[case + ".padded"])) and torch.equal(mask, t(g[case + ".mask"]))
+    assert torch.equal(lens, t(g[case + ".lengths"])) and torch.equal(offs, t(g[case + ".offsets"]))
+
+
+def test_single_cloud_returns_input_object():
+    p2c = torch.tensor([0, 0, 1, 2])
+    assert R.curve_ids_global(p2c, torch.zeros(4, dtype=torch.long)) is p2c          # quirk Q8
+    with pytest.raises(AssertionError):
+        R.segment_starts(torch.tensor([1, 0]))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_feature_diffs(case):
+    g = golden("feature_diffs")
+    x = t(g[case + ".x"]).requires_grad_(True)
+    d = R.feature_diffs(x, t(g[case + ".p2c"]), t(g[case + ".batch"]))
+    assert torch.equal(d.detach(), t(g[case + ".diff"]))
+    (gx,) = torch.autograd.grad((d * t(g[case + ".cot"])).sum(), x)
+    assert float((gx - t(g[case + ".grad_x"])).abs().max()) < 1e-6
+
+
+def test_curve_conv_all_cases():
+    g = golden("curve_conv")
+    tags = sorted({k.split(".")[0] for k in g.files})
+    assert len(tags) == 6
+    for tag in tags:
+        meta = g[tag + ".meta"].tolist()
+        ver, k, with_xyz, with_diff, dims = meta[0], meta[1], bool(meta[2]), bool(meta[3]), meta[4:]
+        cls = R.SymmetricCurve1DConvFastV1 if ver == 1 else R.SymmetricCurve1DConvV2
+        m = cls(dims, k, with_xyz=with_xyz, with_diff=with_diff)
+        m.load_state_dict({n[len(tag) + 8:]: t(g[n]) for n in g.files if n.startswith(tag + ".state0.")}, strict=True)
+        m.train()
+        feats = t(g[tag + ".feats"]).requires_grad_(True) if g[tag + ".feats"].shape[1] else None   # None: x = pos
+        args = (t(g[tag + ".pos"]), t(g[tag + ".batch"]), t(g[tag + ".p2c"]))
+        y = m(feats, *args)[0]
+        assert float((y - t(g[tag + ".y_train"])).abs().max()) < 1e-5, tag
+        lead = [feats] if feats is not None else []
+        grads = torch.autograd.grad((y * t(g[tag + ".cot"])).sum(), lead + list(m.parameters()))
+        if feats is not None:
+            assert float((grads[0] - t(g[tag + ".grad_feats"])).abs().max()) < 2e-4, tag
+        for (n, _), gv in zip(m.named_parameters(), grads[len(lead):]):
+            assert float((gv - t(g[tag + ".grad." + n])).abs().max()) < 2e-4, (tag, n)
+        m.eval()
+        assert float((m(feats, *args)[0] - t(g[tag + ".y_eval"])).abs().max()) < 1e-5, tag
+
+
+def test_curve_fps():
+    g = golden("curve_fps")
+    keys = sorted({k.rsplit(".", 1)[0] for k in g.files})
+    assert len(keys) == 8
+    for key in keys:
+        idx = R.curve_fps(t(g[key + ".pos"]), t(g[key + ".batch"]), t(g[key + ".p2c"]), float(g[key + ".spacing"]),
+                          t(g[key + ".u"]))
+        assert torch.equal(idx, t(g[key + ".idx"])), key
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_curve_groups_and_interpolation(case):
+    g = golden("curve_group")
+    pos, batch, p2c, idx = (t(g[case + s]) for s in (".pos", ".batch", ".p2c", ".idx"))
+    for radius in (0.02, 0.006):
+        row, col = R.curve_radius_group(pos, idx, p2c, batch, radius)
+        key = "%s.r%g" % (case, radius)
+        assert torch.equal(row, t(g[key + ".row"])) and torch.equal(col, t(g[key + ".col"]))
+    for k in (3, 1):
+        row, col = R.curve_knn_superset(pos, idx, p2c, batch, k)
+        assert torch.equal(row, t(g["%s.k%d.row" % (case, k)])) and torch.equal(col, t(g["%s.k%d.col" % (case, k)]))
+    x = t(g[case + ".interp_x"]).requires_grad_(True)
+    y = R.curve_interpolate(x, idx, pos, batch, p2c, 3)
+    assert float((y - t(g[case + ".interp_y"])).abs().max()) < 1e-5
+    (gx,) = torch.autograd.grad((y * t(g[case + ".interp_cot"])).sum(), x)
+    assert float((gx - t(g[case + ".interp_grad_x"])).abs().max()) < 1e-5
+
+
+def test_frnn_bruteforce_known_answers():
+    """FRNN is third party and un-vendored (parity unpinned): anchor the exhaustive oracle on
+    hand-checkable cases."""
+    ax = torch.arange(4, dtype=torch.float32)
+    lat = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(1, -1, 3)
+    n = torch.tensor([64])
+    idx, d2 = R.frnn_bruteforce(lat, lat, n, n, 8, 1.1, return_dists=True)
+    centre = 21                                   # (1,1,1): itself + 6 axis neighbours at distance 1
+    assert idx[0, centre].tolist() == [21, 5, 17, 20, 22, 25, 37, -1]
+    assert d2[0, centre].tolist() == [0, 1, 1, 1, 1, 1, 1, -1]
+    assert idx[0, 0].tolist() == [0, 1, 4, 16, -1, -1, -1, -1]        # corner
+    idx = R.frnn_bruteforce(lat, lat, n, n, 3, 1.0)                   # strict d2 < r*r: only itself
+    assert (idx[0, :, 0] == torch.arange(64)).all() and (idx[0, :, 1:] == -1).all()
+    idx = R.frnn_bruteforce(lat, lat, torch.tensor([2]), n, 2, 5.0)   # rows >= lengths1 are -1
+    assert (idx[0, 2:] == -1).all() and idx[0, 1].tolist() == [1, 0]
+    # against a dense numpy computation on random points
+    gen = torch.Generator().manual_seed(0)
+    p = torch.rand(2, 120, 3, generator=gen)
+    l = torch.tensor([120, 77])
+    got = R.frnn_bruteforce(p, p, l, l, 6, 0.25)
+    for b in range(2):
+        pts = p[b, : l[b]].numpy().astype(np.float64)
+        dm = ((pts[:, None] - pts[None]) ** 2).sum(-1)
+        for i in range(int(l[b])):
+            order = [j for j in np.argsort(dm[i], kind="stable") if dm[i, j] < 0.25 ** 2 * (1 - 1e-6)][:6]
+            assert got[b, i, : len(order)].tolist() == order
