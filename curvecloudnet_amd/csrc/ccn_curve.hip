@@ -215,11 +215,13 @@ __global__ void scatter_rows_kernel(const float* __restrict__ src, int64_t lds_,
 }
 
 // ------------------------------------------------------------------ shared curve helpers
+// NB: sqrtf() is correctly rounded on gfx950 (hipcc default); the __fsqrt_rn intrinsic is NOT (measured: 15% of
+// inputs differ from IEEE by one ulp), which flips arclength buckets.
 __device__ __forceinline__ float edge_len(const float* __restrict__ pos, int64_t i) {  // |pos[i+1] - pos[i]|
   const float dx = pos[3 * (i + 1)] - pos[3 * i];
   const float dy = pos[3 * (i + 1) + 1] - pos[3 * i + 1];
   const float dz = pos[3 * (i + 1) + 2] - pos[3 * i + 2];
-  return __fsqrt_rn(ccn_sqdist3(dx, dy, dz));
+  return sqrtf(ccn_sqdist3(dx, dy, dz));
 }
 
 // ------------------------------------------------------------------ A7: CurveFPS
@@ -378,7 +380,7 @@ __global__ void group_superset_kernel(const float* __restrict__ pos, const int32
     if (cand < 0 || cand >= M) continue;
     const int64_t p = idx[cand];
     if (cid[p] != me) continue;
-    float cd = __fsqrt_rn(ccn_sqdist3(pos[3 * p] - px, pos[3 * p + 1] - py, pos[3 * p + 2] - pz));
+    float cd = sqrtf(ccn_sqdist3(pos[3 * p] - px, pos[3 * p + 1] - py, pos[3 * p + 2] - pz));
     int64_t ci = cand;
 #pragma unroll
     for (int t = 0; t < SUP_MAXK; ++t) {  // static indices only: the lists stay in registers

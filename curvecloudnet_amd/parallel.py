@@ -6,6 +6,7 @@ The reference has no distributed code at all; this is th
 section 8(e).  BatchNorm statistics stay per rank (a rank's result equals the reference run on
 that rank's sub-batch).  Works with the gloo backend on CPU tensors too (used by the tests).
 """
+import contextlib
 import os
 
 import torch
@@ -60,6 +61,7 @@ class GradientAllReduce:
             self._close(cur)
         self._pending = [0] * len(self.buckets)
         self._handles = []
+        self._quiet = False
         if self.world > 1:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -73,7 +75,19 @@ class GradientAllReduce:
             self._bucket_of[p] = len(self.buckets)
         self.buckets.append((flat, list(plist)))
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation over several backward passes: hooks stay quiet inside the block and
+        ``finish()`` reduces every bucket once."""
+        self._quiet = True
+        try:
+            yield
+        finally:
+            self._quiet = False
+
     def _on_grad(self, p):
+        if self._quiet:
+            return
         b = self._bucket_of[p]
         self._pending[b] += 1
         if self._pending[b] == len(self.buckets[b][1]):

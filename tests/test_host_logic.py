@@ -1,0 +1,100 @@
+"""CPU: host-side logic of the drop-in boundary -- config handling, dimension inference, state-dict
+layout (reference checkpoints must load with strict=True), the skip-connection bookkeeping."""
+import copy
+import os
+
+import pytest
+import torch
+import yaml
+
+from tests.util import ROOT, build_pair, hotpath_config
+
+# state-dict keys the reference produces, spot-checked literally
+EXPECTED_KEYS = [
+    "steps.0.conv_modules.0.weight", "steps.0.conv_modules.0.bias", "steps.0.norm_modules.2.running_var",
+    "steps.0.norm_modules.0.num_batches_tracked",
+    "steps.1.conv.local_nn.lins.0.weight", "steps.1.conv.local_nn.norms.2.module.running_mean",
+    "steps.1.conv.attend_nn.lins.1.weight", "steps.1.conv.attend_nn.norms.0.module.weight",
+    "steps.2.mlp.lins.3.weight", "steps.2.mlp.norms.3.module.bias",
+    "steps.3.nn.lins.2.weight", "steps.3.nn.norms.1.module.num_batches_tracked",
+    "steps.4.nn.lins.0.weight", "steps.7.nn.lins.1.weight", "steps.8.conv_modules.2.weight",
+    "mlp.lins.2.weight", "mlp.norms.1.module.running_var",
+]
+
+
+def test_state_dict_layout_and_shapes():
+    ref, mine = build_pair(hotpath_config(1.0), in_dim=4, n_out=20)
+    sd = mine.state_dict()
+    for k in EXPECTED_KEYS:
+        assert k in sd, k
+    assert list(sd.keys()) == list(ref.state_dict().keys())
+    assert sd["steps.0.conv_modules.0.weight"].shape == (32, 8, 3)          # (C_out, 2*C_in, k//2+1)
+    assert sd["steps.1.conv.local_nn.lins.0.weight"].shape == (64, 38)
+    assert sd["steps.1.conv.attend_nn.lins.0.weight"].shape == (256, 256)   # sa-geo attend: [C, C, C]
+    assert sd["steps.3.nn.lins.0.weight"].shape == (64, 134)
+    assert sd["steps.7.nn.lins.0.weight"].shape == (128, 99)
+    assert sd["steps.8.conv_modules.0.weight"].shape == (32, 262, 3)
+    assert sd["steps.9.nn.lins.0.weight"].shape == (128, 160)
+    assert sd["mlp.lins.2.weight"].shape == (20, 64)
+    assert not any(k.endswith("lins.0.bias") for k in sd)                    # use_bias: False
+    assert "steps.0.conv_modules.0.bias" in sd                              # conv bias is always on
+
+
+def test_dimension_inference_matches_reference_rules():
+    from curvecloudnet_amd.model import ModelBase
+    m = ModelBase.__new__(ModelBase)
+    fd = [[32, 32], [64, 128], [128], [64], [7]]
+    assert m._get_input_dim(0, "conv1d-fast-v2", fd, 4, True) == [4, 32, 32]
+    assert m._get_input_dim(0, "sgcnn", fd, 4, True) == [8, 32, 32]
+    assert m._get_input_dim(0, "sa-geo", fd, 3, True) == [6, 32, 32]
+    assert m._get_input_dim(1, "sa-geo", fd, 4, True) == [38, 64, 128]
+    assert m._get_input_dim(1, "sa", fd, 4, False) == [35, 64, 128]
+    assert m._get_input_dim(2, "sgcnn", fd, 4, True) == [262, 128]
+    assert m._get_input_dim(2, "mlp", fd, 4, True) == [131, 128]
+    assert m._get_input_dim(3, "skip-connect", fd, 4, False) == [64]
+    assert m._get_input_dim(3, "fp-geo", fd, 4, True) == [64]
+    with pytest.raises(NotImplementedError):
+        m._get_input_dim(1, "no-such-step", fd, 4, False)
+
+
+def test_attend_widths_follow_version():
+    cfg = hotpath_config(1.0)
+    cfg["steps"][3] = {"step_name": "sgcnn", "with_xyz": True, "aggr_type": "max"}
+    from curvecloudnet_amd.model import ModelBase
+    kw = {k: v for k, v in copy.deepcopy(cfg).items() if k != "type"}
+    m = ModelBase(4, 20, **kw)
+    assert m.steps[1].conv.attend_nn.channel_list == [256, 256, 256]
+    assert m.steps[3].attend_nn is None
+    assert m.step_names[4] == "skip-connect" and m.steps[4].num_skips == 1
+
+
+def test_reference_yaml_schema_is_accepted(tmp_path):
+    """A YAML written in the reference's schema loads through load_model_config / build_model."""
+    from curvecloudnet_amd.model import build_model, load_model_config
+    cfg = {"batch_size": 1, "dataset_source": "kitti", "model": hotpath_config(0.25)}
+    p = tmp_path / "cfg.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    m = build_model(load_model_config(str(p)), in_dim=4, n_out=20)
+    assert len(m.steps) == 10 and m.mlp.channel_list[-1] == 20
+    # checkpoints written by the reference layout load strictly
+    ref, _ = build_pair(hotpath_config(0.25), 4, 20)
+    m.load_state_dict(ref.state_dict(), strict=True)
+
+
+def test_unsupported_steps_fail_loudly():
+    from curvecloudnet_amd.model import ModelBase
+    with pytest.raises(NotImplementedError):
+        ModelBase(3, 5, steps=["sa-global"], feat_dims=[[8]], knn=[None], ratios=[None], radii=[None])
+    with pytest.raises(NotImplementedError):
+        ModelBase(3, 5, steps=["bogus"], feat_dims=[[8]])
+
+
+def test_synthetic_cloud_matches_survey_draw():
+    from curvecloudnet_amd.synth import make_batch, make_cloud
+    c = make_cloud(0)
+    assert c.pos.shape == (49652, 3) and int(c.curve_idxs[-1]) == 2047      # SURVEY.md section 6 draw
+    assert torch.unique(c.pos, dim=0).size(0) == c.pos.size(0)              # no duplicate points
+    b = make_batch([0, 1], n_curves=16)
+    assert b.batch.max() == 1 and b.curve_idxs.min() == 0
+    mixed = make_cloud(3, n_curves=64, mixed_lengths=True)
+    assert mixed.lengths.max() <= 512 and mixed.lengths.min() >= 1
