@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""Headline benchmark: point-clouds/s, forward + backward (+ Adam step), synthetic 2048-curve / ~50k-point
+clouds through the CurveCloudNet hot path on N MI355X GPUs.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+One step = one batch of `--clouds-per-gpu` clouds per GPU: forward, mean-NLL loss, backward, gradient
+all-reduce (N > 1, RCCL), Adam update.  Rank 0 prints ONE JSON line (contract in the task prompt), with
+  roofline      -- the dominant kernel of the timed region, timed live with HIP events on its stream
+  cpu_baseline  -- the CPU oracle (oracle/torch_ref.py, kind "port") timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from curvecloudnet_amd import _lib                                              # noqa: E402
+from curvecloudnet_amd.model import ModelBase, segmentation_loss               # noqa: E402
+from curvecloudnet_amd.parallel import GradientAllReduce, init_process_group_from_env  # noqa: E402
+from curvecloudnet_amd.synth import make_batch, to_device                      # noqa: E402
+from tests.util import hotpath_config                                          # noqa: E402
+
+N_CLASSES = 20
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+
+
+def gemm_label(name, ints):
+    """(kernel label, flops) of a GEMM launch; mirrors the tile dispatch in csrc/ccn_gemm.hip."""
+    if name == "gemm_nt":
+        m, n, k = ints[3], ints[4], ints[5]
+        bn = 32 if n <= 32 else (64 if n <= 64 else 128)
+        return "gemm_kernel<128,%d,4,KC,KC,STORE> (gemm_nt)" % bn, 2.0 * m * n * k
+    if name == "gemm_nn":
+        m, n, k = ints[3], ints[4], ints[5]
+        bn = 32 if k <= 32 else (64 if k <= 64 else 128)
+        return "gemm_kernel<128,%d,4,KC,MC,STORE> (gemm_nn)" % bn, 2.0 * m * n * k
+    if name == "gemm_tn":
+        m, n, k = ints[3], ints[4], ints[5]
+        tile = "32,128,1" if n <= 32 else ("64,64,2" if k <= 64 else "64,128,2")
+        return "gemm_kernel<%s,MC,MC,ATOMIC> (gemm_tn)" % tile, 2.0 * m * n * k
+    return None, 0.0
+
+
+def summarise_profile(records, steps):
+    torch.cuda.synchronize()
+    table = {}
+    for name, ints, beg, end in records:
+        label, flops = gemm_label(name, ints)
+        key = label or name
+        t = table.setdefault(key, {"ms": 0.0, "launches": 0, "flops": 0.0})
+        t["ms"] += beg.elapsed_time(end)
+        t["launches"] += 1
+        t["flops"] += flops
+    total = sum(t["ms"] for t in table.values())
+    rows = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
+    return rows, total
+
+
+def cpu_baseline(cfg, seed):
+    """The oracle timed on the host: 1 cloud (2048 curves, ~50k points) per step, forward + backward + Adam."""
+    from oracle import torch_ref as R
+    import copy
+    kw = {k: v for k, v in copy.deepcopy(cfg).items() if k != "type"}
+    torch.manual_seed(seed)
+    model = R.ModelBase(4, N_CLASSES, **kw).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    data = make_batch([0])
+    labels = torch.randint(0, N_CLASSES, (data.pos.size(0),), generator=torch.Generator().manual_seed(1))
+    times = []
+    for it in range(3):                      # 1 warm-up + 2 timed
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss = R.segmentation_loss(model(data), labels)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": 1.0 / best, "unit": "clouds/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/torch_ref.py ModelBase, 1 cloud (2048 curves, %d points) per step, fwd+bwd+Adam, "
+                      "best of 2 timed steps after 1 warm-up (%.1f s of CPU work)" % (data.pos.size(0), sum(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--clouds-per-gpu", type=int, default=8)
+    ap.add_argument("--width", type=float, default=1.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local_rank = init_process_group_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = hotpath_config(width=args.width)
+    kw = {k: v for k, v in cfg.items() if k != "type"}
+    torch.manual_seed(1234)                                  # identical replicas on every rank
+    model = ModelBase(4, N_CLASSES, **kw).to(dev).train()
+    sync = GradientAllReduce(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, foreach=True)
+
+    b = args.clouds_per_gpu
+    cloud_ids = list(range(rank * b, rank * b + b))          # weak scaling: a fixed number of whole clouds per GPU
+    data = to_device(make_batch(cloud_ids), dev)             # inputs resident in HBM before the timed region
+    n_points = data.pos.size(0)
+    labels = torch.randint(0, N_CLASSES, (n_points,), generator=torch.Generator().manual_seed(rank)).to(dev)
+
+    def step():
+        sync.zero_grad()
+        torch.manual_seed(7)                                 # fixes the CurveFPS phase draws
+        loss = segmentation_loss(model(data), labels)
+        loss.backward()
+        sync.finish()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    if not args.no_kernel_timing:
+        _lib.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    records, _lib.PROFILE = _lib.PROFILE, None
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        return
+
+    result = {
+        "metric": "point-clouds/sec fwd+bwd @50k pts", "value": world * b * args.steps / elapsed, "unit": "clouds/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1] shape: %d clouds/GPU x 2048 curves (~50k points each, %d points "
+                               "on rank 0), fp32 curve-conv + HIP FRNN + MFMA MLP stack; hot-path network of "
+                               "SURVEY.md section 8a (conv1d-fast-v2, sa-geo, mlp, 2x sgcnn K=20, skip-connect, "
+                               "fp-geo, conv1d-fast-v2) at KITTI widths x%g; fwd + mean-NLL + bwd + Adam"
+                               % (b, n_points, args.width),
+                   "clouds_per_gpu": b, "points_per_cloud": n_points // b, "parallelism": "dp%d" % world,
+                   "loss": float(loss)},
+    }
+    if records:
+        rows, total_ms = summarise_profile(records, args.steps)
+        name, top = rows[0]
+        if top["flops"] > 0:
+            achieved = top["flops"] / (top["ms"] * 1e-3) / 1e12
+            result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                                  "kernel": name, "avg_launch_ms": top["ms"] / top["launches"],
+                                  "launches": top["launches"], "share_of_kernel_time": top["ms"] / total_ms}
+        else:
+            result["roofline"] = {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
+                                  "traffic": None, "kernel": name, "avg_launch_ms": top["ms"] / top["launches"],
+                                  "launches": top["launches"], "share_of_kernel_time": top["ms"] / total_ms}
+        result["kernel_time_ms_per_step"] = total_ms / args.steps
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_kernels.txt"), "w") as f:
+            f.write("per-kernel time inside the timed region (HIP events on the launch stream), %d steps\n" % args.steps)
+            for k, t in rows:
+                tf = " %7.1f TFLOP/s" % (t["flops"] / (t["ms"] * 1e-3) / 1e12) if t["flops"] else ""
+                f.write("%9.2f ms %5.1f%% %6d launches  %s%s\n" % (t["ms"], 100 * t["ms"] / total_ms, t["launches"], k, tf))
+    if not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline(cfg, 1234)
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

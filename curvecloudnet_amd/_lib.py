@@ -77,10 +77,21 @@ def check(rc, what):
         raise RuntimeError("libccn_hip %s failed (%d): %s" % (what, rc, lib().ccn_last_error().decode()))
 
 
+PROFILE = None   # bench.py sets this to a list to time every launch with HIP events on the launch stream
+
+
 def call(name, *args):
     """Invoke ``ccn_<name>`` on the current torch stream (appended as the last argument)."""
     fn = getattr(lib(), "ccn_" + name)
+    if PROFILE is None:
+        check(fn(*args, stream()), name)
+        return
+    # torch.cuda.Event records on torch's current stream, which is exactly the stream passed to the kernel
+    beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    beg.record()
     check(fn(*args, stream()), name)
+    end.record()
+    PROFILE.append((name, tuple(a for a in args if isinstance(a, int)), beg, end))
 
 
 def require_gpu(*tensors):
