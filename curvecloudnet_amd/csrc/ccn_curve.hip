@@ -166,31 +166,36 @@ __global__ void diff_concat_bwd_kernel(const float* __restrict__ x, int64_t ldx,
 }
 
 // ------------------------------------------------------------------ A4: shifted rows
-__global__ void im2col_fwd_kernel(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ seg,
-                                  int64_t rows, int64_t C, int64_t taps, float* __restrict__ col) {
-  const int64_t width = taps * C;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * width) return;
-  const int64_t i = t / width, rem = t - i * width;
-  const int64_t tap = rem / C, c = rem - tap * C;
-  const int64_t j = i + tap - taps / 2;
-  float v = 0.0f;
-  if (j >= 0 && j < rows && (seg == nullptr || seg[j] == seg[i])) v = x[j * ldx + c];
-  col[t] = v;
+// one wave per output row; lanes stride over the channels of each tap (256 contiguous bytes per access)
+__global__ __launch_bounds__(256) void im2col_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         const int32_t* __restrict__ seg, int64_t rows, int C,
+                                                         int taps, float* __restrict__ col, int64_t ldcol) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 4 + ry;
+  if (i >= rows) return;
+  const int32_t me = seg ? seg[i] : 0;
+  for (int tap = 0; tap < taps; ++tap) {
+    const int64_t j = i + tap - taps / 2;
+    const bool ok = j >= 0 && j < rows && (seg == nullptr || seg[j] == me);
+    for (int c = cx; c < C; c += 64) col[i * ldcol + tap * C + c] = ok ? x[j * ldx + c] : 0.0f;
+  }
 }
 
-__global__ void im2col_bwd_kernel(const float* __restrict__ dcol, const int32_t* __restrict__ seg, int64_t rows,
-                                  int64_t C, int64_t taps, float* __restrict__ dx, int64_t lddx) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * C) return;
-  const int64_t j = t / C, c = t - j * C;
-  const int64_t width = taps * C;
-  float acc = 0.0f;
-  for (int64_t tap = 0; tap < taps; ++tap) {
-    const int64_t i = j - tap + taps / 2;  // output row whose tap `tap` read x[j]
-    if (i >= 0 && i < rows && (seg == nullptr || seg[i] == seg[j])) acc += dcol[i * width + tap * C + c];
+__global__ __launch_bounds__(256) void im2col_bwd_kernel(const float* __restrict__ dcol, int64_t ldcol,
+                                                         const int32_t* __restrict__ seg, int64_t rows, int C,
+                                                         int taps, float* __restrict__ dx, int64_t lddx) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t j = (int64_t)blockIdx.x * 4 + ry;
+  if (j >= rows) return;
+  const int32_t me = seg ? seg[j] : 0;
+  for (int c = cx; c < C; c += 64) {
+    float acc = 0.0f;
+    for (int tap = 0; tap < taps; ++tap) {
+      const int64_t i = j - tap + taps / 2;  // output row whose tap `tap` read x[j]
+      if (i >= 0 && i < rows && (seg == nullptr || seg[i] == me)) acc += dcol[i * ldcol + tap * C + c];
+    }
+    dx[j * lddx + c] = acc;
   }
-  dx[j * lddx + c] = acc;
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ src, int64_t lds_, const int64_t* __restrict__ index,
@@ -561,21 +566,25 @@ int ccn_diff_concat_bwd(const float* x, int64_t ldx, const int32_t* cid, int64_t
 }
 
 int ccn_im2col_fwd(const float* x, int64_t ldx, const int32_t* seg, int64_t rows, int64_t C, int64_t taps, float* col,
-                   void* stream) {
-  CCN_REQUIRE(x && col && ldx >= C && taps >= 1 && (taps & 1), "im2col_fwd: bad arguments");
-  if (rows * C == 0) return CCN_OK;
-  hipLaunchKernelGGL(im2col_fwd_kernel, dim3(ccn_blocks(rows * taps * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, x,
-                     ldx, seg, rows, C, taps, col);
+                   int64_t ldcol, void* stream) {
+  CCN_REQUIRE(x && col && ldx >= C && taps >= 1 && (taps & 1) && taps < 64 && C > 0 && C < (1 << 24) &&
+                  ldcol >= taps * C,
+              "im2col_fwd: bad arguments");
+  if (rows == 0) return CCN_OK;
+  hipLaunchKernelGGL(im2col_fwd_kernel, dim3(ccn_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, seg, rows,
+                     (int)C, (int)taps, col, ldcol);
   CCN_LAUNCH_OK("im2col_fwd");
   return CCN_OK;
 }
 
-int ccn_im2col_bwd(const float* dcol, const int32_t* seg, int64_t rows, int64_t C, int64_t taps, float* dx,
-                   int64_t lddx, void* stream) {
-  CCN_REQUIRE(dcol && dx && lddx >= C && taps >= 1 && (taps & 1), "im2col_bwd: bad arguments");
-  if (rows * C == 0) return CCN_OK;
-  hipLaunchKernelGGL(im2col_bwd_kernel, dim3(ccn_blocks(rows * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, dcol, seg,
-                     rows, C, taps, dx, lddx);
+int ccn_im2col_bwd(const float* dcol, int64_t ldcol, const int32_t* seg, int64_t rows, int64_t C, int64_t taps,
+                   float* dx, int64_t lddx, void* stream) {
+  CCN_REQUIRE(dcol && dx && lddx >= C && taps >= 1 && (taps & 1) && taps < 64 && C > 0 && C < (1 << 24) &&
+                  ldcol >= taps * C,
+              "im2col_bwd: bad arguments");
+  if (rows == 0) return CCN_OK;
+  hipLaunchKernelGGL(im2col_bwd_kernel, dim3(ccn_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream, dcol, ldcol, seg,
+                     rows, (int)C, (int)taps, dx, lddx);
   CCN_LAUNCH_OK("im2col_bwd");
   return CCN_OK;
 }

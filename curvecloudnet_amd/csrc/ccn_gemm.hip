@@ -298,18 +298,47 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
   }
 }
 
-// sums[w] = sum_p partial[p][w], w < width; one workgroup per 64 columns
-__global__ __launch_bounds__(256) void col_final_kernel(const double* __restrict__ partial, int64_t nparts,
-                                                        int64_t width, double* __restrict__ sums) {
+// Two-level deterministic reduction of the partial rows: sums[w] = sum_p partial[p][w], w < width.
+// Level 1: grid (width/64, slices): every workgroup folds `per_slice` consecutive partial rows into the
+// first row of its slice (in place).  Level 2: one workgroup per 64 columns adds the slice heads.
+__global__ __launch_bounds__(256) void col_slice_kernel(double* __restrict__ partial, int64_t nparts, int64_t width,
+                                                        int64_t per_slice) {
+  __shared__ double red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t w = (int64_t)blockIdx.x * 64 + cx;
+  const int64_t p0 = (int64_t)blockIdx.y * per_slice;
+  const int64_t p1 = p0 + per_slice < nparts ? p0 + per_slice : nparts;
+  double s = 0.0;
+  if (w < width)
+    for (int64_t p = p0 + ry; p < p1; p += 4) s += partial[p * width + w];
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && w < width && p0 < nparts) partial[p0 * width + w] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+}
+
+__global__ __launch_bounds__(256) void col_final_kernel(const double* __restrict__ partial, int64_t nslices,
+                                                        int64_t per_slice, int64_t width, double* __restrict__ sums) {
   __shared__ double red[4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int64_t w = (int64_t)blockIdx.x * 64 + cx;
   double s = 0.0;
   if (w < width)
-    for (int64_t p = ry; p < nparts; p += 4) s += partial[p * width + w];
+    for (int64_t p = ry; p < nslices; p += 4) s += partial[p * per_slice * width + w];
   red[ry][cx] = s;
   __syncthreads();
   if (ry == 0 && w < width) sums[w] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+}
+
+void launch_col_reduce(double* partial, int64_t nparts, int64_t width, double* sums, hipStream_t s) {
+  int64_t nslices = (nparts + 7) / 8;
+  if (nslices > 256) nslices = 256;
+  if (nslices < 1) nslices = 1;
+  const int64_t per_slice = (nparts + nslices - 1) / nslices;
+  nslices = (nparts + per_slice - 1) / per_slice;
+  const unsigned gx = (unsigned)ccn_blocks(width, 64);
+  if (per_slice > 1)
+    hipLaunchKernelGGL(col_slice_kernel, dim3(gx, (unsigned)nslices), dim3(256), 0, s, partial, nparts, width, per_slice);
+  hipLaunchKernelGGL(col_final_kernel, dim3(gx), dim3(256), 0, s, partial, nslices, per_slice, width, sums);
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t rows, int64_t C,
@@ -351,13 +380,16 @@ __global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const flo
   save_rstd[c] = rstd;
 }
 
-__global__ void bn_act_fwd_kernel(const float* __restrict__ Y, int64_t ldy, int64_t rows, int64_t C,
-                                  const float* __restrict__ scale, const float* __restrict__ shift, int act,
-                                  float slope, float* __restrict__ Z, int64_t ldz) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * C) return;
-  const int64_t r = t / C, c = t - r * C;
-  Z[r * ldz + c] = act_fwd(Y[r * ldy + c] * scale[c] + shift[c], act, slope);
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ Y, int64_t ldy, int64_t rows,
+                                                         int C, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int act, float slope,
+                                                         float* __restrict__ Z, int64_t ldz) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * 32;
+  for (int c = cx; c < C; c += 64) {
+    const float sc = scale[c], sh = shift[c];
+    for (int64_t r = r0 + ry; r < r0 + 32 && r < rows; r += 4) Z[r * ldz + c] = act_fwd(Y[r * ldy + c] * sc + sh, act, slope);
+  }
 }
 
 __global__ void bn_act_fwd_vec_kernel(const float4* __restrict__ Y, int64_t ldy4, int64_t rows, int64_t C4,
@@ -375,30 +407,26 @@ __global__ void bn_act_fwd_vec_kernel(const float4* __restrict__ Y, int64_t ldy4
   Z[r * ldz4 + c] = z;
 }
 
-__global__ void bn_act_bwd_apply_kernel(const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ Y,
-                                        int64_t ldy, int64_t rows, int64_t C, const float* __restrict__ scale,
-                                        const float* __restrict__ shift, const float* __restrict__ mean,
-                                        const float* __restrict__ rstd, int act, float slope,
-                                        const double* __restrict__ sums, int training, float* __restrict__ dY,
-                                        int64_t lddy, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * C) return;
-  const int64_t r = t / C, c = t - r * C;
-  const float y = Y[r * ldy + c];
-  const float sc = scale[c];
-  const float g = dZ[r * lddz + c] * act_grad(y * sc + shift[c], act, slope);
-  float out;
-  if (training) {
-    const float inv_n = 1.0f / (float)rows;
-    const float xhat = (y - mean[c]) * rstd[c];
-    out = sc * (g - (float)sums[c] * inv_n - xhat * ((float)sums[C + c] * inv_n));
-  } else {
-    out = sc * g;
-  }
-  dY[r * lddy + c] = out;
-  if (r == 0) {
-    if (dgamma) dgamma[c] = (float)sums[C + c];
-    if (dbeta) dbeta[c] = (float)sums[c];
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
+    const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ Y, int64_t ldy, int64_t rows, int C,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ rstd, int act, float slope, const double* __restrict__ sums, int training,
+    float* __restrict__ dY, int64_t lddy, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * 32;
+  const float inv_n = 1.0f / (float)rows;
+  for (int c = cx; c < C; c += 64) {
+    const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
+    const float m1 = (float)sums[c] * inv_n, m2 = (float)sums[C + c] * inv_n;
+    for (int64_t r = r0 + ry; r < r0 + 32 && r < rows; r += 4) {
+      const float y = Y[r * ldy + c];
+      const float g = dZ[r * lddz + c] * act_grad(y * sc + sh, act, slope);
+      dY[r * lddy + c] = training ? sc * (g - m1 - (y - mu) * rs * m2) : sc * g;
+    }
+    if (blockIdx.x == 0 && ry == 0) {
+      if (dgamma) dgamma[c] = (float)sums[C + c];
+      if (dbeta) dbeta[c] = (float)sums[c];
+    }
   }
 }
 
@@ -485,7 +513,7 @@ int ccn_bn_finalize(const double* colstats, int64_t rows, int64_t C, const float
   CCN_REQUIRE(colstats && scale && shift && save_mean && save_rstd && rows > 0 && C > 0, "bn_finalize: bad arguments");
   const int64_t nparts = ccn_stats_rows(rows);
   double* sums = const_cast<double*>(colstats) + nparts * 2 * C;
-  hipLaunchKernelGGL(col_final_kernel, dim3(ccn_blocks(2 * C, 64)), dim3(256), 0, s, colstats, nparts, 2 * C, sums);
+  launch_col_reduce(const_cast<double*>(colstats), nparts, 2 * C, sums, s);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ccn_blocks(C, 128)), dim3(128), 0, s, sums, rows, C, gamma, beta, eps,
                      momentum, running_mean, running_var, scale, shift, save_mean, save_rstd);
   CCN_LAUNCH_OK("bn_finalize");
@@ -514,8 +542,8 @@ int ccn_bn_act_fwd(const float* Y, int64_t ldy, int64_t rows, int64_t C, const f
                        (const float4*)Y, ldy / 4, rows, C / 4, (const float4*)scale, (const float4*)shift, act, slope,
                        (float4*)Z, ldz / 4);
   else
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ccn_blocks(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, Y, ldy,
-                       rows, C, scale, shift, act, slope, Z, ldz);
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(ccn_blocks(rows, 32)), dim3(256), 0, (hipStream_t)stream, Y, ldy, rows,
+                       (int)C, scale, shift, act, slope, Z, ldz);
   CCN_LAUNCH_OK("bn_act_fwd");
   return CCN_OK;
 }
@@ -530,7 +558,7 @@ int ccn_bn_act_bwd_reduce(const float* dZ, int64_t lddz, const float* Y, int64_t
   double* partial = sums + 2 * C;
   hipLaunchKernelGGL(col_partial_kernel<1>, dim3((unsigned)nparts), dim3(256), 0, s, dZ, lddz, Y, ldy, rows, C, scale,
                      shift, mean, rstd, act, slope, partial);
-  hipLaunchKernelGGL(col_final_kernel, dim3(ccn_blocks(2 * C, 64)), dim3(256), 0, s, partial, nparts, 2 * C, sums);
+  launch_col_reduce(partial, nparts, 2 * C, sums, s);
   CCN_LAUNCH_OK("bn_act_bwd_reduce");
   return CCN_OK;
 }
@@ -541,8 +569,8 @@ int ccn_bn_act_bwd_apply(const float* dZ, int64_t lddz, const float* Y, int64_t 
                          float* dbeta, void* stream) {
   CCN_REQUIRE(dZ && Y && scale && shift && mean && rstd && sums && dY && rows > 0 && C > 0,
               "bn_act_bwd_apply: bad arguments");
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ccn_blocks(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, dZ,
-                     lddz, Y, ldy, rows, C, scale, shift, mean, rstd, act, slope, sums, training, dY, lddy, dgamma,
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ccn_blocks(rows, 32)), dim3(256), 0, (hipStream_t)stream, dZ, lddz,
+                     Y, ldy, rows, (int)C, scale, shift, mean, rstd, act, slope, sums, training, dY, lddy, dgamma,
                      dbeta);
   CCN_LAUNCH_OK("bn_act_bwd_apply");
   return CCN_OK;
@@ -557,7 +585,7 @@ int ccn_colsum(const float* X, int64_t ldx, int64_t rows, int64_t C, double* acc
   hipLaunchKernelGGL(col_partial_kernel<0>, dim3((unsigned)nparts), dim3(256), 0, s, X, ldx, (const float*)nullptr,
                      (int64_t)0, rows, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, 0, 0.f, partial);
-  hipLaunchKernelGGL(col_final_kernel, dim3(ccn_blocks(2 * C, 64)), dim3(256), 0, s, partial, nparts, 2 * C, acc);
+  launch_col_reduce(partial, nparts, 2 * C, acc, s);
   hipLaunchKernelGGL(colsum_out_kernel, dim3(ccn_blocks(C, 128)), dim3(128), 0, s, acc, C, out);
   CCN_LAUNCH_OK("colsum");
   return CCN_OK;

@@ -15,11 +15,61 @@ LEAKY_SLOPE = 0.01  # torch.nn.LeakyReLU default, the only slope the reference u
 
 
 def _mat(t):
-    """contiguous float32 2-D tensor"""
+    """float32 2-D row-major matrix, possibly with a padded leading dimension (a column-slice view)."""
     require_gpu(t)
     if t.dtype != torch.float32:
         raise TypeError("expected float32, got %s" % t.dtype)
+    if t.dim() == 2 and t.size(1) > 0 and t.stride(1) == 1 and t.stride(0) >= t.size(1):
+        return t
     return t.contiguous()
+
+
+def _ld(t):
+    """leading dimension (elements between consecutive rows)"""
+    return max(t.stride(0), t.size(1), 1) if t.dim() == 2 else t.size(-1)
+
+
+def _rows(rows, cols, device, zero=False):
+    """(rows, cols) float32 matrix whose rows start 16-byte aligned (leading dimension padded to a multiple
+    of 4), so that the GEMM loaders can use 16-byte loads for widths like 67, 131, 134 or 259."""
+    ld = (cols + 3) // 4 * 4
+    alloc = torch.zeros if zero else torch.empty
+    buf = alloc((rows, ld), dtype=torch.float32, device=device)
+    return buf if ld == cols else buf[:, :cols]
+
+
+def cat_cols(parts):
+    """torch.cat(parts, dim=1) into an aligned-row buffer (autograd: plain column slices)."""
+    parts = [p for p in parts if p is not None]
+    if len(parts) == 1:
+        return parts[0]
+    return _CatCols.apply(*parts)
+
+
+class _CatCols(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *parts):
+        widths = [p.size(1) for p in parts]
+        out = _rows(parts[0].size(0), sum(widths), parts[0].device)
+        off = 0
+        for p, w in zip(parts, widths):
+            out[:, off:off + w].copy_(p)
+            off += w
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for w in ctx.widths:
+            outs.append(g[:, off:off + w])
+            off += w
+        return tuple(outs)
+
+
+def _pos(t):
+    """(N, 3) positions, densely packed (the index kernels read xyz with stride 3)."""
+    return _mat(t).contiguous()
 
 
 def _i64(t):
@@ -92,8 +142,8 @@ class GatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, index, unique):
         src, index = _mat(src), _i64(index)
-        out = torch.empty((index.numel(), src.size(1)), dtype=src.dtype, device=src.device)
-        call("gather_rows", ptr(src), src.size(1), ptr(index), index.numel(), src.size(1), ptr(out), out.size(1))
+        out = _rows(index.numel(), src.size(1), src.device)
+        call("gather_rows", ptr(src), _ld(src), ptr(index), index.numel(), src.size(1), ptr(out), _ld(out))
         ctx.save_for_backward(index)
         ctx.rows, ctx.unique = src.size(0), unique
         return out
@@ -102,8 +152,8 @@ class GatherRows(torch.autograd.Function):
     def backward(ctx, g):
         (index,) = ctx.saved_tensors
         g = _mat(g)
-        dsrc = torch.zeros((ctx.rows, g.size(1)), dtype=g.dtype, device=g.device)
-        call("scatter_rows", ptr(g), g.size(1), ptr(index), index.numel(), g.size(1), ptr(dsrc), g.size(1),
+        dsrc = _rows(ctx.rows, g.size(1), g.device, zero=True)
+        call("scatter_rows", ptr(g), _ld(g), ptr(index), index.numel(), g.size(1), ptr(dsrc), _ld(dsrc),
              0 if ctx.unique else 1)
         return dsrc, None, None
 
@@ -118,8 +168,8 @@ class ScatterRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, index, rows):
         src, index = _mat(src), _i64(index)
-        out = torch.zeros((rows, src.size(1)), dtype=src.dtype, device=src.device)
-        call("scatter_rows", ptr(src), src.size(1), ptr(index), index.numel(), src.size(1), ptr(out), out.size(1), 0)
+        out = _rows(rows, src.size(1), src.device, zero=True)
+        call("scatter_rows", ptr(src), _ld(src), ptr(index), index.numel(), src.size(1), ptr(out), _ld(out), 0)
         ctx.save_for_backward(index)
         return out
 
@@ -127,8 +177,8 @@ class ScatterRows(torch.autograd.Function):
     def backward(ctx, g):
         (index,) = ctx.saved_tensors
         g = _mat(g)
-        d = torch.empty((index.numel(), g.size(1)), dtype=g.dtype, device=g.device)
-        call("gather_rows", ptr(g), g.size(1), ptr(index), index.numel(), g.size(1), ptr(d), g.size(1))
+        d = _rows(index.numel(), g.size(1), g.device)
+        call("gather_rows", ptr(g), _ld(g), ptr(index), index.numel(), g.size(1), ptr(d), _ld(d))
         return d, None, None
 
 
@@ -143,8 +193,8 @@ class DiffConcat(torch.autograd.Function):
     def forward(ctx, x, cid):
         x = _mat(x)
         n, c = x.shape
-        out = torch.empty((n, 2 * c), dtype=x.dtype, device=x.device)
-        call("diff_concat_fwd", ptr(x), c, ptr(cid), n, c, ptr(out), 2 * c)
+        out = _rows(n, 2 * c, x.device)
+        call("diff_concat_fwd", ptr(x), _ld(x), ptr(cid), n, c, ptr(out), _ld(out))
         ctx.save_for_backward(x, cid)
         return out
 
@@ -153,8 +203,8 @@ class DiffConcat(torch.autograd.Function):
         x, cid = ctx.saved_tensors
         g = _mat(g)
         n, c = x.shape
-        dx = torch.empty_like(x)
-        call("diff_concat_bwd", ptr(x), c, ptr(cid), n, c, ptr(g), 2 * c, ptr(dx), c)
+        dx = _rows(n, c, x.device)
+        call("diff_concat_bwd", ptr(x), _ld(x), ptr(cid), n, c, ptr(g), _ld(g), ptr(dx), _ld(dx))
         return dx, None
 
 
@@ -171,8 +221,8 @@ class Im2Col(torch.autograd.Function):
     def forward(ctx, x, seg, taps):
         x = _mat(x)
         rows, c = x.shape
-        col = torch.empty((rows, taps * c), dtype=x.dtype, device=x.device)
-        call("im2col_fwd", ptr(x), c, ptr(seg), rows, c, taps, ptr(col))
+        col = _rows(rows, taps * c, x.device)
+        call("im2col_fwd", ptr(x), _ld(x), ptr(seg), rows, c, taps, ptr(col), _ld(col))
         ctx.seg, ctx.taps, ctx.c = seg, taps, c
         return col
 
@@ -180,8 +230,8 @@ class Im2Col(torch.autograd.Function):
     def backward(ctx, g):
         g = _mat(g)
         rows = g.size(0)
-        dx = torch.empty((rows, ctx.c), dtype=g.dtype, device=g.device)
-        call("im2col_bwd", ptr(g), ptr(ctx.seg), rows, ctx.c, ctx.taps, ptr(dx), ctx.c)
+        dx = _rows(rows, ctx.c, g.device)
+        call("im2col_bwd", ptr(g), _ld(g), ptr(ctx.seg), rows, ctx.c, ctx.taps, ptr(dx), _ld(dx))
         return dx, None, None
 
 
@@ -194,6 +244,16 @@ def _stats_buffer(rows, c, device):
     return torch.empty((parts + 1) * 2 * c, dtype=torch.float64, device=device)
 
 
+def _aligned_weight(weight):
+    """(N, K) weight with rows padded to a multiple of 4 floats (16-byte loads in the GEMM tiles)."""
+    k = weight.size(1)
+    if k % 4 == 0 and weight.is_contiguous():
+        return weight
+    wp = _rows(weight.size(0), k, weight.device, zero=True)
+    wp.copy_(weight)
+    return wp
+
+
 class LinearBNAct(torch.autograd.Function):
     """y = act(BN(x W^T + b)) with batch statistics taken in the GEMM epilogue.
 
@@ -203,34 +263,36 @@ class LinearBNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum):
-        x, weight = _mat(x), _mat(weight)
+        x = _mat(x)
+        require_gpu(weight)
         m, k = x.shape
         n = weight.size(0)
         if weight.size(1) != k:
             raise ValueError("linear: input has %d channels, weight expects %d" % (k, weight.size(1)))
         dev = x.device
-        y = torch.empty((m, n), dtype=torch.float32, device=dev)
+        w = _aligned_weight(weight.detach())
+        y = _rows(m, n, dev)
         has_bn = gamma is not None
         ctx.has_bn, ctx.act, ctx.training, ctx.has_bias = has_bn, ACT[act], bool(training), bias is not None
         if not has_bn:
-            call("gemm_nt", ptr(x), k, ptr(weight), k, ptr(bias), ptr(y), n, m, n, k, None)
-            ctx.save_for_backward(x, weight)
+            call("gemm_nt", ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, None)
+            ctx.save_for_backward(x, w)
             return y
         par = torch.empty((4, n), dtype=torch.float32, device=dev)      # scale, shift, mean, rstd
         if training:
             if m < 2:
                 raise ValueError("Expected more than 1 value per channel when training")
             stats = _stats_buffer(m, n, dev)
-            call("gemm_nt", ptr(x), k, ptr(weight), k, ptr(bias), ptr(y), n, m, n, k, ptr(stats))
+            call("gemm_nt", ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats))
             call("bn_finalize", ptr(stats), m, n, ptr(gamma), ptr(beta), float(eps), float(momentum),
                  ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
         else:
-            call("gemm_nt", ptr(x), k, ptr(weight), k, ptr(bias), ptr(y), n, m, n, k, None)
+            call("gemm_nt", ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, None)
             call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), n,
                  ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
-        z = torch.empty_like(y)
-        call("bn_act_fwd", ptr(y), n, m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), n)
-        ctx.save_for_backward(x, weight, y, par)
+        z = _rows(m, n, dev)
+        call("bn_act_fwd", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
+        ctx.save_for_backward(x, w, y, par)
         return z
 
     @staticmethod
@@ -238,32 +300,33 @@ class LinearBNAct(torch.autograd.Function):
         g = _mat(g)
         dev = g.device
         if ctx.has_bn:
-            x, weight, y, par = ctx.saved_tensors
+            x, w, y, par = ctx.saved_tensors
             m, n = y.shape
             sums = _stats_buffer(m, n, dev)
-            call("bn_act_bwd_reduce", ptr(g), n, ptr(y), n, m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]),
-                 ctx.act, LEAKY_SLOPE, ptr(sums))
-            dy = torch.empty_like(y)
+            call("bn_act_bwd_reduce", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                 ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums))
+            dy = _rows(m, n, dev)
             dgb = torch.empty((2, n), dtype=torch.float32, device=dev)
-            call("bn_act_bwd_apply", ptr(g), n, ptr(y), n, m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]),
-                 ctx.act, LEAKY_SLOPE, ptr(sums), 1 if ctx.training else 0, ptr(dy), n, ptr(dgb[0]), ptr(dgb[1]))
+            call("bn_act_bwd_apply", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                 ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums), 1 if ctx.training else 0, ptr(dy), _ld(dy),
+                 ptr(dgb[0]), ptr(dgb[1]))
             dgamma, dbeta = dgb[0], dgb[1]
         else:
-            x, weight = ctx.saved_tensors
+            x, w = ctx.saved_tensors
             dy, dgamma, dbeta = g, None, None
             m, n = dy.shape
         k = x.size(1)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((m, k), dtype=torch.float32, device=dev)
-            call("gemm_nn", ptr(dy), n, ptr(weight), k, ptr(dx), k, m, n, k)
-        dw = torch.zeros((n, k), dtype=torch.float32, device=dev)
-        call("gemm_tn", ptr(dy), n, ptr(x), k, ptr(dw), k, m, n, k)
+            dx = _rows(m, k, dev)
+            call("gemm_nn", ptr(dy), _ld(dy), ptr(w), _ld(w), ptr(dx), _ld(dx), m, n, k)
+        dw = _rows(n, k, dev, zero=True)
+        call("gemm_tn", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
         db = None
         if ctx.has_bias:
             acc = _stats_buffer(m, n, dev)
             db = torch.empty(n, dtype=torch.float32, device=dev)
-            call("colsum", ptr(dy), n, m, n, ptr(acc), ptr(db))
+            call("colsum", ptr(dy), _ld(dy), m, n, ptr(acc), ptr(db))
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -284,7 +347,7 @@ def linear_bn_act(x, weight, bias, bn, training, act):
 
 def curve_fps(pos, topo, spacing, u):
     """ref src/models/modules/fps_ops.py:16-39; ``u`` = the reference's torch.rand(1) draw."""
-    pos = _mat(pos)
+    pos = _pos(pos)
     n, dev = pos.size(0), pos.device
     idx = torch.empty(n, dtype=torch.int64, device=dev)
     count = torch.empty(1, dtype=torch.int64, device=dev)
@@ -309,7 +372,7 @@ class EdgeList:
 
 def radius_1d_group_subset(pos, idx, topo, radius):
     """ref point_ops.py:143-193 (quirk Q3 included); returns an EdgeList (row, col as the reference)."""
-    pos, idx = _mat(pos), _i64(idx)
+    pos, idx = _pos(pos), _i64(idx)
     n, m, q, dev = pos.size(0), idx.numel(), topo.num_curves, pos.device
     budget = torch.empty(q + 1, dtype=torch.float32, device=dev)
     offsets = torch.empty(m + 1, dtype=torch.int32, device=dev)
@@ -331,7 +394,7 @@ def radius_1d_group_subset(pos, idx, topo, radius):
 
 def knn_1d_group_superset_dense(pos, idx, topo, k):
     """ref point_ops.py:196-260 in fixed-width form: (nbr (n,k) int64 -1 padded, weight (n,k))."""
-    pos, idx = _mat(pos), _i64(idx)
+    pos, idx = _pos(pos), _i64(idx)
     n, dev = pos.size(0), pos.device
     nbr = torch.empty((n, k), dtype=torch.int64, device=dev)
     w = torch.empty((n, k), dtype=torch.float32, device=dev)
@@ -355,8 +418,8 @@ class CurveInterp(torch.autograd.Function):
         x = _mat(x)
         n, k = nbr.shape
         c = x.size(1)
-        y = torch.empty((n, c), dtype=x.dtype, device=x.device)
-        call("interp_fwd", ptr(x), c, ptr(nbr), ptr(w), n, k, c, ptr(y), c)
+        y = _rows(n, c, x.device)
+        call("interp_fwd", ptr(x), _ld(x), ptr(nbr), ptr(w), n, k, c, ptr(y), _ld(y))
         ctx.save_for_backward(nbr, w)
         ctx.m = x.size(0)
         return y
@@ -367,8 +430,8 @@ class CurveInterp(torch.autograd.Function):
         g = _mat(g)
         n, k = nbr.shape
         c = g.size(1)
-        dx = torch.zeros((ctx.m, c), dtype=g.dtype, device=g.device)
-        call("interp_bwd", ptr(g), c, ptr(nbr), ptr(w), n, k, c, ptr(dx), c)
+        dx = _rows(ctx.m, c, g.device, zero=True)
+        call("interp_bwd", ptr(g), _ld(g), ptr(nbr), ptr(w), n, k, c, ptr(dx), _ld(dx))
         return dx, None, None
 
 
@@ -462,11 +525,11 @@ class MessageBuild(torch.autograd.Function):
         c = 0 if x_src is None else x_src.size(1)
         if x_src is not None:
             x_src = _mat(x_src)
-        pos_src, pos_dst = _mat(pos_src), _mat(pos_dst)
+        pos_src, pos_dst = _pos(pos_src), _pos(pos_dst)
         e = src.numel()
-        msg = torch.empty((e, c + 3), dtype=torch.float32, device=pos_src.device)
-        call("msg_build_fwd", ptr(x_src), c, ptr(pos_src), ptr(pos_dst), ptr(src), ptr(dst), e, c,
-             float(radius) if radius is not None else 0.0, ptr(msg))
+        msg = _rows(e, c + 3, pos_src.device)
+        call("msg_build_fwd", ptr(x_src), _ld(x_src) if c else 0, ptr(pos_src), ptr(pos_dst),
+             ptr(src), ptr(dst), e, c, float(radius) if radius is not None else 0.0, ptr(msg), _ld(msg))
         ctx.save_for_backward(src)
         ctx.c, ctx.n_src = c, (0 if x_src is None else x_src.size(0))
         return msg
@@ -477,8 +540,8 @@ class MessageBuild(torch.autograd.Function):
             return None, None, None, None, None, None
         (src,) = ctx.saved_tensors
         g = _mat(g)
-        dx = torch.zeros((ctx.n_src, ctx.c), dtype=torch.float32, device=g.device)
-        call("msg_build_bwd", ptr(g), ptr(src), src.numel(), ctx.c, ptr(dx), ctx.c)
+        dx = _rows(ctx.n_src, ctx.c, g.device, zero=True)
+        call("msg_build_bwd", ptr(g), _ld(g), ptr(src), src.numel(), ctx.c, ptr(dx), _ld(dx))
         return dx, None, None, None, None, None
 
 
@@ -489,8 +552,8 @@ class SegSoftmaxAgg(torch.autograd.Function):
     def forward(ctx, msg, att, offsets, num_dst):
         msg, att = _mat(msg), _mat(att)
         c = msg.size(1)
-        out = torch.empty((num_dst, c), dtype=torch.float32, device=msg.device)
-        call("seg_softmax_agg_fwd", ptr(msg), ptr(att), ptr(offsets), num_dst, c, ptr(out), c)
+        out = _rows(num_dst, c, msg.device)
+        call("seg_softmax_agg_fwd", ptr(msg), _ld(msg), ptr(att), _ld(att), ptr(offsets), num_dst, c, ptr(out), _ld(out))
         ctx.save_for_backward(msg, att, offsets)
         return out
 
@@ -499,8 +562,9 @@ class SegSoftmaxAgg(torch.autograd.Function):
         msg, att, offsets = ctx.saved_tensors
         g = _mat(g)
         m, c = g.shape
-        dmsg, datt = torch.empty_like(msg), torch.empty_like(att)
-        call("seg_softmax_agg_bwd", ptr(msg), ptr(att), ptr(offsets), m, c, ptr(g), c, ptr(dmsg), ptr(datt))
+        dmsg, datt = _rows(msg.size(0), c, g.device), _rows(att.size(0), c, g.device)
+        call("seg_softmax_agg_bwd", ptr(msg), _ld(msg), ptr(att), _ld(att), ptr(offsets), m, c, ptr(g), _ld(g),
+             ptr(dmsg), _ld(dmsg), ptr(datt), _ld(datt))
         return dmsg, datt, None, None
 
 
@@ -511,9 +575,9 @@ class SegMax(torch.autograd.Function):
     def forward(ctx, msg, offsets, num_dst):
         msg = _mat(msg)
         c = msg.size(1)
-        out = torch.empty((num_dst, c), dtype=torch.float32, device=msg.device)
+        out = _rows(num_dst, c, msg.device)
         arg = torch.empty((num_dst, c), dtype=torch.int32, device=msg.device)
-        call("seg_max_fwd", ptr(msg), ptr(offsets), num_dst, c, ptr(out), c, ptr(arg))
+        call("seg_max_fwd", ptr(msg), _ld(msg), ptr(offsets), num_dst, c, ptr(out), _ld(out), ptr(arg))
         ctx.save_for_backward(arg, offsets)
         ctx.e = msg.size(0)
         return out
@@ -523,8 +587,8 @@ class SegMax(torch.autograd.Function):
         arg, offsets = ctx.saved_tensors
         g = _mat(g)
         m, c = g.shape
-        dmsg = torch.empty((ctx.e, c), dtype=torch.float32, device=g.device)
-        call("seg_max_bwd", ptr(g), c, ptr(arg), ptr(offsets), m, c, ptr(dmsg))
+        dmsg = _rows(ctx.e, c, g.device)
+        call("seg_max_bwd", ptr(g), _ld(g), ptr(arg), ptr(offsets), m, c, ptr(dmsg), _ld(dmsg))
         return dmsg, None, None
 
 
@@ -540,8 +604,8 @@ class SGGather(torch.autograd.Function):
         x = _mat(x)
         b, nmax, k = nbr.shape
         c = x.size(1)
-        feat = torch.empty((b * nmax * (k + 1), 2 * c), dtype=torch.float32, device=x.device)
-        call("sg_gather_fwd", ptr(x), c, ptr(nbr), ptr(cloud_ptr), b, nmax, k, c, ptr(feat))
+        feat = _rows(b * nmax * (k + 1), 2 * c, x.device)
+        call("sg_gather_fwd", ptr(x), _ld(x), ptr(nbr), ptr(cloud_ptr), b, nmax, k, c, ptr(feat), _ld(feat))
         ctx.save_for_backward(nbr, cloud_ptr)
         ctx.n, ctx.c = x.size(0), c
         return feat
@@ -551,8 +615,8 @@ class SGGather(torch.autograd.Function):
         nbr, cloud_ptr = ctx.saved_tensors
         g = _mat(g)
         b, nmax, k = nbr.shape
-        dx = torch.empty((ctx.n, ctx.c), dtype=torch.float32, device=g.device)
-        call("sg_gather_bwd", ptr(g), ptr(nbr), ptr(cloud_ptr), b, nmax, k, ctx.c, ptr(dx), ctx.c)
+        dx = _rows(ctx.n, ctx.c, g.device, zero=True)
+        call("sg_gather_bwd", ptr(g), _ld(g), ptr(nbr), ptr(cloud_ptr), b, nmax, k, ctx.c, ptr(dx), _ld(dx))
         return dx, None, None
 
 
@@ -564,9 +628,9 @@ class SGMax(torch.autograd.Function):
         f = _mat(f)
         b, nmax, k = nbr.shape
         c = f.size(1)
-        out = torch.empty((n, c), dtype=torch.float32, device=f.device)
+        out = _rows(n, c, f.device)
         arg = torch.empty((n, c), dtype=torch.int32, device=f.device)
-        call("sg_max_fwd", ptr(f), ptr(nbr), ptr(cloud_ptr), b, nmax, k, c, ptr(out), c, ptr(arg))
+        call("sg_max_fwd", ptr(f), _ld(f), ptr(nbr), ptr(cloud_ptr), b, nmax, k, c, ptr(out), _ld(out), ptr(arg))
         ctx.save_for_backward(arg, cloud_ptr)
         ctx.shape = (b, nmax, k, c)
         return out
@@ -576,6 +640,6 @@ class SGMax(torch.autograd.Function):
         arg, cloud_ptr = ctx.saved_tensors
         g = _mat(g)
         b, nmax, k, c = ctx.shape
-        df = torch.empty((b * nmax * (k + 1), c), dtype=torch.float32, device=g.device)
-        call("sg_max_bwd", ptr(g), c, ptr(arg), ptr(cloud_ptr), b, nmax, k, c, ptr(df))
+        df = _rows(b * nmax * (k + 1), c, g.device)
+        call("sg_max_bwd", ptr(g), _ld(g), ptr(arg), ptr(cloud_ptr), b, nmax, k, c, ptr(df), _ld(df))
         return df, None, None, None

@@ -43,7 +43,7 @@ def _topology(batch, p2c, kwargs):
 def _with_xyz(x, pos, flag):
     if not flag:
         return x
-    return pos if x is None else torch.cat([x, pos], dim=1)
+    return pos if x is None else ops.cat_cols([x, pos])
 
 
 # --------------------------------------------------------------------------------------
@@ -255,7 +255,7 @@ def _fp_concat(x, x_skip, pos_skip, with_xyz):
         parts.append(x_skip)
     if with_xyz:
         parts.append(pos_skip[:, :3])
-    return torch.cat(parts, dim=1) if len(parts) > 1 else x
+    return ops.cat_cols(parts)
 
 
 class FPModule(nn.Module):
@@ -333,4 +333,4 @@ class SkipConnect(nn.Module):
         self.num_skips, self.nn = num_skips, nn
 
     def forward(self, xs, pos, batch, point2curveidx=None, **kwargs):
-        return self.nn(torch.cat(xs, dim=1)), pos, batch, point2curveidx
+        return self.nn(ops.cat_cols(list(xs))), pos, batch, point2curveidx

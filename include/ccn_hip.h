@@ -75,9 +75,9 @@ int ccn_diff_concat_bwd(const float* x, int64_t ldx, const int32_t* cid, int64_t
  * col[i, t*C + c] = x[i + t - taps/2, c] if that row exists and lies in the same segment, else 0.
  * seg == NULL: the whole buffer is one sequence (V2's padded buffer, fast_conv1d.py:67-72). */
 int ccn_im2col_fwd(const float* x, int64_t ldx, const int32_t* seg, int64_t rows, int64_t C, int64_t taps,
-                   float* col, void* stream);
-int ccn_im2col_bwd(const float* dcol, const int32_t* seg, int64_t rows, int64_t C, int64_t taps, float* dx,
-                   int64_t lddx, void* stream);
+                   float* col, int64_t ldcol, void* stream);
+int ccn_im2col_bwd(const float* dcol, int64_t ldcol, const int32_t* seg, int64_t rows, int64_t C, int64_t taps,
+                   float* dx, int64_t lddx, void* stream);
 
 /* row gather / scatter (fast_conv1d.py:136-141 x_padded[valid] = x ; x = x_padded[valid]; x[idx]) */
 int ccn_gather_rows(const float* src, int64_t lds, const int64_t* index, int64_t m, int64_t C, float* dst,
@@ -165,33 +165,34 @@ int ccn_colsum(const float* X, int64_t ldx, int64_t rows, int64_t C, double* acc
  * feat row (b, i, s) = [g, x_i - g], g = x[neighbour] or 0 (frnn_gather, dgcnn.py:172-173).
  * x is PACKED (N, C) with cloud_ptr (B+1); rows i >= len_b are the zero padding rows of quirk Q4. */
 int ccn_sg_gather_fwd(const float* x, int64_t ldx, const int64_t* idx, const int64_t* cloud_ptr, int64_t B,
-                      int64_t Nmax, int64_t K, int64_t C, float* feat, void* stream);
-int ccn_sg_gather_bwd(const float* dfeat, const int64_t* idx, const int64_t* cloud_ptr, int64_t B, int64_t Nmax,
-                      int64_t K, int64_t C, float* dx, int64_t lddx, void* stream);
+                      int64_t Nmax, int64_t K, int64_t C, float* feat, int64_t ldf, void* stream);
+int ccn_sg_gather_bwd(const float* dfeat, int64_t lddf, const int64_t* idx, const int64_t* cloud_ptr, int64_t B,
+                      int64_t Nmax, int64_t K, int64_t C, float* dx, int64_t lddx, void* stream);
 /* masked max over the K+1 slots (dgcnn.py:187-189, fill -1e2) written to PACKED rows (dgcnn.py:206). */
-int ccn_sg_max_fwd(const float* f, const int64_t* idx, const int64_t* cloud_ptr, int64_t B, int64_t Nmax, int64_t K,
-                   int64_t C, float* out, int64_t ldo, int32_t* arg, void* stream);
+int ccn_sg_max_fwd(const float* f, int64_t ldf, const int64_t* idx, const int64_t* cloud_ptr, int64_t B, int64_t Nmax,
+                   int64_t K, int64_t C, float* out, int64_t ldo, int32_t* arg, void* stream);
 int ccn_sg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const int64_t* cloud_ptr, int64_t B,
-                   int64_t Nmax, int64_t K, int64_t C, float* df, void* stream);
+                   int64_t Nmax, int64_t K, int64_t C, float* df, int64_t lddf, void* stream);
 
 /* ---- A13: src/models/modules/point_conv.py:60-93 PointNetConv2 message + aggregate ----------------
  * msg[e] = [x_src[src[e]], (pos_src[src[e]] - pos_dst[dst[e]]) / radius]   (radius <= 0: no division). */
 int ccn_msg_build_fwd(const float* x_src, int64_t ldx, const float* pos_src, const float* pos_dst,
                       const int64_t* src, const int64_t* dst, int64_t E, int64_t C, float radius, float* msg,
-                      void* stream);
-int ccn_msg_build_bwd(const float* dmsg, const int64_t* src, int64_t E, int64_t C, float* dx, int64_t lddx,
-                      void* stream);
+                      int64_t ldm, void* stream);
+int ccn_msg_build_bwd(const float* dmsg, int64_t lddm, const int64_t* src, int64_t E, int64_t C, float* dx,
+                      int64_t lddx, void* stream);
 /* edges grouped by destination: offsets int32 (M+1).  softmax over each group per channel (PyG softmax,
  * +1e-16 in the denominator), weighted sum (point_conv.py:89-93). */
-int ccn_seg_softmax_agg_fwd(const float* msg, const float* att, const int32_t* offsets, int64_t M, int64_t C,
-                            float* out, int64_t ldo, void* stream);
-int ccn_seg_softmax_agg_bwd(const float* msg, const float* att, const int32_t* offsets, int64_t M, int64_t C,
-                            const float* dout, int64_t lddo, float* dmsg, float* datt, void* stream);
+int ccn_seg_softmax_agg_fwd(const float* msg, int64_t ldm, const float* att, int64_t lda, const int32_t* offsets,
+                            int64_t M, int64_t C, float* out, int64_t ldo, void* stream);
+int ccn_seg_softmax_agg_bwd(const float* msg, int64_t ldm, const float* att, int64_t lda, const int32_t* offsets,
+                            int64_t M, int64_t C, const float* dout, int64_t lddo, float* dmsg, int64_t lddm,
+                            float* datt, int64_t ldda, void* stream);
 /* scatter_max (point_conv.py:81-82): empty groups give 0. */
-int ccn_seg_max_fwd(const float* msg, const int32_t* offsets, int64_t M, int64_t C, float* out, int64_t ldo,
-                    int32_t* arg, void* stream);
+int ccn_seg_max_fwd(const float* msg, int64_t ldm, const int32_t* offsets, int64_t M, int64_t C, float* out,
+                    int64_t ldo, int32_t* arg, void* stream);
 int ccn_seg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const int32_t* offsets, int64_t M,
-                    int64_t C, float* dmsg, void* stream);
+                    int64_t C, float* dmsg, int64_t lddm, void* stream);
 
 #ifdef __cplusplus
 }
