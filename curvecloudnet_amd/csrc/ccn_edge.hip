@@ -124,6 +124,147 @@ __global__ __launch_bounds__(TPB) void sg_max_bwd_kernel(const float* __restrict
   }
 }
 
+// ------------------------------------------------------------------ A15, algebraic form of the first edge layer
+// W [x_j ; x_i - x_j] = (Wa - Wb) x_j + Wb x_i  =>  y(b,i,s) = P[j] + S[i] with the per-point products
+// PS = X [Wa-Wb ; Wb]^T (N x 2*Co: P = columns [0,Co), S = columns [Co,2Co)).  The 21x larger edge GEMM
+// and the 2C-wide edge tensor disappear; what is left per dense row is a gather-add.
+// Quirk Q4 is kept: statistics run over all B*Nmax*(K+1) rows (missing neighbours contribute S[i],
+// padding rows contribute `pad` = the bias, i.e. what a zero input row gives).
+constexpr int SG_PTS = 32;  // points per wave => 128 points per workgroup
+
+__device__ __forceinline__ float edge_act(float z, int act, float slope) {
+  if (act == CCN_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (act == CCN_ACT_LEAKY) return z > 0.f ? z : z * slope;
+  return z;
+}
+__device__ __forceinline__ float edge_act_grad(float z, int act, float slope) {
+  if (act == CCN_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == CCN_ACT_LEAKY) return z > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+// MODE 0: column sums of y and y^2          (forward batch statistics)
+// MODE 1: column sums of g and g*xhat       (backward, g = dZ * act'(y*scale+shift))
+template <int MODE>
+__global__ __launch_bounds__(TPB) void sg_edge_stats_kernel(
+    const float* __restrict__ ps, int64_t ldps, const float* __restrict__ pad, const int64_t* __restrict__ idx,
+    const int64_t* __restrict__ cloud_ptr, int64_t B, int64_t Nmax, int K, int Co, const float* __restrict__ dZ,
+    int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ rstd, int act, float slope, double* __restrict__ partial) {
+  __shared__ double red[4][64][2];
+  CCN_LANES;
+  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * SG_PTS;
+  for (int c0 = 0; c0 < Co; c0 += 64) {
+    const int c = c0 + cx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < Co) {
+      const float padv = pad ? pad[c] : 0.f;
+      float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
+      if (MODE == 1) {
+        sc = scale[c];
+        sh = shift[c];
+        mu = mean[c];
+        rs = rstd[c];
+      }
+      for (int t = 0; t < SG_PTS; ++t) {
+        const int64_t bi = first + t;
+        if (bi >= B * Nmax) break;
+        const int64_t b = bi / Nmax, i = bi - b * Nmax;
+        const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
+        const bool live = i < len;
+        const float si = live ? ps[(base + i) * ldps + Co + c] : padv;
+        for (int s = 0; s <= K; ++s) {
+          int64_t j = -1;
+          if (live) j = s == 0 ? i : idx[bi * K + (s - 1)];
+          const float y = (j >= 0 ? ps[(base + j) * ldps + c] : 0.f) + si;
+          if (MODE == 0) {
+            s1 += (double)y;
+            s2 += (double)y * (double)y;
+          } else {
+            const float g = dZ[(bi * (K + 1) + s) * lddz + c] * edge_act_grad(y * sc + sh, act, slope);
+            s1 += (double)g;
+            s2 += (double)(g * ((y - mu) * rs));
+          }
+        }
+      }
+    }
+    red[ry][cx][0] = s1;
+    red[ry][cx][1] = s2;
+    __syncthreads();
+    if (ry == 0 && c < Co) {
+      double a = 0.0, b2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a += red[w][cx][0];
+        b2 += red[w][cx][1];
+      }
+      partial[(int64_t)blockIdx.x * 2 * Co + c] = a;
+      partial[(int64_t)blockIdx.x * 2 * Co + Co + c] = b2;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(TPB) void sg_edge_apply_kernel(const float* __restrict__ ps, int64_t ldps,
+                                                            const float* __restrict__ pad,
+                                                            const int64_t* __restrict__ idx,
+                                                            const int64_t* __restrict__ cloud_ptr, int64_t B,
+                                                            int64_t Nmax, int K, int Co,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int act, float slope,
+                                                            float* __restrict__ Z, int64_t ldz) {
+  CCN_LANES;
+  const int64_t bi = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (bi >= B * Nmax) return;
+  const int64_t b = bi / Nmax, i = bi - b * Nmax;
+  const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
+  const bool live = i < len;
+  float* out = Z + bi * (K + 1) * ldz;
+  for (int c = cx; c < Co; c += 64) {
+    const float si = live ? ps[(base + i) * ldps + Co + c] : (pad ? pad[c] : 0.f);
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    for (int s = 0; s <= K; ++s) {
+      int64_t j = -1;
+      if (live) j = s == 0 ? i : idx[bi * K + (s - 1)];
+      const float y = (j >= 0 ? ps[(base + j) * ldps + c] : 0.f) + si;
+      out[s * ldz + c] = edge_act(y * sc + sh, act, slope);
+    }
+  }
+}
+
+// dPS must be zero on entry.  dS[i] is owned by point i (plain store), dP[j] is accumulated atomically.
+__global__ __launch_bounds__(TPB) void sg_edge_bwd_kernel(
+    const float* __restrict__ ps, int64_t ldps, const float* __restrict__ pad, const int64_t* __restrict__ idx,
+    const int64_t* __restrict__ cloud_ptr, int64_t B, int64_t Nmax, int K, int Co, const float* __restrict__ dZ,
+    int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ rstd, int act, float slope, const double* __restrict__ sums, int64_t rows_total,
+    int training, float* __restrict__ dps, int64_t lddps) {
+  CCN_LANES;
+  const int64_t bi = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (bi >= B * Nmax) return;
+  const int64_t b = bi / Nmax, i = bi - b * Nmax;
+  const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
+  if (i >= len) return;  // padding rows feed nothing upstream
+  const float inv_n = 1.0f / (float)rows_total;
+  for (int c = cx; c < Co; c += 64) {
+    const float si = ps[(base + i) * ldps + Co + c];
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    const float mu = mean ? mean[c] : 0.f, rs = rstd ? rstd[c] : 0.f;
+    const float m1 = (training && sums) ? (float)sums[c] * inv_n : 0.f;
+    const float m2 = (training && sums) ? (float)sums[Co + c] * inv_n : 0.f;
+    float ds = 0.f;
+    for (int s = 0; s <= K; ++s) {
+      const int64_t j = s == 0 ? i : idx[bi * K + (s - 1)];
+      const float y = (j >= 0 ? ps[(base + j) * ldps + c] : 0.f) + si;
+      const float g = dZ[(bi * (K + 1) + s) * lddz + c] * edge_act_grad(y * sc + sh, act, slope);
+      const float dy = training ? sc * (g - m1 - (y - mu) * rs * m2) : sc * g;
+      ds += dy;
+      if (j >= 0) atomicAdd(&dps[(base + j) * lddps + c], dy);
+    }
+    dps[(base + i) * lddps + Co + c] = ds;
+  }
+}
+
 // ------------------------------------------------------------------ A13: PointNetConv2 message
 __global__ __launch_bounds__(TPB) void msg_build_fwd_kernel(const float* __restrict__ x_src, int64_t ldx,
                                                             const float* __restrict__ pos_src,
@@ -257,6 +398,61 @@ inline unsigned row_blocks(int64_t rows) { return (unsigned)((rows + ROWS_PER_WG
 #define CCN_SMALL_INT(v) ((v) > 0 && (v) < (1 << 30))
 
 extern "C" {
+
+int64_t ccn_sg_edge_stats_rows(int64_t B, int64_t Nmax) { return (B * Nmax + 4 * SG_PTS - 1) / (4 * SG_PTS); }
+
+int ccn_sg_edge_stats(const float* ps, int64_t ldps, const float* pad, const int64_t* idx, const int64_t* cloud_ptr,
+                      int64_t B, int64_t Nmax, int64_t K, int64_t Co, double* partial, void* stream) {
+  CCN_REQUIRE(ps && idx && cloud_ptr && partial && B > 0 && Nmax > 0 && CCN_SMALL_INT(K) && CCN_SMALL_INT(Co) &&
+                  ldps >= 2 * Co,
+              "sg_edge_stats: bad arguments");
+  hipLaunchKernelGGL(sg_edge_stats_kernel<0>, dim3((unsigned)ccn_sg_edge_stats_rows(B, Nmax)), dim3(TPB), 0,
+                     (hipStream_t)stream, ps, ldps, pad, idx, cloud_ptr, B, Nmax, (int)K, (int)Co,
+                     (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, 0, 0.f, partial);
+  CCN_LAUNCH_OK("sg_edge_stats");
+  return CCN_OK;
+}
+
+int ccn_sg_edge_apply(const float* ps, int64_t ldps, const float* pad, const int64_t* idx, const int64_t* cloud_ptr,
+                      int64_t B, int64_t Nmax, int64_t K, int64_t Co, const float* scale, const float* shift, int act,
+                      float slope, float* Z, int64_t ldz, void* stream) {
+  CCN_REQUIRE(ps && idx && cloud_ptr && Z && B > 0 && Nmax > 0 && CCN_SMALL_INT(K) && CCN_SMALL_INT(Co) &&
+                  ldps >= 2 * Co && ldz >= Co,
+              "sg_edge_apply: bad arguments");
+  hipLaunchKernelGGL(sg_edge_apply_kernel, dim3(row_blocks(B * Nmax)), dim3(TPB), 0, (hipStream_t)stream, ps, ldps, pad,
+                     idx, cloud_ptr, B, Nmax, (int)K, (int)Co, scale, shift, act, slope, Z, ldz);
+  CCN_LAUNCH_OK("sg_edge_apply");
+  return CCN_OK;
+}
+
+int ccn_sg_edge_bwd_stats(const float* ps, int64_t ldps, const float* pad, const int64_t* idx,
+                          const int64_t* cloud_ptr, int64_t B, int64_t Nmax, int64_t K, int64_t Co, const float* dZ,
+                          int64_t lddz, const float* scale, const float* shift, const float* mean, const float* rstd,
+                          int act, float slope, double* partial, void* stream) {
+  CCN_REQUIRE(ps && idx && cloud_ptr && dZ && scale && shift && mean && rstd && partial && B > 0 && Nmax > 0 &&
+                  CCN_SMALL_INT(K) && CCN_SMALL_INT(Co) && ldps >= 2 * Co && lddz >= Co,
+              "sg_edge_bwd_stats: bad arguments");
+  hipLaunchKernelGGL(sg_edge_stats_kernel<1>, dim3((unsigned)ccn_sg_edge_stats_rows(B, Nmax)), dim3(TPB), 0,
+                     (hipStream_t)stream, ps, ldps, pad, idx, cloud_ptr, B, Nmax, (int)K, (int)Co, dZ, lddz, scale,
+                     shift, mean, rstd, act, slope, partial);
+  CCN_LAUNCH_OK("sg_edge_bwd_stats");
+  return CCN_OK;
+}
+
+int ccn_sg_edge_bwd(const float* ps, int64_t ldps, const float* pad, const int64_t* idx, const int64_t* cloud_ptr,
+                    int64_t B, int64_t Nmax, int64_t K, int64_t Co, const float* dZ, int64_t lddz, const float* scale,
+                    const float* shift, const float* mean, const float* rstd, int act, float slope, const double* sums,
+                    int training, float* dps, int64_t lddps, void* stream) {
+  CCN_REQUIRE(ps && idx && cloud_ptr && dZ && dps && B > 0 && Nmax > 0 && CCN_SMALL_INT(K) && CCN_SMALL_INT(Co) &&
+                  ldps >= 2 * Co && lddz >= Co && lddps >= 2 * Co,
+              "sg_edge_bwd: bad arguments");
+  hipLaunchKernelGGL(sg_edge_bwd_kernel, dim3(row_blocks(B * Nmax)), dim3(TPB), 0, (hipStream_t)stream, ps, ldps, pad,
+                     idx, cloud_ptr, B, Nmax, (int)K, (int)Co, dZ, lddz, scale, shift, mean, rstd, act, slope, sums,
+                     B * Nmax * (K + 1), training, dps, lddps);
+  CCN_LAUNCH_OK("sg_edge_bwd");
+  return CCN_OK;
+}
 
 int ccn_sg_gather_fwd(const float* x, int64_t ldx, const int64_t* idx, const int64_t* cloud_ptr, int64_t B,
                       int64_t Nmax, int64_t K, int64_t C, float* feat, int64_t ldf, void* stream) {

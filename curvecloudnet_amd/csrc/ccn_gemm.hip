@@ -102,6 +102,66 @@ __device__ __forceinline__ float4 frag_read(const float* __restrict__ lds, int r
   }
 }
 
+// accumulator tiles -> C (+bias, +BatchNorm partial statistics) or atomic accumulation.
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+template <int BM, int BN, int WM, int EPI, int NT>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NT], float* __restrict__ As, const float* __restrict__ bias,
+                                              float* __restrict__ C, int64_t ldc, int64_t M, int64_t N, int64_t m0,
+                                              int64_t n0, int wm, int wn, int i, int h,
+                                              double* __restrict__ colstats) {
+  constexpr int WN = 4 / WM;
+  constexpr int WCOLS = BN / WN;
+  double* stat_lds = reinterpret_cast<double*>(As);  // [WM][BN][2] doubles, reused after the last barrier
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ncol_local = wn * WCOLS + t * 32 + i;
+    const int64_t n = n0 + ncol_local;
+    const float bv = (EPI == EPI_STORE && bias != nullptr && n < N) ? bias[n] : 0.f;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m < M && n < N) {
+        const float v = acc[t][r] + bv;
+        if (EPI == EPI_STORE) {
+          C[m * ldc + n] = v;
+          if (colstats != nullptr) {
+            s1 += (double)v;
+            s2 += (double)v * (double)v;
+          }
+        } else {
+          atomicAdd(&C[m * ldc + n], v);
+        }
+      }
+    }
+    if (EPI == EPI_STORE && colstats != nullptr) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) {
+        stat_lds[(wm * BN + ncol_local) * 2] = s1;
+        stat_lds[(wm * BN + ncol_local) * 2 + 1] = s2;
+      }
+    }
+  }
+  if (EPI == EPI_STORE && colstats != nullptr) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < BN; c += GEMM_TPB) {
+      const int64_t n = n0 + c;
+      if (n < N) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+          s1 += stat_lds[(w * BN + c) * 2];
+          s2 += stat_lds[(w * BN + c) * 2 + 1];
+        }
+        double* dst = colstats + (int64_t)blockIdx.x * 2 * N;  // one partial row per M tile (deterministic)
+        dst[n] = s1;
+        dst[N + n] = s2;
+      }
+    }
+  }
+}
+
 // C[M x N] (+)= A[M x K] * B[K x N]; K range split over blockIdx.z
 template <int BM, int BN, int WM, int ALAY, int BLAY, int EPI>
 __global__ __launch_bounds__(GEMM_TPB) void gemm_kernel(const float* __restrict__ A, int64_t lda,
@@ -159,59 +219,164 @@ __global__ __launch_bounds__(GEMM_TPB) void gemm_kernel(const float* __restrict_
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-  double* stat_lds = reinterpret_cast<double*>(As);  // [WM][BN][2] doubles, reused after the last barrier
+  gemm_epilogue<BM, BN, WM, EPI, NT>(acc, As, bias, C, ldc, M, N, m0, n0, wm, wn, i, h, colstats);
+}
+
+
+// ------------------------------------------------------------------ fast path: 16-byte aligned operands
+// Branch-free tile loads (addresses clamped into the allocation; rows/columns outside the problem only
+// ever feed output elements that are never stored, the K tail is zeroed with selects), two LDS buffers
+// and ONE barrier per 32-deep K slice: the global loads of slice s+1 are issued before the MFMAs of
+// slice s and written to the other buffer after them.
+template <int ROWS, int LAY>
+struct FastLoader {
+  static constexpr int PT = Tile<ROWS, LAY>::PER_THREAD;
+  const float* ptr[PT];   // KC: &p[row*ld + kq*4]   MC: &p[rq*4] (row index contiguous)
+  int64_t ld;
+  int kk[PT];             // KC: kq*4   MC: k row inside the slice
+
+  __device__ __forceinline__ void init(const float* __restrict__ p, int64_t ld_, int64_t row0, int64_t nrows) {
+    ld = ld_;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int ncol_local = wn * WCOLS + t * 32 + i;
-    const int64_t n = n0 + ncol_local;
-    const float bv = (EPI == EPI_STORE && bias != nullptr && n < N) ? bias[n] : 0.f;
-    double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (m < M && n < N) {
-        const float v = acc[t][r] + bv;
-        if (EPI == EPI_STORE) {
-          C[m * ldc + n] = v;
-          if (colstats != nullptr) {
-            s1 += (double)v;
-            s2 += (double)v * (double)v;
-          }
-        } else {
-          atomicAdd(&C[m * ldc + n], v);
-        }
-      }
-    }
-    if (EPI == EPI_STORE && colstats != nullptr) {
-      s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 32, 64);
-      if (h == 0) {
-        stat_lds[(wm * BN + ncol_local) * 2] = s1;
-        stat_lds[(wm * BN + ncol_local) * 2 + 1] = s2;
+    for (int it = 0; it < PT; ++it) {
+      const int slot = threadIdx.x + it * GEMM_TPB;
+      if (LAY == KC) {
+        const int r = slot >> 3, kq = slot & 7;
+        int64_t row = row0 + r;
+        row = row < nrows ? row : nrows - 1;
+        ptr[it] = p + row * ld + kq * 4;
+        kk[it] = kq * 4;
+      } else {
+        constexpr int Q = ROWS / 4;
+        const int k = slot / Q, rq = slot - k * Q;
+        int64_t row = row0 + rq * 4;
+        row = row <= ld - 4 ? row : ld - 4;
+        ptr[it] = p + row;
+        kk[it] = k;
       }
     }
   }
-  if (EPI == EPI_STORE && colstats != nullptr) {
+  // full slice: every k in [k0, k0+32) is inside the problem
+  __device__ __forceinline__ void load_full(int64_t k0, float4 (&regs)[PT]) const {
+#pragma unroll
+    for (int it = 0; it < PT; ++it) {
+      if (LAY == KC)
+        regs[it] = *reinterpret_cast<const float4*>(ptr[it] + k0);
+      else
+        regs[it] = *reinterpret_cast<const float4*>(ptr[it] + (k0 + kk[it]) * ld);
+    }
+  }
+  // last, partial slice: clamp the address, zero what lies at k >= kend
+  __device__ __forceinline__ void load_tail(int64_t k0, int64_t kend, float4 (&regs)[PT]) const {
+#pragma unroll
+    for (int it = 0; it < PT; ++it) {
+      const int64_t k = k0 + kk[it];
+      float4 v;
+      if (LAY == KC) {
+        const int64_t kc = k <= ld - 4 ? k : ld - 4;
+        v = *reinterpret_cast<const float4*>(ptr[it] + (kc - kk[it]));
+        v.x = k + 0 < kend ? v.x : 0.f;
+        v.y = k + 1 < kend ? v.y : 0.f;
+        v.z = k + 2 < kend ? v.z : 0.f;
+        v.w = k + 3 < kend ? v.w : 0.f;
+      } else {
+        const int64_t kc = k < kend ? k : kend - 1;
+        v = *reinterpret_cast<const float4*>(ptr[it] + kc * ld);
+        if (k >= kend) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      regs[it] = v;
+    }
+  }
+};
+
+template <int BM, int BN, int WM, int ALAY, int BLAY, int EPI, bool DBUF>
+__global__ __launch_bounds__(GEMM_TPB) void gemm_fast_kernel(const float* __restrict__ A, int64_t lda,
+                                                             const float* __restrict__ B, int64_t ldb,
+                                                             const float* __restrict__ bias, float* __restrict__ C,
+                                                             int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                                             int64_t kchunk, double* __restrict__ colstats) {
+  constexpr int WN = 4 / WM;
+  constexpr int WCOLS = BN / WN;
+  constexpr int NT = WCOLS / 32;
+  constexpr int AF = Tile<BM, ALAY>::FLOATS, BF = Tile<BN, BLAY>::FLOATS;
+  static_assert(BM == 32 * WM && NT >= 1, "tile shape");
+  // DBUF: two LDS buffers, one barrier per slice (deep K).  !DBUF: one buffer, two barriers, twice the
+  // workgroups per CU (short K, HBM-bound layers).
+  __shared__ __attribute__((aligned(16))) float lds[(DBUF ? 2 : 1) * (AF + BF)];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int i = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  FastLoader<BM, ALAY> la;
+  FastLoader<BN, BLAY> lb;
+  la.init(A, lda, m0, M);
+  lb.init(B, ldb, n0, N);
+  float4 ra[Tile<BM, ALAY>::PER_THREAD], rb[Tile<BN, BLAY>::PER_THREAD];
+
+  if (kbeg < kend) {
+    if (kbeg + BK <= kend) {
+      la.load_full(kbeg, ra);
+      lb.load_full(kbeg, rb);
+    } else {
+      la.load_tail(kbeg, kend, ra);
+      lb.load_tail(kbeg, kend, rb);
+    }
+    tile_store<BM, ALAY>(lds, ra);
+    tile_store<BN, BLAY>(lds + AF, rb);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    const float* As = lds + buf * (AF + BF);
+    const float* Bs = As + AF;
+    const int64_t kn = k0 + BK;
+    if (kn < kend) {
+      if (kn + BK <= kend) {
+        la.load_full(kn, ra);
+        lb.load_full(kn, rb);
+      } else {
+        la.load_tail(kn, kend, ra);
+        lb.load_tail(kn, kend, rb);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 a4 = frag_read<BM, ALAY>(As, wm * 32 + i, q, h);
+      float4 b4[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) b4[t] = frag_read<BN, BLAY>(Bs, wn * WCOLS + t * 32 + i, q, h);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[t].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[t].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[t].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[t].w, acc[t], 0, 0, 0);
+      }
+    }
+    if (kn < kend) {
+      if (!DBUF) __syncthreads();
+      float* An = lds + (DBUF ? (buf ^ 1) : 0) * (AF + BF);
+      tile_store<BM, ALAY>(An, ra);
+      tile_store<BN, BLAY>(An + AF, rb);
+    }
     __syncthreads();
-    for (int c = threadIdx.x; c < BN; c += GEMM_TPB) {
-      const int64_t n = n0 + c;
-      if (n < N) {
-        double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int w = 0; w < WM; ++w) {
-          s1 += stat_lds[(w * BN + c) * 2];
-          s2 += stat_lds[(w * BN + c) * 2 + 1];
-        }
-        double* dst = colstats + (int64_t)blockIdx.x * 2 * N;  // one partial row per M tile (deterministic)
-        dst[n] = s1;
-        dst[N + n] = s2;
-      }
-    }
+    if (DBUF) buf ^= 1;
   }
+  gemm_epilogue<BM, BN, WM, EPI, NT>(acc, lds, bias, C, ldc, M, N, m0, n0, wm, wn, i, h, colstats);
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+static bool g_force_generic = false;  // test hook (ccn_gemm_force_generic)
 
 template <int BM, int BN, int WM, int ALAY, int BLAY, int EPI>
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
@@ -226,8 +391,19 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const 
     ccn_set_error("gemm: grid too large");
     return CCN_ERR_ARG;
   }
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, ALAY, BLAY, EPI>), dim3((unsigned)gm, (unsigned)gn, (unsigned)gz),
-                     dim3(GEMM_TPB), 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, kchunk, a_vec, b_vec, colstats);
+  // fast path needs 16-byte aligned rows and at least one 16-byte group per row to clamp into
+  const bool fast = a_vec && b_vec && lda >= 4 && ldb >= 4 && !g_force_generic;
+  if (fast && kchunk > 96)
+    hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WM, ALAY, BLAY, EPI, true>),
+                       dim3((unsigned)gm, (unsigned)gn, (unsigned)gz), dim3(GEMM_TPB), 0, s, A, lda, B, ldb, bias, C, ldc,
+                       M, N, K, kchunk, colstats);
+  else if (fast)
+    hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WM, ALAY, BLAY, EPI, false>),
+                       dim3((unsigned)gm, (unsigned)gn, (unsigned)gz), dim3(GEMM_TPB), 0, s, A, lda, B, ldb, bias, C, ldc,
+                       M, N, K, kchunk, colstats);
+  else
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, ALAY, BLAY, EPI>), dim3((unsigned)gm, (unsigned)gn, (unsigned)gz),
+                       dim3(GEMM_TPB), 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, kchunk, a_vec, b_vec, colstats);
   return CCN_OK;
 }
 
@@ -441,6 +617,11 @@ extern "C" {
 
 int64_t ccn_stats_rows(int64_t rows) { return (rows + RED_ROWS - 1) / RED_ROWS; }
 
+int ccn_gemm_force_generic(int on) {
+  g_force_generic = on != 0;
+  return CCN_OK;
+}
+
 int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                 int64_t M, int64_t N, int64_t K, double* colstats, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -517,6 +698,27 @@ int ccn_bn_finalize(const double* colstats, int64_t rows, int64_t C, const float
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ccn_blocks(C, 128)), dim3(128), 0, s, sums, rows, C, gamma, beta, eps,
                      momentum, running_mean, running_var, scale, shift, save_mean, save_rstd);
   CCN_LAUNCH_OK("bn_finalize");
+  return CCN_OK;
+}
+
+int ccn_bn_finalize_n(const double* partial, int64_t nparts, int64_t rows, int64_t C, const float* gamma,
+                      const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                      float* scale, float* shift, float* save_mean, float* save_rstd, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(partial && scale && shift && save_mean && save_rstd && rows > 0 && C > 0 && nparts > 0,
+              "bn_finalize_n: bad arguments");
+  double* sums = const_cast<double*>(partial) + nparts * 2 * C;
+  launch_col_reduce(const_cast<double*>(partial), nparts, 2 * C, sums, s);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ccn_blocks(C, 128)), dim3(128), 0, s, sums, rows, C, gamma, beta, eps,
+                     momentum, running_mean, running_var, scale, shift, save_mean, save_rstd);
+  CCN_LAUNCH_OK("bn_finalize_n");
+  return CCN_OK;
+}
+
+int ccn_reduce_partials(double* partial, int64_t nparts, int64_t width, double* sums, void* stream) {
+  CCN_REQUIRE(partial && sums && nparts > 0 && width > 0, "reduce_partials: bad arguments");
+  launch_col_reduce(partial, nparts, width, sums, (hipStream_t)stream);
+  CCN_LAUNCH_OK("reduce_partials");
   return CCN_OK;
 }
 

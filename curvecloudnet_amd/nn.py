@@ -43,12 +43,16 @@ class MLP(nn.Module):
     def out_channels(self):
         return self.channel_list[-1]
 
-    def forward(self, x):
-        for lin, norm in zip(self.lins, self.norms):
+    def forward(self, x, start=0):
+        """``start`` > 0 resumes after the first ``start`` layers (a caller computed them in fused form)."""
+        n_hidden = len(self.norms)
+        for idx, (lin, norm) in enumerate(zip(self.lins, self.norms)):
+            if idx < start:
+                continue
             x = ops.linear_bn_act(x, lin.weight, lin.bias, norm.module, self.training, self.act)
             if self.dropout > 0.0:
                 x = F.dropout(x, p=self.dropout, training=self.training)
-        if self.plain_last:
+        if self.plain_last and start <= n_hidden:
             last = self.lins[-1]
             x = ops.linear_bn_act(x, last.weight, last.bias, None, self.training, None)
             if self.dropout > 0.0:

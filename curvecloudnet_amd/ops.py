@@ -319,7 +319,11 @@ class LinearBNAct(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _rows(m, k, dev)
-            call("gemm_nn", ptr(dy), _ld(dy), ptr(w), _ld(w), ptr(dx), _ld(dx), m, n, k)
+            # dX = dY W as an "NT" product with W^T (k x n): both operands then stream along their contiguous
+            # index, which is the fastest tile layout (the weight transpose is a few KB..MB)
+            wt = _rows(k, n, dev, zero=(n % 4 != 0))
+            wt.copy_(w[:, :k].t())
+            call("gemm_nt", ptr(dy), _ld(dy), ptr(wt), _ld(wt), None, ptr(dx), _ld(dx), m, k, n, None)
         dw = _rows(n, k, dev, zero=True)
         call("gemm_tn", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
         db = None
@@ -643,3 +647,73 @@ class SGMax(torch.autograd.Function):
         df = _rows(b * nmax * (k + 1), c, g.device)
         call("sg_max_bwd", ptr(g), _ld(g), ptr(arg), ptr(cloud_ptr), b, nmax, k, c, ptr(df), _ld(df))
         return df, None, None, None
+
+
+class SGEdgeLayer(torch.autograd.Function):
+    """First edge layer of the dense SGCNN path in algebraic form (ref dgcnn.py:166-177 + the first
+    Linear/BatchNorm/activation of ``self.nn``):  W [x_j ; x_i - x_j] = (Wa - Wb) x_j + Wb x_i.
+
+    ``ps`` (N, 2*Co) holds P = X (Wa-Wb)^T and S = X Wb^T per point; the dense row (b, i, slot) is
+    P[neighbour] + S[i].  Batch statistics are taken over all B*Nmax*(K+1) rows (quirk Q4) without
+    materialising the pre-activation tensor; backward recomputes it from ``ps``."""
+
+    @staticmethod
+    def forward(ctx, ps, nbr, cloud_ptr, gamma, beta, running_mean, running_var, training, act, eps, momentum):
+        ps = _mat(ps)
+        b, nmax, k = nbr.shape
+        co = ps.size(1) // 2
+        rows = b * nmax * (k + 1)
+        dev = ps.device
+        has_bn = gamma is not None
+        ctx.has_bn, ctx.act, ctx.training = has_bn, ACT[act], bool(training)
+        par = None
+        if has_bn:
+            par = torch.empty((4, co), dtype=torch.float32, device=dev)
+            if training:
+                nparts = lib().ccn_sg_edge_stats_rows(b, nmax)
+                partial = torch.empty((nparts + 1) * 2 * co, dtype=torch.float64, device=dev)
+                call("sg_edge_stats", ptr(ps), _ld(ps), None, ptr(nbr), ptr(cloud_ptr), b, nmax, k, co, ptr(partial))
+                call("bn_finalize_n", ptr(partial), nparts, rows, co, ptr(gamma), ptr(beta), float(eps),
+                     float(momentum), ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                     ptr(par[3]))
+            else:
+                call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), co,
+                     ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        z = _rows(rows, co, dev)
+        call("sg_edge_apply", ptr(ps), _ld(ps), None, ptr(nbr), ptr(cloud_ptr), b, nmax, k, co,
+             ptr(par[0]) if has_bn else None, ptr(par[1]) if has_bn else None, ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
+        ctx.save_for_backward(ps, nbr, cloud_ptr, par if has_bn else ps.new_empty(0))
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        ps, nbr, cloud_ptr, par = ctx.saved_tensors
+        g = _mat(g)
+        b, nmax, k = nbr.shape
+        co = ps.size(1) // 2
+        dev = g.device
+        sums = dgamma = dbeta = None
+        pp = [None] * 4
+        if ctx.has_bn:
+            pp = [ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3])]
+            nparts = lib().ccn_sg_edge_stats_rows(b, nmax)
+            partial = torch.empty((nparts + 1) * 2 * co, dtype=torch.float64, device=dev)
+            call("sg_edge_bwd_stats", ptr(ps), _ld(ps), None, ptr(nbr), ptr(cloud_ptr), b, nmax, k, co, ptr(g), _ld(g),
+                 *pp, ctx.act, LEAKY_SLOPE, ptr(partial))
+            sums = partial[nparts * 2 * co:]
+            call("reduce_partials", ptr(partial), nparts, 2 * co, ptr(sums))
+            dbeta, dgamma = sums[:co].float(), sums[co:].float()
+        dps = _rows(ps.size(0), 2 * co, dev, zero=True)
+        call("sg_edge_bwd", ptr(ps), _ld(ps), None, ptr(nbr), ptr(cloud_ptr), b, nmax, k, co, ptr(g), _ld(g), *pp,
+             ctx.act, LEAKY_SLOPE, ptr(sums) if sums is not None else None, 1 if ctx.training else 0, ptr(dps), _ld(dps))
+        return dps, None, None, dgamma, dbeta, None, None, None, None, None, None
+
+
+def sg_edge_layer(ps, nbr, cloud_ptr, bn, training, act):
+    if bn is None:
+        return SGEdgeLayer.apply(ps, nbr, cloud_ptr, None, None, None, None, False, None, 0.0, 0.0)
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    use_batch_stats = training or not bn.track_running_stats
+    return SGEdgeLayer.apply(ps, nbr, cloud_ptr, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats,
+                             act, bn.eps, bn.momentum if bn.momentum is not None else 0.1)

@@ -295,6 +295,7 @@ class SGCNNLayer(nn.Module):
         self.nn, self.k, self.r, self.with_xyz = nn, k, r, with_xyz
         self.attend_nn, self.aggr_type = attend_nn, aggr_type
         self.use_fast_knn, self.use_sparse_feat_agg = use_fast_knn, use_sparse_feat_agg
+        self.force_edge_gemm = False        # tests: run the literal gather + GEMM formulation
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
         if self.use_sparse_feat_agg or not self.use_fast_knn:
@@ -306,8 +307,19 @@ class SGCNNLayer(nn.Module):
         padded, _ = ops.to_batch_padded(pos, topo)
         radius = 0.25 if self.r is None else self.r
         nbr = ops.fast_knn(padded, padded, topo.lengths, topo.lengths, self.k, radius)
-        feat = ops.SGGather.apply(x, nbr, topo.cloud_ptr)
-        feat = self.nn(feat)
+        lin0 = self.nn.lins[0]
+        if lin0.bias is None and self.nn.dropout == 0.0 and not self.force_edge_gemm:
+            # first layer in algebraic form: two per-point products + a gather-add instead of a GEMM over
+            # 21x the rows (ops.SGEdgeLayer); exact up to fp32 re-association
+            c = x.size(1)
+            w = lin0.weight
+            ps = ops.linear_bn_act(x, torch.cat([w[:, :c] - w[:, c:], w[:, c:]], dim=0), None, None, False, None)
+            hidden0 = len(self.nn.norms) > 0
+            feat = ops.sg_edge_layer(ps, nbr, topo.cloud_ptr, self.nn.norms[0].module if hidden0 else None,
+                                     self.training, self.nn.act if hidden0 else None)
+            feat = self.nn(feat, start=1)
+        else:
+            feat = self.nn(ops.SGGather.apply(x, nbr, topo.cloud_ptr))
         out = ops.SGMax.apply(feat, nbr, topo.cloud_ptr, topo.n)
         return out, pos, batch, point2curveidx
 

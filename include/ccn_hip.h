@@ -136,6 +136,7 @@ int ccn_dense_to_csr_fill(const int64_t* idx, const int64_t* cloud_ptr1, const i
  * (deterministic, no atomics); ccn_bn_finalize reduces them (using the last 2*N doubles as scratch)
  * into the BatchNorm batch statistics (torch.nn.BatchNorm1d inside PyG MLP; fast_conv1d.py:30,73). */
 int64_t ccn_stats_rows(int64_t rows); /* partial-statistics rows a reduction over `rows` rows produces (= ceil(rows/128)) */
+int ccn_gemm_force_generic(int on); /* test hook: route every GEMM through the unaligned-operand kernel */
 int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                 int64_t M, int64_t N, int64_t K, double* colstats, void* stream); /* Y = A W^T + b */
 int ccn_gemm_nn(const float* dY, int64_t lddy, const float* W, int64_t ldw, float* dX, int64_t lddx, int64_t M,
@@ -168,6 +169,32 @@ int ccn_sg_gather_fwd(const float* x, int64_t ldx, const int64_t* idx, const int
                       int64_t Nmax, int64_t K, int64_t C, float* feat, int64_t ldf, void* stream);
 int ccn_sg_gather_bwd(const float* dfeat, int64_t lddf, const int64_t* idx, const int64_t* cloud_ptr, int64_t B,
                       int64_t Nmax, int64_t K, int64_t C, float* dx, int64_t lddx, void* stream);
+/* ---- A15, first edge layer in algebraic form:  W [x_j ; x_i - x_j] = (Wa-Wb) x_j + Wb x_i.
+ * ps (N, 2*Co): P = X (Wa-Wb)^T in columns [0,Co), S = X Wb^T (+bias) in [Co,2Co).  Dense row (b,i,s) is
+ * y = P[neighbour] + S[i] (missing neighbour: S[i]; padding row: pad[c], NULL = 0), exactly the rows of
+ * dgcnn.py:173-177 incl. quirk Q4.  stats: one partial row {sum y, sum y^2} per 128 points
+ * (ccn_sg_edge_stats_rows) in the layout ccn_bn_finalize_n reduces.  apply: Z = act(y*scale+shift) (scale NULL:
+ * identity).  bwd_stats / bwd: BatchNorm+activation backward and the scatter into dps (zero on entry). */
+int64_t ccn_sg_edge_stats_rows(int64_t B, int64_t Nmax);
+int ccn_sg_edge_stats(const float* ps, int64_t ldps, const float* pad, const int64_t* idx, const int64_t* cloud_ptr,
+                      int64_t B, int64_t Nmax, int64_t K, int64_t Co, double* partial, void* stream);
+int ccn_sg_edge_apply(const float* ps, int64_t ldps, const float* pad, const int64_t* idx, const int64_t* cloud_ptr,
+                      int64_t B, int64_t Nmax, int64_t K, int64_t Co, const float* scale, const float* shift, int act,
+                      float slope, float* Z, int64_t ldz, void* stream);
+int ccn_sg_edge_bwd_stats(const float* ps, int64_t ldps, const float* pad, const int64_t* idx,
+                          const int64_t* cloud_ptr, int64_t B, int64_t Nmax, int64_t K, int64_t Co, const float* dZ,
+                          int64_t lddz, const float* scale, const float* shift, const float* mean, const float* rstd,
+                          int act, float slope, double* partial, void* stream);
+int ccn_sg_edge_bwd(const float* ps, int64_t ldps, const float* pad, const int64_t* idx, const int64_t* cloud_ptr,
+                    int64_t B, int64_t Nmax, int64_t K, int64_t Co, const float* dZ, int64_t lddz, const float* scale,
+                    const float* shift, const float* mean, const float* rstd, int act, float slope, const double* sums,
+                    int training, float* dps, int64_t lddps, void* stream);
+/* reductions of caller-provided partial rows (nparts x 2C doubles, followed by 2C doubles of scratch) */
+int ccn_bn_finalize_n(const double* partial, int64_t nparts, int64_t rows, int64_t C, const float* gamma,
+                      const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                      float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
+int ccn_reduce_partials(double* partial, int64_t nparts, int64_t width, double* sums, void* stream);
+
 /* masked max over the K+1 slots (dgcnn.py:187-189, fill -1e2) written to PACKED rows (dgcnn.py:206). */
 int ccn_sg_max_fwd(const float* f, int64_t ldf, const int64_t* idx, const int64_t* cloud_ptr, int64_t B, int64_t Nmax,
                    int64_t K, int64_t C, float* out, int64_t ldo, int32_t* arg, void* stream);

@@ -58,6 +58,28 @@ def test_linear_plain_fwd_bwd(M, K, N):
         _close(a, r, 5e-5, name)
 
 
+def test_linear_generic_kernel_path_matches_fast_path():
+    """Unaligned operands take the generic GEMM kernel; force it and compare with the aligned fast path."""
+    ops = _ops()
+    from curvecloudnet_amd import _lib
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(700, 134, generator=gen).to(DEV).requires_grad_(True)
+    w = (torch.randn(70, 134, generator=gen) / 12).to(DEV).requires_grad_(True)
+    cot = torch.randn(700, 70, generator=gen).to(DEV)
+    outs = []
+    for force in (0, 1):
+        _lib.lib().ccn_gemm_force_generic(force)
+        try:
+            y = ops.linear_bn_act(x, w, None, None, False, None)
+            outs.append((y.detach().clone(),) + tuple(g.clone() for g in torch.autograd.grad((y * cot).sum(), [x, w])))
+        finally:
+            _lib.lib().ccn_gemm_force_generic(0)
+    for a, b in zip(*outs):
+        _close(a, b, 2e-5, "generic vs fast")
+    yr = F.linear(x.detach().cpu(), w.detach().cpu())
+    _close(outs[0][0], yr, 2e-5, "fast vs torch")
+
+
 @pytest.mark.parametrize("M,K,N,act,bias", [(500, 38, 64, "leaky_relu", False), (2000, 134, 64, "relu", False),
                                              (129, 16, 40, "relu", True), (4100, 64, 256, "leaky_relu", True)])
 @pytest.mark.parametrize("training", [True, False])
@@ -208,6 +230,27 @@ def test_sgcnn_layer_vs_oracle(ids):
                       lambda: steps.SGCNNLayer(MLP([2 * (c + 3), 32, 24], bias=False), 8, r=0.03, with_xyz=True))
     x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4))
     _run_pair(ref, mine, [x, d.pos, d.batch, d.curve_idxs], seed=0)
+
+
+def test_sgcnn_algebraic_first_layer_matches_literal_edge_gemm():
+    """(Wa-Wb) x_j + Wb x_i  ==  W [x_j ; x_i - x_j]: both product formulations, forward and gradients."""
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([2, 3], n_curves=50)
+    c = 21
+    torch.manual_seed(0)
+    mod = steps.SGCNNLayer(MLP([2 * (c + 3), 40, 24], bias=False), 12, r=0.05, with_xyz=True).to(DEV).train()
+    x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4)).to(DEV)
+    cot = torch.randn(d.pos.size(0), 24, generator=torch.Generator().manual_seed(5)).to(DEV)
+    res = []
+    for literal in (False, True):
+        mod.force_edge_gemm = literal
+        xi = x.clone().requires_grad_(True)
+        out = mod(xi, d.pos.to(DEV), d.batch.to(DEV), d.curve_idxs.to(DEV))[0]
+        res.append([out.detach()] + list(torch.autograd.grad((out * cot).sum(), [xi] + list(mod.parameters()))))
+    for a, b in zip(*res):
+        _close(a, b, 1e-4, "algebraic vs literal")
 
 
 @pytest.mark.parametrize("aggr", ["attend", "max"])

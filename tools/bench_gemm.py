@@ -2,6 +2,7 @@
 import sys
 import torch
 from curvecloudnet_amd._lib import call, ptr, lib
+from curvecloudnet_amd.ops import _rows, _ld
 
 SHAPES = [  # (rows, C_in, C_out)
     (4200000, 134, 64), (4200000, 64, 64), (4200000, 262, 128), (4200000, 128, 128),
@@ -19,16 +20,16 @@ def timeit(fn, n=5):
     return b.elapsed_time(e) / n
 print("%-26s %10s %10s %10s   (TFLOP/s)" % ("rows x Cin -> Cout", *("%s" % w for w in ["nt", "nn", "tn"])))
 for m, k, n in SHAPES:
-    x = torch.randn(m, k, device=dev); w = torch.randn(n, k, device=dev) * 0.05
-    y = torch.empty(m, n, device=dev); dx = torch.empty(m, k, device=dev); dw = torch.zeros(n, k, device=dev)
+    x = _rows(m, k, dev); x.normal_(); w = _rows(n, k, dev, zero=True); w.normal_(); w.mul_(0.05)
+    y = _rows(m, n, dev); y.normal_(); dx = _rows(m, k, dev); dw = _rows(n, k, dev, zero=True)
     stats = torch.empty((lib().ccn_stats_rows(m) + 1) * 2 * n, dtype=torch.float64, device=dev)
     res = {}
     if "nt" in which:
-        res["nt"] = timeit(lambda: call("gemm_nt", ptr(x), k, ptr(w), k, None, ptr(y), n, m, n, k, ptr(stats)))
+        res["nt"] = timeit(lambda: call("gemm_nt", ptr(x), _ld(x), ptr(w), _ld(w), None, ptr(y), _ld(y), m, n, k, ptr(stats)))
     if "nn" in which:
-        res["nn"] = timeit(lambda: call("gemm_nn", ptr(y), n, ptr(w), k, ptr(dx), k, m, n, k))
+        res["nn"] = timeit(lambda: call("gemm_nn", ptr(y), _ld(y), ptr(w), _ld(w), ptr(dx), _ld(dx), m, n, k))
     if "tn" in which:
-        res["tn"] = timeit(lambda: call("gemm_tn", ptr(y), n, ptr(x), k, ptr(dw), k, m, n, k))
+        res["tn"] = timeit(lambda: call("gemm_tn", ptr(y), _ld(y), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k))
     fl = 2.0 * m * n * k
     print("%9d x %4d -> %4d " % (m, k, n) + " ".join("%10.1f" % (fl / (res[w] * 1e-3) / 1e12) if w in res else "%10s" % "-" for w in ["nt", "nn", "tn"])
           + "   ms: " + " ".join("%.3f" % res[w] for w in res))
