@@ -649,6 +649,66 @@ class SGMax(torch.autograd.Function):
         return df, None, None, None
 
 
+# --------------------------------------------------------------------------------------
+# section 8(f) rows: exact kNN interpolation, voxel and farthest-point sampling
+# --------------------------------------------------------------------------------------
+
+def knn_points_packed(pos_q, topo_q, pos_s, topo_s, k):
+    """pytorch3d.ops.knn_points semantics on packed clouds: (nbr (Nq,k) packed source index, weight)."""
+    pos_q, pos_s = _pos(pos_q), _pos(pos_s)
+    nq, dev = pos_q.size(0), pos_q.device
+    nbr = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    w = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    call("knn_points", ptr(pos_q), ptr(topo_q.cloud_ptr), ptr(pos_s), ptr(topo_s.cloud_ptr), topo_q.num_clouds,
+         topo_q.max_cloud, k, ptr(nbr), ptr(w))
+    return nbr, w
+
+
+def knn_interpolate(x, pos_x, pos_y, topo_x, topo_y, k=3):
+    """ref point_ops.py:293-341 knn_interpolate_pytorch3d (inverse squared distance, exact kNN)."""
+    nbr, w = knn_points_packed(pos_y, topo_y, pos_x, topo_x, k)
+    return CurveInterp.apply(x, nbr, w)
+
+
+def voxel_fps(pos, batch, voxel_size, rnd=None):
+    """ref src/models/modules/fps_ops.py:42-60 VoxelFPS: one point per occupied voxel, in the
+    lexicographic (cloud, voxel) order torch.unique gives.  ``rnd``: the reference's torch.rand(N) draw."""
+    pos, batch = _pos(pos), _i64(batch)
+    n, dev = pos.size(0), pos.device
+    if rnd is None:
+        rnd = torch.rand(n)
+    rnd = rnd.to(device=dev, dtype=torch.float32).contiguous()
+    key = torch.empty(n, dtype=torch.int64, device=dev)
+    score = torch.empty(n, dtype=torch.float32, device=dev)
+    bad = torch.empty(1, dtype=torch.int64, device=dev)
+    call("voxel_keys", ptr(pos), ptr(batch), ptr(rnd), n, float(voxel_size), ptr(key), ptr(score), ptr(bad))
+    uniq, voxel_of = torch.unique(key, return_inverse=True)          # sorted keys (device radix sort: plumbing)
+    m = uniq.numel()
+    if int(bad.item()):
+        raise ValueError("voxel_fps: voxel coordinates exceed the 18-bit key range")
+    scratch = torch.empty(m, dtype=torch.int64, device=dev)
+    idx = torch.empty(m, dtype=torch.int64, device=dev)
+    call("voxel_argmin", ptr(score), ptr(voxel_of.contiguous()), n, m, ptr(scratch), ptr(idx))
+    return idx
+
+
+def fps(pos, topo, ratio, start=None):
+    """ref point_ops.py:57-70 fps_pytorch3d (sample_farthest_points, random start): sorted packed indices."""
+    pos = _pos(pos)
+    dev = pos.device
+    lengths = topo.lengths.cpu()
+    keep = torch.ceil(lengths * ratio).long()                        # the reference's float32 arithmetic
+    out_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(keep, 0)])
+    if start is None:
+        start = torch.tensor([int(torch.randint(int(l), (1,))) for l in lengths.tolist()], dtype=torch.int64)
+    total = int(out_ptr[-1])
+    mind = torch.empty(topo.n, dtype=torch.float32, device=dev)
+    out = torch.empty(total, dtype=torch.int64, device=dev)
+    call("fps", ptr(pos), ptr(topo.cloud_ptr), ptr(start.to(dev)), ptr(out_ptr.to(dev)), topo.num_clouds, ptr(mind),
+         ptr(out))
+    return torch.sort(out)[0]
+
+
 class SGEdgeLayer(torch.autograd.Function):
     """First edge layer of the dense SGCNN path in algebraic form (ref dgcnn.py:166-177 + the first
     Linear/BatchNorm/activation of ``self.nn``):  W [x_j ; x_i - x_j] = (Wa - Wb) x_j + Wb x_i.

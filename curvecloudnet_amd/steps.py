@@ -21,10 +21,16 @@ class ForwardContext:
     def __init__(self, num_clouds=None):
         self.num_clouds = num_clouds
         self._topo = {}
+        self._zeros = {}
 
-    def topology(self, batch, p2c):
-        if p2c is None:
-            p2c = torch.zeros_like(batch)
+    def topology(self, batch, p2c, curves=True):
+        """curves=False: only the cloud tables are needed (levels whose points were re-ordered by voxel
+        sampling no longer carry sorted curve ids)."""
+        if p2c is None or not curves:
+            key0 = (batch.data_ptr(), batch.numel())
+            if key0 not in self._zeros:
+                self._zeros[key0] = torch.zeros_like(batch)
+            p2c = self._zeros[key0]
         key = (batch.data_ptr(), p2c.data_ptr(), batch.numel())
         hit = self._topo.get(key)
         if hit is None:
@@ -33,11 +39,11 @@ class ForwardContext:
         return hit[0]
 
 
-def _topology(batch, p2c, kwargs):
+def _topology(batch, p2c, kwargs, curves=True):
     ctx = kwargs.get("_ccn_ctx")
     if ctx is None:
-        return ops.CurveTopology(batch, p2c if p2c is not None else torch.zeros_like(batch))
-    return ctx.topology(batch, p2c)
+        return ops.CurveTopology(batch, p2c if (p2c is not None and curves) else torch.zeros_like(batch))
+    return ctx.topology(batch, p2c, curves)
 
 
 def _with_xyz(x, pos, flag):
@@ -208,18 +214,20 @@ class SAModule(nn.Module):
                                   normalize_radius=self.normalize_radius)
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
-        topo = _topology(batch, point2curveidx, kwargs)
+        topo = _topology(batch, point2curveidx, kwargs, curves=self.downsample_type == "curve-fps")
         if self.downsample_type == "random":
             idx = torch.sort(torch.randperm(pos.size(0))[: int(pos.size(0) * self.ratio)])[0].to(pos.device)
         elif self.downsample_type == "curve-fps":
             idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
+        elif self.downsample_type == "voxel":
+            idx = ops.voxel_fps(pos, batch, self.voxel_size)
         else:
-            raise NotImplementedError("downsample_type=%r is a 'next' row (SURVEY.md section 8f)" % self.downsample_type)
+            idx = ops.fps(pos, topo, self.ratio)
         if not self.use_fast_knn:
             raise NotImplementedError("ball_query grouping (use_fast_knn=False) is a 'next' row (SURVEY.md section 8f)")
         pos_q, batch_q = pos[idx], batch[idx]
         p2c_q = None if point2curveidx is None else point2curveidx[idx]
-        topo_q = _topology(batch_q, p2c_q, kwargs)
+        topo_q = _topology(batch_q, p2c_q, kwargs, curves=False)
         edges = ops.frnn_edges(pos_q, topo_q, pos, topo, self.knn, self.r)
         x = self.conv((x, None), (pos, pos_q), edges)
         return x, pos_q, batch_q, p2c_q
@@ -259,7 +267,7 @@ def _fp_concat(x, x_skip, pos_skip, with_xyz):
 
 
 class FPModule(nn.Module):
-    """ref pointnet2.py:119-143 (exact 3-NN interpolation; 'next' row)."""
+    """ref pointnet2.py:119-143: exact k-NN inverse-squared-distance interpolation, concat skip, MLP."""
 
     def __init__(self, k, nn, with_xyz=False):
         super().__init__()
@@ -267,7 +275,11 @@ class FPModule(nn.Module):
 
     def forward(self, x, pos, batch, x_skip, pos_skip, batch_skip, point2curveidx=None, point2curveidx_skip=None,
                 **kwargs):
-        raise NotImplementedError("FPModule (pytorch3d knn_points interpolation) is a 'next' row (SURVEY.md section 8f)")
+        topo_x = _topology(batch, point2curveidx, kwargs, curves=False)
+        topo_y = _topology(batch_skip, point2curveidx_skip, kwargs, curves=False)
+        x = ops.knn_interpolate(x, pos, pos_skip, topo_x, topo_y, self.k)
+        x = self.nn(_fp_concat(x, x_skip, pos_skip, self.with_xyz))
+        return x, pos_skip, batch_skip, point2curveidx_skip
 
 
 class CurveFPModule(FPModule):
@@ -302,7 +314,7 @@ class SGCNNLayer(nn.Module):
             raise NotImplementedError("sparse aggregation / exact kNN is a 'next' row (SURVEY.md section 8f)")
         if self.aggr_type != "max":
             raise NotImplementedError("dense SGCNN with aggr_type=%r is not used by the FRNN configs" % self.aggr_type)
-        topo = _topology(batch, point2curveidx, kwargs)
+        topo = _topology(batch, point2curveidx, kwargs, curves=False)
         x = _with_xyz(x, pos, self.with_xyz)
         padded, _ = ops.to_batch_padded(pos, topo)
         radius = 0.25 if self.r is None else self.r

@@ -221,6 +221,24 @@ int ccn_seg_max_fwd(const float* msg, int64_t ldm, const int32_t* offsets, int64
 int ccn_seg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const int32_t* offsets, int64_t M,
                     int64_t C, float* dmsg, int64_t lddm, void* stream);
 
+/* ---- section 8(f) "next" rows ------------------------------------------------------------------------
+ * knn_points: pytorch3d.ops.knn_points as used by knn_interpolate_pytorch3d (point_ops.py:91, 331-336): per cloud
+ * the K nearest source points of every query, ascending (d2, index); nbr = PACKED source index (-1 if the cloud has
+ * fewer than K points), weight = 1 / clamp(|x - y|^2, 1e-16).  q_ptr / s_ptr: int64 (B+1) cloud offsets. */
+int ccn_knn_points(const float* q, const int64_t* q_ptr, const float* src, const int64_t* s_ptr, int64_t B,
+                   int64_t max_q, int64_t K, int64_t* nbr, float* weight, void* stream);
+/* VoxelFPS (fps_ops.py:42-60): key = (cloud, floor(p/v)) packed in lexicographic order, score = distance to the
+ * voxel corner + rnd*v/4; argmin: per voxel the point with the smallest score.  bad: device int64 = #points whose
+ * voxel coordinates do not fit 18 bits. */
+int ccn_voxel_keys(const float* pos, const int64_t* batch, const float* rnd, int64_t n, float voxel, int64_t* key,
+                   float* score, int64_t* bad, void* stream);
+int ccn_voxel_argmin(const float* score, const int64_t* voxel_of, int64_t n, int64_t num_voxels, int64_t* scratch,
+                     int64_t* idx, void* stream);
+/* sample_farthest_points (point_ops.py:57-70): per cloud out_ptr[b+1]-out_ptr[b] samples starting at start[b];
+ * out = packed point indices in selection order; mind: float scratch (n). */
+int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, const int64_t* out_ptr, int64_t B,
+            float* mind, int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

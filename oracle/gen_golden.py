@@ -215,6 +215,20 @@ def main():
         close(y2, y, "curve_interpolate", 1e-5)
         close(torch.autograd.grad((y2 * cot).sum(), xs2)[0], gx, "curve_interpolate grad", 1e-5)
     np.savez_compressed(os.path.join(OUT, "curve_group.npz"), **blob)
+    # ---------------- section 8(f): VoxelFPS (reference code with the scatter_min shim) ----------------
+    blob = {}
+    for ci, name in enumerate(("three_clouds", "long_curves")):
+        _, pos, batch, p2c = curve_case(ci + 1 if name == "three_clouds" else 3, CASES[name])
+        for vs in (0.01, 0.03):
+            torch.manual_seed(40 + ci)
+            rnd = torch.rand(pos.size(0))
+            torch.manual_seed(40 + ci)
+            idx = fo.VoxelFPS(vs)(pos.clone(), batch.clone())
+            key = "%s.v%g" % (name, vs)
+            blob[key + ".pos"], blob[key + ".batch"], blob[key + ".rnd"] = np_(pos), np_(batch), np_(rnd)
+            blob[key + ".voxel"], blob[key + ".idx"] = np.float64(vs), np_(idx)
+            eq(R.voxel_fps(pos, batch, vs, rnd), idx, "voxel_fps " + key)
+    np.savez_compressed(os.path.join(OUT, "voxel_fps.npz"), **blob)
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print("  %-24s %7.1f KB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))

@@ -536,17 +536,33 @@ def farthest_point_indices(pos, batch, ratio, start=None):
     for b in range(bounds.numel() - 1):
         lo, hi = int(bounds[b]), int(bounds[b + 1])
         p = pos[lo:hi]
-        n_keep = int(math.ceil((hi - lo) * ratio))
+        n_keep = int(torch.ceil(torch.tensor([hi - lo]) * ratio))          # the reference's float32 product
         cur = int(start[b]) if start is not None else int(torch.randint(hi - lo, (1,)))
         d = torch.full((hi - lo,), float("inf"), dtype=pos.dtype)
         chosen = []
         for _ in range(n_keep):
             chosen.append(cur)
             diff = p - p[cur]
-            d = torch.minimum(d, (diff * diff).sum(-1))
+            # explicit (dx*dx + dy*dy) + dz*dz in float32: FPS is chaotic, the HIP kernel uses the same expression
+            d2 = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1]) + diff[:, 2] * diff[:, 2]
+            d = torch.minimum(d, d2)
             cur = int(torch.argmax(d))
         out.append(torch.tensor(chosen, dtype=torch.long) + lo)
     return torch.sort(torch.cat(out))[0]
+
+
+def voxel_fps(pos, batch, voxel_size, rnd):
+    """ref fps_ops.py:51-60 VoxelFPS: per occupied (cloud, voxel) the point closest to the voxel corner after a
+    random perturbation ``rnd * voxel_size / 4``; result in the lexicographic voxel order of torch.unique."""
+    scaled = pos / voxel_size
+    vox = torch.floor(scaled).long()
+    cells = torch.cat([batch.view(-1, 1), vox], dim=-1)
+    _, cell_of = torch.unique(cells, dim=0, return_inverse=True)
+    score = torch.linalg.norm(vox - scaled, dim=-1) + rnd * voxel_size / 4
+    order = np.lexsort((np.arange(pos.size(0)), score.numpy(), cell_of.numpy()))   # by cell, then score, then index
+    cells_sorted = cell_of.numpy()[order]
+    first = np.concatenate([[True], cells_sorted[1:] != cells_sorted[:-1]])
+    return torch.from_numpy(order[first].astype(np.int64))
 
 
 class SAModule(nn.Module):
@@ -572,7 +588,7 @@ class SAModule(nn.Module):
         elif self.downsample_type == "fps":
             idx = farthest_point_indices(pos, batch, self.ratio)
         else:
-            raise NotImplementedError("voxel down-sampling is a 'next' row (SURVEY.md section 8f)")
+            idx = voxel_fps(pos, batch, self.voxel_size, torch.rand(pos.size(0)))
         if not self.use_fast_knn:
             raise NotImplementedError("ball_query grouping is a 'next' row (SURVEY.md section 8f)")
         row, col = group_fixed_radius(pos[idx], pos, batch[idx], batch, self.knn, self.r)

@@ -213,3 +213,49 @@ def test_frnn_edges_match_oracle_flat_lists():
     topo_q = ops.CurveTopology(batch[idxd], p2c[idxd])
     e = ops.frnn_edges(pos[idxd], topo_q, pos, topo, 16, 0.05)
     assert torch.equal(e.row.cpu(), want[0]) and torch.equal(e.col.cpu(), want[1])
+
+
+# ---------------------------------------------------------------- section 8(f): samplers and exact kNN
+def test_voxel_fps_golden_and_oracle():
+    ops = _ops()
+    from oracle import torch_ref as R
+    g = golden("voxel_fps")
+    for key in sorted({k.rsplit(".", 1)[0] for k in g.files}):
+        got = ops.voxel_fps(t(g[key + ".pos"], DEV), t(g[key + ".batch"], DEV), float(g[key + ".voxel"]), t(g[key + ".rnd"]))
+        assert torch.equal(got.cpu(), t(g[key + ".idx"])), key
+    d = _synth([0, 1, 2], n_curves=400)
+    for vs in (0.025, 0.07):
+        rnd = torch.rand(d.pos.size(0), generator=torch.Generator().manual_seed(3))
+        want = R.voxel_fps(d.pos, d.batch, vs, rnd)
+        got = ops.voxel_fps(d.pos.to(DEV), d.batch.to(DEV), vs, rnd)
+        assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("ids,ratio", [([0], 0.3), ([1, 2, 3], 0.25)])
+def test_fps_matches_oracle(ids, ratio):
+    ops = _ops()
+    from oracle import torch_ref as R
+    d = _synth(ids, n_curves=40)
+    start = [5, 17, 3][: len(ids)]
+    want = R.farthest_point_indices(d.pos, d.batch, ratio, start=start)
+    topo = ops.CurveTopology(d.batch.to(DEV), d.curve_idxs.to(DEV))
+    got = ops.fps(d.pos.to(DEV), topo, ratio, start=torch.tensor(start))
+    assert torch.equal(got.cpu(), want)
+
+
+def test_knn_points_matches_bruteforce():
+    ops = _ops()
+    from oracle import torch_ref as R
+    d = _synth([4, 5], n_curves=120)
+    sub = R.voxel_fps(d.pos, d.batch, 0.05, torch.rand(d.pos.size(0), generator=torch.Generator().manual_seed(0)))
+    pos_x, batch_x = d.pos[sub], d.batch[sub]
+    qp, _, l1, _ = R.padded_layout(d.pos, d.batch)
+    sp, _, l2, off2 = R.padded_layout(pos_x, batch_x)
+    want = R.knn_bruteforce(qp, sp, l1, l2, 3)
+    want[1:] += off2.view(-1, 1, 1)
+    mask = torch.arange(qp.size(1))[None, :] < l1[:, None]
+    topo_y = ops.CurveTopology(d.batch.to(DEV), torch.zeros_like(d.batch).to(DEV))
+    topo_x = ops.CurveTopology(batch_x.to(DEV), torch.zeros_like(batch_x).to(DEV))
+    nbr, w = ops.knn_points_packed(d.pos.to(DEV), topo_y, pos_x.to(DEV), topo_x, 3)
+    assert torch.equal(nbr.cpu(), want[mask])
+    assert bool((w > 0).all())

@@ -92,3 +92,32 @@ def test_full_size_cloud_properties():
     torch.manual_seed(1)
     again = model(data)
     assert maxdiff(again, out) < 1e-5      # the same draw gives the same forward (BN stats are order-independent)
+
+
+def test_full_kitti_config_matches_oracle():
+    """The complete KITTI / nuScenes step list (33 steps: sa-geo, voxel and farthest-point SA levels, FP
+    up-sampling, 10 SGCNN layers) at 1/8 width: logits and gradients against the CPU oracle."""
+    from oracle import torch_ref as R
+    from curvecloudnet_amd.configs import kitti_config
+    from curvecloudnet_amd.model import segmentation_loss
+    from curvecloudnet_amd.synth import make_batch
+    ref, mine = build_pair(kitti_config(width=0.125), in_dim=4, n_out=20)
+    mine = mine.to(DEV)
+    data = make_batch([0, 1], n_curves=200)
+    y = _labels(data.pos.size(0), 20, 3)
+    ref.train(); mine.train()
+    torch.manual_seed(5)
+    out_r = ref(data)
+    R.segmentation_loss(out_r, y).backward()
+    torch.manual_seed(5)
+    out_d = mine(batch_to(data, DEV))
+    segmentation_loss(out_d, y.to(DEV)).backward()
+    assert out_d.shape == out_r.shape
+    assert maxdiff(out_d, out_r) < 5e-4, maxdiff(out_d, out_r)
+    errs = []
+    for (n, pr), (_, pd) in zip(ref.named_parameters(), mine.named_parameters()):
+        floor = 1e-4 * pr.grad.numel() ** 0.5
+        errs.append((float((pd.grad.cpu() - pr.grad).norm() / max(float(pr.grad.norm()), floor)), n))
+    print("worst gradient tensors:", sorted(errs)[-5:])
+    assert max(e[0] for e in errs) < 5e-2, max(errs)
+    assert sorted(e[0] for e in errs)[len(errs) // 2] < 5e-3

@@ -98,3 +98,16 @@ def test_synthetic_cloud_matches_survey_draw():
     assert b.batch.max() == 1 and b.curve_idxs.min() == 0
     mixed = make_cloud(3, n_curves=64, mixed_lengths=True)
     assert mixed.lengths.max() <= 512 and mixed.lengths.min() >= 1
+
+
+def test_kitti_config_equals_reference_yaml_when_available():
+    """Only in the build container (the reference tree is not shipped): the programmatic config is the YAML."""
+    path = "/root/reference/configs/curvecloudnet-eval/kitti-curvecloudnet.yaml"
+    from curvecloudnet_amd.configs import kitti_config, nuscenes_config
+    cfg = kitti_config()
+    assert len(cfg["steps"]) == 33 and cfg["feat_dims"][17] == [3072, 2048, 1024] and cfg["feat_dims"][30] == [99, 128, 128]
+    if os.path.exists(path):
+        assert yaml.safe_load(open(path))["model"] == cfg
+        assert yaml.safe_load(open(path.replace("kitti", "nuscenes")))["model"] == nuscenes_config()
+    ref, mine = build_pair(kitti_config(0.125), 4, 20)
+    assert sum(p.numel() for p in mine.parameters()) == sum(p.numel() for p in ref.parameters())

@@ -92,6 +92,27 @@ def test_curve_groups_and_interpolation(case):
     assert float((gx - t(g[case + ".interp_grad_x"])).abs().max()) < 1e-5
 
 
+def test_voxel_fps():
+    g = golden("voxel_fps")
+    keys = sorted({k.rsplit(".", 1)[0] for k in g.files})
+    assert len(keys) == 4
+    for key in keys:
+        idx = R.voxel_fps(t(g[key + ".pos"]), t(g[key + ".batch"]), float(g[key + ".voxel"]), t(g[key + ".rnd"]))
+        assert torch.equal(idx, t(g[key + ".idx"])), key
+
+
+def test_farthest_points_and_exact_knn_known_answers():
+    # a line of points: FPS from index 0 picks the far end, then the middle
+    pos = torch.stack([torch.arange(9, dtype=torch.float32), torch.zeros(9), torch.zeros(9)], 1)
+    idx = R.farthest_point_indices(pos, torch.zeros(9, dtype=torch.long), 3 / 9, start=[0])
+    assert idx.tolist() == [0, 4, 8]
+    nn = R.knn_bruteforce(pos[None], pos[None], torch.tensor([9]), torch.tensor([9]), 3)
+    assert nn[0, 0].tolist() == [0, 1, 2] and nn[0, 4].tolist() == [4, 3, 5]      # ties: smaller index first
+    y = R.knn_interpolate(pos[:, :1].clone(), pos, pos + 0.25, torch.zeros(9, dtype=torch.long),
+                          torch.zeros(9, dtype=torch.long), 1)
+    assert torch.allclose(y, pos[:, :1])
+
+
 def test_frnn_bruteforce_known_answers():
     """FRNN is third party and un-vendored (parity unpinned): anchor the exhaustive oracle on
     hand-checkable cases."""
