@@ -25,6 +25,7 @@ from curvecloudnet_amd import _lib                                              
 from curvecloudnet_amd.model import ModelBase, segmentation_loss               # noqa: E402
 from curvecloudnet_amd.parallel import GradientAllReduce, init_process_group_from_env  # noqa: E402
 from curvecloudnet_amd.synth import make_batch, to_device                      # noqa: E402
+from curvecloudnet_amd.configs import kitti_config                             # noqa: E402
 from tests.util import hotpath_config                                          # noqa: E402
 
 N_CLASSES = 20
@@ -64,7 +65,7 @@ def summarise_profile(records, steps):
     return rows, total
 
 
-def cpu_baseline(cfg, seed):
+def cpu_baseline(cfg, seed, timed_steps=2):
     """The oracle timed on the host: 1 cloud (2048 curves, ~50k points) per step, forward + backward + Adam."""
     from oracle import torch_ref as R
     import copy
@@ -75,7 +76,7 @@ def cpu_baseline(cfg, seed):
     data = make_batch([0])
     labels = torch.randint(0, N_CLASSES, (data.pos.size(0),), generator=torch.Generator().manual_seed(1))
     times = []
-    for it in range(3):                      # 1 warm-up + 2 timed
+    for it in range(1 + timed_steps):        # 1 warm-up + timed steps
         t0 = time.perf_counter()
         opt.zero_grad()
         loss = R.segmentation_loss(model(data), labels)
@@ -85,14 +86,18 @@ def cpu_baseline(cfg, seed):
     best = min(times[1:])
     return {"value": 1.0 / best, "unit": "clouds/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "oracle/torch_ref.py ModelBase, 1 cloud (2048 curves, %d points) per step, fwd+bwd+Adam, "
-                      "best of 2 timed steps after 1 warm-up (%.1f s of CPU work)" % (data.pos.size(0), sum(times))}
+                      "best of %d timed step(s) after 1 warm-up (%.1f s of CPU work)"
+                      % (data.pos.size(0), timed_steps, sum(times))}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=["kitti", "hotpath"], default="kitti",
+                    help="kitti: the reference's full KITTI/nuScenes model (33 steps, 28.8 M parameters); "
+                         "hotpath: the section-8a subset without the voxel/FPS levels")
     ap.add_argument("--clouds-per-gpu", type=int, default=8)
     ap.add_argument("--width", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -107,7 +112,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    cfg = hotpath_config(width=args.width)
+    cfg = kitti_config(width=args.width) if args.config == "kitti" else hotpath_config(width=args.width)
     kw = {k: v for k, v in cfg.items() if k != "type"}
     torch.manual_seed(1234)                                  # identical replicas on every rank
     model = ModelBase(4, N_CLASSES, **kw).to(dev).train()
@@ -157,12 +162,16 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1] shape: %d clouds/GPU x 2048 curves (~50k points each, %d points "
-                               "on rank 0), fp32 curve-conv + HIP FRNN + MFMA MLP stack; hot-path network of "
-                               "SURVEY.md section 8a (conv1d-fast-v2, sa-geo, mlp, 2x sgcnn K=20, skip-connect, "
-                               "fp-geo, conv1d-fast-v2) at KITTI widths x%g; fwd + mean-NLL + bwd + Adam"
-                               % (b, n_points, args.width),
+                               "on rank 0), fp32 curve-conv + HIP FRNN + MFMA MLP stack; network = %s at width x%g; "
+                               "fwd + mean-NLL + bwd + Adam"
+                               % (b, n_points,
+                                  "the reference's kitti-curvecloudnet.yaml model section (33 steps, all levels)"
+                                  if args.config == "kitti" else
+                                  "section-8a hot-path subset (conv1d-fast-v2, sa-geo, mlp, 2x sgcnn, skip, fp-geo, conv)",
+                                  args.width),
+                   "network": args.config, "parameters": sum(p.numel() for p in model.parameters()),
                    "clouds_per_gpu": b, "points_per_cloud": n_points // b, "parallelism": "dp%d" % world,
-                   "loss": float(loss)},
+                   "loss": float(loss.detach())},
     }
     if records:
         rows, total_ms = summarise_profile(records, args.steps)
@@ -185,7 +194,7 @@ def main():
                 tf = " %7.1f TFLOP/s" % (t["flops"] / (t["ms"] * 1e-3) / 1e12) if t["flops"] else ""
                 f.write("%9.2f ms %5.1f%% %6d launches  %s%s\n" % (t["ms"], 100 * t["ms"] / total_ms, t["launches"], k, tf))
     if not args.no_cpu_baseline and world == 1:
-        result["cpu_baseline"] = cpu_baseline(cfg, 1234)
+        result["cpu_baseline"] = cpu_baseline(cfg, 1234, timed_steps=1 if args.config == "kitti" else 2)
     print(json.dumps(result))
 
 

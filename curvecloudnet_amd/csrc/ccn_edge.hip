@@ -130,7 +130,7 @@ __global__ __launch_bounds__(TPB) void sg_max_bwd_kernel(const float* __restrict
 // and the 2C-wide edge tensor disappear; what is left per dense row is a gather-add.
 // Quirk Q4 is kept: statistics run over all B*Nmax*(K+1) rows (missing neighbours contribute S[i],
 // padding rows contribute `pad` = the bias, i.e. what a zero input row gives).
-constexpr int SG_PTS = 32;  // points per wave => 128 points per workgroup
+constexpr int SG_PTS_MAX = 32;  // points per wave (fewer on small levels so that the grid still fills the chip)
 
 __device__ __forceinline__ float edge_act(float z, int act, float slope) {
   if (act == CCN_ACT_RELU) return z > 0.f ? z : 0.f;
@@ -150,12 +150,12 @@ __global__ __launch_bounds__(TPB) void sg_edge_stats_kernel(
     const float* __restrict__ ps, int64_t ldps, const float* __restrict__ pad, const int64_t* __restrict__ idx,
     const int64_t* __restrict__ cloud_ptr, int64_t B, int64_t Nmax, int K, int Co, const float* __restrict__ dZ,
     int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
-    const float* __restrict__ rstd, int act, float slope, double* __restrict__ partial) {
+    const float* __restrict__ rstd, int act, float slope, int pts, double* __restrict__ partial) {
   __shared__ double red[4][64][2];
   CCN_LANES;
-  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * SG_PTS;
-  for (int c0 = 0; c0 < Co; c0 += 64) {
-    const int c = c0 + cx;
+  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * pts;
+  {
+    const int c = blockIdx.y * 64 + cx;  // one 64-channel chunk per workgroup
     double s1 = 0.0, s2 = 0.0;
     if (c < Co) {
       const float padv = pad ? pad[c] : 0.f;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(TPB) void sg_edge_stats_kernel(
         mu = mean[c];
         rs = rstd[c];
       }
-      for (int t = 0; t < SG_PTS; ++t) {
+      for (int t = 0; t < pts; ++t) {
         const int64_t bi = first + t;
         if (bi >= B * Nmax) break;
         const int64_t b = bi / Nmax, i = bi - b * Nmax;
@@ -201,7 +201,6 @@ __global__ __launch_bounds__(TPB) void sg_edge_stats_kernel(
       partial[(int64_t)blockIdx.x * 2 * Co + c] = a;
       partial[(int64_t)blockIdx.x * 2 * Co + Co + c] = b2;
     }
-    __syncthreads();
   }
 }
 
@@ -399,17 +398,30 @@ inline unsigned row_blocks(int64_t rows) { return (unsigned)((rows + ROWS_PER_WG
 
 extern "C" {
 
-int64_t ccn_sg_edge_stats_rows(int64_t B, int64_t Nmax) { return (B * Nmax + 4 * SG_PTS - 1) / (4 * SG_PTS); }
+static int sg_pts(int64_t B, int64_t Nmax, int64_t Co) {
+  // aim at >= 2048 workgroups: groups * channel chunks
+  const int64_t chunks = (Co + 63) / 64;
+  int64_t pts = B * Nmax * chunks / (4 * 2048);
+  if (pts > SG_PTS_MAX) pts = SG_PTS_MAX;
+  if (pts < 1) pts = 1;
+  return (int)pts;
+}
+
+int64_t ccn_sg_edge_stats_rows(int64_t B, int64_t Nmax, int64_t Co) {
+  const int pts = sg_pts(B, Nmax, Co);
+  return (B * Nmax + 4 * pts - 1) / (4 * pts);
+}
 
 int ccn_sg_edge_stats(const float* ps, int64_t ldps, const float* pad, const int64_t* idx, const int64_t* cloud_ptr,
                       int64_t B, int64_t Nmax, int64_t K, int64_t Co, double* partial, void* stream) {
   CCN_REQUIRE(ps && idx && cloud_ptr && partial && B > 0 && Nmax > 0 && CCN_SMALL_INT(K) && CCN_SMALL_INT(Co) &&
                   ldps >= 2 * Co,
               "sg_edge_stats: bad arguments");
-  hipLaunchKernelGGL(sg_edge_stats_kernel<0>, dim3((unsigned)ccn_sg_edge_stats_rows(B, Nmax)), dim3(TPB), 0,
+  hipLaunchKernelGGL(sg_edge_stats_kernel<0>,
+                     dim3((unsigned)ccn_sg_edge_stats_rows(B, Nmax, Co), (unsigned)((Co + 63) / 64)), dim3(TPB), 0,
                      (hipStream_t)stream, ps, ldps, pad, idx, cloud_ptr, B, Nmax, (int)K, (int)Co,
                      (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, 0, 0.f, partial);
+                     (const float*)nullptr, (const float*)nullptr, 0, 0.f, sg_pts(B, Nmax, Co), partial);
   CCN_LAUNCH_OK("sg_edge_stats");
   return CCN_OK;
 }
@@ -433,9 +445,10 @@ int ccn_sg_edge_bwd_stats(const float* ps, int64_t ldps, const float* pad, const
   CCN_REQUIRE(ps && idx && cloud_ptr && dZ && scale && shift && mean && rstd && partial && B > 0 && Nmax > 0 &&
                   CCN_SMALL_INT(K) && CCN_SMALL_INT(Co) && ldps >= 2 * Co && lddz >= Co,
               "sg_edge_bwd_stats: bad arguments");
-  hipLaunchKernelGGL(sg_edge_stats_kernel<1>, dim3((unsigned)ccn_sg_edge_stats_rows(B, Nmax)), dim3(TPB), 0,
+  hipLaunchKernelGGL(sg_edge_stats_kernel<1>,
+                     dim3((unsigned)ccn_sg_edge_stats_rows(B, Nmax, Co), (unsigned)((Co + 63) / 64)), dim3(TPB), 0,
                      (hipStream_t)stream, ps, ldps, pad, idx, cloud_ptr, B, Nmax, (int)K, (int)Co, dZ, lddz, scale,
-                     shift, mean, rstd, act, slope, partial);
+                     shift, mean, rstd, act, slope, sg_pts(B, Nmax, Co), partial);
   CCN_LAUNCH_OK("sg_edge_bwd_stats");
   return CCN_OK;
 }

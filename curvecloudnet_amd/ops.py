@@ -688,7 +688,8 @@ def voxel_fps(pos, batch, voxel_size, rnd=None):
         raise ValueError("voxel_fps: voxel coordinates exceed the 18-bit key range")
     scratch = torch.empty(m, dtype=torch.int64, device=dev)
     idx = torch.empty(m, dtype=torch.int64, device=dev)
-    call("voxel_argmin", ptr(score), ptr(voxel_of.contiguous()), n, m, ptr(scratch), ptr(idx))
+    voxel_of = voxel_of.contiguous()
+    call("voxel_argmin", ptr(score), ptr(voxel_of), n, m, ptr(scratch), ptr(idx))
     return idx
 
 
@@ -704,8 +705,8 @@ def fps(pos, topo, ratio, start=None):
     total = int(out_ptr[-1])
     mind = torch.empty(topo.n, dtype=torch.float32, device=dev)
     out = torch.empty(total, dtype=torch.int64, device=dev)
-    call("fps", ptr(pos), ptr(topo.cloud_ptr), ptr(start.to(dev)), ptr(out_ptr.to(dev)), topo.num_clouds, ptr(mind),
-         ptr(out))
+    start_d, out_ptr_d = start.to(dev), out_ptr.to(dev)     # named: must outlive the asynchronous launch
+    call("fps", ptr(pos), ptr(topo.cloud_ptr), ptr(start_d), ptr(out_ptr_d), topo.num_clouds, ptr(mind), ptr(out))
     return torch.sort(out)[0]
 
 
@@ -730,7 +731,7 @@ class SGEdgeLayer(torch.autograd.Function):
         if has_bn:
             par = torch.empty((4, co), dtype=torch.float32, device=dev)
             if training:
-                nparts = lib().ccn_sg_edge_stats_rows(b, nmax)
+                nparts = lib().ccn_sg_edge_stats_rows(b, nmax, co)
                 partial = torch.empty((nparts + 1) * 2 * co, dtype=torch.float64, device=dev)
                 call("sg_edge_stats", ptr(ps), _ld(ps), None, ptr(nbr), ptr(cloud_ptr), b, nmax, k, co, ptr(partial))
                 call("bn_finalize_n", ptr(partial), nparts, rows, co, ptr(gamma), ptr(beta), float(eps),
@@ -756,7 +757,7 @@ class SGEdgeLayer(torch.autograd.Function):
         pp = [None] * 4
         if ctx.has_bn:
             pp = [ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3])]
-            nparts = lib().ccn_sg_edge_stats_rows(b, nmax)
+            nparts = lib().ccn_sg_edge_stats_rows(b, nmax, co)
             partial = torch.empty((nparts + 1) * 2 * co, dtype=torch.float64, device=dev)
             call("sg_edge_bwd_stats", ptr(ps), _ld(ps), None, ptr(nbr), ptr(cloud_ptr), b, nmax, k, co, ptr(g), _ld(g),
                  *pp, ctx.act, LEAKY_SLOPE, ptr(partial))

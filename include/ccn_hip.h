@@ -172,10 +172,10 @@ int ccn_sg_gather_bwd(const float* dfeat, int64_t lddf, const int64_t* idx, cons
 /* ---- A15, first edge layer in algebraic form:  W [x_j ; x_i - x_j] = (Wa-Wb) x_j + Wb x_i.
  * ps (N, 2*Co): P = X (Wa-Wb)^T in columns [0,Co), S = X Wb^T (+bias) in [Co,2Co).  Dense row (b,i,s) is
  * y = P[neighbour] + S[i] (missing neighbour: S[i]; padding row: pad[c], NULL = 0), exactly the rows of
- * dgcnn.py:173-177 incl. quirk Q4.  stats: one partial row {sum y, sum y^2} per 128 points
- * (ccn_sg_edge_stats_rows) in the layout ccn_bn_finalize_n reduces.  apply: Z = act(y*scale+shift) (scale NULL:
+ * dgcnn.py:173-177 incl. quirk Q4.  stats: one partial row {sum y, sum y^2} per point group
+ * (ccn_sg_edge_stats_rows of them) in the layout ccn_bn_finalize_n reduces.  apply: Z = act(y*scale+shift) (scale NULL:
  * identity).  bwd_stats / bwd: BatchNorm+activation backward and the scatter into dps (zero on entry). */
-int64_t ccn_sg_edge_stats_rows(int64_t B, int64_t Nmax);
+int64_t ccn_sg_edge_stats_rows(int64_t B, int64_t Nmax, int64_t Co);
 int ccn_sg_edge_stats(const float* ps, int64_t ldps, const float* pad, const int64_t* idx, const int64_t* cloud_ptr,
                       int64_t B, int64_t Nmax, int64_t K, int64_t Co, double* partial, void* stream);
 int ccn_sg_edge_apply(const float* ps, int64_t ldps, const float* pad, const int64_t* idx, const int64_t* cloud_ptr,

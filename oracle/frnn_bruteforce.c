@@ -16,6 +16,7 @@
 
 static void search(const float *p1, const float *p2, int64_t n1, int64_t n2, int64_t K, int use_r, float r2,
                    int64_t *idx, float *dist) {
+#pragma omp parallel for schedule(static, 64)
   for (int64_t i = 0; i < n1; ++i) {
     int64_t *oi = idx + i * K;
     float *od = dist + i * K;
@@ -41,7 +42,6 @@ static void search(const float *p1, const float *p2, int64_t n1, int64_t n2, int
 
 void ccn_oracle_frnn(const float *points1, const float *points2, const int64_t *lengths1, const int64_t *lengths2,
                      int64_t B, int64_t P1, int64_t P2, int64_t K, const float *r, int64_t *idx, float *dist) {
-#pragma omp parallel for schedule(dynamic, 1)
   for (int64_t b = 0; b < B; ++b)
     search(points1 + b * P1 * 3, points2 + b * P2 * 3, lengths1[b], lengths2[b], K, 1, r[b] * r[b],
            idx + b * P1 * K, dist + b * P1 * K);
@@ -49,7 +49,6 @@ void ccn_oracle_frnn(const float *points1, const float *points2, const int64_t *
 
 void ccn_oracle_knn(const float *points1, const float *points2, const int64_t *lengths1, const int64_t *lengths2,
                     int64_t B, int64_t P1, int64_t P2, int64_t K, int64_t *idx, float *dist) {
-#pragma omp parallel for schedule(dynamic, 1)
   for (int64_t b = 0; b < B; ++b)
     search(points1 + b * P1 * 3, points2 + b * P2 * 3, lengths1[b], lengths2[b], K, 0, 0.0f,
            idx + b * P1 * K, dist + b * P1 * K);
