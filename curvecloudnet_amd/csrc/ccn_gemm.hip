@@ -375,8 +375,235 @@ __global__ __launch_bounds__(GEMM_TPB) void gemm_fast_kernel(const float* __rest
   gemm_epilogue<BM, BN, WM, EPI, NT>(acc, lds, bias, C, ldc, M, N, m0, n0, wm, wn, i, h, colstats);
 }
 
+
+// ------------------------------------------------------------------ LDS-DMA pipeline (Y = A W^T, both operands KC)
+// 256 x BN tile, 8 waves (one 32-row band each), BK = 32.  Tiles reach LDS with global_load_lds_dwordx4
+// (no VGPR staging): one wave instruction copies 8 rows x 128 B into a linear 1 KiB span, so the tile rows are
+// NOT padded; bank conflicts are avoided by swizzling on the SOURCE side instead -- LDS chunk c (16 B) of row r
+// holds global chunk c ^ ((r >> 1) & 7), and a fragment read of global chunk g = 2q + h goes to LDS chunk
+// g ^ ((r >> 1) & 7): each 16-lane group of ds_read_b128 then covers all 16 distinct 16-B slots.
+// Three stages: the DMA of slice u+2 is issued right after the barrier of iteration u and has two full
+// compute phases to land; waits are counted (vmcnt(NA+NB) leaves the youngest slice in flight) and the barrier
+// is a raw s_barrier, so nothing drains the queue.  A K remainder (< 32) is loaded once through registers
+// (zero-filled) into stage 0 before the pipeline starts; summation order over K slices is immaterial.
+constexpr int GL_TPB = 512;
+constexpr int GL_BM = 256;
+
+__device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// one K group (q) of fragments for lane (i, h): A band row and NT B rows, 16 bytes each, swizzled chunk
+template <int NT>
+__device__ __forceinline__ void lds_read_frag(uint32_t a_row_b, uint32_t b_row_b, int q, int h, int swz, f32x4& fa,
+                                              f32x4 (&fb)[NT]) {
+  const uint32_t ch = 16u * (uint32_t)((2 * q + h) ^ swz);
+  asm volatile("ds_read_b128 %0, %1" : "=v"(fa) : "v"(a_row_b + ch) : "memory");
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[t]) : "v"(b_row_b + ch), "n"(t * 32 * BK * 4) : "memory");
+}
+
+template <int BN>
+__global__ __launch_bounds__(GL_TPB) void gemm_glds_kernel(const float* __restrict__ A, int64_t lda,
+                                                           const float* __restrict__ B, int64_t ldb,
+                                                           const float* __restrict__ bias, float* __restrict__ C,
+                                                           int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                                           double* __restrict__ colstats) {
+  constexpr int NT = BN / 32;
+  constexpr int AF = GL_BM * BK, BF = BN * BK, STAGE = AF + BF;
+  constexpr int NA = GL_BM / 8 / 8;                 // LDS-DMA instructions per wave per slice for A (4)
+  constexpr int NB = BN >= 64 ? BN / 64 : 1;        // ... and for B (waves 4-7 repeat rows when BN = 32)
+  __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int swz = (i >> 1) & 7;
+  const int64_t m0 = (int64_t)blockIdx.x * GL_BM, n0 = (int64_t)blockIdx.y * BN;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+  const uint32_t a_off = (uint32_t)((wave * 32 + i) * BK * 4);        // this lane's A row inside a stage (bytes)
+  const uint32_t b_off = (uint32_t)((AF + i * BK) * 4);               // B row i; tile t adds an immediate
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // ---- per-lane DMA sources: row group g covers tile rows 8g .. 8g+7, lane -> (row 8g + lane/8, chunk lane%8)
+  const int lr = lane >> 3, lc = lane & 7;
+  const float* a_src[NA];
+  const float* b_src[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int r = 8 * (wave * NA + j) + lr;
+    int64_t row = m0 + r;
+    row = row < M ? row : M - 1;
+    a_src[j] = A + row * lda + 4 * (lc ^ ((r >> 1) & 7));
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int g = BN >= 64 ? wave * NB + j : (wave & 3);
+    const int r = 8 * g + lr;
+    int64_t row = n0 + r;
+    row = row < N ? row : N - 1;
+    b_src[j] = B + row * ldb + 4 * (lc ^ ((r >> 1) & 7));
+  }
+  const int has_tail = (K % BK) != 0;
+  const int64_t nfull = K / BK;
+  const int T = (int)nfull + has_tail;
+
+  auto issue = [&](int u) {  // LDS-DMA of full slice u (ring position u % 3)
+    float* st = lds + (u % 3) * STAGE;
+    const int64_t k0 = (int64_t)(u - has_tail) * BK;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) glds16(a_src[j] + k0, st + (8 * (wave * NA + j)) * BK);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int g = BN >= 64 ? wave * NB + j : (wave & 3);
+      glds16(b_src[j] + k0, st + AF + (8 * g) * BK);
+    }
+  };
+
+  if (has_tail) {  // K remainder through registers, zero filled, same swizzled image, stage 0
+    const int64_t kt = nfull * BK;
+#pragma unroll
+    for (int it = 0; it < ((GL_BM + BN) * 8 + GL_TPB - 1) / GL_TPB; ++it) {
+      const int slot = threadIdx.x + it * GL_TPB;
+      if (slot >= (GL_BM + BN) * 8) break;
+      const bool isA = slot < GL_BM * 8;
+      const int sl = isA ? slot : slot - GL_BM * 8;
+      const int r = sl >> 3, kq = sl & 7;
+      const float* p = isA ? A : B;
+      const int64_t ld = isA ? lda : ldb;
+      int64_t row = (isA ? m0 : n0) + r;
+      const int64_t lim = isA ? M : N;
+      row = row < lim ? row : lim - 1;
+      const int64_t k = kt + kq * 4;
+      const int64_t kc = k <= ld - 4 ? k : ld - 4;
+      float4 v = *reinterpret_cast<const float4*>(p + row * ld + kc);
+      v.x = k + 0 < K ? v.x : 0.f;
+      v.y = k + 1 < K ? v.y : 0.f;
+      v.z = k + 2 < K ? v.z : 0.f;
+      v.w = k + 3 < K ? v.w : 0.f;
+      float* dst = lds + (isA ? 0 : AF) + r * BK + 4 * (kq ^ ((r >> 1) & 7));
+      *reinterpret_cast<float4*>(dst) = v;
+    }
+  }
+  int next = has_tail;
+  for (; next < T && next < 2; ++next) issue(next);
+
+  for (int u = 0; u < T; ++u) {
+    if (u >= has_tail) {
+      if (u + 1 < next)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the register-path ds_writes of the tail slice
+    }
+    __builtin_amdgcn_s_barrier();
+    if (next < T) {
+      issue(next);
+      ++next;
+    }
+    // Fragment reads are inline asm on purpose: hipcc orders every compiler-visible ds_read behind ALL pending
+    // LDS-DMA (s_waitcnt vmcnt(0)), which would drain the two slices in flight.  The data dependence that matters
+    // (slice u landed) is the counted vmcnt + barrier above.  Reads of K group q+1 are issued before the MFMAs of
+    // group q and waited for with a counted lgkmcnt.
+    const uint32_t stage_b = lds_base + (uint32_t)((u % 3) * STAGE * 4);
+    f32x4 fa[2], fb[2][NT];
+    lds_read_frag<NT>(stage_b + a_off, stage_b + b_off, 0, h, swz, fa[0], fb[0]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (q < 3) {
+        lds_read_frag<NT>(stage_b + a_off, stage_b + b_off, q + 1, h, swz, fa[(q + 1) & 1], fb[(q + 1) & 1]);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT + 1) : "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1].x, fb[q & 1][t].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1].y, fb[q & 1][t].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1].z, fb[q & 1][t].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1].w, fb[q & 1][t].w, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)); the statistics of the
+  // two 128-row halves go to two partial rows so that the ccn_stats_rows(M) convention holds
+  double* stat_lds = reinterpret_cast<double*>(lds);  // [8][BN][2]
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int ncol = t * 32 + i;
+    const int64_t n = n0 + ncol;
+    const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (m < M && n < N) {
+        const float v = acc[t][r] + bv;
+        C[m * ldc + n] = v;
+        if (colstats != nullptr) {
+          s1 += (double)v;
+          s2 += (double)v * (double)v;
+        }
+      }
+    }
+    if (colstats != nullptr) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (h == 0) {
+        stat_lds[(wave * BN + ncol) * 2] = s1;
+        stat_lds[(wave * BN + ncol) * 2 + 1] = s2;
+      }
+    }
+  }
+  if (colstats != nullptr) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * BN; e += GL_TPB) {
+      const int half = e / BN, c = e - half * BN;
+      const int64_t n = n0 + c;
+      const int64_t prow = (int64_t)blockIdx.x * 2 + half;
+      if (n < N && prow * 128 < M) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          s1 += stat_lds[((half * 4 + w) * BN + c) * 2];
+          s2 += stat_lds[((half * 4 + w) * BN + c) * 2 + 1];
+        }
+        double* dst = colstats + prow * 2 * N;
+        dst[n] = s1;
+        dst[N + n] = s2;
+      }
+    }
+  }
+}
+
+template <int BN>
+int launch_glds(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s) {
+  const int64_t gm = (M + GL_BM - 1) / GL_BM, gn = (N + BN - 1) / BN;
+  if (gm > 2147483647LL || gn > 65535) {
+    ccn_set_error("gemm: grid too large");
+    return CCN_ERR_ARG;
+  }
+  hipLaunchKernelGGL((gemm_glds_kernel<BN>), dim3((unsigned)gm, (unsigned)gn), dim3(GL_TPB), 0, s, A, lda, W, ldw,
+                     bias, Y, ldy, M, N, K, colstats);
+  return CCN_OK;
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static bool g_force_generic = false;  // test hook (ccn_gemm_force_generic)
+static bool g_use_glds = true;        // test / A-B hook (ccn_gemm_use_dma)
 
 template <int BM, int BN, int WM, int ALAY, int BLAY, int EPI>
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
@@ -617,6 +844,11 @@ extern "C" {
 
 int64_t ccn_stats_rows(int64_t rows) { return (rows + RED_ROWS - 1) / RED_ROWS; }
 
+int ccn_gemm_use_dma(int on) {
+  g_use_glds = on != 0;
+  return CCN_OK;
+}
+
 int ccn_gemm_force_generic(int on) {
   g_force_generic = on != 0;
   return CCN_OK;
@@ -630,6 +862,19 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
               (long long)M, (long long)N, (long long)K);
   if (M == 0) return CCN_OK;
   int rc;
+  const bool dma_ok = aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && lda >= 4 && ldw >= 4 &&
+                      !g_force_generic && g_use_glds && M >= 1024 && K >= 32;
+  if (dma_ok) {
+    if (N <= 32)
+      rc = launch_glds<32>(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s);
+    else if (N <= 64)
+      rc = launch_glds<64>(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s);
+    else
+      rc = launch_glds<128>(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s);
+    if (rc) return rc;
+    CCN_LAUNCH_OK("gemm_nt");
+    return CCN_OK;
+  }
   if (N <= 32)
     rc = launch_gemm<128, 32, 4, KC, KC, EPI_STORE>(A, lda, W, ldw, bias, Y, ldy, M, N, K, 1, colstats, s);
   else if (N <= 64)

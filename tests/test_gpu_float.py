@@ -58,6 +58,31 @@ def test_linear_plain_fwd_bwd(M, K, N):
         _close(a, r, 5e-5, name)
 
 
+@pytest.mark.parametrize("M,K,N", [(3000, 67, 20), (4100, 256, 64), (2500, 134, 192), (1024, 32, 128)])
+def test_gemm_dma_pipeline_matches_register_staged_kernel(M, K, N):
+    """Y = X W^T + b with BatchNorm partial statistics: LDS-DMA pipeline kernel vs the register-staged kernel."""
+    from curvecloudnet_amd import _lib
+    from curvecloudnet_amd._lib import call, lib, ptr
+    from curvecloudnet_amd.ops import _ld, _rows
+    gen = torch.Generator().manual_seed(M + K)
+    x = _rows(M, K, DEV); x.copy_(torch.randn(M, K, generator=gen))
+    w = _rows(N, K, DEV, zero=True); w.copy_(torch.randn(N, K, generator=gen) / K ** 0.5)
+    b = torch.randn(N, generator=gen).to(DEV)
+    outs = []
+    for dma in (1, 0):
+        lib().ccn_gemm_use_dma(dma)
+        try:
+            y = _rows(M, N, DEV)
+            stats = torch.zeros((lib().ccn_stats_rows(M) + 1) * 2 * N, dtype=torch.float64, device=DEV)
+            call("gemm_nt", ptr(x), _ld(x), ptr(w), _ld(w), ptr(b), ptr(y), _ld(y), M, N, K, ptr(stats))
+            outs.append((y.clone(), stats[: lib().ccn_stats_rows(M) * 2 * N].view(-1, 2 * N).sum(0).float()))
+        finally:
+            lib().ccn_gemm_use_dma(1)
+    _close(outs[0][0], outs[1][0], 2e-5, "dma vs staged")
+    _close(outs[0][1], outs[1][1], 1e-5, "statistics")
+    _close(outs[0][0], F.linear(x.cpu(), w.cpu(), b.cpu()), 5e-5, "vs torch")
+
+
 def test_linear_generic_kernel_path_matches_fast_path():
     """Unaligned operands take the generic GEMM kernel; force it and compare with the aligned fast path."""
     ops = _ops()
