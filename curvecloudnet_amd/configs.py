@@ -9,6 +9,79 @@ def _w(c, width):
     return max(4, int(round(c * width)))
 
 
+def _derive(steps, free, num_skips, store, width, x_channels):
+    """feat_dims with the concatenation widths of skip-connect / fp / fp-geo filled in (ref base.py:159-209)."""
+    names = [st if isinstance(st, str) else st["step_name"] for st in steps]
+    feat_dims, w_in, prop, down = [], [x_channels], [], []     # w_in[i]: channels of x entering step i (0: x is None -> pos)
+    for i, (name, dims) in enumerate(zip(names, free)):
+        dims = [None if d is None else _w(d, width) for d in dims]
+        cur = w_in[i]
+        if name == "skip-connect":
+            take = prop[-num_skips[i]:]
+            del prop[-num_skips[i]:]
+            dims[0] = cur + sum(w_in[j] or 3 for j in take)
+        elif name in ("fp", "fp-geo"):
+            j = down.pop()
+            dims[0] = cur + (w_in[j] or 3) + 3
+        feat_dims.append(dims)
+        w_in.append(dims[-1])
+        if name in store:
+            prop.append(i)
+        if name in ("sa", "sa-geo"):
+            down.append(i)
+    return feat_dims
+
+
+def shapenet_seg_config(width=1.0, kortx=False):
+    """configs/curvecloudnet-eval/shapenet-seg-curvecloudnet.yaml:29-363 (``kortx=True``: the
+    kortx-testsplit variant: narrower front, k=7 convolutions, K=30)."""
+    s = lambda **kw: dict(**kw)                                                     # noqa: E731
+    sa = s(step_name="sa", aggr_type="attend", normalize_radius=True, use_fast_knn=False, downsample_type="fps")
+    sg_xyz = s(step_name="sgcnn", with_xyz=True, use_fast_knn=False, use_sparse_feat_agg=True)
+    sg = s(step_name="sgcnn", use_fast_knn=False, use_sparse_feat_agg=True)
+    conv = s(step_name="conv1d-fast-v1", with_diff=True, with_xyz=True)
+    steps = [
+        s(step_name="sa-geo", curve_fps_arclen=0.04 if kortx else 0.03, use_curve_fps=True, use_curve_knn=True,
+          with_xyz=True, aggr_type="attend", normalize_radius=True),
+        s(step_name="mlp", plain_last=False, with_xyz=True), dict(conv), "skip-connect",
+        dict(sa), dict(sg_xyz), "skip-connect", dict(sa), dict(sg_xyz), "skip-connect", dict(sa), dict(sg_xyz), dict(sg),
+        "skip-connect",
+        s(step_name="fp", with_xyz=True), dict(sg), "skip-connect",
+        s(step_name="fp", with_xyz=True), dict(sg), "skip-connect",
+        s(step_name="fp", with_xyz=True), dict(conv), "skip-connect",
+        s(step_name="fp-geo", with_xyz=True), dict(conv), "skip-connect",
+    ]
+    if kortx:
+        free = [[64, 128, 256, 512], [256, 128, 64], [64, 64], [None, 128], [128, 128, 128], [128, 128], [None, 256],
+                [256, 256, 256], [256, 256], [None, 512], [512, 512, 512], [512, 512], [512, 512], [None, 1024, 512],
+                [None, 512, 256], [256, 256], [None, 512, 256], [None, 256, 128], [128, 128], [None, 256, 128],
+                [None, 128, 64], [64, 48], [None, 64, 64], [None, 64, 64], [64, 64], [None, 64, 64]]
+    else:
+        free = [[64, 128, 256, 512, 1024], [512, 256, 128], [128, 128], [None, 128], [128, 128, 128], [128, 128],
+                [None, 256], [256, 256, 256], [256, 256], [None, 512], [512, 512, 512], [512, 512], [512, 512],
+                [None, 1024, 512], [None, 512, 256], [256, 256], [None, 512, 256], [None, 256, 128], [128, 128],
+                [None, 256, 128], [None, 128, 128], [128, 128], [None, 128, 128], [None, 128, 128], [64, 64],
+                [None, 128, 64]]
+    num_skips = [None, None, None, 1, None, None, 1, None, None, 1, None, None, None, 2, None, None, 1, None, None, 1,
+                 None, None, 1, None, None, 1]
+    store = ["conv1d-fast-v1", "sgcnn"]
+    k = 30 if kortx else 20
+    ks = 7 if kortx else 5
+    return dict(
+        type="generic", use_bias=True, version=1.0, steps=copy.deepcopy(steps),
+        feat_dims=_derive(steps, free, num_skips, store, width, 0),
+        out_mlp={"dims": [_w(64, width), _w(64, width)], "dropout": 0.0, "with_seg_category": True},
+        knn=[None, None, k, None, None, k, None, None, k, None, None, k, k, k, 3, k, None, 3, k, None, 3, k, None, 3, None,
+             None],
+        ratios=[None] * 4 + [0.25, None, None, 0.25, None, None, 0.25 if kortx else 0.5] + [None] * 15,
+        radii=([0.075, None, None, None, 0.2, None, None, 0.4, None, None, 0.8] if kortx else
+               [0.04, None, None, None, 0.18, None, None, 0.35, None, None, 0.7]) + [None] * 15,
+        num_skips=num_skips,
+        kernel_sizes=[None, None, ks] + [None] * 18 + [ks, None, None, ks, None],
+        skip_connect_state_store=store,
+    )
+
+
 def kitti_config(width=1.0, first_voxel=0.025, in_dim=4):
     s = lambda **kw: dict(**kw)                                                     # noqa: E731
     sa_vox = lambda v: s(step_name="sa", aggr_type="attend", downsample_type="voxel", voxel_size=v,   # noqa: E731

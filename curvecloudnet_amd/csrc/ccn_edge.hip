@@ -301,6 +301,38 @@ __global__ __launch_bounds__(TPB) void msg_build_bwd_kernel(const float* __restr
   for (int c = cx; c < C; c += 64) atomicAdd(&dx[j * lddx + c], dmsg[e * lddm + c]);
 }
 
+// ------------------------------------------------------------------ sparse edge conv message (dgcnn.py:227-228)
+// msg[e] = [x_i, x_j - x_i], i = dst[e] (the query), j = src[e] (its neighbour)
+__global__ __launch_bounds__(TPB) void edge_feat_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const int64_t* __restrict__ src,
+                                                            const int64_t* __restrict__ dst, int64_t E, int C,
+                                                            float* __restrict__ msg, int64_t ldm) {
+  CCN_LANES;
+  const int64_t e = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (e >= E) return;
+  const int64_t j = src[e], i = dst[e];
+  for (int c = cx; c < C; c += 64) {
+    const float xi = x[i * ldx + c];
+    msg[e * ldm + c] = xi;
+    msg[e * ldm + C + c] = x[j * ldx + c] - xi;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void edge_feat_bwd_kernel(const float* __restrict__ dmsg, int64_t lddm,
+                                                            const int64_t* __restrict__ src,
+                                                            const int64_t* __restrict__ dst, int64_t E, int C,
+                                                            float* __restrict__ dx, int64_t lddx) {
+  CCN_LANES;
+  const int64_t e = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (e >= E) return;
+  const int64_t j = src[e], i = dst[e];
+  for (int c = cx; c < C; c += 64) {
+    const float a = dmsg[e * lddm + c], b = dmsg[e * lddm + C + c];
+    atomicAdd(&dx[i * lddx + c], a - b);
+    atomicAdd(&dx[j * lddx + c], b);
+  }
+}
+
 // ------------------------------------------------------------------ grouped (CSR) aggregation
 __global__ __launch_bounds__(TPB) void seg_softmax_agg_fwd_kernel(const float* __restrict__ msg, int64_t ldm,
                                                                   const float* __restrict__ att, int64_t lda,
@@ -531,6 +563,27 @@ int ccn_msg_build_bwd(const float* dmsg, int64_t lddm, const int64_t* src, int64
   hipLaunchKernelGGL(msg_build_bwd_kernel, dim3(row_blocks(E)), dim3(TPB), 0, (hipStream_t)stream, dmsg, lddm, src, E,
                      (int)C, dx, lddx);
   CCN_LAUNCH_OK("msg_build_bwd");
+  return CCN_OK;
+}
+
+int ccn_edge_feat_fwd(const float* x, int64_t ldx, const int64_t* src, const int64_t* dst, int64_t E, int64_t C,
+                      float* msg, int64_t ldm, void* stream) {
+  CCN_REQUIRE(x && src && dst && msg && CCN_SMALL_INT(C) && ldx >= C && ldm >= 2 * C, "edge_feat_fwd: bad arguments");
+  if (E == 0) return CCN_OK;
+  hipLaunchKernelGGL(edge_feat_fwd_kernel, dim3(row_blocks(E)), dim3(TPB), 0, (hipStream_t)stream, x, ldx, src, dst, E,
+                     (int)C, msg, ldm);
+  CCN_LAUNCH_OK("edge_feat_fwd");
+  return CCN_OK;
+}
+
+int ccn_edge_feat_bwd(const float* dmsg, int64_t lddm, const int64_t* src, const int64_t* dst, int64_t E, int64_t C,
+                      float* dx, int64_t lddx, void* stream) {
+  CCN_REQUIRE(dmsg && src && dst && dx && CCN_SMALL_INT(C) && lddx >= C && lddm >= 2 * C,
+              "edge_feat_bwd: bad arguments");
+  if (E == 0) return CCN_OK;
+  hipLaunchKernelGGL(edge_feat_bwd_kernel, dim3(row_blocks(E)), dim3(TPB), 0, (hipStream_t)stream, dmsg, lddm, src, dst,
+                     E, (int)C, dx, lddx);
+  CCN_LAUNCH_OK("edge_feat_bwd");
   return CCN_OK;
 }
 

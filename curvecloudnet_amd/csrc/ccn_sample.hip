@@ -82,6 +82,43 @@ __global__ __launch_bounds__(KNN_TPB) void knn_points_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------- ball query (pytorch3d.ops.ball_query)
+// first K points (index order) with d2 < r*r, -1 padded; one query per thread, sources through LDS tiles
+__global__ __launch_bounds__(KNN_TPB) void ball_query_kernel(const float* __restrict__ q,
+                                                             const int64_t* __restrict__ len1,
+                                                             const float* __restrict__ src,
+                                                             const int64_t* __restrict__ len2, int64_t P1, int64_t P2,
+                                                             int K, float r2, int64_t* __restrict__ idx) {
+  __shared__ float tile[KNN_TILE * 3];
+  const int64_t b = blockIdx.y;
+  const int64_t nq = len1[b], ns = len2[b];
+  const int64_t iq = (int64_t)blockIdx.x * KNN_TPB + threadIdx.x;
+  const bool in_range = iq < P1;
+  const bool live = iq < nq;
+  int64_t* out = idx + (b * P1 + (in_range ? iq : 0)) * K;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (live) {
+    qx = q[3 * (b * P1 + iq)];
+    qy = q[3 * (b * P1 + iq) + 1];
+    qz = q[3 * (b * P1 + iq) + 2];
+  }
+  int have = 0;
+  for (int64_t t0 = 0; t0 < ns; t0 += KNN_TILE) {
+    const int64_t cnt = ns - t0 < KNN_TILE ? ns - t0 : KNN_TILE;
+    __syncthreads();
+    for (int64_t e = threadIdx.x; e < cnt * 3; e += KNN_TPB) tile[e] = src[3 * (b * P2 + t0) + e];
+    __syncthreads();
+    if (live) {
+      for (int64_t j = 0; j < cnt && have < K; ++j) {
+        const float d2 = ccn_sqdist3(tile[3 * j] - qx, tile[3 * j + 1] - qy, tile[3 * j + 2] - qz);
+        if (d2 < r2) out[have++] = t0 + j;
+      }
+    }
+  }
+  if (in_range)
+    for (int s = have; s < K; ++s) out[s] = -1;
+}
+
 // ---------------------------------------------------------------- voxel sampling
 // key = (cloud, floor(x/v), floor(y/v), floor(z/v)) packed so that integer order == lexicographic order
 // (what torch.unique(dim=0) sorts by); score = |voxel corner - p/v| + rand * v / 4  (fps_ops.py:52-56).
@@ -205,6 +242,17 @@ int ccn_knn_points(const float* q, const int64_t* q_ptr, const float* src, const
   hipLaunchKernelGGL(knn_points_kernel, dim3(ccn_blocks(max_q, KNN_TPB), (unsigned)B), dim3(KNN_TPB), 0,
                      (hipStream_t)stream, q, q_ptr, src, s_ptr, (int)K, nbr, weight);
   CCN_LAUNCH_OK("knn_points");
+  return CCN_OK;
+}
+
+int ccn_ball_query(const float* points1, const int64_t* lengths1, const float* points2, const int64_t* lengths2,
+                   int64_t B, int64_t P1, int64_t P2, int64_t K, float radius, int64_t* idx, void* stream) {
+  CCN_REQUIRE(points1 && lengths1 && points2 && lengths2 && idx && B > 0 && B < 65536 && P1 > 0 && P2 > 0 && K > 0 &&
+                  K < (1 << 20),
+              "ball_query: bad arguments");
+  hipLaunchKernelGGL(ball_query_kernel, dim3(ccn_blocks(P1, KNN_TPB), (unsigned)B), dim3(KNN_TPB), 0,
+                     (hipStream_t)stream, points1, lengths1, points2, lengths2, P1, P2, (int)K, radius * radius, idx);
+  CCN_LAUNCH_OK("ball_query");
   return CCN_OK;
 }
 

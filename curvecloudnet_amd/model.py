@@ -9,7 +9,7 @@ import torch.nn.functional as F
 import yaml
 
 from .nn import MLP
-from .steps import (CurveFPModule, CurveSAModule, ForwardContext, FPModule, SAModule, SGCNNLayer, SharedMLP,
+from .steps import (CurveFPModule, CurveSAModule, ForwardContext, FPModule, GlobalSAModule, SAModule, SGCNNLayer, SharedMLP,
                     SkipConnect, SymmetricCurve1DConvFastV1, SymmetricCurve1DConvV2)
 
 _DOWNSAMPLING_STEPS = ("sa", "sa-geo", "sa-global", "pt-transition-down")
@@ -106,7 +106,9 @@ class ModelBase(torch.nn.Module):
                                  with_xyz=kwargs["with_xyz"])
         if step_name == "mlp":
             return SharedMLP(dims, **kwargs)
-        if step_name in ("sa-global", "dgcnn", "dgcnn-rad"):
+        if step_name == "sa-global":
+            return GlobalSAModule(self.mlp_func(dims, bias=b), **kwargs)
+        if step_name in ("dgcnn", "dgcnn-rad"):
             raise NotImplementedError("step %r is outside the hot path built so far (SURVEY.md section 8f)" % step_name)
         raise NotImplementedError("Have not implemented step %s yet!" % step_name)
 

@@ -493,14 +493,35 @@ def to_batch_padded(t, topo):
     return out, mask
 
 
-def frnn_edges(pos_q, topo_q, pos_s, topo_s, k, radius):
-    """ref point_ops.py:73-111 (operation="knn", accel_knn=True): EdgeList of (query, point)."""
-    if radius is None:
-        print("Not setting radius for Fast-KNN!")          # quirk Q7
-        radius = 0.25
+EXACT_KNN_RADIUS = 1.0e9     # r*r stays finite in float32: every point passes the radius test => exact kNN
+
+
+def ball_query(points1, points2, lengths1, lengths2, K, radius):
+    """pytorch3d.ops.ball_query as the reference calls it (point_ops.py:81): (B,P1,K) int64, first K in index order."""
+    p1, p2 = _mat(points1), _mat(points2)
+    b, n1, n2, dev = p1.size(0), p1.size(1), p2.size(1), p1.device
+    l1, l2 = _i64(lengths1.to(dev)), _i64(lengths2.to(dev))
+    idx = torch.empty((b, n1, K), dtype=torch.int64, device=dev)
+    call("ball_query", ptr(p1), ptr(l1), ptr(p2), ptr(l2), b, n1, n2, K, float(radius), ptr(idx))
+    return idx
+
+
+def frnn_edges(pos_q, topo_q, pos_s, topo_s, k, radius, operation="knn", accel_knn=True):
+    """ref point_ops.py:73-111 knn_ball_group_pytorch3d: EdgeList of (query, point) from FRNN (accel_knn), exact
+    kNN (accel_knn=False: the same grid search with an unbounded radius) or ball query (K=128, index order)."""
     qp, _ = to_batch_padded(pos_q, topo_q)
     sp, _ = to_batch_padded(pos_s, topo_s)
-    nbr = fast_knn(qp, sp, topo_q.lengths, topo_s.lengths, k, radius)
+    if operation == "ball-group":
+        assert radius is not None
+        k = 128
+        nbr = ball_query(qp, sp, topo_q.lengths, topo_s.lengths, k, radius)
+    elif accel_knn:
+        if radius is None:
+            print("Not setting radius for Fast-KNN!")          # quirk Q7
+            radius = 0.25
+        nbr = fast_knn(qp, sp, topo_q.lengths, topo_s.lengths, k, radius)
+    else:
+        nbr = fast_knn(qp, sp, topo_q.lengths, topo_s.lengths, k, EXACT_KNN_RADIUS)
     b, p1, dev = nbr.size(0), nbr.size(1), nbr.device
     m = topo_q.n
     counts = torch.empty(m + 1, dtype=torch.int32, device=dev)
@@ -547,6 +568,28 @@ class MessageBuild(torch.autograd.Function):
         dx = _rows(ctx.n_src, ctx.c, g.device, zero=True)
         call("msg_build_bwd", ptr(g), _ld(g), ptr(src), src.numel(), ctx.c, ptr(dx), _ld(dx))
         return dx, None, None, None, None, None
+
+
+class EdgeFeat(torch.autograd.Function):
+    """cat([x_i, x_j - x_i]) per edge (ref dgcnn.py:227-228, the sparse path's message input)."""
+
+    @staticmethod
+    def forward(ctx, x, src, dst):
+        x = _mat(x)
+        e, c = src.numel(), x.size(1)
+        msg = _rows(e, 2 * c, x.device)
+        call("edge_feat_fwd", ptr(x), _ld(x), ptr(src), ptr(dst), e, c, ptr(msg), _ld(msg))
+        ctx.save_for_backward(src, dst)
+        ctx.n, ctx.c = x.size(0), c
+        return msg
+
+    @staticmethod
+    def backward(ctx, g):
+        src, dst = ctx.saved_tensors
+        g = _mat(g)
+        dx = _rows(ctx.n, ctx.c, g.device, zero=True)
+        call("edge_feat_bwd", ptr(g), _ld(g), ptr(src), ptr(dst), src.numel(), ctx.c, ptr(dx), _ld(dx))
+        return dx, None, None
 
 
 class SegSoftmaxAgg(torch.autograd.Function):

@@ -223,12 +223,11 @@ class SAModule(nn.Module):
             idx = ops.voxel_fps(pos, batch, self.voxel_size)
         else:
             idx = ops.fps(pos, topo, self.ratio)
-        if not self.use_fast_knn:
-            raise NotImplementedError("ball_query grouping (use_fast_knn=False) is a 'next' row (SURVEY.md section 8f)")
         pos_q, batch_q = pos[idx], batch[idx]
         p2c_q = None if point2curveidx is None else point2curveidx[idx]
         topo_q = _topology(batch_q, p2c_q, kwargs, curves=False)
-        edges = ops.frnn_edges(pos_q, topo_q, pos, topo, self.knn, self.r)
+        edges = ops.frnn_edges(pos_q, topo_q, pos, topo, self.knn, self.r,
+                               operation="knn" if self.use_fast_knn else "ball-group")
         x = self.conv((x, None), (pos, pos_q), edges)
         return x, pos_q, batch_q, p2c_q
 
@@ -310,12 +309,22 @@ class SGCNNLayer(nn.Module):
         self.force_edge_gemm = False        # tests: run the literal gather + GEMM formulation
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
-        if self.use_sparse_feat_agg or not self.use_fast_knn:
-            raise NotImplementedError("sparse aggregation / exact kNN is a 'next' row (SURVEY.md section 8f)")
-        if self.aggr_type != "max":
-            raise NotImplementedError("dense SGCNN with aggr_type=%r is not used by the FRNN configs" % self.aggr_type)
         topo = _topology(batch, point2curveidx, kwargs, curves=False)
         x = _with_xyz(x, pos, self.with_xyz)
+        if self.use_sparse_feat_agg:
+            # ref dgcnn.py:209-246 forward_slow: edge list from FRNN / exact kNN, message nn([x_i, x_j - x_i]),
+            # per-query max or softmax-attention over the CSR groups (BatchNorm sees the real edges only)
+            if self.aggr_type not in ("max", "attend"):
+                raise NotImplementedError("aggr_type=%r" % self.aggr_type)
+            edges = ops.frnn_edges(pos, topo, pos, topo, self.k, self.r, accel_knn=self.use_fast_knn)
+            msg = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row))
+            if self.aggr_type == "max":
+                out = ops.SegMax.apply(msg, edges.offsets, edges.num_dst)
+            else:
+                out = ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst)
+            return out, pos, batch, point2curveidx
+        if not self.use_fast_knn or self.aggr_type != "max":
+            raise NotImplementedError("dense SGCNN path: only the FRNN + max configuration the shipped configs use")
         padded, _ = ops.to_batch_padded(pos, topo)
         radius = 0.25 if self.r is None else self.r
         nbr = ops.fast_knn(padded, padded, topo.lengths, topo.lengths, self.k, radius)
@@ -334,6 +343,24 @@ class SGCNNLayer(nn.Module):
             feat = self.nn(ops.SGGather.apply(x, nbr, topo.cloud_ptr))
         out = ops.SGMax.apply(feat, nbr, topo.cloud_ptr, topo.n)
         return out, pos, batch, point2curveidx
+
+
+class GlobalSAModule(nn.Module):
+    """ref pointnet2.py:81-116: nn([x, pos]) then per-cloud max pooling (ShapeNet classification head)."""
+
+    def __init__(self, nn, **kwargs):
+        super().__init__()
+        self.nn = nn
+        self.pooling = kwargs.get("pooling", "max")
+        if self.pooling != "max":
+            raise NotImplementedError("Pooling strategy %s not implemented!" % self.pooling)
+
+    def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
+        topo = _topology(batch, point2curveidx, kwargs, curves=False)
+        f = self.nn(ops.cat_cols([x, pos]))
+        f = ops.SegMax.apply(f, topo.cloud_ptr.to(torch.int32), topo.num_clouds)
+        first = topo.cloud_ptr[:-1]
+        return f, pos[first], batch[first], None if point2curveidx is None else point2curveidx[first]
 
 
 # --------------------------------------------------------------------------------------

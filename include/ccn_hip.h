@@ -228,6 +228,16 @@ int ccn_seg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const i
  * fewer than K points), weight = 1 / clamp(|x - y|^2, 1e-16).  q_ptr / s_ptr: int64 (B+1) cloud offsets. */
 int ccn_knn_points(const float* q, const int64_t* q_ptr, const float* src, const int64_t* s_ptr, int64_t B,
                    int64_t max_q, int64_t K, int64_t* nbr, float* weight, void* stream);
+/* ball_query: pytorch3d.ops.ball_query as called at point_ops.py:81 (SA with use_fast_knn: False): padded
+ * (B,P,3) inputs, idx (B,P1,K) int64 = the first K points2 in index order with d2 < r*r, -1 padded. */
+int ccn_ball_query(const float* points1, const int64_t* lengths1, const float* points2, const int64_t* lengths2,
+                   int64_t B, int64_t P1, int64_t P2, int64_t K, float radius, int64_t* idx, void* stream);
+/* sparse edge conv message (dgcnn.py:227-228, forward_slow): msg[e] = [x_i, x_j - x_i], i = dst[e], j = src[e];
+ * bwd accumulates into dx (zero on entry). */
+int ccn_edge_feat_fwd(const float* x, int64_t ldx, const int64_t* src, const int64_t* dst, int64_t E, int64_t C,
+                      float* msg, int64_t ldm, void* stream);
+int ccn_edge_feat_bwd(const float* dmsg, int64_t lddm, const int64_t* src, const int64_t* dst, int64_t E, int64_t C,
+                      float* dx, int64_t lddx, void* stream);
 /* VoxelFPS (fps_ops.py:42-60): key = (cloud, floor(p/v)) packed in lexicographic order, score = distance to the
  * voxel corner + rnd*v/4; argmin: per voxel the point with the smallest score.  bad: device int64 = #points whose
  * voxel coordinates do not fit 18 bits. */

@@ -53,3 +53,21 @@ void ccn_oracle_knn(const float *points1, const float *points2, const int64_t *l
     search(points1 + b * P1 * 3, points2 + b * P2 * 3, lengths1[b], lengths2[b], K, 0, 0.0f,
            idx + b * P1 * K, dist + b * P1 * K);
 }
+
+/* pytorch3d.ops.ball_query semantics (point_ops.py:81): the first K points2 (in index order) with d2 < r*r; -1 padded. */
+void ccn_oracle_ball_query(const float *points1, const float *points2, const int64_t *lengths1,
+                           const int64_t *lengths2, int64_t B, int64_t P1, int64_t P2, int64_t K, float r,
+                           int64_t *idx) {
+  const float r2 = r * r;
+  for (int64_t b = 0; b < B; ++b) {
+    const float *p1 = points1 + b * P1 * 3, *p2 = points2 + b * P2 * 3;
+#pragma omp parallel for schedule(static, 64)
+    for (int64_t i = 0; i < lengths1[b]; ++i) {
+      int64_t have = 0;
+      for (int64_t j = 0; j < lengths2[b] && have < K; ++j) {
+        const float dx = p2[3 * j] - p1[3 * i], dy = p2[3 * j + 1] - p1[3 * i + 1], dz = p2[3 * j + 2] - p1[3 * i + 2];
+        if (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) < r2) idx[(b * P1 + i) * K + have++] = j;
+      }
+    }
+  }
+}

@@ -348,6 +348,8 @@ def _brute_lib():
         lib.ccn_oracle_frnn.restype = None
         lib.ccn_oracle_knn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 4 + [ctypes.c_void_p] * 2
         lib.ccn_oracle_knn.restype = None
+        lib.ccn_oracle_ball_query.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] * 4 + [ctypes.c_float, ctypes.c_void_p]
+        lib.ccn_oracle_ball_query.restype = None
         _BRUTE = lib
     return _BRUTE
 
@@ -391,13 +393,31 @@ def knn_bruteforce(points1, points2, lengths1, lengths2, K):
     return torch.from_numpy(idx)
 
 
-def group_fixed_radius(p1, p2, batch1, batch2, knn, radius, return_dense=False):
-    """ref point_ops.py:73-111 ``knn_ball_group_pytorch3d`` (operation="knn", accel_knn=True)."""
-    if radius is None:
+def ball_query_bruteforce(points1, points2, lengths1, lengths2, K, r):
+    """pytorch3d ``ball_query`` semantics (ref point_ops.py:81): first K in index order with d2 < r*r."""
+    p1 = np.ascontiguousarray(points1.detach().numpy(), dtype=np.float32)
+    p2 = np.ascontiguousarray(points2.detach().numpy(), dtype=np.float32)
+    B, P1, _ = p1.shape
+    l1 = np.ascontiguousarray(lengths1.numpy(), dtype=np.int64)
+    l2 = np.ascontiguousarray(lengths2.numpy(), dtype=np.int64)
+    idx = np.full((B, P1, K), -1, dtype=np.int64)
+    _brute_lib().ccn_oracle_ball_query(p1.ctypes.data, p2.ctypes.data, l1.ctypes.data, l2.ctypes.data, B, P1,
+                                       p2.shape[1], K, float(r), idx.ctypes.data)
+    return torch.from_numpy(idx)
+
+
+def group_fixed_radius(p1, p2, batch1, batch2, knn, radius, return_dense=False, operation="knn", accel_knn=True):
+    """ref point_ops.py:73-111 ``knn_ball_group_pytorch3d``: FRNN (accel_knn), exact kNN, or ball query (K=128)."""
+    if radius is None and operation == "knn" and accel_knn:
         radius = 0.25                                  # quirk Q7
     q_pad, mask1, len1, off1 = padded_layout(p1, batch1)
     s_pad, mask2, len2, off2 = padded_layout(p2, batch2)
-    nbr = frnn_bruteforce(q_pad, s_pad, len1, len2, knn, radius)
+    if operation == "ball-group":
+        nbr = ball_query_bruteforce(q_pad, s_pad, len1, len2, 128, radius)
+    elif accel_knn:
+        nbr = frnn_bruteforce(q_pad, s_pad, len1, len2, knn, radius)
+    else:
+        nbr = knn_bruteforce(q_pad, s_pad, len1, len2, knn)
     if return_dense:
         return nbr, len2, mask1
     keep = (nbr != -1) & mask1[:, :, None]
@@ -589,9 +609,8 @@ class SAModule(nn.Module):
             idx = farthest_point_indices(pos, batch, self.ratio)
         else:
             idx = voxel_fps(pos, batch, self.voxel_size, torch.rand(pos.size(0)))
-        if not self.use_fast_knn:
-            raise NotImplementedError("ball_query grouping is a 'next' row (SURVEY.md section 8f)")
-        row, col = group_fixed_radius(pos[idx], pos, batch[idx], batch, self.knn, self.r)
+        row, col = group_fixed_radius(pos[idx], pos, batch[idx], batch, self.knn, self.r,
+                                      operation="knn" if self.use_fast_knn else "ball-group")
         x = self.conv(x, pos, pos[idx], col, row)
         p2c = None if point2curveidx is None else point2curveidx[idx]
         return x, pos[idx], batch[idx], p2c
@@ -676,17 +695,29 @@ class SGCNNLayer(nn.Module):
     statistics run over all B*Nmax*(K+1) rows, masking afterwards)."""
 
     def __init__(self, nn, k, aggr="max", r=1.0, num_workers=1, with_xyz=False, attend_nn=None, aggr_type="max",
-                 use_sparse_feat_agg=False, **kwargs):
+                 use_sparse_feat_agg=False, use_fast_knn=True, **kwargs):
         super().__init__()
         assert aggr_type in ("max", "attend", "mean", "weighted-sum")
         self.nn, self.k, self.r, self.with_xyz = nn, k, r, with_xyz
         self.attend_nn, self.aggr_type, self.use_sparse_feat_agg = attend_nn, aggr_type, use_sparse_feat_agg
+        self.use_fast_knn = use_fast_knn
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
         if self.with_xyz:
             x = pos if x is None else torch.cat([x, pos], dim=1)
         if self.use_sparse_feat_agg:
-            raise NotImplementedError("sparse aggregation is a 'next' row (SURVEY.md section 8f)")
+            # ref dgcnn.py:209-246 forward_slow: message nn([x_i, x_j - x_i]) over the edge list, aggregate per query
+            row, col = group_fixed_radius(pos, pos, batch, batch, self.k, self.r, accel_knn=self.use_fast_knn)
+            msg = self.nn(torch.cat([x[row], x[col] - x[row]], dim=-1))
+            n = x.size(0)
+            if self.aggr_type == "max":
+                dense, valid = _segment_dense(msg, row, n)
+                dense = torch.where(valid[:, :, None], dense, torch.full((), float("-inf"), dtype=msg.dtype))
+                out = torch.where(valid.any(dim=1)[:, None], dense.max(dim=1)[0], torch.zeros((), dtype=msg.dtype))
+            else:
+                w = segment_softmax(self.attend_nn(msg), row, n)
+                out = torch.zeros((n, msg.size(1)), dtype=msg.dtype).index_add(0, row, msg * w)
+            return out, pos, batch, point2curveidx
         nbr, len2, mask1 = group_fixed_radius(pos, pos, batch, batch, self.k, self.r, return_dense=True)
         B, N = nbr.shape[:2]
         me = torch.arange(N).view(1, N, 1).expand(B, N, 1)
@@ -712,6 +743,26 @@ class SGCNNLayer(nn.Module):
             a = torch.where(mask[..., None], a, torch.full((), -5e2, dtype=f.dtype))
             f = (f * F.softmax(a, dim=2)).sum(dim=2)
         return f[mask1], pos, batch, point2curveidx
+
+
+class GlobalSAModule(nn.Module):
+    """ref pointnet2.py:81-116: per-cloud max (or mean) pooling of nn([x, pos])."""
+
+    def __init__(self, nn, **kwargs):
+        super().__init__()
+        self.nn, self.pooling = nn, kwargs.get("pooling", "max")
+
+    def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
+        f = self.nn(torch.cat([x, pos], dim=1))
+        n_clouds = int(batch.max().item()) + 1
+        if self.pooling == "max":
+            dense, valid = _segment_dense(f, batch, n_clouds)
+            f = torch.where(valid[:, :, None], dense, torch.full((), float("-inf"), dtype=f.dtype)).max(dim=1)[0]
+        else:
+            cnt = torch.bincount(batch, minlength=n_clouds).to(f.dtype)
+            f = torch.zeros((n_clouds, f.size(1)), dtype=f.dtype).index_add(0, batch, f) / cnt[:, None]
+        first = torch.cat([torch.zeros(1, dtype=torch.long), segment_starts(batch)])
+        return f, pos[first], batch[first], None if point2curveidx is None else point2curveidx[first]
 
 
 class SharedMLP(nn.Module):
@@ -808,6 +859,8 @@ class ModelBase(nn.Module):
                             k=kw["knn"][i], **kw)
         if name == "sgcnn":
             return SGCNNLayer(MLP(dims, bias=b), kw["knn"][i], r=kw["radii"][i], attend_nn=self._attend(dims, kw, False), **kw)
+        if name == "sa-global":
+            return GlobalSAModule(MLP(dims, bias=b), **kw)
         if name == "sa-geo":
             return CurveSAModule(kw["ratios"][i], kw["radii"][i], MLP(dims, act="leaky_relu", bias=b),
                                  attend_nn=self._attend(dims, kw, False), **kw)

@@ -222,7 +222,7 @@ def _pair(make_ref, make_mine):
     return ref.train(), mine.to(DEV).train()
 
 
-def _run_pair(ref, mine, args_cpu, seed, n_out_check=1):
+def _run_pair(ref, mine, args_cpu, seed, n_out_check=1, gtol=3e-4):
     args_dev = [a.to(DEV) if torch.is_tensor(a) else a for a in args_cpu]
     xr = args_cpu[0].clone().requires_grad_(True)
     xd = args_dev[0].clone().requires_grad_(True)
@@ -239,7 +239,7 @@ def _run_pair(ref, mine, args_cpu, seed, n_out_check=1):
     gd = torch.autograd.grad((out_d[0] * cot.to(DEV)).sum(), [xd] + list(mine.parameters()))
     names = ["x"] + [n for n, _ in ref.named_parameters()]
     for a, b, n in zip(gd, gr, names):
-        _close(a, b, 3e-4, "grad " + n)
+        _close(a, b, gtol, "grad " + n)
     return out_r, out_d
 
 
@@ -319,3 +319,41 @@ def test_curve_sa_and_fp_modules_vs_oracle():
                             lambda: steps.CurveFPModule(3, MLP([40 + c + 3, 32, 16], act="leaky_relu", bias=False), with_xyz=True))
     xs = out_r[0].detach()
     _run_pair(ref_fp, mine_fp, [xs, idx, x, d.pos, d.batch, d.curve_idxs], seed=0)
+
+
+@pytest.mark.parametrize("aggr,fast", [("max", False), ("attend", False), ("max", True)])
+def test_sparse_sgcnn_vs_oracle(aggr, fast):
+    from oracle import torch_ref as R
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([1, 2], n_curves=40)
+    c = 9
+
+    def mk(mod, mlp):
+        att = mlp([24, 24, 24], act="leaky_relu", bias=True) if aggr == "attend" else None
+        return mod(mlp([2 * (c + 3), 32, 24], bias=True), 12, r=0.05, with_xyz=True, attend_nn=att, aggr_type=aggr,
+                   use_sparse_feat_agg=True, use_fast_knn=fast)
+    ref, mine = _pair(lambda: mk(R.SGCNNLayer, R.MLP), lambda: mk(steps.SGCNNLayer, MLP))
+    x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4))
+    _run_pair(ref, mine, [x, d.pos, d.batch, d.curve_idxs], seed=0)
+
+
+def test_sa_ball_query_fps_and_global_sa_vs_oracle():
+    from oracle import torch_ref as R
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([5, 6], n_curves=30)
+    c = 6
+
+    def mk(mod, mlp):
+        return mod(0.25, 0.2, mlp([c + 3, 32, 24], bias=True), None, downsample_type="fps", aggr_type="attend",
+                   attend_nn=mlp([24, 24, 24], act="leaky_relu", bias=True), normalize_radius=True, use_fast_knn=False)
+    ref, mine = _pair(lambda: mk(R.SAModule, R.MLP), lambda: mk(steps.SAModule, MLP))
+    x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4))
+    out_r, _ = _run_pair(ref, mine, [x, d.pos, d.batch, d.curve_idxs], seed=3)
+    ref_g, mine_g = _pair(lambda: R.GlobalSAModule(R.MLP([24 + 3, 32, 16], bias=True)),
+                          lambda: steps.GlobalSAModule(MLP([24 + 3, 32, 16], bias=True)))
+    outs = _run_pair(ref_g, mine_g, [out_r[0].detach(), out_r[1], out_r[2], out_r[3]], seed=0, gtol=3e-3)  # max-pool ties
+    assert outs[0][0].shape == (2, 16)

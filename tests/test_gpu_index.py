@@ -259,3 +259,17 @@ def test_knn_points_matches_bruteforce():
     nbr, w = ops.knn_points_packed(d.pos.to(DEV), topo_y, pos_x.to(DEV), topo_x, 3)
     assert torch.equal(nbr.cpu(), want[mask])
     assert bool((w > 0).all())
+
+
+def test_ball_query_and_exact_knn_match_oracle():
+    ops = _ops()
+    from oracle import torch_ref as R
+    p1, p2, l1, l2 = _frnn_case(3, 300, 700, 128, 0.3, seed=11)
+    for r in (0.15, 0.6):
+        want = R.ball_query_bruteforce(p1, p2, l1, l2, 128, r)
+        got = ops.ball_query(p1.to(DEV), p2.to(DEV), l1.to(DEV), l2.to(DEV), 128, r)
+        assert torch.equal(got.cpu(), want), r
+    for K in (3, 20, 30):        # exact kNN = the grid search with an unbounded radius
+        want = R.knn_bruteforce(p1, p2, l1, l2, K)
+        got = ops.fast_knn(p1.to(DEV), p2.to(DEV), l1.to(DEV), l2.to(DEV), K, ops.EXACT_KNN_RADIUS)
+        assert torch.equal(got.cpu(), want), K

@@ -123,3 +123,35 @@ def test_full_kitti_config_matches_oracle():
     # defect shows up as O(1) errors
     assert max(e[0] for e in errs) < 1e-1, max(errs)
     assert sorted(e[0] for e in errs)[len(errs) // 2] < 2e-2
+
+
+def test_shapenet_seg_config_matches_oracle():
+    """The ShapeNet-seg / Kortx step list (x=None input, biased MLPs, v1 attention widths, conv1d-fast-v1, ball-query SA
+    with farthest point sampling, sparse exact-kNN SGCNN, FP, category one-hot head) at 1/8 width."""
+    from oracle import torch_ref as R
+    from curvecloudnet_amd.configs import shapenet_seg_config
+    from curvecloudnet_amd.model import segmentation_loss
+    from curvecloudnet_amd.synth import make_batch
+    ref, mine = build_pair(shapenet_seg_config(width=0.125), in_dim=3, n_out=50)
+    mine = mine.to(DEV)
+    data = make_batch([0, 1], n_curves=90)
+    data.x = None
+    data.pos = data.pos / 3.0                       # ShapeNet clouds live in the unit ball
+    cats = torch.tensor([3, 11])
+    y = _labels(data.pos.size(0), 50, 3)
+    ref.train(); mine.train()
+    torch.manual_seed(5)
+    out_r = ref(data, **{"shapenet-categories": cats})
+    R.segmentation_loss(out_r, y).backward()
+    torch.manual_seed(5)
+    out_d = mine(batch_to(data, DEV), **{"shapenet-categories": cats.to(DEV)})
+    segmentation_loss(out_d, y.to(DEV)).backward()
+    assert out_d.shape == out_r.shape == (data.pos.size(0), 50)
+    assert maxdiff(out_d, out_r) < 5e-4, maxdiff(out_d, out_r)
+    errs = []
+    for (n, pr), (_, pd) in zip(ref.named_parameters(), mine.named_parameters()):
+        floor = 1e-4 * pr.grad.numel() ** 0.5
+        errs.append((float((pd.grad.cpu() - pr.grad).norm() / max(float(pr.grad.norm()), floor)), n))
+    print("worst gradient tensors:", sorted(errs)[-5:])
+    assert max(e[0] for e in errs) < 1e-1, max(errs)
+    assert sorted(e[0] for e in errs)[len(errs) // 2] < 2e-2

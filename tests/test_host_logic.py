@@ -84,7 +84,7 @@ def test_reference_yaml_schema_is_accepted(tmp_path):
 def test_unsupported_steps_fail_loudly():
     from curvecloudnet_amd.model import ModelBase
     with pytest.raises(NotImplementedError):
-        ModelBase(3, 5, steps=["sa-global"], feat_dims=[[8]], knn=[None], ratios=[None], radii=[None])
+        ModelBase(3, 5, steps=["dgcnn"], feat_dims=[[8]], knn=[4], ratios=[None], radii=[None])
     with pytest.raises(NotImplementedError):
         ModelBase(3, 5, steps=["bogus"], feat_dims=[[8]])
 
@@ -111,3 +111,10 @@ def test_kitti_config_equals_reference_yaml_when_available():
         assert yaml.safe_load(open(path.replace("kitti", "nuscenes")))["model"] == nuscenes_config()
     ref, mine = build_pair(kitti_config(0.125), 4, 20)
     assert sum(p.numel() for p in mine.parameters()) == sum(p.numel() for p in ref.parameters())
+    from curvecloudnet_amd.configs import shapenet_seg_config
+    base = "/root/reference/configs/curvecloudnet-eval/%s-curvecloudnet.yaml"
+    if os.path.exists(path):
+        assert yaml.safe_load(open(base % "shapenet-seg"))["model"] == shapenet_seg_config()
+        assert yaml.safe_load(open(base % "kortx-testsplit"))["model"] == shapenet_seg_config(kortx=True)
+    ref, mine = build_pair(shapenet_seg_config(0.125), 3, 50)
+    assert "lin_categorical.lins.0.weight" in mine.state_dict() and mine.mlp.channel_list[0] == 8 + 64
