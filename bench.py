@@ -62,6 +62,19 @@ def summarise_profile(records, steps):
         t["flops"] += flops
     total = sum(t["ms"] for t in table.values())
     rows = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
+    # per-shape view of the GEMMs (which layers carry the time)
+    shapes = {}
+    for name, ints, beg, end in records:
+        if name.startswith("gemm_"):
+            key = (name, ints[3], ints[4], ints[5])
+            t = shapes.setdefault(key, [0.0, 0])
+            t[0] += beg.elapsed_time(end)
+            t[1] += 1
+    with open(os.path.join(ROOT, "gpurun_out", "bench_gemm_shapes.txt"), "w") as f:
+        f.write("GEMM time by (entry, M, N, K) over %d steps\n" % steps)
+        for (name, m, n, k), (ms, cnt) in sorted(shapes.items(), key=lambda kv: -kv[1][0])[:60]:
+            f.write("%8.2f ms %4d x %-8s M=%-9d N=%-5d K=%-5d %6.1f TFLOP/s\n"
+                    % (ms, cnt, name, m, n, k, 2.0 * m * n * k * cnt / (ms * 1e-3) / 1e12))
     return rows, total
 
 
@@ -104,7 +117,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
-    rank, world, local_rank = init_process_group_from_env()
+    # CCN_DIST_BACKEND=gloo + CCN_FORCE_DEVICE=0 rehearse the N>1 code path with several ranks on ONE GPU
+    rank, world, local_rank = init_process_group_from_env(backend=os.environ.get("CCN_DIST_BACKEND"))
+    local_rank = int(os.environ.get("CCN_FORCE_DEVICE", local_rank))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():

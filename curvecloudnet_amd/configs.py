@@ -82,6 +82,68 @@ def shapenet_seg_config(width=1.0, kortx=False):
     )
 
 
+def a2d2_config(width=1.0):
+    """configs/curvecloudnet-eval/audi-curvecloudnet.yaml (in_dim 4; FRNN + attention in the sparse SGCNN steps)."""
+    s = lambda **kw: dict(**kw)                                                     # noqa: E731
+    sa = s(step_name="sa", aggr_type="attend", normalize_radius=True, use_fast_knn=False, downsample_type="fps")
+    sg_xyz = s(step_name="sgcnn", with_xyz=True, aggr_type="attend", use_sparse_feat_agg=True)
+    sg = s(step_name="sgcnn", aggr_type="attend", use_sparse_feat_agg=True)
+    conv = s(step_name="conv1d-fast-v1", with_diff=True, with_xyz=True)
+    steps = [
+        s(step_name="sa-geo", curve_fps_arclen=0.01, use_curve_fps=True, use_curve_knn=True, with_xyz=True,
+          aggr_type="attend", normalize_radius=True),
+        s(step_name="mlp", plain_last=False, with_xyz=True), dict(conv), "skip-connect",
+        dict(sa), dict(sg_xyz), "skip-connect", dict(sa), dict(sg_xyz), "skip-connect", dict(sa), dict(sg_xyz), dict(sg),
+        "skip-connect",
+        s(step_name="fp", with_xyz=True), dict(sg), "skip-connect",
+        s(step_name="fp", with_xyz=True), dict(sg), "skip-connect",
+        s(step_name="fp", with_xyz=True), dict(conv), "skip-connect",
+        s(step_name="fp-geo", with_xyz=True), dict(conv), "skip-connect",
+    ]
+    free = [[64, 128, 256, 512], [256, 128, 64], [64, 64], [None, 128], [128, 128, 128], [128, 128], [None, 256],
+            [256, 256, 256], [256, 256], [None, 512], [512, 512, 512], [512, 512], [512, 512], [None, 1024, 512],
+            [None, 512, 256], [256, 256], [None, 512, 256], [None, 256, 128], [128, 128], [None, 256, 128],
+            [None, 128, 64], [64, 64], [None, 64, 64], [None, 128, 128], [128, 128], [None, 128, 64]]
+    num_skips = [None, None, None, 1, None, None, 1, None, None, 1, None, None, None, 2, None, None, 1, None, None, 1,
+                 None, None, 1, None, None, 1]
+    store = ["conv1d-fast-v1", "sgcnn"]
+    return dict(
+        type="generic", use_bias=True, version=1.0, steps=copy.deepcopy(steps),
+        feat_dims=_derive(steps, free, num_skips, store, width, 1),
+        out_mlp={"dims": [_w(64, width), _w(64, width)], "dropout": 0.0},
+        knn=[None, None, 30, None, None, 30, None, None, 30, None, None, 30, 30, 30, 3, 30, None, 3, 30, None, 3, 30, None,
+             3, None, None],
+        ratios=[None] * 4 + [0.35, None, None, 0.25, None, None, 0.25] + [None] * 15,
+        radii=[0.015, None, 0.1, None, 0.03, 0.25, None, 0.06, 0.5, None, 0.15, 1.5, 1.5, None, None, 0.5, None, None, 0.25,
+               None, None, 0.1, None, None, None, None],
+        num_skips=num_skips,
+        kernel_sizes=[None, None, 5] + [None] * 18 + [5, None, None, 5, None],
+        skip_connect_state_store=store,
+    )
+
+
+def shapenet_cls_config(width=1.0):
+    """configs/curvecloudnet-eval/shapenet-class-curvecloudnet.yaml (15 steps, ends in the global pooling step)."""
+    full = shapenet_seg_config(1.0, kortx=True)
+    steps = copy.deepcopy(full["steps"][:14]) + ["sa-global"]
+    free = [[64, 128, 256, 512], [256, 128, 64], [64, 64], [None, 128], [128, 128, 128], [128, 128], [None, 256],
+            [256, 256, 256], [256, 256], [None, 512], [512, 512, 512], [512, 512], [512, 512], [None, 1024, 1024],
+            [1024, 1024]]
+    num_skips = [None, None, None, 1, None, None, 1, None, None, 1, None, None, None, 2, None]
+    store = ["conv1d-fast-v1", "sgcnn"]
+    return dict(
+        type="generic", use_bias=True, version=1.0, steps=steps,
+        feat_dims=_derive(steps, free, num_skips, store, width, 0),
+        out_mlp={"dims": [_w(512, width), _w(256, width), _w(128, width)], "dropout": 0.0, "with_seg_category": False},
+        knn=[None, None, 30, None, None, 30, None, None, 30, None, None, 30, 30, 30, None],
+        ratios=[None] * 4 + [0.25, None, None, 0.25, None, None, 0.25] + [None] * 4,
+        radii=[0.075, None, None, None, 0.2, None, None, 0.4, None, None, 0.8] + [None] * 4,
+        num_skips=num_skips,
+        kernel_sizes=[None, None, 7] + [None] * 12,
+        skip_connect_state_store=store,
+    )
+
+
 def kitti_config(width=1.0, first_voxel=0.025, in_dim=4):
     s = lambda **kw: dict(**kw)                                                     # noqa: E731
     sa_vox = lambda v: s(step_name="sa", aggr_type="attend", downsample_type="voxel", voxel_size=v,   # noqa: E731

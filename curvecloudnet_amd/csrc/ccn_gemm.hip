@@ -863,7 +863,7 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
   if (M == 0) return CCN_OK;
   int rc;
   const bool dma_ok = aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && lda >= 4 && ldw >= 4 &&
-                      !g_force_generic && g_use_glds && M >= 1024 && K >= 32;
+                      !g_force_generic && g_use_glds && M >= 1024 && K >= 128;  // short K: the multi-workgroup-per-CU kernels win
   if (dma_ok) {
     if (N <= 32)
       rc = launch_glds<32>(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s);

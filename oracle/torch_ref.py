@@ -296,7 +296,7 @@ def curve_interpolate(x, idx, pos_y, batch_y, point2curveidx_y, k):
     with torch.no_grad():
         y_idx, x_idx = curve_knn_superset(pos_y, idx, point2curveidx_y, batch_y, k)
         d = torch.linalg.norm(pos_x[x_idx] - pos_y[y_idx], dim=-1, keepdim=True) ** 2
-        w = 1.0 / torch.clamp(d, min=1e-16)
+        w = (1.0 / torch.clamp(d, min=1e-16)).to(x.dtype)
     n = pos_y.size(0)
     num = torch.zeros((n, x.size(1)), dtype=x.dtype).index_add(0, y_idx, x[x_idx] * w)
     den = torch.zeros((n, 1), dtype=x.dtype).index_add(0, y_idx, w)
@@ -654,7 +654,7 @@ def knn_interpolate(x, pos_x, pos_y, batch_x, batch_y, k):
         qid[1:] += off1.view(-1, 1, 1)
         y_idx, x_idx = qid[keep], col[keep]
         diff = pos_x[x_idx] - pos_y[y_idx]
-        w = 1.0 / torch.clamp((diff * diff).sum(dim=-1, keepdim=True), min=1e-16)
+        w = (1.0 / torch.clamp((diff * diff).sum(dim=-1, keepdim=True), min=1e-16)).to(x.dtype)
     n = pos_y.size(0)
     num = torch.zeros((n, x.size(1)), dtype=x.dtype).index_add(0, y_idx, x[x_idx] * w)
     den = torch.zeros((n, 1), dtype=x.dtype).index_add(0, y_idx, w)

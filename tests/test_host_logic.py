@@ -118,3 +118,11 @@ def test_kitti_config_equals_reference_yaml_when_available():
         assert yaml.safe_load(open(base % "kortx-testsplit"))["model"] == shapenet_seg_config(kortx=True)
     ref, mine = build_pair(shapenet_seg_config(0.125), 3, 50)
     assert "lin_categorical.lins.0.weight" in mine.state_dict() and mine.mlp.channel_list[0] == 8 + 64
+    from curvecloudnet_amd.configs import a2d2_config, shapenet_cls_config
+    if os.path.exists(path):
+        assert yaml.safe_load(open(base % "audi"))["model"] == a2d2_config()
+        assert yaml.safe_load(open(base % "shapenet-class"))["model"] == shapenet_cls_config()
+    for cfg, in_dim, n_out, params in ((a2d2_config(), 4, 55, 10266679), (shapenet_cls_config(), 3, 16, 10272400),
+                                       (kitti_config(), 4, 20, 28767232), (shapenet_seg_config(), 3, 50, 11747378)):
+        from curvecloudnet_amd.model import build_model
+        assert sum(p.numel() for p in build_model(cfg, in_dim, n_out).parameters()) == params
