@@ -34,20 +34,37 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
 def gemm_label(name, ints):
-    """(kernel label, flops) of a GEMM launch; mirrors the tile dispatch in csrc/ccn_gemm.hip."""
+    """(kernel symbol as rocprofv3 prints it, flops) of a GEMM launch; mirrors the dispatch in csrc/ccn_gemm.hip."""
+    if name not in ("gemm_nt", "gemm_nn", "gemm_tn"):
+        return None, 0.0
+    ld_a, ld_b, _, m, n, k = ints[:6]
+    flops = 2.0 * m * n * k
+    aligned = ld_a % 4 == 0 and ld_b % 4 == 0
     if name == "gemm_nt":
-        m, n, k = ints[3], ints[4], ints[5]
         bn = 32 if n <= 32 else (64 if n <= 64 else 128)
-        return "gemm_kernel<128,%d,4,KC,KC,STORE> (gemm_nt)" % bn, 2.0 * m * n * k
+        if aligned and m >= 1024 and k >= 128:
+            return "gemm_glds_kernel<%d>" % bn, flops
+        kern = "gemm_fast_kernel" if aligned else "gemm_kernel"
+        return "%s<128, %d, 4, 0, 0, 0%s>" % (kern, bn, (", true" if k > 96 else ", false") if aligned else ""), flops
     if name == "gemm_nn":
-        m, n, k = ints[3], ints[4], ints[5]
         bn = 32 if k <= 32 else (64 if k <= 64 else 128)
-        return "gemm_kernel<128,%d,4,KC,MC,STORE> (gemm_nn)" % bn, 2.0 * m * n * k
-    if name == "gemm_tn":
-        m, n, k = ints[3], ints[4], ints[5]
-        tile = "32,128,1" if n <= 32 else ("64,64,2" if k <= 64 else "64,128,2")
-        return "gemm_kernel<%s,MC,MC,ATOMIC> (gemm_tn)" % tile, 2.0 * m * n * k
-    return None, 0.0
+        return "gemm_fast_kernel<128, %d, 4, 0, 1, 0>" % bn, flops
+    tile = "32, 128, 1" if n <= 32 else ("64, 64, 2" if k <= 64 else "64, 128, 2")
+    return "gemm_fast_kernel<%s, 1, 1, 1, true>" % tile, flops
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when the kernel is not in the profile."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        table = json.load(open(path))
+        for name, t in table.items():
+            if kernel in name:
+                return {"bytes_per_launch": t["fetch_bytes_per_launch_corrected"] + t["write_bytes_per_launch"],
+                        "source": os.path.relpath(path, ROOT), "launches_profiled": t["launches"]}
+    return None
 
 
 def summarise_profile(records, steps):
@@ -193,8 +210,11 @@ def main():
         name, top = rows[0]
         if top["flops"] > 0:
             achieved = top["flops"] / (top["ms"] * 1e-3) / 1e12
+            tr = pmc_traffic(name)
             result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                                  "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                                  "traffic": tr["bytes_per_launch"] if tr else None, "traffic_source": tr,
+                                  "flops_per_launch": top["flops"] / top["launches"],
                                   "kernel": name, "avg_launch_ms": top["ms"] / top["launches"],
                                   "launches": top["launches"], "share_of_kernel_time": top["ms"] / total_ms}
         else:
