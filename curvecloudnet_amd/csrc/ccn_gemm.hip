@@ -102,7 +102,22 @@ __device__ __forceinline__ float4 frag_read(const float* __restrict__ lds, int r
   }
 }
 
-// accumulator tiles -> C (+bias, +BatchNorm partial statistics) or atomic accumulation.
+// The bias is the INITIAL value of the accumulators (column n = lane&31 of every register of a tile): loading it
+// in the epilogue would put a global load in front of every conditional store, and since vmcnt retires loads and
+// stores in order hipcc then waits vmcnt(0) before each of the 16*NT stores (measured: ~14 us per 256x128 tile).
+template <int NT>
+__device__ __forceinline__ void acc_init(f32x16 (&acc)[NT], const float* __restrict__ bias, int64_t n_first, int64_t N,
+                                         int i) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int64_t n = n_first + t * 32 + i;
+    const float b = (bias != nullptr && n < N) ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = b;
+  }
+}
+
+// accumulator tiles -> C (+BatchNorm partial statistics) or atomic accumulation.
 // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 template <int BM, int BN, int WM, int EPI, int NT>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NT], float* __restrict__ As, const float* __restrict__ bias,
@@ -116,13 +131,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[NT], float* __restri
   for (int t = 0; t < NT; ++t) {
     const int ncol_local = wn * WCOLS + t * 32 + i;
     const int64_t n = n0 + ncol_local;
-    const float bv = (EPI == EPI_STORE && bias != nullptr && n < N) ? bias[n] : 0.f;
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (m < M && n < N) {
-        const float v = acc[t][r] + bv;
+        const float v = acc[t][r];
         if (EPI == EPI_STORE) {
           C[m * ldc + n] = v;
           if (colstats != nullptr) {
@@ -184,10 +198,7 @@ __global__ __launch_bounds__(GEMM_TPB) void gemm_kernel(const float* __restrict_
   const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
 
   f32x16 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  acc_init<NT>(acc, (EPI == EPI_STORE && blockIdx.z == 0) ? bias : nullptr, n0 + wn * WCOLS, N, i);
 
   float4 ra[Tile<BM, ALAY>::PER_THREAD], rb[Tile<BN, BLAY>::PER_THREAD];
   if (kbeg < kend) {
@@ -312,10 +323,7 @@ __global__ __launch_bounds__(GEMM_TPB) void gemm_fast_kernel(const float* __rest
   const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
 
   f32x16 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  acc_init<NT>(acc, (EPI == EPI_STORE && blockIdx.z == 0) ? bias : nullptr, n0 + wn * WCOLS, N, i);
 
   FastLoader<BM, ALAY> la;
   FastLoader<BN, BLAY> lb;
@@ -428,10 +436,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_kernel(const float* __restri
   const uint32_t b_off = (uint32_t)((AF + i * BK) * 4);               // B row i; tile t adds an immediate
 
   f32x16 acc[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  acc_init<NT>(acc, bias, n0, N, i);
 
   // ---- per-lane DMA sources: row group g covers tile rows 8g .. 8g+7, lane -> (row 8g + lane/8, chunk lane%8)
   const int lr = lane >> 3, lc = lane & 7;
@@ -544,13 +549,12 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_kernel(const float* __restri
   for (int t = 0; t < NT; ++t) {
     const int ncol = t * 32 + i;
     const int64_t n = n0 + ncol;
-    const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
       if (m < M && n < N) {
-        const float v = acc[t][r] + bv;
+        const float v = acc[t][r];
         C[m * ldc + n] = v;
         if (colstats != nullptr) {
           s1 += (double)v;
@@ -601,9 +605,190 @@ int launch_glds(const float* A, int64_t lda, const float* W, int64_t ldw, const 
   return CCN_OK;
 }
 
+
+// ------------------------------------------------------------------ persistent form of the LDS-DMA kernel
+// One workgroup per CU walks the output tiles (K % 32 == 0, no bias).  The K slices of consecutive tiles form ONE
+// stream through the 3-stage ring, so the DMA of the next tile's first two slices is already in flight while the
+// current tile is finished, and the epilogue's global stores (issued and forgotten) drain under the next tile's
+// MFMAs: with a single 8-wave workgroup per CU nothing else could hide the pipeline fill or the 128 KiB of
+// stores per tile (measured on the one-tile-per-workgroup kernel: 75 TFLOP/s at K=128 vs 132 at K=4096).
+// vmcnt retires loads, stores and LDS-DMA in issue order, so the counted waits are arranged as follows: before
+// the stores every DMA issued so far is waited for (it is at least one compute phase old) and remembered as
+// landed; the next two slices then need no wait, and later counted waits see the stores as the oldest entries.
+template <int BN>
+__global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const float* __restrict__ A, int64_t lda,
+                                                                      const float* __restrict__ B, int64_t ldb,
+                                                                      float* __restrict__ C, int64_t ldc, int64_t M,
+                                                                      int64_t N, int64_t K, int64_t tiles, int64_t gn,
+                                                                      double* __restrict__ colstats) {
+  constexpr int NT = BN / 32;
+  constexpr int AF = GL_BM * BK, BF = BN * BK, STAGE = AF + BF;
+  constexpr int NA = GL_BM / 8 / 8;
+  constexpr int NB = BN >= 64 ? BN / 64 : 1;
+  __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int swz = (i >> 1) & 7;
+  const int lr = lane >> 3, lc = lane & 7;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+  const uint32_t a_off = (uint32_t)((wave * 32 + i) * BK * 4);
+  const uint32_t b_off = (uint32_t)((AF + i * BK) * 4);
+  const int T = (int)(K / BK);
+
+  // ---- issue cursor (runs two slices ahead of the compute cursor, across tile boundaries)
+  const float* a_src[NA];
+  const float* b_src[NB];
+  int64_t it_tile = blockIdx.x;
+  int it_u = 0;
+  int64_t gi = 0;  // slices issued so far
+  auto issue_next = [&]() {
+    if (it_tile >= tiles) return;
+    if (it_u == 0) {
+      const int64_t im0 = (it_tile / gn) * GL_BM, in0 = (it_tile % gn) * BN;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int r = 8 * (wave * NA + j) + lr;
+        int64_t row = im0 + r;
+        row = row < M ? row : M - 1;
+        a_src[j] = A + row * lda + 4 * (lc ^ ((r >> 1) & 7));
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int g = BN >= 64 ? wave * NB + j : (wave & 3);
+        const int r = 8 * g + lr;
+        int64_t row = in0 + r;
+        row = row < N ? row : N - 1;
+        b_src[j] = B + row * ldb + 4 * (lc ^ ((r >> 1) & 7));
+      }
+    }
+    float* st = lds + (gi % 3) * STAGE;
+    const int64_t k0 = (int64_t)it_u * BK;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) glds16(a_src[j] + k0, st + (8 * (wave * NA + j)) * BK);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int g = BN >= 64 ? wave * NB + j : (wave & 3);
+      glds16(b_src[j] + k0, st + AF + (8 * g) * BK);
+    }
+    ++gi;
+    if (++it_u == T) {
+      it_u = 0;
+      it_tile += gridDim.x;
+    }
+  };
+  issue_next();
+  issue_next();
+
+  int64_t g = 0;       // slices computed so far
+  int64_t landed = 0;  // slices [0, landed) are known to be in LDS for this wave
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t m0 = (tile / gn) * GL_BM, n0 = (tile % gn) * BN;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int u = 0; u < T; ++u, ++g) {
+      if (g >= landed) {
+        if (g + 1 < gi)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      issue_next();
+      const uint32_t stage_b = lds_base + (uint32_t)((g % 3) * STAGE * 4);
+      f32x4 fa[2], fb[2][NT];
+      lds_read_frag<NT>(stage_b + a_off, stage_b + b_off, 0, h, swz, fa[0], fb[0]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < 3) {
+          lds_read_frag<NT>(stage_b + a_off, stage_b + b_off, q + 1, h, swz, fa[(q + 1) & 1], fb[(q + 1) & 1]);
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NT + 1) : "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1].x, fb[q & 1][t].x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1].y, fb[q & 1][t].y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1].z, fb[q & 1][t].z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1].w, fb[q & 1][t].w, acc[t], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- tile epilogue.  Everything issued so far (<= 2 slices of the next tile) is waited for first.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landed = gi;
+    double* stat_lds = reinterpret_cast<double*>(lds + ((g + 2) % 3) * STAGE);  // the stage just consumed
+    if (colstats != nullptr) __builtin_amdgcn_s_barrier();                     // every wave is done reading it
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int ncol = t * 32 + i;
+      const int64_t n = n0 + ncol;
+      double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < M && n < N) {
+          const float v = acc[t][r];
+          C[m * ldc + n] = v;
+          if (colstats != nullptr) {
+            s1 += (double)v;
+            s2 += (double)v * (double)v;
+          }
+        }
+      }
+      if (colstats != nullptr) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0) {
+          stat_lds[(wave * BN + ncol) * 2] = s1;
+          stat_lds[(wave * BN + ncol) * 2 + 1] = s2;
+        }
+      }
+    }
+    if (colstats != nullptr) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < 2 * BN; e += GL_TPB) {
+        const int half = e / BN, c = e - half * BN;
+        const int64_t n = n0 + c;
+        const int64_t prow = (tile / gn) * 2 + half;
+        if (n < N && prow * 128 < M) {
+          double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            s1 += stat_lds[((half * 4 + w) * BN + c) * 2];
+            s2 += stat_lds[((half * 4 + w) * BN + c) * 2 + 1];
+          }
+          double* dst = colstats + prow * 2 * N;
+          dst[n] = s1;
+          dst[N + n] = s2;
+        }
+      }
+    }
+  }
+}
+
+template <int BN>
+int launch_glds_persistent(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M,
+                           int64_t N, int64_t K, double* colstats, hipStream_t s) {
+  const int64_t gm = (M + GL_BM - 1) / GL_BM, gn = (N + BN - 1) / BN;
+  const int64_t tiles = gm * gn;
+  const int64_t grid = tiles < 256 ? tiles : 256;  // one workgroup per CU (147 KB of LDS each)
+  hipLaunchKernelGGL((gemm_glds_persistent_kernel<BN>), dim3((unsigned)grid), dim3(GL_TPB), 0, s, A, lda, W, ldw, Y,
+                     ldy, M, N, K, tiles, gn, colstats);
+  return CCN_OK;
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static bool g_force_generic = false;  // test hook (ccn_gemm_force_generic)
 static bool g_use_glds = true;        // test / A-B hook (ccn_gemm_use_dma)
+static bool g_use_persistent = true;  // A-B hook (ccn_gemm_use_dma(2) = DMA without the persistent tile loop)
 
 template <int BM, int BN, int WM, int ALAY, int BLAY, int EPI>
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
@@ -846,6 +1031,7 @@ int64_t ccn_stats_rows(int64_t rows) { return (rows + RED_ROWS - 1) / RED_ROWS; 
 
 int ccn_gemm_use_dma(int on) {
   g_use_glds = on != 0;
+  g_use_persistent = on == 1;
   return CCN_OK;
 }
 
@@ -864,6 +1050,18 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
   int rc;
   const bool dma_ok = aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && lda >= 4 && ldw >= 4 &&
                       !g_force_generic && g_use_glds && M >= 1024 && K >= 128;  // short K: the multi-workgroup-per-CU kernels win
+  if (dma_ok && bias == nullptr && K % BK == 0 && g_use_persistent &&
+      ((M + GL_BM - 1) / GL_BM) * ((N + 127) / 128) >= 512) {
+    if (N <= 32)
+      rc = launch_glds_persistent<32>(A, lda, W, ldw, Y, ldy, M, N, K, colstats, s);
+    else if (N <= 64)
+      rc = launch_glds_persistent<64>(A, lda, W, ldw, Y, ldy, M, N, K, colstats, s);
+    else
+      rc = launch_glds_persistent<128>(A, lda, W, ldw, Y, ldy, M, N, K, colstats, s);
+    if (rc) return rc;
+    CCN_LAUNCH_OK("gemm_nt");
+    return CCN_OK;
+  }
   if (dma_ok) {
     if (N <= 32)
       rc = launch_glds<32>(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s);

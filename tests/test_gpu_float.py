@@ -83,6 +83,30 @@ def test_gemm_dma_pipeline_matches_register_staged_kernel(M, K, N):
     _close(outs[0][0], F.linear(x.cpu(), w.cpu(), b.cpu()), 5e-5, "vs torch")
 
 
+@pytest.mark.parametrize("M,K,N", [(140000, 128, 128), (270001, 64 + 64, 64), (150000, 256, 192), (300000, 160, 20)])
+def test_gemm_persistent_dma_kernel(M, K, N):
+    """No bias, K % 32 == 0, >= 512 tiles: the persistent LDS-DMA kernel (tiles streamed through one ring) against
+    the one-tile-per-workgroup DMA kernel and torch; statistics partial rows included."""
+    from curvecloudnet_amd._lib import call, lib, ptr
+    from curvecloudnet_amd.ops import _ld, _rows
+    gen = torch.Generator().manual_seed(M + K)
+    x = _rows(M, K, DEV); x.copy_(torch.randn(M, K, generator=gen))
+    w = _rows(N, K, DEV, zero=True); w.copy_(torch.randn(N, K, generator=gen) / K ** 0.5)
+    outs = []
+    for mode in (1, 2):
+        lib().ccn_gemm_use_dma(mode)
+        try:
+            y = _rows(M, N, DEV); y.fill_(float("nan"))
+            stats = torch.zeros((lib().ccn_stats_rows(M) + 1) * 2 * N, dtype=torch.float64, device=DEV)
+            call("gemm_nt", ptr(x), _ld(x), ptr(w), _ld(w), None, ptr(y), _ld(y), M, N, K, ptr(stats))
+            outs.append((y.clone(), stats[: lib().ccn_stats_rows(M) * 2 * N].clone()))
+        finally:
+            lib().ccn_gemm_use_dma(1)
+    assert torch.equal(outs[0][0], outs[1][0])                  # same per-element fma order
+    assert torch.equal(outs[0][1], outs[1][1])
+    _close(outs[0][0], x.cpu() @ w.cpu().t(), 5e-5, "vs torch")
+
+
 def test_linear_generic_kernel_path_matches_fast_path():
     """Unaligned operands take the generic GEMM kernel; force it and compare with the aligned fast path."""
     ops = _ops()
