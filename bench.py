@@ -202,6 +202,7 @@ def main():
                                   "section-8a hot-path subset (conv1d-fast-v2, sa-geo, mlp, 2x sgcnn, skip, fp-geo, conv)",
                                   args.width),
                    "network": args.config, "parameters": sum(p.numel() for p in model.parameters()),
+                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                    "clouds_per_gpu": b, "points_per_cloud": n_points // b, "parallelism": "dp%d" % world,
                    "loss": float(loss.detach())},
     }
