@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 
 from curvecloudnet_amd import _lib                                              # noqa: E402
 from curvecloudnet_amd.model import ModelBase, segmentation_loss               # noqa: E402
-from curvecloudnet_amd.parallel import GradientAllReduce, init_process_group_from_env  # noqa: E402
+from curvecloudnet_amd.parallel import FlatAdam, GradientAllReduce, init_process_group_from_env  # noqa: E402
 from curvecloudnet_amd.synth import make_batch, to_device                      # noqa: E402
 from curvecloudnet_amd.configs import kitti_config                             # noqa: E402
 from tests.util import hotpath_config                                          # noqa: E402
@@ -149,7 +149,7 @@ def main():
     torch.manual_seed(1234)                                  # identical replicas on every rank
     model = ModelBase(4, N_CLASSES, **kw).to(dev).train()
     sync = GradientAllReduce(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, foreach=True)
+    opt = FlatAdam(sync, lr=1e-3)                            # torch.optim.Adam arithmetic, one launch per bucket
 
     b = args.clouds_per_gpu
     cloud_ids = list(range(rank * b, rank * b + b))          # weak scaling: a fixed number of whole clouds per GPU

@@ -118,7 +118,7 @@ class ModelBase(torch.nn.Module):
         if hasattr(data, "labels"):
             kwargs["shapenet-categories"] = data.labels
         num_clouds = getattr(data, "num_clouds", None) or getattr(data, "num_graphs", None)
-        kwargs["_ccn_ctx"] = ForwardContext(num_clouds)
+        kwargs["_ccn_ctx"] = ForwardContext(num_clouds, device=pos.device)
         hist = {"x": [x], "pos": [pos], "batch": [batch], "p2c": [p2c], "idx": []}
         proportional, downsampled = [], []
         cloud_of_point = batch

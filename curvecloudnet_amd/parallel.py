@@ -120,3 +120,50 @@ class GradientAllReduce:
     @property
     def num_bytes(self):
         return sum(f.numel() * f.element_size() for f, _ in self.buckets)
+
+
+class FlatAdam:
+    """``torch.optim.Adam`` (the reference harness' optimiser, src/main.py:56) over the flat buckets of a
+    ``GradientAllReduce``: the parameters of a bucket are re-homed into one contiguous buffer laid out like
+    the gradient bucket, and a step is one ``ccn_adam_step`` launch per bucket (a handful per step instead
+    of several hundred per-tensor updates, whose host-side cost left the GPU idle between steps).
+
+    Build it after the module sits on its device; ``module.to(...)`` afterwards would detach the views.
+    """
+
+    def __init__(self, sync, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.sync, self.lr, self.betas, self.eps, self.weight_decay = sync, lr, betas, eps, weight_decay
+        self.steps = 0
+        self.state = []            # (flat params, exp_avg, exp_avg_sq) per bucket
+        for gflat, plist in sync.buckets:
+            if not gflat.is_cuda:
+                raise RuntimeError("FlatAdam runs the HIP kernel: parameters must be on the GPU")
+            pflat = torch.empty_like(gflat)
+            off = 0
+            with torch.no_grad():
+                for p in plist:
+                    view = pflat[off: off + p.numel()].view_as(p)
+                    view.copy_(p)
+                    p.data = view
+                    off += p.numel()
+            self.state.append((pflat, torch.zeros_like(gflat), torch.zeros_like(gflat)))
+
+    def zero_grad(self):
+        self.sync.zero_grad()
+
+    @torch.no_grad()
+    def step(self):
+        from ._lib import call, ptr
+        self.steps += 1
+        for (gflat, _), (pflat, m, v) in zip(self.sync.buckets, self.state):
+            call("adam_step", ptr(pflat), ptr(gflat), ptr(m), ptr(v), gflat.numel(), float(self.lr), float(self.betas[0]),
+                 float(self.betas[1]), float(self.eps), float(self.weight_decay), self.steps)
+
+    def state_dict(self):
+        return {"steps": self.steps, "exp_avg": [m for _, m, _ in self.state], "exp_avg_sq": [v for _, _, v in self.state]}
+
+    def load_state_dict(self, sd):
+        self.steps = int(sd["steps"])
+        for (_, m, v), a, b in zip(self.state, sd["exp_avg"], sd["exp_avg_sq"]):
+            m.copy_(a)
+            v.copy_(b)

@@ -7,6 +7,7 @@ per-forward ``ForwardContext`` under ``kwargs['_ccn_ctx']`` so that the curve/cl
 resolution level are built once and shared by every step at that level.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -14,14 +15,86 @@ import torch.nn as nn
 from . import ops
 from .nn import MLP
 
+_GEOMETRY_STREAMS = {}
+
+
+def _geometry_stream(device):
+    """One side stream per device for the position-only work (sampling, neighbour search, index tables).
+    CCN_GEOMETRY_STREAM=0 keeps everything on the caller's stream; =stress delays the side stream at
+    every block so that a missing dependency shows up as a wrong result (tests)."""
+    mode = os.environ.get("CCN_GEOMETRY_STREAM", "1")
+    if mode == "0" or device.type != "cuda":
+        return None, mode
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _GEOMETRY_STREAMS:
+        _GEOMETRY_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _GEOMETRY_STREAMS[key], mode
+
+
+def _walk_tensors(obj, depth=0):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _walk_tensors(o, depth)
+    elif isinstance(obj, (ops.CurveTopology, ops.EdgeList)) and depth < 2:
+        for o in vars(obj).values():
+            yield from _walk_tensors(o, depth + 1)
+
+
+class _GeometryBlock:
+    """``with ctx.geometry() as geo:`` runs the enclosed position-only work on the side stream; host syncs
+    inside it (element counts read back) wait for that stream only, so the feature kernels already queued
+    on the main stream keep the GPU busy meanwhile.  Everything the feature path will read must go through
+    ``geo.publish(...)``: the main stream then waits for the block's event and the allocator is told that
+    those tensors are in use on the main stream too."""
+
+    def __init__(self, ctx):
+        self.ctx, self._scope = ctx, None
+
+    def __enter__(self):
+        ctx = self.ctx
+        if ctx is not None and ctx.side is not None:
+            self._scope = torch.cuda.stream(ctx.side)
+            self._scope.__enter__()
+            if ctx.stress:
+                torch.cuda._sleep(2_000_000)
+        return self
+
+    def publish(self, *objs):
+        ctx = self.ctx
+        if ctx is not None and ctx.side is not None:
+            for t in _walk_tensors(objs):
+                if t.is_cuda:
+                    t.record_stream(ctx.main)
+        return objs[0] if len(objs) == 1 else objs
+
+    def __exit__(self, et, ev, tb):
+        if self._scope is not None:
+            done = self.ctx.side.record_event()
+            self._scope.__exit__(et, ev, tb)
+            self.ctx.main.wait_event(done)
+        return False
+
 
 class ForwardContext:
-    """Caches ``CurveTopology`` objects for the (batch, curve-id) tensor pairs seen in one forward."""
+    """Per-forward state: the ``CurveTopology`` cache for the (batch, curve-id) pairs seen, and the
+    side stream the geometry blocks run on."""
 
-    def __init__(self, num_clouds=None):
+    def __init__(self, num_clouds=None, device=None):
         self.num_clouds = num_clouds
         self._topo = {}
         self._zeros = {}
+        self.side, self.main, self.stress = None, None, False
+        if device is not None:
+            self.side, mode = _geometry_stream(device)
+            if self.side is not None:
+                self.main = torch.cuda.current_stream(device)
+                self.stress = mode == "stress"
+                self.side.wait_stream(self.main)          # the level-0 inputs were produced on the main stream
+
+    def geometry(self):
+        return _GeometryBlock(self)
 
     def topology(self, batch, p2c, curves=True):
         """curves=False: only the cloud tables are needed (levels whose points were re-ordered by voxel
@@ -37,6 +110,10 @@ class ForwardContext:
             hit = (ops.CurveTopology(batch, p2c, self.num_clouds), batch, p2c)   # tensors kept alive with the entry
             self._topo[key] = hit
         return hit[0]
+
+
+def _geometry(kwargs):
+    return _GeometryBlock(kwargs.get("_ccn_ctx"))
 
 
 def _topology(batch, p2c, kwargs, curves=True):
@@ -108,7 +185,8 @@ class SymmetricCurve1DConvFastV1(nn.Module):
         self.conv_modules, self.norm_modules = _conv_stack(feat_dims, kernel_size, bias, with_diff, True)
 
     def forward(self, x, pos, batch, point2curveidx, **kwargs):
-        topo = _topology(batch, point2curveidx, kwargs)
+        with _geometry(kwargs) as geo:
+            topo = geo.publish(_topology(batch, point2curveidx, kwargs))
         x = _with_xyz(x, pos, self.with_xyz)
         for conv, norm in zip(self.conv_modules, self.norm_modules):
             if self.with_diff:
@@ -130,10 +208,12 @@ class SymmetricCurve1DConvV2(nn.Module):
         self.conv_modules, self.norm_modules = _conv_stack(feat_dims, kernel_size, bias, with_diff, False)
 
     def forward(self, x, pos, batch, point2curveidx, **kwargs):
-        topo = _topology(batch, point2curveidx, kwargs)
-        x = _with_xyz(x, pos, self.with_xyz)
         pad = (self.kernel_size // 2) * (len(self.feat_dims) - 1) if self.kernel_size > 1 else 0
-        rows = torch.arange(topo.n, device=pos.device) + pad * (topo.cid.long() + 1)
+        with _geometry(kwargs) as geo:
+            topo = _topology(batch, point2curveidx, kwargs)
+            rows = torch.arange(topo.n, device=pos.device) + pad * (topo.cid.long() + 1)
+            geo.publish(topo, rows)
+        x = _with_xyz(x, pos, self.with_xyz)
         n_rows = topo.n + (topo.num_curves + 1) * pad
         if self.with_diff:
             x = ops.DiffConcat.apply(x, topo.cid)
@@ -156,10 +236,11 @@ class CurveFPS(nn.Module):
         self.arclen_spacing = arclen_spacing
 
     def forward(self, pos, batch, point2curveidx, u=None, **kwargs):
-        topo = _topology(batch, point2curveidx, kwargs)
         if u is None:
             u = torch.rand(1)
-        return ops.curve_fps(pos, topo, self.arclen_spacing, float(u))
+        with _geometry(kwargs) as geo:
+            topo = _topology(batch, point2curveidx, kwargs)
+            return geo.publish(ops.curve_fps(pos, topo, self.arclen_spacing, float(u)))
 
 
 # --------------------------------------------------------------------------------------
@@ -214,20 +295,22 @@ class SAModule(nn.Module):
                                   normalize_radius=self.normalize_radius)
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
-        topo = _topology(batch, point2curveidx, kwargs, curves=self.downsample_type == "curve-fps")
-        if self.downsample_type == "random":
-            idx = torch.sort(torch.randperm(pos.size(0))[: int(pos.size(0) * self.ratio)])[0].to(pos.device)
-        elif self.downsample_type == "curve-fps":
-            idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
-        elif self.downsample_type == "voxel":
-            idx = ops.voxel_fps(pos, batch, self.voxel_size)
-        else:
-            idx = ops.fps(pos, topo, self.ratio)
-        pos_q, batch_q = pos[idx], batch[idx]
-        p2c_q = None if point2curveidx is None else point2curveidx[idx]
-        topo_q = _topology(batch_q, p2c_q, kwargs, curves=False)
-        edges = ops.frnn_edges(pos_q, topo_q, pos, topo, self.knn, self.r,
-                               operation="knn" if self.use_fast_knn else "ball-group")
+        with _geometry(kwargs) as geo:
+            topo = _topology(batch, point2curveidx, kwargs, curves=self.downsample_type == "curve-fps")
+            if self.downsample_type == "random":
+                idx = torch.sort(torch.randperm(pos.size(0))[: int(pos.size(0) * self.ratio)])[0].to(pos.device)
+            elif self.downsample_type == "curve-fps":
+                idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
+            elif self.downsample_type == "voxel":
+                idx = ops.voxel_fps(pos, batch, self.voxel_size)
+            else:
+                idx = ops.fps(pos, topo, self.ratio)
+            pos_q, batch_q = pos[idx], batch[idx]
+            p2c_q = None if point2curveidx is None else point2curveidx[idx]
+            topo_q = _topology(batch_q, p2c_q, kwargs, curves=False)
+            edges = ops.frnn_edges(pos_q, topo_q, pos, topo, self.knn, self.r,
+                                   operation="knn" if self.use_fast_knn else "ball-group")
+            geo.publish(pos_q, batch_q, p2c_q, edges)
         x = self.conv((x, None), (pos, pos_q), edges)
         return x, pos_q, batch_q, p2c_q
 
@@ -245,15 +328,17 @@ class CurveSAModule(nn.Module):
                                   attend_nn=attend_nn, normalize_radius=self.normalize_radius)
 
     def forward(self, x, pos, batch, point2curveidx, **kwargs):
-        topo = _topology(batch, point2curveidx, kwargs)
-        x = _with_xyz(x, pos[:, :3], self.with_xyz)
         if not self.use_curve_fps:
-            raise NotImplementedError("farthest point sampling is a 'next' row (SURVEY.md section 8f)")
-        idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
-        edges = ops.radius_1d_group_subset(pos, idx, topo, self.r)
-        pos_q = pos[idx]
+            raise NotImplementedError("the shipped configs always set use_curve_fps (ref pointnet2.py:165-168)")
+        with _geometry(kwargs) as geo:
+            topo = _topology(batch, point2curveidx, kwargs)
+            idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
+            edges = ops.radius_1d_group_subset(pos, idx, topo, self.r)
+            pos_q, batch_q, p2c_q = pos[idx], batch[idx], point2curveidx[idx]
+            geo.publish(idx, edges, pos_q, batch_q, p2c_q)
+        x = _with_xyz(x, pos[:, :3], self.with_xyz)
         x = self.conv((x, None), (pos, pos_q), edges)
-        return x, pos_q, batch[idx], point2curveidx[idx], None, idx
+        return x, pos_q, batch_q, p2c_q, None, idx
 
 
 def _fp_concat(x, x_skip, pos_skip, with_xyz):
@@ -274,9 +359,11 @@ class FPModule(nn.Module):
 
     def forward(self, x, pos, batch, x_skip, pos_skip, batch_skip, point2curveidx=None, point2curveidx_skip=None,
                 **kwargs):
-        topo_x = _topology(batch, point2curveidx, kwargs, curves=False)
-        topo_y = _topology(batch_skip, point2curveidx_skip, kwargs, curves=False)
-        x = ops.knn_interpolate(x, pos, pos_skip, topo_x, topo_y, self.k)
+        with _geometry(kwargs) as geo:
+            topo_x = _topology(batch, point2curveidx, kwargs, curves=False)
+            topo_y = _topology(batch_skip, point2curveidx_skip, kwargs, curves=False)
+            nbr, w = geo.publish(*ops.knn_points_packed(pos_skip, topo_y, pos, topo_x, self.k))
+        x = ops.CurveInterp.apply(x, nbr, w)
         x = self.nn(_fp_concat(x, x_skip, pos_skip, self.with_xyz))
         return x, pos_skip, batch_skip, point2curveidx_skip
 
@@ -285,8 +372,10 @@ class CurveFPModule(FPModule):
     """ref pointnet2.py:184-205: interpolate along curves from the sampled points, concat skip, MLP."""
 
     def forward(self, x, idx, x_skip, pos_skip, batch_skip, point2curveidx_skip=None, **kwargs):
-        topo = _topology(batch_skip, point2curveidx_skip, kwargs)
-        x = ops.knn_interpolate_1D(x, idx, pos_skip, topo, self.k)
+        with _geometry(kwargs) as geo:
+            topo = _topology(batch_skip, point2curveidx_skip, kwargs)
+            nbr, w = geo.publish(*ops.knn_1d_group_superset_dense(pos_skip, idx, topo, self.k))
+        x = ops.CurveInterp.apply(x, nbr, w)
         x = self.nn(_fp_concat(x, x_skip, pos_skip, self.with_xyz))
         return x, pos_skip, batch_skip, point2curveidx_skip
 
@@ -309,14 +398,15 @@ class SGCNNLayer(nn.Module):
         self.force_edge_gemm = False        # tests: run the literal gather + GEMM formulation
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
-        topo = _topology(batch, point2curveidx, kwargs, curves=False)
         x = _with_xyz(x, pos, self.with_xyz)
         if self.use_sparse_feat_agg:
             # ref dgcnn.py:209-246 forward_slow: edge list from FRNN / exact kNN, message nn([x_i, x_j - x_i]),
             # per-query max or softmax-attention over the CSR groups (BatchNorm sees the real edges only)
             if self.aggr_type not in ("max", "attend"):
                 raise NotImplementedError("aggr_type=%r" % self.aggr_type)
-            edges = ops.frnn_edges(pos, topo, pos, topo, self.k, self.r, accel_knn=self.use_fast_knn)
+            with _geometry(kwargs) as geo:
+                topo = _topology(batch, point2curveidx, kwargs, curves=False)
+                edges = geo.publish(ops.frnn_edges(pos, topo, pos, topo, self.k, self.r, accel_knn=self.use_fast_knn))
             msg = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row))
             if self.aggr_type == "max":
                 out = ops.SegMax.apply(msg, edges.offsets, edges.num_dst)
@@ -325,9 +415,12 @@ class SGCNNLayer(nn.Module):
             return out, pos, batch, point2curveidx
         if not self.use_fast_knn or self.aggr_type != "max":
             raise NotImplementedError("dense SGCNN path: only the FRNN + max configuration the shipped configs use")
-        padded, _ = ops.to_batch_padded(pos, topo)
-        radius = 0.25 if self.r is None else self.r
-        nbr = ops.fast_knn(padded, padded, topo.lengths, topo.lengths, self.k, radius)
+        with _geometry(kwargs) as geo:
+            topo = _topology(batch, point2curveidx, kwargs, curves=False)
+            padded, _ = ops.to_batch_padded(pos, topo)
+            radius = 0.25 if self.r is None else self.r
+            nbr = ops.fast_knn(padded, padded, topo.lengths, topo.lengths, self.k, radius)
+            geo.publish(topo, nbr)
         lin0 = self.nn.lins[0]
         if lin0.bias is None and self.nn.dropout == 0.0 and not self.force_edge_gemm:
             # first layer in algebraic form: two per-point products + a gather-add instead of a GEMM over
@@ -356,11 +449,15 @@ class GlobalSAModule(nn.Module):
             raise NotImplementedError("Pooling strategy %s not implemented!" % self.pooling)
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
-        topo = _topology(batch, point2curveidx, kwargs, curves=False)
+        with _geometry(kwargs) as geo:
+            topo = _topology(batch, point2curveidx, kwargs, curves=False)
+            offsets = topo.cloud_ptr.to(torch.int32)
+            first = topo.cloud_ptr[:-1]
+            out = (pos[first], batch[first], None if point2curveidx is None else point2curveidx[first])
+            geo.publish(offsets, out)
         f = self.nn(ops.cat_cols([x, pos]))
-        f = ops.SegMax.apply(f, topo.cloud_ptr.to(torch.int32), topo.num_clouds)
-        first = topo.cloud_ptr[:-1]
-        return f, pos[first], batch[first], None if point2curveidx is None else point2curveidx[first]
+        f = ops.SegMax.apply(f, offsets, topo.num_clouds)
+        return (f,) + out
 
 
 # --------------------------------------------------------------------------------------

@@ -250,6 +250,12 @@ int ccn_voxel_argmin(const float* score, const int64_t* voxel_of, int64_t n, int
 int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, const int64_t* out_ptr, int64_t B,
             float* mind, int64_t* out, void* stream);
 
+/* Harness row H (src/main.py:56 torch.optim.Adam; src/run/kitti_seg.py:19-63 train loop): one Adam update over a
+ * flat, 16-byte aligned run of n parameters (param, grad, exp_avg, exp_avg_sq contiguous fp32), same arithmetic as
+ * torch.optim.Adam(amsgrad=False, maximize=False): step >= 1 is the 1-based update count. */
+int ccn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

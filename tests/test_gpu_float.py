@@ -403,3 +403,30 @@ def test_sa_ball_query_fps_and_global_sa_vs_oracle():
                           lambda: steps.GlobalSAModule(MLP([24 + 3, 32, 16], bias=True)))
     outs = _run_pair(ref_g, mine_g, [out_r[0].detach(), out_r[1], out_r[2], out_r[3]], seed=0, gtol=3e-3)  # max-pool ties
     assert outs[0][0].shape == (2, 16)
+
+
+def test_flat_adam_matches_torch_adam():
+    """parallel.FlatAdam (one ccn_adam_step launch per gradient bucket) against torch.optim.Adam on the same
+    parameters and gradient sequence; agreement to about one ulp of the parameter per step."""
+    from curvecloudnet_amd.parallel import FlatAdam, GradientAllReduce
+    torch.manual_seed(0)
+    shapes = [(64, 37), (64,), (128, 64), (3, 5, 7), (1,), (1000, 33)]
+    ref_params = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    holder = torch.nn.ParameterList([torch.nn.Parameter(p.detach().clone()) for p in ref_params])
+    sync = GradientAllReduce(holder, bucket_bytes=40_000)
+    assert len(sync.buckets) > 1
+    mine = FlatAdam(sync, lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    ref = torch.optim.Adam(ref_params, lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    for it in range(5):
+        mine.zero_grad()
+        ref.zero_grad()
+        for pr, pm in zip(ref_params, holder):
+            g = torch.randn(pr.shape, device=DEV, generator=None) * (10.0 ** (it - 2))
+            pr.grad = g.clone()
+            pm.grad.copy_(g)
+        ref.step()
+        mine.step()
+        for pr, pm in zip(ref_params, holder):
+            assert float((pr.detach() - pm.detach()).abs().max()) < 1e-6 * (it + 1), it      # an ulp of |p| <= 4 per step
+    # gradients are still views of the buckets and parameters views of the flat parameter buffers
+    assert holder[0].grad.data_ptr() >= sync.buckets[-1][0].data_ptr() or len(sync.buckets) > 1

@@ -187,3 +187,34 @@ def test_remaining_reference_configs_match_oracle(which):
     assert maxdiff(out_d, out_r) < 1e-3, maxdiff(out_d, out_r)
     out_d.square().mean().backward()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in mine.parameters())
+
+
+def test_geometry_stream_modes_agree(monkeypatch):
+    """The position-only work runs on a side stream (steps.ForwardContext.geometry).  Three runs of the
+    same model and input -- side stream off, on, and on with the side stream artificially delayed at every
+    block -- must give bit-identical logits (the forward has no atomics) and the same gradients up to the
+    atomic-add order of the weight-gradient kernels.  A missing stream dependency fails the stress run."""
+    from curvecloudnet_amd import configs
+    from curvecloudnet_amd.model import build_model, segmentation_loss
+    from curvecloudnet_amd.synth import make_batch
+    torch.manual_seed(2)
+    model = build_model(configs.kitti_config(width=0.125), in_dim=4, n_out=20).to(DEV).train()
+    data = batch_to(make_batch([3, 4], n_curves=160), DEV)
+    y = _labels(data.pos.size(0), 20, 8).to(DEV)
+    runs = {}
+    for mode in ("0", "1", "stress", "stress"):
+        monkeypatch.setenv("CCN_GEOMETRY_STREAM", mode)
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(11)
+        out = model(data)
+        segmentation_loss(out, y).backward()
+        torch.cuda.synchronize()
+        grads = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+        assert torch.isfinite(out).all()
+        key = mode if mode not in runs else mode + "2"
+        runs[key] = (out.detach().clone(), grads.clone())
+    base_out, base_grad = runs["0"]
+    for mode, (out, grads) in runs.items():
+        assert torch.equal(out, base_out), "logits differ between CCN_GEOMETRY_STREAM=0 and %s" % mode
+        rel = float((grads - base_grad).norm() / base_grad.norm())
+        assert rel < 1e-4, (mode, rel)

@@ -1,0 +1,48 @@
+"""Summarise a rocprofv3 --kernel-trace CSV: GPU busy time (union of kernel intervals), idle gaps and the
+kernels that precede the largest gaps.  Usage: python tools/trace_gaps.py <kernel_trace.csv> [last_fraction]"""
+import csv
+import sys
+from collections import defaultdict
+
+path = sys.argv[1]
+frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+rows = []
+with open(path) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
+rows.sort()
+t0, t1 = rows[0][0], max(r[1] for r in rows)
+cut = t1 - int((t1 - t0) * frac)                      # the steady-state tail of the run
+rows = [r for r in rows if r[0] >= cut]
+span = max(r[1] for r in rows) - rows[0][0]
+busy, cur_s, cur_e = 0, rows[0][0], rows[0][1]
+gaps = []
+prev_name = rows[0][2]
+for s, e, name, q in rows[1:]:
+    if s > cur_e:
+        busy += cur_e - cur_s
+        gaps.append((s - cur_e, prev_name, name))
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+    if e >= cur_e:
+        prev_name = name
+busy += cur_e - cur_s
+per_queue = defaultdict(int)
+for s, e, name, q in rows:
+    per_queue[q] += e - s
+print("window %.1f ms, busy %.1f ms (%.1f%%), idle %.1f ms in %d gaps" % (span / 1e6, busy / 1e6, 100.0 * busy / span,
+                                                                          (span - busy) / 1e6, len(gaps)))
+print("kernel time per queue (ms):", {q: round(v / 1e6, 1) for q, v in per_queue.items()})
+hist = defaultdict(lambda: [0, 0])
+for g, a, b in gaps:
+    k = (a[:50], b[:50])
+    hist[k][0] += g
+    hist[k][1] += 1
+print("largest idle contributors (after kernel -> before kernel):")
+for (a, b), (tot, cnt) in sorted(hist.items(), key=lambda kv: -kv[1][0])[:25]:
+    print("  %8.2f ms %5d x  %s -> %s" % (tot / 1e6, cnt, a, b))
+buckets = [0, 0, 0, 0]
+for g, _, _ in gaps:
+    buckets[0 if g < 5e3 else 1 if g < 5e4 else 2 if g < 5e5 else 3] += g
+print("idle by gap size: <5us %.1f ms, 5-50us %.1f ms, 50-500us %.1f ms, >500us %.1f ms" % tuple(b / 1e6 for b in buckets))
