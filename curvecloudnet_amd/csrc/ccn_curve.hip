@@ -451,6 +451,37 @@ __global__ void interp_bwd_kernel(const float* __restrict__ dy, int64_t lddy, co
   }
 }
 
+// ---- dataset-side curve splitter (kitti_dataset.py:73-92, nuscenes_dataset.py:101-118) ----
+// split[i] (i >= 1): beam change, or fp64 |p_i - p_{i-1}| > (double)(thresh * sqrtf(|p_i.xy|)) with the right-hand
+// side in fp32.  torch's CPU norms are fma chains: sqrt(fma(z,z,fma(y,y,x*x))) -- reproduced literally (this file is
+// compiled with -ffp-contract=off, so only the explicit fma calls fuse).
+__global__ void curve_split_flags_kernel(const float* __restrict__ pos, const int64_t* __restrict__ beam, int64_t n,
+                                         float thresh, int32_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (i == 0) {
+    flag[0] = 0;
+    return;
+  }
+  const float x1 = pos[3 * i], y1 = pos[3 * i + 1], z1 = pos[3 * i + 2];
+  const double dx = (double)x1 - (double)pos[3 * i - 3], dy = (double)y1 - (double)pos[3 * i - 2],
+               dz = (double)z1 - (double)pos[3 * i - 1];
+  const double edge = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
+  const float radius = sqrtf(fmaf(y1, y1, x1 * x1));
+  const float rhs = thresh * sqrtf(radius);
+  int f = edge > (double)rhs;
+  if (beam != nullptr) f |= (beam[i] != beam[i - 1]);
+  flag[i] = f;
+}
+
+__global__ void curve_split_widen_kernel(const int32_t* __restrict__ run, int64_t n, int64_t* __restrict__ curve,
+                                         int64_t* __restrict__ num_curves) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  curve[i] = run[i];
+  if (i == n - 1) num_curves[0] = (int64_t)run[i] + 1;
+}
+
 }  // namespace
 
 // ====================================================================== C ABI
@@ -724,6 +755,30 @@ int ccn_interp_bwd(const float* dy, int64_t lddy, const int64_t* nbr, const floa
   hipLaunchKernelGGL(interp_bwd_kernel, dim3(ccn_blocks(n * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, lddy, nbr,
                      weight, n, (int)k, C, dx, lddx);
   CCN_LAUNCH_OK("interp_bwd");
+  return CCN_OK;
+}
+
+size_t ccn_curve_split_workspace_bytes(int64_t n) {
+  return 2 * ccn_align256((size_t)(n + 1) * 4) + ccn_scan_scratch_bytes(n) + 512;
+}
+
+int ccn_curve_split(const float* pos, const int64_t* beam, int64_t n, float thresh, int64_t* curve_idx,
+                    int64_t* num_curves, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(pos && curve_idx && num_curves && n > 0, "curve_split: bad arguments");
+  CCN_REQUIRE(n < (int64_t)1 << 31, "curve_split: more than 2^31 points");
+  CCN_REQUIRE(ws_bytes >= ccn_curve_split_workspace_bytes(n), "curve_split: workspace too small");
+  CcnArena a(ws, ws_bytes);
+  int32_t* flag = a.take<int32_t>(n + 1);
+  int32_t* run = a.take<int32_t>(n + 1);
+  void* scratch = a.take<char>(ccn_scan_scratch_bytes(n));
+  CCN_REQUIRE(a.ok(), "curve_split: workspace carve failed");
+  const int nb = ccn_blocks(n, TPB);
+  hipLaunchKernelGGL(curve_split_flags_kernel, dim3(nb), dim3(TPB), 0, s, pos, beam, n, thresh, flag);
+  int rc = ccn_scan_i32(flag, run, n, true, nullptr, scratch, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(curve_split_widen_kernel, dim3(nb), dim3(TPB), 0, s, run, n, curve_idx, num_curves);
+  CCN_LAUNCH_OK("curve_split");
   return CCN_OK;
 }
 

@@ -250,6 +250,14 @@ int ccn_voxel_argmin(const float* score, const int64_t* voxel_of, int64_t n, int
 int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, const int64_t* out_ptr, int64_t B,
             float* mind, int64_t* out, void* stream);
 
+/* Dataset-side curve splitter (src/data/kitti_dataset.py:73-92 with beam == NULL,
+ * src/data/nuscenes_dataset.py:101-118 on the beam-sorted sweep): curve_idx[0] = 0, a new curve starts at i where
+ * beam[i] != beam[i-1] or the fp64 edge length |p_i - p_{i-1}| exceeds thresh * sqrt(|p_i.xy|) (fp32 right-hand side,
+ * as the reference evaluates it).  Bit-exact with the reference's cumsum; num_curves: device int64 = last id + 1. */
+size_t ccn_curve_split_workspace_bytes(int64_t n);
+int ccn_curve_split(const float* pos, const int64_t* beam, int64_t n, float thresh, int64_t* curve_idx,
+                    int64_t* num_curves, void* ws, size_t ws_bytes, void* stream);
+
 /* Harness row H (src/main.py:56 torch.optim.Adam; src/run/kitti_seg.py:19-63 train loop): one Adam update over a
  * flat, 16-byte aligned run of n parameters (param, grad, exp_avg, exp_avg_sq contiguous fp32), same arithmetic as
  * torch.optim.Adam(amsgrad=False, maximize=False): step >= 1 is the 1-based update count. */

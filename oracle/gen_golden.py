@@ -229,6 +229,45 @@ def main():
             blob[key + ".voxel"], blob[key + ".idx"] = np.float64(vs), np_(idx)
             eq(R.voxel_fps(pos, batch, vs, rnd), idx, "voxel_fps " + key)
     np.savez_compressed(os.path.join(OUT, "voxel_fps.npz"), **blob)
+
+    # ---------------- section 8(f) #4: dataset-side curve splitters and the Lovasz-softmax loss ----------------
+    from oracle.ref_import import load_reference_harness
+    lov, sem_kitti, sem_nuscenes = load_reference_harness()
+
+    class _Self:
+        CURVE_THRESH = 0.08
+
+    blob = {}
+    for ci, (n, scale, jump) in enumerate(((3000, 0.02, 0.01), (6000, 0.05, 0.03), (1, 0.0, 0.0), (2, 0.05, 0.0))):
+        g = torch.Generator().manual_seed(500 + ci)
+        steps = torch.randn(n, 3, generator=g) * scale
+        steps[torch.rand(n, generator=g) < jump] *= 40.0          # discontinuities: new curves
+        pts = (torch.cumsum(steps, 0) + torch.tensor([6.0, -3.0, 0.5])).float()
+        beams = torch.randint(0, 5, (n,), generator=g)
+        refl = torch.rand(n, generator=g)
+        labels = torch.randint(0, 17, (n,), generator=g)
+        key = "split%d" % ci
+        kitti = sem_kitti._get_curves(_Self(), pts.clone()).long()
+        nus = sem_nuscenes._get_curves(_Self(), pts.clone(), beams.clone(), labels.clone(), refl.clone())
+        eq(R.split_curves(pts), kitti, "split_curves kitti " + key)
+        mine = R.get_curves_nuscenes(pts, beams, labels, refl)
+        for a, b, what in zip(mine, nus, ("points", "curves", "labels", "reflectance", "inverse")):
+            eq(a, b, "get_curves_nuscenes %s %s" % (what, key))
+        blob[key + ".points"], blob[key + ".beams"] = np_(pts), np_(beams)
+        blob[key + ".kitti"], blob[key + ".nus_curves"], blob[key + ".nus_inverse"] = np_(kitti), np_(nus[1]), np_(nus[4])
+    for ci, (n, c, absent) in enumerate(((4000, 20, 3), (1500, 7, 0), (64, 4, 2))):
+        g = torch.Generator().manual_seed(600 + ci)
+        probas = torch.softmax(torch.randn(n, c, generator=g) * 2.0, dim=-1).requires_grad_(True)
+        labels = torch.randint(0, c - absent, (n,), generator=g)
+        loss = lov.lovasz_softmax_flat(probas, labels)
+        grad, = torch.autograd.grad(loss, probas)
+        mine = R.lovasz_softmax_flat(probas, labels)
+        close(mine, loss, "lovasz loss %d" % ci, 1e-7)
+        close(torch.autograd.grad(mine, probas)[0], grad, "lovasz grad %d" % ci, 1e-7)
+        key = "lovasz%d" % ci
+        blob[key + ".probas"], blob[key + ".labels"] = np_(probas), np_(labels)
+        blob[key + ".loss"], blob[key + ".grad"] = np_(loss), np_(grad)
+    np.savez_compressed(os.path.join(OUT, "harness.npz"), **blob)
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print("  %-24s %7.1f KB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))

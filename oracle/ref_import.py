@@ -75,3 +75,26 @@ def load_reference():
     import src.models.utils.point_ops as po
     import src.models.modules.fps_ops as fo
     return fc, po, fo
+
+
+def load_reference_harness():
+    """Returns (lovasz_losses module, SemKITTI, SemNuScenes) of the reference, imported in place: the Lovasz loss of
+    the training harness and the dataset-side curve splitters (only their ``_get_curves`` methods are called)."""
+    load_reference()
+
+    class _Base:                                   # torch_geometric.data.Dataset / Data are only base classes here
+        def __init__(self, *a, **k):
+            pass
+
+    _stub("torch_geometric.data", Data=_Base, Dataset=_Base)
+    for name in ("cv2", "mitsuba", "nuscenes"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:                       # noqa: BLE001 -- visualisation-only dependencies
+                _stub(name)
+    _stub("src.visualization.mitsuba_render", render_pc_kitti=None)
+    import src.models.utils.lovasz_losses as lov
+    import src.data.kitti_dataset as kd
+    import src.data.nuscenes_dataset as nd
+    return lov, kd.SemKITTI, nd.SemNuScenes

@@ -916,3 +916,73 @@ class ModelBase(nn.Module):
 def segmentation_loss(logits, target):
     """Mean negative log-likelihood over points (ref src/run/kitti_seg.py:184-192)."""
     return F.nll_loss(F.log_softmax(logits, dim=-1), target)
+
+
+# --------------------------------------------------------------------------------------
+# harness rows (SURVEY.md section 8f #4): Lovasz-softmax loss and the dataset-side curve splitters
+# --------------------------------------------------------------------------------------
+
+def lovasz_gradient(fg_sorted):
+    """Gradient of the Lovasz extension w.r.t. the sorted errors (ref src/models/utils/lovasz_losses.py:19-31)."""
+    total = fg_sorted.sum()
+    inter = total - fg_sorted.float().cumsum(0)
+    union = total + (1 - fg_sorted).float().cumsum(0)
+    jac = 1.0 - inter / union
+    if fg_sorted.numel() > 1:
+        jac[1:] = jac[1:] - jac[:-1]
+    return jac
+
+
+def lovasz_softmax_flat(probas, labels):
+    """ref lovasz_losses.py:174-202 with classes='present': mean over the classes that occur in ``labels`` of
+    <errors sorted descending, lovasz_gradient(foreground in that order)>."""
+    if probas.numel() == 0:
+        return probas * 0.0
+    per_class = []
+    for c in range(probas.size(1)):
+        fg = (labels == c).float()
+        if fg.sum() == 0:
+            continue
+        err = (fg - probas[:, c]).abs()
+        err_sorted, order = torch.sort(err, 0, descending=True)
+        per_class.append(torch.dot(err_sorted, lovasz_gradient(fg[order])))
+    return sum(per_class) / len(per_class)
+
+
+def seg_loss_kitti(pred, gt, ignore=0, use_lovasz=False, class_weights=None):
+    """ref src/run/kitti_seg.py:184-202: (loss, per-point NLL); mean over ALL points of the ignore-masked NLL,
+    plus 2x the Lovasz-softmax loss over the non-ignored points."""
+    logp = F.log_softmax(pred, dim=-1)
+    if class_weights is None:
+        per_point = F.nll_loss(logp, gt, reduction="none", ignore_index=ignore)
+    else:
+        assert ignore == 0
+        w = torch.cat([torch.zeros(1, dtype=class_weights.dtype), class_weights], dim=0)
+        per_point = F.nll_loss(logp, gt, reduction="none", weight=w)
+    loss = per_point.mean()
+    if use_lovasz:
+        keep = gt != ignore
+        loss = loss + 2 * lovasz_softmax_flat(F.softmax(pred, dim=-1)[keep], gt[keep]).mean()
+    return loss, per_point
+
+
+def split_curves(points, beam_idxs=None, thresh=0.08):
+    """Curve ids of a sweep in acquisition order (ref src/data/kitti_dataset.py:73-92 with beam_idxs=None,
+    src/data/nuscenes_dataset.py:101-118 after the beam sort): a new curve starts where the beam changes or where
+    the fp64 edge length exceeds thresh * sqrt(xy-radius of the later point) (fp32 right-hand side).  int64 (N,)."""
+    edges = points[1:].double() - points[:-1].double()
+    edge_len = torch.linalg.norm(edges, dim=-1)
+    radius = torch.linalg.norm(points[1:, :2], dim=-1)
+    split = edge_len > (thresh * torch.sqrt(radius))
+    if beam_idxs is not None:
+        split = split | ((beam_idxs[1:] - beam_idxs[:-1]) != 0)
+    return torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(split, dim=0)], dim=0)
+
+
+def get_curves_nuscenes(points, beam_idxs, labels, reflectance, thresh=0.08):
+    """ref nuscenes_dataset.py:91-118: stable sort by beam, split, and the inverse permutation."""
+    order = torch.sort(beam_idxs, stable=True)[1]
+    inverse = torch.empty_like(order)
+    inverse[order] = torch.arange(points.size(0)).to(order)
+    points, beam_idxs, labels, reflectance = points[order], beam_idxs[order], labels[order], reflectance[order]
+    return points, split_curves(points, beam_idxs, thresh), labels, reflectance, inverse
