@@ -119,6 +119,35 @@ __global__ __launch_bounds__(KNN_TPB) void ball_query_kernel(const float* __rest
     for (int s = have; s < K; ++s) out[s] = -1;
 }
 
+// ball query in a D-dimensional feature space (dgcnn.py:114-127 DGCNNLayerRadius -> point_ops.py:81 with feature
+// vectors as points): same rule as above, distance = sum_d (a_d - b_d)^2 accumulated in index order.  One query per
+// thread; the candidate row address is wave-uniform (one broadcast load per element).
+__global__ __launch_bounds__(KNN_TPB) void ball_query_nd_kernel(const float* __restrict__ q, int64_t ldq,
+                                                                const int64_t* __restrict__ len1,
+                                                                const float* __restrict__ src, int64_t lds_,
+                                                                const int64_t* __restrict__ len2, int64_t P1, int64_t P2,
+                                                                int D, int K, float r2, int64_t* __restrict__ idx) {
+  const int64_t b = blockIdx.y;
+  const int64_t nq = len1[b], ns = len2[b];
+  const int64_t iq = (int64_t)blockIdx.x * KNN_TPB + threadIdx.x;
+  if (iq >= P1) return;
+  int64_t* out = idx + (b * P1 + iq) * K;
+  int have = 0;
+  if (iq < nq) {
+    const float* qr = q + (b * P1 + iq) * ldq;
+    for (int64_t j = 0; j < ns && have < K; ++j) {
+      const float* sr = src + (b * P2 + j) * lds_;
+      float d2 = 0.f;
+      for (int d = 0; d < D; ++d) {
+        const float diff = qr[d] - sr[d];
+        d2 += diff * diff;
+      }
+      if (d2 < r2) out[have++] = j;
+    }
+  }
+  for (int s = have; s < K; ++s) out[s] = -1;
+}
+
 // ---------------------------------------------------------------- voxel sampling
 // key = (cloud, floor(x/v), floor(y/v), floor(z/v)) packed so that integer order == lexicographic order
 // (what torch.unique(dim=0) sorts by); score = |voxel corner - p/v| + rand * v / 4  (fps_ops.py:52-56).
@@ -253,6 +282,19 @@ int ccn_ball_query(const float* points1, const int64_t* lengths1, const float* p
   hipLaunchKernelGGL(ball_query_kernel, dim3(ccn_blocks(P1, KNN_TPB), (unsigned)B), dim3(KNN_TPB), 0,
                      (hipStream_t)stream, points1, lengths1, points2, lengths2, P1, P2, (int)K, radius * radius, idx);
   CCN_LAUNCH_OK("ball_query");
+  return CCN_OK;
+}
+
+int ccn_ball_query_nd(const float* points1, int64_t ld1, const int64_t* lengths1, const float* points2, int64_t ld2,
+                      const int64_t* lengths2, int64_t B, int64_t P1, int64_t P2, int64_t D, int64_t K, float radius,
+                      int64_t* idx, void* stream) {
+  CCN_REQUIRE(points1 && lengths1 && points2 && lengths2 && idx && B > 0 && B < 65536 && P1 > 0 && P2 > 0 && K > 0 &&
+                  K < (1 << 20) && D > 0 && D < (1 << 20) && ld1 >= D && ld2 >= D,
+              "ball_query_nd: bad arguments");
+  hipLaunchKernelGGL(ball_query_nd_kernel, dim3(ccn_blocks(P1, KNN_TPB), (unsigned)B), dim3(KNN_TPB), 0,
+                     (hipStream_t)stream, points1, ld1, lengths1, points2, ld2, lengths2, P1, P2, (int)D, (int)K,
+                     radius * radius, idx);
+  CCN_LAUNCH_OK("ball_query_nd");
   return CCN_OK;
 }
 

@@ -9,7 +9,8 @@ import torch.nn.functional as F
 import yaml
 
 from .nn import MLP
-from .steps import (CurveFPModule, CurveSAModule, ForwardContext, FPModule, GlobalSAModule, SAModule, SGCNNLayer, SharedMLP,
+from .steps import (CurveFPModule, CurveSAModule, DGCNNLayer, DGCNNLayerRadius, ForwardContext, FPModule, GlobalSAModule,
+                    SAModule, SGCNNLayer, SharedMLP,
                     SkipConnect, SymmetricCurve1DConvFastV1, SymmetricCurve1DConvV2)
 
 _DOWNSAMPLING_STEPS = ("sa", "sa-geo", "sa-global", "pt-transition-down")
@@ -108,8 +109,10 @@ class ModelBase(torch.nn.Module):
             return SharedMLP(dims, **kwargs)
         if step_name == "sa-global":
             return GlobalSAModule(self.mlp_func(dims, bias=b), **kwargs)
-        if step_name in ("dgcnn", "dgcnn-rad"):
-            raise NotImplementedError("step %r is outside the hot path built so far (SURVEY.md section 8f)" % step_name)
+        if step_name == "dgcnn":
+            return DGCNNLayer(self.mlp_func(dims, bias=b), kwargs["knn"][step_idx], with_xyz=kwargs["with_xyz"])
+        if step_name == "dgcnn-rad":
+            return DGCNNLayerRadius(self.mlp_func(dims, bias=b), kwargs["radii"][step_idx], with_xyz=kwargs["with_xyz"])
         raise NotImplementedError("Have not implemented step %s yet!" % step_name)
 
     # ---- ref base.py:133-209

@@ -502,7 +502,13 @@ def ball_query(points1, points2, lengths1, lengths2, K, radius):
     b, n1, n2, dev = p1.size(0), p1.size(1), p2.size(1), p1.device
     l1, l2 = _i64(lengths1.to(dev)), _i64(lengths2.to(dev))
     idx = torch.empty((b, n1, K), dtype=torch.int64, device=dev)
-    call("ball_query", ptr(p1), ptr(l1), ptr(p2), ptr(l2), b, n1, n2, K, float(radius), ptr(idx))
+    d = p1.size(2)
+    if p2.size(2) != d:
+        raise ValueError("points1 and points2 must have the same dimension")
+    if d == 3:
+        call("ball_query", ptr(p1), ptr(l1), ptr(p2), ptr(l2), b, n1, n2, K, float(radius), ptr(idx))
+    else:       # feature-space search of the dgcnn-rad step
+        call("ball_query_nd", ptr(p1), d, ptr(l1), ptr(p2), d, ptr(l2), b, n1, n2, d, K, float(radius), ptr(idx))
     return idx
 
 

@@ -438,6 +438,55 @@ class SGCNNLayer(nn.Module):
         return out, pos, batch, point2curveidx
 
 
+class _DynamicEdgeConv(nn.Module):
+    """ref dgcnn.py:16-95 DynamicEdgeConv: the neighbourhood is searched between FEATURE vectors, message
+    nn([x_i, x_j - x_i]), max over each query's neighbours (empty groups give 0)."""
+
+    def _search(self, feats, topo):
+        raise NotImplementedError
+
+    def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
+        x = _with_xyz(x, pos, self.with_xyz)
+        ctx = kwargs.get("_ccn_ctx")
+        if ctx is not None and ctx.side is not None:
+            ctx.side.wait_stream(ctx.main)           # the search reads features produced on the main stream
+        with _geometry(kwargs) as geo:
+            topo = _topology(batch, point2curveidx, kwargs, curves=False)
+            edges = geo.publish(self._search(x.detach(), topo))
+        msg = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row))
+        return ops.SegMax.apply(msg, edges.offsets, edges.num_dst), pos, batch, point2curveidx
+
+
+class DGCNNLayer(_DynamicEdgeConv):
+    """ref dgcnn.py:98-111 (step "dgcnn").  The reference searches with FRNN (``knn_ball_group_pytorch3d`` defaults
+    to accel_knn=True, radius 0.25 -- quirk Q7), which only exists for 2-D / 3-D points: the step is usable where the
+    feature vector is the position (x=None, with_xyz) or another 3-channel feature, and fails otherwise."""
+
+    def __init__(self, nn, k, aggr="max", num_workers=1, with_xyz=False, **kwargs):
+        super().__init__()
+        if aggr != "max":
+            raise NotImplementedError("aggr=%r" % aggr)
+        self.nn, self.k, self.r, self.with_xyz = nn, k, None, with_xyz
+
+    def _search(self, feats, topo):
+        if feats.size(1) != 3:
+            raise ValueError("dgcnn: FRNN searches 3-D points only (got %d feature channels)" % feats.size(1))
+        return ops.frnn_edges(feats, topo, feats, topo, self.k, None, operation="knn", accel_knn=True)
+
+
+class DGCNNLayerRadius(_DynamicEdgeConv):
+    """ref dgcnn.py:114-127 (step "dgcnn-rad"): ball query (first 128 in index order) between feature vectors."""
+
+    def __init__(self, nn, r, aggr="max", num_workers=1, with_xyz=False, **kwargs):
+        super().__init__()
+        if aggr != "max":
+            raise NotImplementedError("aggr=%r" % aggr)
+        self.nn, self.k, self.r, self.with_xyz = nn, None, r, with_xyz
+
+    def _search(self, feats, topo):
+        return ops.frnn_edges(feats, topo, feats, topo, None, self.r, operation="ball-group")
+
+
 class GlobalSAModule(nn.Module):
     """ref pointnet2.py:81-116: nn([x, pos]) then per-cloud max pooling (ShapeNet classification head)."""
 

@@ -232,6 +232,12 @@ int ccn_knn_points(const float* q, const int64_t* q_ptr, const float* src, const
  * (B,P,3) inputs, idx (B,P1,K) int64 = the first K points2 in index order with d2 < r*r, -1 padded. */
 int ccn_ball_query(const float* points1, const int64_t* lengths1, const float* points2, const int64_t* lengths2,
                    int64_t B, int64_t P1, int64_t P2, int64_t K, float radius, int64_t* idx, void* stream);
+/* ball query between D-dimensional feature vectors (dgcnn.py:114-127 DGCNNLayerRadius: the ball-group search of
+ * point_ops.py:81 on features): padded (B,P,ld) rows of D floats, same first-K-in-index-order rule, d2 summed over
+ * the D components in order. */
+int ccn_ball_query_nd(const float* points1, int64_t ld1, const int64_t* lengths1, const float* points2, int64_t ld2,
+                      const int64_t* lengths2, int64_t B, int64_t P1, int64_t P2, int64_t D, int64_t K, float radius,
+                      int64_t* idx, void* stream);
 /* sparse edge conv message (dgcnn.py:227-228, forward_slow): msg[e] = [x_i, x_j - x_i], i = dst[e], j = src[e];
  * bwd accumulates into dx (zero on entry). */
 int ccn_edge_feat_fwd(const float* x, int64_t ldx, const int64_t* src, const int64_t* dst, int64_t E, int64_t C,

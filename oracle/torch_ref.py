@@ -406,6 +406,24 @@ def ball_query_bruteforce(points1, points2, lengths1, lengths2, K, r):
     return torch.from_numpy(idx)
 
 
+def ball_query_nd(points1, points2, lengths1, lengths2, K, r):
+    """pytorch3d ``ball_query`` between D-dimensional rows (the feature-space search of ref dgcnn.py:114-127):
+    d2 accumulated over the components in order, first K in index order with d2 < r*r."""
+    B, P1, D = points1.shape
+    idx = torch.full((B, P1, K), -1, dtype=torch.long)
+    for b in range(B):
+        q, s = points1[b, : int(lengths1[b])].detach(), points2[b, : int(lengths2[b])].detach()
+        d2 = torch.zeros((q.size(0), s.size(0)), dtype=q.dtype)
+        for d in range(D):
+            diff = q[:, d, None] - s[None, :, d]
+            d2 = d2 + diff * diff
+        inside = d2 < r * r
+        order = inside.cumsum(1)
+        rows, cols = (inside & (order <= K)).nonzero(as_tuple=True)
+        idx[b, rows, order[rows, cols] - 1] = cols
+    return idx
+
+
 def group_fixed_radius(p1, p2, batch1, batch2, knn, radius, return_dense=False, operation="knn", accel_knn=True):
     """ref point_ops.py:73-111 ``knn_ball_group_pytorch3d``: FRNN (accel_knn), exact kNN, or ball query (K=128)."""
     if radius is None and operation == "knn" and accel_knn:
@@ -413,8 +431,11 @@ def group_fixed_radius(p1, p2, batch1, batch2, knn, radius, return_dense=False, 
     q_pad, mask1, len1, off1 = padded_layout(p1, batch1)
     s_pad, mask2, len2, off2 = padded_layout(p2, batch2)
     if operation == "ball-group":
-        nbr = ball_query_bruteforce(q_pad, s_pad, len1, len2, 128, radius)
+        query = ball_query_bruteforce if q_pad.size(2) == 3 else ball_query_nd
+        nbr = query(q_pad, s_pad, len1, len2, 128, radius)
     elif accel_knn:
+        if q_pad.size(2) != 3:
+            raise ValueError("FRNN searches 3-D points only")
         nbr = frnn_bruteforce(q_pad, s_pad, len1, len2, knn, radius)
     else:
         nbr = knn_bruteforce(q_pad, s_pad, len1, len2, knn)
@@ -745,6 +766,33 @@ class SGCNNLayer(nn.Module):
         return f[mask1], pos, batch, point2curveidx
 
 
+class DGCNNLayer(nn.Module):
+    """ref dgcnn.py:16-111 (step "dgcnn"): neighbours searched between feature vectors with the FRNN default of
+    ``knn_ball_group_pytorch3d`` (radius 0.25), message nn([x_i, x_j - x_i]), max per query (0 for empty groups)."""
+
+    def __init__(self, nn, k, aggr="max", num_workers=1, with_xyz=False, **kwargs):
+        super().__init__()
+        self.nn, self.k, self.r, self.with_xyz, self.operation = nn, k, None, with_xyz, "knn"
+
+    def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
+        if self.with_xyz:
+            x = pos if x is None else torch.cat([x, pos], dim=1)
+        row, col = group_fixed_radius(x.detach(), x.detach(), batch, batch, self.k, self.r, operation=self.operation)
+        msg = self.nn(torch.cat([x[row], x[col] - x[row]], dim=-1))
+        dense, valid = _segment_dense(msg, row, x.size(0))
+        dense = torch.where(valid[:, :, None], dense, torch.full((), float("-inf"), dtype=msg.dtype))
+        out = torch.where(valid.any(dim=1)[:, None], dense.max(dim=1)[0], torch.zeros((), dtype=msg.dtype))
+        return out, pos, batch, point2curveidx
+
+
+class DGCNNLayerRadius(DGCNNLayer):
+    """ref dgcnn.py:114-127 (step "dgcnn-rad"): ball query (K=128, index order) between feature vectors."""
+
+    def __init__(self, nn, r, aggr="max", num_workers=1, with_xyz=False, **kwargs):
+        super().__init__(nn, None, aggr, num_workers, with_xyz)
+        self.r, self.operation = r, "ball-group"
+
+
 class GlobalSAModule(nn.Module):
     """ref pointnet2.py:81-116: per-cloud max (or mean) pooling of nn([x, pos])."""
 
@@ -861,6 +909,10 @@ class ModelBase(nn.Module):
             return SGCNNLayer(MLP(dims, bias=b), kw["knn"][i], r=kw["radii"][i], attend_nn=self._attend(dims, kw, False), **kw)
         if name == "sa-global":
             return GlobalSAModule(MLP(dims, bias=b), **kw)
+        if name == "dgcnn":
+            return DGCNNLayer(MLP(dims, bias=b), kw["knn"][i], with_xyz=kw["with_xyz"])
+        if name == "dgcnn-rad":
+            return DGCNNLayerRadius(MLP(dims, bias=b), kw["radii"][i], with_xyz=kw["with_xyz"])
         if name == "sa-geo":
             return CurveSAModule(kw["ratios"][i], kw["radii"][i], MLP(dims, act="leaky_relu", bias=b),
                                  attend_nn=self._attend(dims, kw, False), **kw)

@@ -430,3 +430,46 @@ def test_flat_adam_matches_torch_adam():
             assert float((pr.detach() - pm.detach()).abs().max()) < 1e-6 * (it + 1), it      # an ulp of |p| <= 4 per step
     # gradients are still views of the buckets and parameters views of the flat parameter buffers
     assert holder[0].grad.data_ptr() >= sync.buckets[-1][0].data_ptr() or len(sync.buckets) > 1
+
+
+def test_dgcnn_steps_vs_oracle():
+    """Steps "dgcnn" (FRNN between 3-channel feature vectors, the only case the reference's search supports) and
+    "dgcnn-rad" (ball query between 7-channel feature vectors)."""
+    from oracle import torch_ref as R
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([1, 2], n_curves=30)
+    n = d.pos.size(0)
+    ref, mine = _pair(lambda: R.DGCNNLayer(R.MLP([6, 16, 12], bias=True), 8),
+                      lambda: steps.DGCNNLayer(MLP([6, 16, 12], bias=True), 8))
+    x3 = d.pos * 0.5 + 0.01 * torch.randn(n, 3, generator=torch.Generator().manual_seed(1))
+    _run_pair(ref, mine, [x3, d.pos, d.batch, d.curve_idxs], seed=0)
+    with pytest.raises(ValueError):
+        mine(torch.randn(n, 5, device=DEV), d.pos.to(DEV), d.batch.to(DEV), d.curve_idxs.to(DEV))
+    ref, mine = _pair(lambda: R.DGCNNLayerRadius(R.MLP([14, 16, 12], bias=False), 0.6),
+                      lambda: steps.DGCNNLayerRadius(MLP([14, 16, 12], bias=False), 0.6))
+    x7 = 0.3 * torch.randn(n, 7, generator=torch.Generator().manual_seed(2))
+    out_r, _ = _run_pair(ref, mine, [x7, d.pos, d.batch, d.curve_idxs], seed=0)
+    assert float(out_r[0].abs().max()) > 0
+
+
+def test_dgcnn_steps_in_model_base():
+    """ModelBase builds "dgcnn" with the reference's dimensions and state-dict keys and trains through it."""
+    from oracle import torch_ref as R
+    from curvecloudnet_amd.model import ModelBase
+    from curvecloudnet_amd.synth import make_batch
+    from tests.util import batch_to
+    cfg = dict(steps=["dgcnn", "sgcnn", "mlp"], feat_dims=[[16, 16], [24, 24], [32]], knn=[8, 6, None],
+               radii=[None, 0.05, None], with_xyz=True, use_bias=False, out_mlp={"dims": [16], "dropout": 0.0})
+    torch.manual_seed(0)
+    mine = ModelBase(3, 5, **cfg)
+    ref = R.ModelBase(3, 5, **cfg)
+    assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    mine = mine.to(DEV).train()
+    data = make_batch([3], n_curves=20)
+    data.x = None
+    out = mine(batch_to(data, DEV))
+    assert out.shape == (data.pos.size(0), 5) and torch.isfinite(out).all()
+    out.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mine.parameters())

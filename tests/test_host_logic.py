@@ -84,9 +84,11 @@ def test_reference_yaml_schema_is_accepted(tmp_path):
 def test_unsupported_steps_fail_loudly():
     from curvecloudnet_amd.model import ModelBase
     with pytest.raises(NotImplementedError):
-        ModelBase(3, 5, steps=["dgcnn"], feat_dims=[[8]], knn=[4], ratios=[None], radii=[None])
-    with pytest.raises(NotImplementedError):
         ModelBase(3, 5, steps=["bogus"], feat_dims=[[8]])
+    with pytest.raises(NotImplementedError):        # the reference's _get_input_dim knows "dgcnn-rad" only as a first step
+        ModelBase(3, 5, steps=["mlp", "dgcnn-rad"], feat_dims=[[8], [8]], radii=[None, 0.5])
+    m = ModelBase(3, 5, steps=["dgcnn"], feat_dims=[[8]], knn=[4], ratios=[None], radii=[None])
+    assert m.steps[0].nn.channel_list == [6, 8]
 
 
 def test_synthetic_cloud_matches_survey_draw():
