@@ -25,15 +25,14 @@ from curvecloudnet_amd import _lib                                              
 from curvecloudnet_amd.model import ModelBase, segmentation_loss               # noqa: E402
 from curvecloudnet_amd.parallel import FlatAdam, GradientAllReduce, init_process_group_from_env  # noqa: E402
 from curvecloudnet_amd.synth import make_batch, to_device                      # noqa: E402
-from curvecloudnet_amd.configs import kitti_config                             # noqa: E402
+from curvecloudnet_amd import configs as ref_configs                           # noqa: E402
 from tests.util import hotpath_config                                          # noqa: E402
 
-N_CLASSES = 20
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
-def gemm_label(name, ints):
+def gemm_label(name, ints, nulls=()):
     """(kernel symbol as rocprofv3 prints it, flops) of a GEMM launch; mirrors the dispatch in csrc/ccn_gemm.hip."""
     if name not in ("gemm_nt", "gemm_nn", "gemm_tn"):
         return None, 0.0
@@ -43,6 +42,9 @@ def gemm_label(name, ints):
     if name == "gemm_nt":
         bn = 32 if n <= 32 else (64 if n <= 64 else 128)
         if aligned and m >= 1024 and k >= 128:
+            no_bias = 4 in nulls                               # gemm_nt(A, lda, W, ldw, bias, ...)
+            if no_bias and k % 32 == 0 and ((m + 255) // 256) * ((n + 127) // 128) >= 512:
+                return "gemm_glds_persistent_kernel<%d>" % bn, flops
             return "gemm_glds_kernel<%d>" % bn, flops
         kern = "gemm_fast_kernel" if aligned else "gemm_kernel"
         return "%s<128, %d, 4, 0, 0, 0%s>" % (kern, bn, (", true" if k > 96 else ", false") if aligned else ""), flops
@@ -70,8 +72,8 @@ def pmc_traffic(kernel):
 def summarise_profile(records, steps):
     torch.cuda.synchronize()
     table = {}
-    for name, ints, beg, end in records:
-        label, flops = gemm_label(name, ints)
+    for name, ints, beg, end, nulls in records:
+        label, flops = gemm_label(name, ints, nulls)
         key = label or name
         t = table.setdefault(key, {"ms": 0.0, "launches": 0, "flops": 0.0})
         t["ms"] += beg.elapsed_time(end)
@@ -81,7 +83,7 @@ def summarise_profile(records, steps):
     rows = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
     # per-shape view of the GEMMs (which layers carry the time)
     shapes = {}
-    for name, ints, beg, end in records:
+    for name, ints, beg, end, _ in records:
         if name.startswith("gemm_"):
             key = (name, ints[3], ints[4], ints[5])
             t = shapes.setdefault(key, [0.0, 0])
@@ -95,16 +97,40 @@ def summarise_profile(records, steps):
     return rows, total
 
 
-def cpu_baseline(cfg, seed, timed_steps=2):
-    """The oracle timed on the host: 1 cloud (2048 curves, ~50k points) per step, forward + backward + Adam."""
+NETWORKS = {
+    # name: (config builder, in_dim, classes, description)
+    "kitti": (ref_configs.kitti_config, 4, 20, "the reference's kitti-curvecloudnet.yaml model section (33 steps, all levels)"),
+    "nuscenes": (ref_configs.nuscenes_config, 4, 17, "the reference's nuscenes-curvecloudnet.yaml model section"),
+    "a2d2": (ref_configs.a2d2_config, 4, 55, "the reference's audi-curvecloudnet.yaml model section"),
+    "shapenet-seg": (ref_configs.shapenet_seg_config, 3, 50, "the reference's shapenet-seg-curvecloudnet.yaml model section"),
+    "kortx": (lambda width=1.0: ref_configs.shapenet_seg_config(width, kortx=True), 3, 50,
+              "the reference's kortx-testsplit-curvecloudnet.yaml model section (k=7 curve convolutions, exact kNN K=30)"),
+    "hotpath": (hotpath_config, 4, 20,
+                "section-8a hot-path subset (conv1d-fast-v2, sa-geo, mlp, 2x sgcnn, skip, fp-geo, conv)"),
+}
+
+
+def make_input(cloud_ids, in_dim, args):
+    """Synthetic clouds in the layout the reference's datasets hand to the model: LiDAR sets carry reflectance in x
+    (in_dim 4); the object sets have x=None, positions normalised to the unit ball and a category id per cloud."""
+    data = make_batch(cloud_ids, n_curves=args.curves, mixed_lengths=args.mixed_lengths)
+    if in_dim == 3:
+        data.x = None
+        data.pos = data.pos / 3.0
+        data.labels = torch.arange(len(cloud_ids)) % 16
+    return data
+
+
+def cpu_baseline(cfg, in_dim, n_classes, args, seed, timed_steps=2):
+    """The oracle timed on the host: 1 cloud per step, forward + backward + Adam."""
     from oracle import torch_ref as R
     import copy
     kw = {k: v for k, v in copy.deepcopy(cfg).items() if k != "type"}
     torch.manual_seed(seed)
-    model = R.ModelBase(4, N_CLASSES, **kw).train()
+    model = R.ModelBase(in_dim, n_classes, **kw).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    data = make_batch([0])
-    labels = torch.randint(0, N_CLASSES, (data.pos.size(0),), generator=torch.Generator().manual_seed(1))
+    data = make_input([0], in_dim, args)
+    labels = torch.randint(0, n_classes, (data.pos.size(0),), generator=torch.Generator().manual_seed(1))
     times = []
     for it in range(1 + timed_steps):        # 1 warm-up + timed steps
         t0 = time.perf_counter()
@@ -115,9 +141,9 @@ def cpu_baseline(cfg, seed, timed_steps=2):
         times.append(time.perf_counter() - t0)
     best = min(times[1:])
     return {"value": 1.0 / best, "unit": "clouds/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle/torch_ref.py ModelBase, 1 cloud (2048 curves, %d points) per step, fwd+bwd+Adam, "
+            "sample": "oracle/torch_ref.py ModelBase, 1 cloud (%d curves, %d points) per step, fwd+bwd+Adam, "
                       "best of %d timed step(s) after 1 warm-up (%.1f s of CPU work)"
-                      % (data.pos.size(0), timed_steps, sum(times))}
+                      % (args.curves, data.pos.size(0), timed_steps, sum(times))}
 
 
 def main():
@@ -125,10 +151,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["kitti", "hotpath"], default="kitti",
-                    help="kitti: the reference's full KITTI/nuScenes model (33 steps, 28.8 M parameters); "
-                         "hotpath: the section-8a subset without the voxel/FPS levels")
+    ap.add_argument("--config", choices=sorted(NETWORKS), default="kitti",
+                    help="kitti (default): the reference's full KITTI model (33 steps, 28.8 M parameters); "
+                         "hotpath: the section-8a subset without the voxel/FPS levels; the others: the remaining "
+                         "shipped model sections")
     ap.add_argument("--clouds-per-gpu", type=int, default=8)
+    ap.add_argument("--curves", type=int, default=2048, help="curves per cloud (2048 ~ 50k points; 4900 ~ 120k)")
+    ap.add_argument("--mixed-lengths", action="store_true", help="log-normal curve lengths (BASELINE configs[4])")
     ap.add_argument("--width", type=float, default=1.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -144,18 +173,19 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    cfg = kitti_config(width=args.width) if args.config == "kitti" else hotpath_config(width=args.width)
+    make_cfg, in_dim, n_classes, net_desc = NETWORKS[args.config]
+    cfg = make_cfg(width=args.width)
     kw = {k: v for k, v in cfg.items() if k != "type"}
     torch.manual_seed(1234)                                  # identical replicas on every rank
-    model = ModelBase(4, N_CLASSES, **kw).to(dev).train()
+    model = ModelBase(in_dim, n_classes, **kw).to(dev).train()
     sync = GradientAllReduce(model)
     opt = FlatAdam(sync, lr=1e-3)                            # torch.optim.Adam arithmetic, one launch per bucket
 
     b = args.clouds_per_gpu
     cloud_ids = list(range(rank * b, rank * b + b))          # weak scaling: a fixed number of whole clouds per GPU
-    data = to_device(make_batch(cloud_ids), dev)             # inputs resident in HBM before the timed region
+    data = to_device(make_input(cloud_ids, in_dim, args), dev)   # inputs resident in HBM before the timed region
     n_points = data.pos.size(0)
-    labels = torch.randint(0, N_CLASSES, (n_points,), generator=torch.Generator().manual_seed(rank)).to(dev)
+    labels = torch.randint(0, n_classes, (n_points,), generator=torch.Generator().manual_seed(rank)).to(dev)
 
     def step():
         sync.zero_grad()
@@ -193,14 +223,10 @@ def main():
         "metric": "point-clouds/sec fwd+bwd @50k pts", "value": world * b * args.steps / elapsed, "unit": "clouds/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1] shape: %d clouds/GPU x 2048 curves (~50k points each, %d points "
+        "config": {"workload": "BASELINE configs[1] shape: %d clouds/GPU x %d curves (~%dk points each, %d points "
                                "on rank 0), fp32 curve-conv + HIP FRNN + MFMA MLP stack; network = %s at width x%g; "
                                "fwd + mean-NLL + bwd + Adam"
-                               % (b, n_points,
-                                  "the reference's kitti-curvecloudnet.yaml model section (33 steps, all levels)"
-                                  if args.config == "kitti" else
-                                  "section-8a hot-path subset (conv1d-fast-v2, sa-geo, mlp, 2x sgcnn, skip, fp-geo, conv)",
-                                  args.width),
+                               % (b, args.curves, round(n_points / b / 1000), n_points, net_desc, args.width),
                    "network": args.config, "parameters": sum(p.numel() for p in model.parameters()),
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                    "clouds_per_gpu": b, "points_per_cloud": n_points // b, "parallelism": "dp%d" % world,
@@ -230,7 +256,7 @@ def main():
                 tf = " %7.1f TFLOP/s" % (t["flops"] / (t["ms"] * 1e-3) / 1e12) if t["flops"] else ""
                 f.write("%9.2f ms %5.1f%% %6d launches  %s%s\n" % (t["ms"], 100 * t["ms"] / total_ms, t["launches"], k, tf))
     if not args.no_cpu_baseline and world == 1:
-        result["cpu_baseline"] = cpu_baseline(cfg, 1234, timed_steps=1 if args.config == "kitti" else 2)
+        result["cpu_baseline"] = cpu_baseline(cfg, in_dim, n_classes, args, 1234, timed_steps=2 if args.config == "hotpath" else 1)
     print(json.dumps(result))
 
 

@@ -91,7 +91,9 @@ def call(name, *args):
     beg.record()
     check(fn(*args, stream()), name)
     end.record()
-    PROFILE.append((name, tuple(a for a in args if isinstance(a, int)), beg, end))
+    # integer arguments (sizes / leading dimensions) and the positions of NULL pointers identify the kernel variant
+    PROFILE.append((name, tuple(a for a in args if isinstance(a, int)), beg, end,
+                    tuple(i for i, a in enumerate(args) if a is None)))
 
 
 def require_gpu(*tensors):
