@@ -56,16 +56,21 @@ def gemm_label(name, ints, nulls=()):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_traffic.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None when the kernel is not in the profile."""
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc*.json, written by
+    tools/collect_profiles.sh + tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc
+    runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; a third pass holds
+    SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE).  None when the kernel is not in the newest profile that has it."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc*.json")), reverse=True):
         table = json.load(open(path))
         for name, t in table.items():
-            if kernel in name:
-                return {"bytes_per_launch": t["fetch_bytes_per_launch_corrected"] + t["write_bytes_per_launch"],
-                        "source": os.path.relpath(path, ROOT), "launches_profiled": t["launches"]}
+            if kernel + "(" in name:
+                out = {"bytes_per_launch": t["fetch_bytes_per_launch_corrected"] + t["write_bytes_per_launch"],
+                       "source": os.path.relpath(path, ROOT), "launches_profiled": t["launches"]}
+                for k in ("mfma_pipe_utilisation", "effective_clock_ghz"):
+                    if k in t:
+                        out[k] = round(t[k], 4)
+                return out
     return None
 
 
