@@ -264,6 +264,148 @@ __global__ __launch_bounds__(TPB) void sg_edge_bwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------ A13, algebraic form of the first message layer
+// W [x_j ; (p_j - p_i)/r] + b = PX[j] + Wp (p_j - p_i)/r + b with the per-point product PX = X Wx^T (N_src rows
+// instead of E edge rows); the 3-column position part is evaluated per edge from the relative position itself
+// (no cancellation between large coordinates).  BatchNorm statistics run over the E real edges.
+constexpr int PN_EDGES_MAX = 32;  // edges per wave in the statistics kernels
+
+struct PnEdge {
+  int64_t j;
+  float r0, r1, r2;
+};
+__device__ __forceinline__ PnEdge pn_edge(const float* __restrict__ pos_src, const float* __restrict__ pos_dst,
+                                          const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t e,
+                                          float radius) {
+  PnEdge o;
+  o.j = src[e];
+  const int64_t q = dst[e];
+  o.r0 = pos_src[3 * o.j] - pos_dst[3 * q];
+  o.r1 = pos_src[3 * o.j + 1] - pos_dst[3 * q + 1];
+  o.r2 = pos_src[3 * o.j + 2] - pos_dst[3 * q + 2];
+  if (radius > 0.f) {
+    o.r0 = __fdiv_rn(o.r0, radius);
+    o.r1 = __fdiv_rn(o.r1, radius);
+    o.r2 = __fdiv_rn(o.r2, radius);
+  }
+  return o;
+}
+
+// MODE 0: column sums of y and y^2;  MODE 1: column sums of g and g*xhat, g = dZ * act'(y*scale+shift)
+template <int MODE>
+__global__ __launch_bounds__(TPB) void pn_edge_stats_kernel(
+    const float* __restrict__ px, int64_t ldpx, const float* __restrict__ wp, int64_t ldwp,
+    const float* __restrict__ bias, const float* __restrict__ pos_src, const float* __restrict__ pos_dst,
+    const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, int Co, float radius,
+    const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope, int per_wave,
+    double* __restrict__ partial) {
+  __shared__ double red[4][64][2];
+  CCN_LANES;
+  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * per_wave;
+  const int c = blockIdx.y * 64 + cx;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < Co) {
+    const float w0 = wp[c * ldwp], w1 = wp[c * ldwp + 1], w2 = wp[c * ldwp + 2];
+    const float bv = bias ? bias[c] : 0.f;
+    float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
+    if (MODE == 1) {
+      sc = scale[c];
+      sh = shift[c];
+      mu = mean[c];
+      rs = rstd[c];
+    }
+    for (int t = 0; t < per_wave; ++t) {
+      const int64_t e = first + t;
+      if (e >= E) break;
+      const PnEdge ed = pn_edge(pos_src, pos_dst, src, dst, e, radius);
+      const float y = px[ed.j * ldpx + c] + (w0 * ed.r0 + w1 * ed.r1 + w2 * ed.r2) + bv;
+      if (MODE == 0) {
+        s1 += (double)y;
+        s2 += (double)y * (double)y;
+      } else {
+        const float g = dZ[e * lddz + c] * edge_act_grad(y * sc + sh, act, slope);
+        s1 += (double)g;
+        s2 += (double)(g * ((y - mu) * rs));
+      }
+    }
+  }
+  red[ry][cx][0] = s1;
+  red[ry][cx][1] = s2;
+  __syncthreads();
+  if (ry == 0 && c < Co) {
+    double a = 0.0, b2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      a += red[w][cx][0];
+      b2 += red[w][cx][1];
+    }
+    partial[(int64_t)blockIdx.x * 2 * Co + c] = a;
+    partial[(int64_t)blockIdx.x * 2 * Co + Co + c] = b2;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void pn_edge_apply_kernel(
+    const float* __restrict__ px, int64_t ldpx, const float* __restrict__ wp, int64_t ldwp,
+    const float* __restrict__ bias, const float* __restrict__ pos_src, const float* __restrict__ pos_dst,
+    const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, int Co, float radius,
+    const float* __restrict__ scale, const float* __restrict__ shift, int act, float slope, float* __restrict__ Z,
+    int64_t ldz) {
+  CCN_LANES;
+  const int64_t e = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (e >= E) return;
+  const PnEdge ed = pn_edge(pos_src, pos_dst, src, dst, e, radius);
+  for (int c = cx; c < Co; c += 64) {
+    const float y = px[ed.j * ldpx + c] + (wp[c * ldwp] * ed.r0 + wp[c * ldwp + 1] * ed.r1 + wp[c * ldwp + 2] * ed.r2) +
+                    (bias ? bias[c] : 0.f);
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    Z[e * ldz + c] = edge_act(y * sc + sh, act, slope);
+  }
+}
+
+// dPX must be zero on entry (atomic accumulation per source point).  Each wave walks `per_wave` consecutive edges
+// and keeps the sums dWp[c][0..2] = sum dy*rel, dbias[c] = sum dy in registers; wpart: [gridDim.x*4][4][Co] doubles.
+__global__ __launch_bounds__(TPB) void pn_edge_bwd_kernel(
+    const float* __restrict__ px, int64_t ldpx, const float* __restrict__ wp, int64_t ldwp,
+    const float* __restrict__ bias, const float* __restrict__ pos_src, const float* __restrict__ pos_dst,
+    const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, int Co, float radius,
+    const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope,
+    const double* __restrict__ sums, int training, int per_wave, float* __restrict__ dpx, int64_t lddpx,
+    double* __restrict__ wpart) {
+  CCN_LANES;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + ry;
+  const int64_t first = wave_id * per_wave;
+  const float inv_n = 1.0f / (float)E;
+  for (int c = cx; c < Co; c += 64) {
+    const float w0 = wp[c * ldwp], w1 = wp[c * ldwp + 1], w2 = wp[c * ldwp + 2];
+    const float bv = bias ? bias[c] : 0.f;
+    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+    const float mu = mean ? mean[c] : 0.f, rs = rstd ? rstd[c] : 0.f;
+    const float m1 = (training && sums) ? (float)sums[c] * inv_n : 0.f;
+    const float m2 = (training && sums) ? (float)sums[Co + c] * inv_n : 0.f;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, ab = 0.0;
+    for (int t = 0; t < per_wave; ++t) {
+      const int64_t e = first + t;
+      if (e >= E) break;
+      const PnEdge ed = pn_edge(pos_src, pos_dst, src, dst, e, radius);
+      const float y = px[ed.j * ldpx + c] + (w0 * ed.r0 + w1 * ed.r1 + w2 * ed.r2) + bv;
+      const float g = dZ[e * lddz + c] * edge_act_grad(y * sc + sh, act, slope);
+      const float dy = (training && sums) ? sc * (g - m1 - (y - mu) * rs * m2) : sc * g;
+      atomicAdd(&dpx[ed.j * lddpx + c], dy);
+      a0 += (double)(dy * ed.r0);
+      a1 += (double)(dy * ed.r1);
+      a2 += (double)(dy * ed.r2);
+      ab += (double)dy;
+    }
+    double* o = wpart + wave_id * 4 * Co;
+    o[c] = a0;
+    o[Co + c] = a1;
+    o[2 * Co + c] = a2;
+    o[3 * Co + c] = ab;
+  }
+}
+
 // ------------------------------------------------------------------ A13: PointNetConv2 message
 __global__ __launch_bounds__(TPB) void msg_build_fwd_kernel(const float* __restrict__ x_src, int64_t ldx,
                                                             const float* __restrict__ pos_src,
@@ -541,6 +683,87 @@ int ccn_sg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const in
   hipLaunchKernelGGL(sg_max_bwd_kernel, dim3(row_blocks(B * Nmax)), dim3(TPB), 0, (hipStream_t)stream, dout, lddo, arg,
                      cloud_ptr, B, Nmax, (int)K, (int)C, df, lddf);
   CCN_LAUNCH_OK("sg_max_bwd");
+  return CCN_OK;
+}
+
+// ---- PointNetConv2 first layer, algebraic form (point_conv.py:35-93 with local_nn.lins[0] split as [Wx | Wp])
+static int pn_per_wave(int64_t E, int64_t Co) {
+  const int64_t chunks = (Co + 63) / 64;
+  int64_t per = E * chunks / (4 * 2048);
+  if (per > PN_EDGES_MAX) per = PN_EDGES_MAX;
+  if (per < 1) per = 1;
+  return (int)per;
+}
+
+int64_t ccn_pn_edge_stats_rows(int64_t E, int64_t Co) {
+  const int per = pn_per_wave(E, Co);
+  return (E + 4 * per - 1) / (4 * per);
+}
+
+int64_t ccn_pn_edge_bwd_rows(int64_t E) {
+  // waves of the backward kernel (each owns one row of 4*Co partial sums): ~2048 workgroups of 4 waves
+  int64_t per = (E + 8191) / 8192;
+  if (per < 1) per = 1;
+  return ((E + per - 1) / per + 3) / 4 * 4;
+}
+
+int ccn_pn_edge_stats(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                      const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                      int64_t Co, float radius, double* partial, void* stream) {
+  CCN_REQUIRE(px && wp && pos_src && pos_dst && src && dst && partial && E > 0 && CCN_SMALL_INT(Co) && ldpx >= Co &&
+                  ldwp >= 3,
+              "pn_edge_stats: bad arguments");
+  hipLaunchKernelGGL(pn_edge_stats_kernel<0>, dim3((unsigned)ccn_pn_edge_stats_rows(E, Co), (unsigned)((Co + 63) / 64)),
+                     dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp, bias, pos_src, pos_dst, src, dst, E, (int)Co,
+                     radius, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, 0, 0.f, pn_per_wave(E, Co), partial);
+  CCN_LAUNCH_OK("pn_edge_stats");
+  return CCN_OK;
+}
+
+int ccn_pn_edge_apply(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                      const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                      int64_t Co, float radius, const float* scale, const float* shift, int act, float slope, float* Z,
+                      int64_t ldz, void* stream) {
+  CCN_REQUIRE(px && wp && pos_src && pos_dst && src && dst && Z && E > 0 && CCN_SMALL_INT(Co) && ldpx >= Co &&
+                  ldwp >= 3 && ldz >= Co,
+              "pn_edge_apply: bad arguments");
+  hipLaunchKernelGGL(pn_edge_apply_kernel, dim3(row_blocks(E)), dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp,
+                     bias, pos_src, pos_dst, src, dst, E, (int)Co, radius, scale, shift, act, slope, Z, ldz);
+  CCN_LAUNCH_OK("pn_edge_apply");
+  return CCN_OK;
+}
+
+int ccn_pn_edge_bwd_stats(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                          const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                          int64_t Co, float radius, const float* dZ, int64_t lddz, const float* scale,
+                          const float* shift, const float* mean, const float* rstd, int act, float slope,
+                          double* partial, void* stream) {
+  CCN_REQUIRE(px && wp && pos_src && pos_dst && src && dst && dZ && scale && shift && mean && rstd && partial && E > 0 &&
+                  CCN_SMALL_INT(Co) && ldpx >= Co && ldwp >= 3 && lddz >= Co,
+              "pn_edge_bwd_stats: bad arguments");
+  hipLaunchKernelGGL(pn_edge_stats_kernel<1>, dim3((unsigned)ccn_pn_edge_stats_rows(E, Co), (unsigned)((Co + 63) / 64)),
+                     dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp, bias, pos_src, pos_dst, src, dst, E, (int)Co,
+                     radius, dZ, lddz, scale, shift, mean, rstd, act, slope, pn_per_wave(E, Co), partial);
+  CCN_LAUNCH_OK("pn_edge_bwd_stats");
+  return CCN_OK;
+}
+
+int ccn_pn_edge_bwd(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                    const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                    int64_t Co, float radius, const float* dZ, int64_t lddz, const float* scale, const float* shift,
+                    const float* mean, const float* rstd, int act, float slope, const double* sums, int training,
+                    float* dpx, int64_t lddpx, double* wpart, void* stream) {
+  CCN_REQUIRE(px && wp && pos_src && pos_dst && src && dst && dZ && dpx && wpart && E > 0 && CCN_SMALL_INT(Co) &&
+                  ldpx >= Co && ldwp >= 3 && lddz >= Co && lddpx >= Co,
+              "pn_edge_bwd: bad arguments");
+  const int64_t waves = ccn_pn_edge_bwd_rows(E);
+  int64_t per = (E + 8191) / 8192;
+  if (per < 1) per = 1;
+  hipLaunchKernelGGL(pn_edge_bwd_kernel, dim3((unsigned)(waves / 4)), dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp,
+                     ldwp, bias, pos_src, pos_dst, src, dst, E, (int)Co, radius, dZ, lddz, scale, shift, mean, rstd, act,
+                     slope, sums, training, (int)per, dpx, lddpx, wpart);
+  CCN_LAUNCH_OK("pn_edge_bwd");
   return CCN_OK;
 }
 

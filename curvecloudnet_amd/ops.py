@@ -827,3 +827,82 @@ def sg_edge_layer(ps, nbr, cloud_ptr, bn, training, act):
     use_batch_stats = training or not bn.track_running_stats
     return SGEdgeLayer.apply(ps, nbr, cloud_ptr, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats,
                              act, bn.eps, bn.momentum if bn.momentum is not None else 0.1)
+
+
+class PNEdgeLayer(torch.autograd.Function):
+    """First layer of PointNetConv2's ``local_nn`` in algebraic form (ref point_conv.py:35-93):
+    ``W [x_j ; (p_j - p_i)/r] + b = PX[j] + Wp (p_j - p_i)/r + b`` with ``PX = X Wx^T`` computed once per SOURCE POINT
+    (the caller's GEMM) instead of once per edge; BatchNorm statistics over the E edges and the activation are fused
+    into the gather passes.  Exact up to fp32 re-association of the C+3 term dot product."""
+
+    @staticmethod
+    def forward(ctx, px, wp, bias, pos_src, pos_dst, src, dst, radius, gamma, beta, running_mean, running_var, training,
+                act, eps, momentum):
+        px, wp = _mat(px), _mat(wp.contiguous())
+        e, co, dev = src.numel(), px.size(1), px.device
+        has_bn = gamma is not None
+        ctx.has_bn, ctx.act, ctx.training, ctx.radius = has_bn, ACT[act], bool(training), float(radius or 0.0)
+        ctx.has_bias = bias is not None
+        geo = (ptr(pos_src), ptr(pos_dst), ptr(src), ptr(dst), e, co, ctx.radius)
+        par = None
+        if has_bn:
+            par = torch.empty((4, co), dtype=torch.float32, device=dev)
+            if training:
+                nparts = lib().ccn_pn_edge_stats_rows(e, co)
+                partial = torch.empty((nparts + 1) * 2 * co, dtype=torch.float64, device=dev)
+                call("pn_edge_stats", ptr(px), _ld(px), ptr(wp), _ld(wp), ptr(bias), *geo, ptr(partial))
+                call("bn_finalize_n", ptr(partial), nparts, e, co, ptr(gamma), ptr(beta), float(eps), float(momentum),
+                     ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+            else:
+                call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), co,
+                     ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        z = _rows(e, co, dev)
+        call("pn_edge_apply", ptr(px), _ld(px), ptr(wp), _ld(wp), ptr(bias), *geo, ptr(par[0]) if has_bn else None,
+             ptr(par[1]) if has_bn else None, ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
+        ctx.save_for_backward(px, wp, bias if bias is not None else px.new_empty(0), pos_src, pos_dst, src, dst,
+                              par if has_bn else px.new_empty(0))
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        px, wp, bias, pos_src, pos_dst, src, dst, par = ctx.saved_tensors
+        g = _mat(g)
+        e, co, dev = src.numel(), px.size(1), g.device
+        bias_p = ptr(bias) if ctx.has_bias else None
+        geo = (ptr(pos_src), ptr(pos_dst), ptr(src), ptr(dst), e, co, ctx.radius)
+        sums = dgamma = dbeta = None
+        pp = [None] * 4
+        if ctx.has_bn:
+            pp = [ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3])]
+            nparts = lib().ccn_pn_edge_stats_rows(e, co)
+            partial = torch.empty((nparts + 1) * 2 * co, dtype=torch.float64, device=dev)
+            call("pn_edge_bwd_stats", ptr(px), _ld(px), ptr(wp), _ld(wp), bias_p, *geo, ptr(g), _ld(g), *pp, ctx.act,
+                 LEAKY_SLOPE, ptr(partial))
+            sums = partial[nparts * 2 * co:]
+            call("reduce_partials", ptr(partial), nparts, 2 * co, ptr(sums))
+            dbeta, dgamma = sums[:co].float(), sums[co:].float()
+        dpx = _rows(px.size(0), co, dev, zero=True)
+        nw = lib().ccn_pn_edge_bwd_rows(e)
+        wpart = torch.zeros((nw + 1) * 4 * co, dtype=torch.float64, device=dev)
+        call("pn_edge_bwd", ptr(px), _ld(px), ptr(wp), _ld(wp), bias_p, *geo, ptr(g), _ld(g), *pp, ctx.act, LEAKY_SLOPE,
+             ptr(sums) if sums is not None else None, 1 if (ctx.training and ctx.has_bn) else 0, ptr(dpx), _ld(dpx),
+             ptr(wpart))
+        tot = wpart[nw * 4 * co:]
+        call("reduce_partials", ptr(wpart), nw, 4 * co, ptr(tot))
+        tot = tot.view(4, co).float()
+        dwp = tot[:3].t().contiguous()
+        dbias = tot[3].contiguous() if ctx.has_bias else None
+        return dpx, dwp, dbias, None, None, None, None, None, dgamma, dbeta, None, None, None, None, None, None
+
+
+def pn_edge_layer(px, wp, bias, pos_src, pos_dst, edges, radius, bn, training, act):
+    pos_src, pos_dst = _pos(pos_src), _pos(pos_dst)
+    if bn is None:
+        return PNEdgeLayer.apply(px, wp, bias, pos_src, pos_dst, edges.col, edges.row, radius, None, None, None, None,
+                                 False, None, 0.0, 0.0)
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    use_batch_stats = training or not bn.track_running_stats
+    return PNEdgeLayer.apply(px, wp, bias, pos_src, pos_dst, edges.col, edges.row, radius, bn.weight, bn.bias,
+                             bn.running_mean, bn.running_var, use_batch_stats, act, bn.eps,
+                             bn.momentum if bn.momentum is not None else 0.1)

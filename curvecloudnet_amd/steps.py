@@ -260,13 +260,27 @@ class PointNetConv2(nn.Module):
             raise NotImplementedError("aggr_type %r is not used by any reference config" % aggr_type)
         self.local_nn, self.global_nn, self.attend_nn = local_nn, global_nn, attend_nn
         self.aggr_type, self.normalize_radius = aggr_type, normalize_radius
+        self.force_edge_gemm = False        # tests: run the literal message + GEMM formulation
 
     def forward(self, x, pos, edges):
         x_src = x[0] if isinstance(x, tuple) else x
         pos_src, pos_dst = pos if isinstance(pos, tuple) else (pos, pos)
-        msg = ops.MessageBuild.apply(x_src, pos_src, pos_dst, edges.col, edges.row, self.normalize_radius)
-        if self.local_nn is not None:
-            msg = self.local_nn(msg)
+        nn0 = self.local_nn
+        if (nn0 is not None and x_src is not None and not self.force_edge_gemm and nn0.dropout == 0.0
+                and edges.num_edges > 0):
+            # first layer in algebraic form: one product per SOURCE POINT + a gather pass per edge (ops.PNEdgeLayer)
+            # instead of materialising the (E, C+3) messages and running the GEMM over the edges
+            c = x_src.size(1)
+            lin0 = nn0.lins[0]
+            px = ops.linear_bn_act(x_src, lin0.weight[:, :c], None, None, False, None)
+            hidden0 = len(nn0.norms) > 0
+            msg = ops.pn_edge_layer(px, lin0.weight[:, c:], lin0.bias, pos_src, pos_dst, edges, self.normalize_radius,
+                                    nn0.norms[0].module if hidden0 else None, self.training, nn0.act if hidden0 else None)
+            msg = nn0(msg, start=1)
+        else:
+            msg = ops.MessageBuild.apply(x_src, pos_src, pos_dst, edges.col, edges.row, self.normalize_radius)
+            if nn0 is not None:
+                msg = nn0(msg)
         if self.aggr_type == "max":
             out = ops.SegMax.apply(msg, edges.offsets, edges.num_dst)
         else:

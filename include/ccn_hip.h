@@ -232,6 +232,31 @@ int ccn_knn_points(const float* q, const int64_t* q_ptr, const float* src, const
  * (B,P,3) inputs, idx (B,P1,K) int64 = the first K points2 in index order with d2 < r*r, -1 padded. */
 int ccn_ball_query(const float* points1, const int64_t* lengths1, const float* points2, const int64_t* lengths2,
                    int64_t B, int64_t P1, int64_t P2, int64_t K, float radius, int64_t* idx, void* stream);
+/* PointNetConv2 first message layer in algebraic form (point_conv.py:35-93; local_nn.lins[0].weight = [Wx | Wp]):
+ *   y[e] = PX[src[e]] + Wp (pos_src[src[e]] - pos_dst[dst[e]]) / radius + bias,   PX = X Wx^T  (N_src x Co, one GEMM over the
+ * source points instead of the E edge rows; radius <= 0: no division), followed by BatchNorm over the E edges + activation.
+ * stats: partial [ccn_pn_edge_stats_rows(E,Co)][2*Co] doubles (sum y, sum y^2 | sum g, sum g*xhat) for ccn_bn_finalize_n /
+ * ccn_reduce_partials; bwd: dPX (zero on entry, atomic per source point) and wpart [ccn_pn_edge_bwd_rows(E)][4*Co] doubles
+ * holding per-wave sums of dy*rel_x, dy*rel_y, dy*rel_z, dy (=> dWp columns and dbias after ccn_reduce_partials). */
+int64_t ccn_pn_edge_stats_rows(int64_t E, int64_t Co);
+int64_t ccn_pn_edge_bwd_rows(int64_t E);
+int ccn_pn_edge_stats(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                      const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                      int64_t Co, float radius, double* partial, void* stream);
+int ccn_pn_edge_apply(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                      const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                      int64_t Co, float radius, const float* scale, const float* shift, int act, float slope, float* Z,
+                      int64_t ldz, void* stream);
+int ccn_pn_edge_bwd_stats(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                          const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                          int64_t Co, float radius, const float* dZ, int64_t lddz, const float* scale,
+                          const float* shift, const float* mean, const float* rstd, int act, float slope,
+                          double* partial, void* stream);
+int ccn_pn_edge_bwd(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                    const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                    int64_t Co, float radius, const float* dZ, int64_t lddz, const float* scale, const float* shift,
+                    const float* mean, const float* rstd, int act, float slope, const double* sums, int training,
+                    float* dpx, int64_t lddpx, double* wpart, void* stream);
 /* ball query between D-dimensional feature vectors (dgcnn.py:114-127 DGCNNLayerRadius: the ball-group search of
  * point_ops.py:81 on features): padded (B,P,ld) rows of D floats, same first-K-in-index-order rule, d2 summed over
  * the D components in order. */

@@ -137,6 +137,9 @@ def test_linear_bn_act_vs_torch(M, K, N, act, bias, training):
     gen = torch.Generator().manual_seed(M + N)
     x = torch.randn(M, K, generator=gen) + 0.3
     cot = torch.randn(M, N, generator=gen)
+    # fixed parameters: a pre-activation within rounding distance of 0 flips the (Leaky)ReLU slope between the CPU and
+    # the GPU result and moves one row of dx by ~0.1 -- with unseeded weights that happened in about one run in ten
+    torch.manual_seed(1000 + M + N)
     lin = torch.nn.Linear(K, N, bias=bias)
     bn = torch.nn.BatchNorm1d(N)
     bn.weight.data.uniform_(0.5, 1.5)
@@ -150,7 +153,11 @@ def test_linear_bn_act_vs_torch(M, K, N, act, bias, training):
     bn.train(training)
     fn = F.relu if act == "relu" else F.leaky_relu
     xr = x.clone().requires_grad_(True)
-    yr = fn(bn(lin(xr)))
+    pre = bn(lin(xr))
+    # ... and no cotangent where the pre-activation is within rounding distance of the kink (CPU results differ
+    # between host CPU models by an ulp, so a seed alone does not pin which side of 0 such an element falls on)
+    cot = cot * (pre.detach().abs() > 1e-4)
+    yr = fn(pre)
     params_r = [xr, lin.weight, bn.weight, bn.bias] + ([lin.bias] if bias else [])
     gr = torch.autograd.grad((yr * cot).sum(), params_r)
     xd = x.to(DEV).requires_grad_(True)
@@ -473,3 +480,28 @@ def test_dgcnn_steps_in_model_base():
     assert out.shape == (data.pos.size(0), 5) and torch.isfinite(out).all()
     out.square().mean().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in mine.parameters())
+
+
+@pytest.mark.parametrize("aggr,bias,norm_r", [("attend", False, True), ("max", True, False)])
+def test_pointnetconv_algebraic_first_layer_matches_literal(aggr, bias, norm_r):
+    """PX[j] + Wp rel + b  ==  W [x_j ; rel] + b: both product formulations of the SA module, forward and gradients."""
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([2, 3], n_curves=50)
+    c = 20
+    torch.manual_seed(0)
+    att = MLP([24, 12, 24], act="leaky_relu", bias=bias) if aggr == "attend" else None
+    mod = steps.SAModule(0.5, 0.06, MLP([c + 3, 40, 24], bias=bias), 16, downsample_type="curve-fps", curve_fps_arclen=0.01,
+                         attend_nn=att, aggr_type=aggr, normalize_radius=norm_r).to(DEV).train()
+    x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4)).to(DEV)
+    res = []
+    for literal in (False, True):
+        mod.conv.force_edge_gemm = literal
+        xi = x.clone().requires_grad_(True)
+        torch.manual_seed(9)
+        out = mod(xi, d.pos.to(DEV), d.batch.to(DEV), d.curve_idxs.to(DEV))[0]
+        cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+        res.append([out.detach()] + list(torch.autograd.grad((out * cot).sum(), [xi] + list(mod.parameters()))))
+    for a, b in zip(*res):
+        _close(a, b, 2e-4, "algebraic vs literal")
