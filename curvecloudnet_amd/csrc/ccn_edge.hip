@@ -12,6 +12,32 @@ constexpr int ROWS_PER_WG = 4;  // one row per wave at a time
 
 #define CCN_LANES const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6
 
+// Neighbour list of one dense row held across the wave: lane s keeps the neighbour of slot s+1 (one coalesced load per
+// point instead of a dependent scalar load in front of every gathered row), read back with a wave-uniform lane
+// index.  K > 64 falls back to direct loads.
+struct SgNbrs {
+  const int64_t* p;
+  int64_t v;
+  int K;
+};
+__device__ __forceinline__ SgNbrs sg_nbrs(const int64_t* __restrict__ idx, int64_t bi, int K, int lane, bool live) {
+  SgNbrs n;
+  n.p = idx + bi * K;
+  n.K = K;
+  n.v = (live && K <= 64 && lane < K) ? n.p[lane] : -1;
+  return n;
+}
+// slot s >= 1
+__device__ __forceinline__ int64_t sg_nbr(const SgNbrs& n, int s) {
+  if (n.K <= 64) {
+    const int lo = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)n.v & 0xffffffffu), s - 1);
+    const int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)n.v >> 32), s - 1);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+  }
+  return n.p[s - 1];
+}
+constexpr int SG_UNROLL = 4;  // gathered rows in flight per lane
+
 // ------------------------------------------------------------------ A15: dense SGCNN path
 // dense row e = (b*Nmax + i)*(K+1) + s ; slot 0 is the self loop, slot s>0 is FRNN neighbour s-1.
 // One wave per (b, i): loops over the K+1 slots; the self row is read once per channel.
@@ -84,22 +110,34 @@ __global__ __launch_bounds__(TPB) void sg_max_fwd_kernel(const float* __restrict
   const int64_t b = bi / Nmax, i = bi - b * Nmax;
   const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
   if (i >= len) return;
+  const SgNbrs nb = sg_nbrs(idx, bi, K, cx, true);
   const float* row = f + bi * (K + 1) * ldf;
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int c = c0 + cx;
-    if (c >= C) continue;
-    float best = row[c];  // slot 0 (self) is always valid
+    const int cc = c < C ? c : C - 1;
+    float best = row[cc];  // slot 0 (self) is always valid
     int at = 0;
-    for (int s = 1; s <= K; ++s) {
-      const bool ok = idx[bi * K + (s - 1)] != -1;
-      const float v = ok ? row[s * ldf + c] : -1e2f;
-      if (v > best) {
-        best = v;
-        at = ok ? s : -1;
+    for (int s0 = 1; s0 <= K; s0 += SG_UNROLL) {
+      float v[SG_UNROLL];
+      bool ok[SG_UNROLL];
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u) {
+        const int s = s0 + u;
+        ok[u] = s <= K && sg_nbr(nb, s <= K ? s : K) != -1;
+        v[u] = ok[u] ? row[s * ldf + cc] : -1e2f;
+      }
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u) {
+        if (s0 + u <= K && v[u] > best) {
+          best = v[u];
+          at = ok[u] ? s0 + u : -1;
+        }
       }
     }
-    out[(base + i) * ldo + c] = best;
-    arg[(base + i) * C + c] = at;
+    if (c < C) {
+      out[(base + i) * ldo + c] = best;
+      arg[(base + i) * C + c] = at;
+    }
   }
 }
 
@@ -157,14 +195,16 @@ __global__ __launch_bounds__(TPB) void sg_edge_stats_kernel(
   {
     const int c = blockIdx.y * 64 + cx;  // one 64-channel chunk per workgroup
     double s1 = 0.0, s2 = 0.0;
-    if (c < Co) {
-      const float padv = pad ? pad[c] : 0.f;
+    // all 64 lanes walk the points (the neighbour list lives across the wave); lanes past Co only skip the sums
+    const int cc = c < Co ? c : Co - 1;
+    {
+      const float padv = pad ? pad[cc] : 0.f;
       float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
       if (MODE == 1) {
-        sc = scale[c];
-        sh = shift[c];
-        mu = mean[c];
-        rs = rstd[c];
+        sc = scale[cc];
+        sh = shift[cc];
+        mu = mean[cc];
+        rs = rstd[cc];
       }
       for (int t = 0; t < pts; ++t) {
         const int64_t bi = first + t;
@@ -172,18 +212,30 @@ __global__ __launch_bounds__(TPB) void sg_edge_stats_kernel(
         const int64_t b = bi / Nmax, i = bi - b * Nmax;
         const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
         const bool live = i < len;
-        const float si = live ? ps[(base + i) * ldps + Co + c] : padv;
-        for (int s = 0; s <= K; ++s) {
-          int64_t j = -1;
-          if (live) j = s == 0 ? i : idx[bi * K + (s - 1)];
-          const float y = (j >= 0 ? ps[(base + j) * ldps + c] : 0.f) + si;
-          if (MODE == 0) {
-            s1 += (double)y;
-            s2 += (double)y * (double)y;
-          } else {
-            const float g = dZ[(bi * (K + 1) + s) * lddz + c] * edge_act_grad(y * sc + sh, act, slope);
-            s1 += (double)g;
-            s2 += (double)(g * ((y - mu) * rs));
+        const SgNbrs nb = sg_nbrs(idx, bi, K, cx, live);
+        const float si = live ? ps[(base + i) * ldps + Co + cc] : padv;
+        for (int s0 = 0; s0 <= K; s0 += SG_UNROLL) {
+          float pv[SG_UNROLL], dz[SG_UNROLL];
+#pragma unroll
+          for (int u = 0; u < SG_UNROLL; ++u) {
+            const int s = s0 + u;
+            int64_t j = -1;
+            if (live && s <= K) j = s == 0 ? i : sg_nbr(nb, s);
+            pv[u] = j >= 0 ? ps[(base + j) * ldps + cc] : 0.f;
+            if (MODE == 1) dz[u] = s <= K ? dZ[(bi * (K + 1) + s) * lddz + cc] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < SG_UNROLL; ++u) {
+            if (s0 + u > K) continue;
+            const float y = pv[u] + si;
+            if (MODE == 0) {
+              s1 += (double)y;
+              s2 += (double)y * (double)y;
+            } else {
+              const float g = dz[u] * edge_act_grad(y * sc + sh, act, slope);
+              s1 += (double)g;
+              s2 += (double)(g * ((y - mu) * rs));
+            }
           }
         }
       }
@@ -219,14 +271,23 @@ __global__ __launch_bounds__(TPB) void sg_edge_apply_kernel(const float* __restr
   const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
   const bool live = i < len;
   float* out = Z + bi * (K + 1) * ldz;
-  for (int c = cx; c < Co; c += 64) {
-    const float si = live ? ps[(base + i) * ldps + Co + c] : (pad ? pad[c] : 0.f);
-    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
-    for (int s = 0; s <= K; ++s) {
-      int64_t j = -1;
-      if (live) j = s == 0 ? i : idx[bi * K + (s - 1)];
-      const float y = (j >= 0 ? ps[(base + j) * ldps + c] : 0.f) + si;
-      out[s * ldz + c] = edge_act(y * sc + sh, act, slope);
+  const SgNbrs nb = sg_nbrs(idx, bi, K, cx, live);
+  for (int c0 = 0; c0 < Co; c0 += 64) {
+    const int c = c0 + cx, cc = c < Co ? c : Co - 1;
+    const float si = live ? ps[(base + i) * ldps + Co + cc] : (pad ? pad[cc] : 0.f);
+    const float sc = scale ? scale[cc] : 1.f, sh = shift ? shift[cc] : 0.f;
+    for (int s0 = 0; s0 <= K; s0 += SG_UNROLL) {
+      float pv[SG_UNROLL];
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u) {
+        const int s = s0 + u;
+        int64_t j = -1;
+        if (live && s <= K) j = s == 0 ? i : sg_nbr(nb, s);
+        pv[u] = j >= 0 ? ps[(base + j) * ldps + cc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u)
+        if (s0 + u <= K && c < Co) out[(s0 + u) * ldz + c] = edge_act((pv[u] + si) * sc + sh, act, slope);
     }
   }
 }
@@ -245,22 +306,36 @@ __global__ __launch_bounds__(TPB) void sg_edge_bwd_kernel(
   const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
   if (i >= len) return;  // padding rows feed nothing upstream
   const float inv_n = 1.0f / (float)rows_total;
-  for (int c = cx; c < Co; c += 64) {
-    const float si = ps[(base + i) * ldps + Co + c];
-    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
-    const float mu = mean ? mean[c] : 0.f, rs = rstd ? rstd[c] : 0.f;
-    const float m1 = (training && sums) ? (float)sums[c] * inv_n : 0.f;
-    const float m2 = (training && sums) ? (float)sums[Co + c] * inv_n : 0.f;
+  const SgNbrs nb = sg_nbrs(idx, bi, K, cx, true);
+  for (int c0 = 0; c0 < Co; c0 += 64) {
+    const int c = c0 + cx, cc = c < Co ? c : Co - 1;
+    const float si = ps[(base + i) * ldps + Co + cc];
+    const float sc = scale ? scale[cc] : 1.f, sh = shift ? shift[cc] : 0.f;
+    const float mu = mean ? mean[cc] : 0.f, rs = rstd ? rstd[cc] : 0.f;
+    const float m1 = (training && sums) ? (float)sums[cc] * inv_n : 0.f;
+    const float m2 = (training && sums) ? (float)sums[Co + cc] * inv_n : 0.f;
     float ds = 0.f;
-    for (int s = 0; s <= K; ++s) {
-      const int64_t j = s == 0 ? i : idx[bi * K + (s - 1)];
-      const float y = (j >= 0 ? ps[(base + j) * ldps + c] : 0.f) + si;
-      const float g = dZ[(bi * (K + 1) + s) * lddz + c] * edge_act_grad(y * sc + sh, act, slope);
-      const float dy = training ? sc * (g - m1 - (y - mu) * rs * m2) : sc * g;
-      ds += dy;
-      if (j >= 0) atomicAdd(&dps[(base + j) * lddps + c], dy);
+    for (int s0 = 0; s0 <= K; s0 += SG_UNROLL) {
+      float pv[SG_UNROLL], dz[SG_UNROLL];
+      int64_t jj[SG_UNROLL];
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u) {
+        const int s = s0 + u;
+        jj[u] = s > K ? -1 : (s == 0 ? i : sg_nbr(nb, s));
+        pv[u] = jj[u] >= 0 ? ps[(base + jj[u]) * ldps + cc] : 0.f;
+        dz[u] = s <= K ? dZ[(bi * (K + 1) + s) * lddz + cc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u) {
+        if (s0 + u > K) continue;
+        const float y = pv[u] + si;
+        const float g = dz[u] * edge_act_grad(y * sc + sh, act, slope);
+        const float dy = training ? sc * (g - m1 - (y - mu) * rs * m2) : sc * g;
+        ds += dy;
+        if (jj[u] >= 0 && c < Co) atomicAdd(&dps[(base + jj[u]) * lddps + c], dy);
+      }
     }
-    dps[(base + i) * lddps + Co + c] = ds;
+    if (c < Co) dps[(base + i) * lddps + Co + c] = ds;
   }
 }
 
@@ -274,20 +349,35 @@ struct PnEdge {
   int64_t j;
   float r0, r1, r2;
 };
-__device__ __forceinline__ PnEdge pn_edge(const float* __restrict__ pos_src, const float* __restrict__ pos_dst,
-                                          const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t e,
-                                          float radius) {
-  PnEdge o;
-  o.j = src[e];
-  const int64_t q = dst[e];
-  o.r0 = pos_src[3 * o.j] - pos_dst[3 * q];
-  o.r1 = pos_src[3 * o.j + 1] - pos_dst[3 * q + 1];
-  o.r2 = pos_src[3 * o.j + 2] - pos_dst[3 * q + 2];
-  if (radius > 0.f) {
-    o.r0 = __fdiv_rn(o.r0, radius);
-    o.r1 = __fdiv_rn(o.r1, radius);
-    o.r2 = __fdiv_rn(o.r2, radius);
+// Geometry of 64 consecutive edges, one per lane (source index and relative position), handed to the whole wave
+// edge by edge with readlane: the index -> position -> feature-row chain is paid once per 64 edges, and the
+// feature-row gathers of 4 edges are in flight together.
+__device__ __forceinline__ PnEdge pn_edge_lane(const float* __restrict__ pos_src, const float* __restrict__ pos_dst,
+                                               const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                               int64_t e, int64_t e_end, float radius) {
+  PnEdge o = {-1, 0.f, 0.f, 0.f};
+  if (e < e_end) {
+    o.j = src[e];
+    const int64_t q = dst[e];
+    o.r0 = pos_src[3 * o.j] - pos_dst[3 * q];
+    o.r1 = pos_src[3 * o.j + 1] - pos_dst[3 * q + 1];
+    o.r2 = pos_src[3 * o.j + 2] - pos_dst[3 * q + 2];
+    if (radius > 0.f) {
+      o.r0 = __fdiv_rn(o.r0, radius);
+      o.r1 = __fdiv_rn(o.r1, radius);
+      o.r2 = __fdiv_rn(o.r2, radius);
+    }
   }
+  return o;
+}
+__device__ __forceinline__ PnEdge pn_edge_bcast(const PnEdge& g, int t) {
+  PnEdge o;
+  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)g.j & 0xffffffffu), t);
+  const int hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)g.j >> 32), t);
+  o.j = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint64_t)(uint32_t)lo);
+  o.r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.r0), t));
+  o.r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.r1), t));
+  o.r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g.r2), t));
   return o;
 }
 
@@ -302,29 +392,40 @@ __global__ __launch_bounds__(TPB) void pn_edge_stats_kernel(
     double* __restrict__ partial) {
   __shared__ double red[4][64][2];
   CCN_LANES;
-  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * per_wave;
-  const int c = blockIdx.y * 64 + cx;
+  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * per_wave;  // per_wave <= 64
+  const int64_t last = first + per_wave < E ? first + per_wave : E;
+  const int c = blockIdx.y * 64 + cx, cc = c < Co ? c : Co - 1;
   double s1 = 0.0, s2 = 0.0;
-  if (c < Co) {
-    const float w0 = wp[c * ldwp], w1 = wp[c * ldwp + 1], w2 = wp[c * ldwp + 2];
-    const float bv = bias ? bias[c] : 0.f;
-    float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
-    if (MODE == 1) {
-      sc = scale[c];
-      sh = shift[c];
-      mu = mean[c];
-      rs = rstd[c];
+  const float w0 = wp[cc * ldwp], w1 = wp[cc * ldwp + 1], w2 = wp[cc * ldwp + 2];
+  const float bv = bias ? bias[cc] : 0.f;
+  float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
+  if (MODE == 1) {
+    sc = scale[cc];
+    sh = shift[cc];
+    mu = mean[cc];
+    rs = rstd[cc];
+  }
+  const PnEdge mine = pn_edge_lane(pos_src, pos_dst, src, dst, first + cx, last, radius);
+  const int cnt = first < last ? (int)(last - first) : 0;
+  for (int t0 = 0; t0 < cnt; t0 += 4) {
+    PnEdge ed[4];
+    float pv[4], dz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ed[u] = pn_edge_bcast(mine, (t0 + u) & 63);
+      const bool ok = t0 + u < cnt;
+      pv[u] = ok ? px[ed[u].j * ldpx + cc] : 0.f;
+      if (MODE == 1) dz[u] = ok ? dZ[(first + t0 + u) * lddz + cc] : 0.f;
     }
-    for (int t = 0; t < per_wave; ++t) {
-      const int64_t e = first + t;
-      if (e >= E) break;
-      const PnEdge ed = pn_edge(pos_src, pos_dst, src, dst, e, radius);
-      const float y = px[ed.j * ldpx + c] + (w0 * ed.r0 + w1 * ed.r1 + w2 * ed.r2) + bv;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (t0 + u >= cnt) continue;
+      const float y = pv[u] + (w0 * ed[u].r0 + w1 * ed[u].r1 + w2 * ed[u].r2) + bv;
       if (MODE == 0) {
         s1 += (double)y;
         s2 += (double)y * (double)y;
       } else {
-        const float g = dZ[e * lddz + c] * edge_act_grad(y * sc + sh, act, slope);
+        const float g = dz[u] * edge_act_grad(y * sc + sh, act, slope);
         s1 += (double)g;
         s2 += (double)(g * ((y - mu) * rs));
       }
@@ -345,6 +446,7 @@ __global__ __launch_bounds__(TPB) void pn_edge_stats_kernel(
   }
 }
 
+constexpr int PN_APPLY_EDGES = 16;  // edges per wave in the apply kernel
 __global__ __launch_bounds__(TPB) void pn_edge_apply_kernel(
     const float* __restrict__ px, int64_t ldpx, const float* __restrict__ wp, int64_t ldwp,
     const float* __restrict__ bias, const float* __restrict__ pos_src, const float* __restrict__ pos_dst,
@@ -352,14 +454,31 @@ __global__ __launch_bounds__(TPB) void pn_edge_apply_kernel(
     const float* __restrict__ scale, const float* __restrict__ shift, int act, float slope, float* __restrict__ Z,
     int64_t ldz) {
   CCN_LANES;
-  const int64_t e = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
-  if (e >= E) return;
-  const PnEdge ed = pn_edge(pos_src, pos_dst, src, dst, e, radius);
-  for (int c = cx; c < Co; c += 64) {
-    const float y = px[ed.j * ldpx + c] + (wp[c * ldwp] * ed.r0 + wp[c * ldwp + 1] * ed.r1 + wp[c * ldwp + 2] * ed.r2) +
-                    (bias ? bias[c] : 0.f);
-    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
-    Z[e * ldz + c] = edge_act(y * sc + sh, act, slope);
+  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * PN_APPLY_EDGES;
+  if (first >= E) return;
+  const int64_t last = first + PN_APPLY_EDGES < E ? first + PN_APPLY_EDGES : E;
+  const int cnt = (int)(last - first);
+  const PnEdge mine = pn_edge_lane(pos_src, pos_dst, src, dst, first + cx, last, radius);
+  for (int c0 = 0; c0 < Co; c0 += 64) {
+    const int c = c0 + cx, cc = c < Co ? c : Co - 1;
+    const float w0 = wp[cc * ldwp], w1 = wp[cc * ldwp + 1], w2 = wp[cc * ldwp + 2];
+    const float bv = bias ? bias[cc] : 0.f;
+    const float sc = scale ? scale[cc] : 1.f, sh = shift ? shift[cc] : 0.f;
+    for (int t0 = 0; t0 < cnt; t0 += 4) {
+      PnEdge ed[4];
+      float pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ed[u] = pn_edge_bcast(mine, (t0 + u) & 63);
+        pv[u] = t0 + u < cnt ? px[ed[u].j * ldpx + cc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (t0 + u >= cnt || c >= Co) continue;
+        const float y = pv[u] + (w0 * ed[u].r0 + w1 * ed[u].r1 + w2 * ed[u].r2) + bv;
+        Z[(first + t0 + u) * ldz + c] = edge_act(y * sc + sh, act, slope);
+      }
+    }
   }
 }
 
@@ -376,33 +495,53 @@ __global__ __launch_bounds__(TPB) void pn_edge_bwd_kernel(
   CCN_LANES;
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + ry;
   const int64_t first = wave_id * per_wave;
+  if (first >= E) return;  // wpart is zero-initialised by the caller
+  const int64_t last = first + per_wave < E ? first + per_wave : E;
   const float inv_n = 1.0f / (float)E;
-  for (int c = cx; c < Co; c += 64) {
-    const float w0 = wp[c * ldwp], w1 = wp[c * ldwp + 1], w2 = wp[c * ldwp + 2];
-    const float bv = bias ? bias[c] : 0.f;
-    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
-    const float mu = mean ? mean[c] : 0.f, rs = rstd ? rstd[c] : 0.f;
-    const float m1 = (training && sums) ? (float)sums[c] * inv_n : 0.f;
-    const float m2 = (training && sums) ? (float)sums[Co + c] * inv_n : 0.f;
+  for (int c0 = 0; c0 < Co; c0 += 64) {
+    const int c = c0 + cx, cc = c < Co ? c : Co - 1;
+    const float w0 = wp[cc * ldwp], w1 = wp[cc * ldwp + 1], w2 = wp[cc * ldwp + 2];
+    const float bv = bias ? bias[cc] : 0.f;
+    const float sc = scale ? scale[cc] : 1.f, sh = shift ? shift[cc] : 0.f;
+    const float mu = mean ? mean[cc] : 0.f, rs = rstd ? rstd[cc] : 0.f;
+    const float m1 = (training && sums) ? (float)sums[cc] * inv_n : 0.f;
+    const float m2 = (training && sums) ? (float)sums[Co + cc] * inv_n : 0.f;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, ab = 0.0;
-    for (int t = 0; t < per_wave; ++t) {
-      const int64_t e = first + t;
-      if (e >= E) break;
-      const PnEdge ed = pn_edge(pos_src, pos_dst, src, dst, e, radius);
-      const float y = px[ed.j * ldpx + c] + (w0 * ed.r0 + w1 * ed.r1 + w2 * ed.r2) + bv;
-      const float g = dZ[e * lddz + c] * edge_act_grad(y * sc + sh, act, slope);
-      const float dy = (training && sums) ? sc * (g - m1 - (y - mu) * rs * m2) : sc * g;
-      atomicAdd(&dpx[ed.j * lddpx + c], dy);
-      a0 += (double)(dy * ed.r0);
-      a1 += (double)(dy * ed.r1);
-      a2 += (double)(dy * ed.r2);
-      ab += (double)dy;
+    for (int64_t e0 = first; e0 < last; e0 += 64) {
+      const int64_t e1 = e0 + 64 < last ? e0 + 64 : last;
+      const int cnt = (int)(e1 - e0);
+      const PnEdge mine = pn_edge_lane(pos_src, pos_dst, src, dst, e0 + cx, e1, radius);
+      for (int t0 = 0; t0 < cnt; t0 += 4) {
+        PnEdge ed[4];
+        float pv[4], dz[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          ed[u] = pn_edge_bcast(mine, (t0 + u) & 63);
+          const bool ok = t0 + u < cnt;
+          pv[u] = ok ? px[ed[u].j * ldpx + cc] : 0.f;
+          dz[u] = ok ? dZ[(e0 + t0 + u) * lddz + cc] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (t0 + u >= cnt) continue;
+          const float y = pv[u] + (w0 * ed[u].r0 + w1 * ed[u].r1 + w2 * ed[u].r2) + bv;
+          const float g = dz[u] * edge_act_grad(y * sc + sh, act, slope);
+          const float dy = (training && sums) ? sc * (g - m1 - (y - mu) * rs * m2) : sc * g;
+          if (c < Co) atomicAdd(&dpx[ed[u].j * lddpx + c], dy);
+          a0 += (double)(dy * ed[u].r0);
+          a1 += (double)(dy * ed[u].r1);
+          a2 += (double)(dy * ed[u].r2);
+          ab += (double)dy;
+        }
+      }
     }
-    double* o = wpart + wave_id * 4 * Co;
-    o[c] = a0;
-    o[Co + c] = a1;
-    o[2 * Co + c] = a2;
-    o[3 * Co + c] = ab;
+    if (c < Co) {
+      double* o = wpart + wave_id * 4 * Co;
+      o[c] = a0;
+      o[Co + c] = a1;
+      o[2 * Co + c] = a2;
+      o[3 * Co + c] = ab;
+    }
   }
 }
 
@@ -476,6 +615,23 @@ __global__ __launch_bounds__(TPB) void edge_feat_bwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------ grouped (CSR) aggregation
+// One streaming pass with a running maximum (the sums are rescaled when the maximum moves), 4 edge rows in flight
+// per lane: the group's att / msg rows are read once in forward and twice in backward.
+struct SoftAcc {
+  float top, tot, acc;
+};
+__device__ __forceinline__ void soft_push(SoftAcc& s, float a, float v) {
+  if (a > s.top) {
+    const float k = __expf(s.top - a);  // exp(-inf) = 0 on the first element
+    s.tot *= k;
+    s.acc *= k;
+    s.top = a;
+  }
+  const float p = __expf(a - s.top);
+  s.tot += p;
+  s.acc += p * v;
+}
+
 __global__ __launch_bounds__(TPB) void seg_softmax_agg_fwd_kernel(const float* __restrict__ msg, int64_t ldm,
                                                                   const float* __restrict__ att, int64_t lda,
                                                                   const int32_t* __restrict__ offsets, int64_t M,
@@ -485,15 +641,20 @@ __global__ __launch_bounds__(TPB) void seg_softmax_agg_fwd_kernel(const float* _
   if (i >= M) return;
   const int32_t lo = offsets[i], hi = offsets[i + 1];
   for (int c = cx; c < C; c += 64) {
-    float top = -__builtin_inff();
-    for (int32_t e = lo; e < hi; ++e) top = fmaxf(top, att[(int64_t)e * lda + c]);
-    float tot = 0.f;
-    for (int32_t e = lo; e < hi; ++e) tot += __expf(att[(int64_t)e * lda + c] - top);
-    const float inv = 1.0f / (tot + 1e-16f);
-    float acc = 0.f;
-    for (int32_t e = lo; e < hi; ++e)
-      acc += msg[(int64_t)e * ldm + c] * (__expf(att[(int64_t)e * lda + c] - top) * inv);
-    out[i * ldo + c] = acc;
+    SoftAcc s = {-__builtin_inff(), 0.f, 0.f};
+    int32_t e = lo;
+    for (; e + 4 <= hi; e += 4) {
+      float a[4], v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = att[(int64_t)(e + u) * lda + c];
+        v[u] = msg[(int64_t)(e + u) * ldm + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) soft_push(s, a[u], v[u]);
+    }
+    for (; e < hi; ++e) soft_push(s, att[(int64_t)e * lda + c], msg[(int64_t)e * ldm + c]);
+    out[i * ldo + c] = s.acc * (1.0f / (s.tot + 1e-16f));
   }
 }
 
@@ -510,16 +671,38 @@ __global__ __launch_bounds__(TPB) void seg_softmax_agg_bwd_kernel(const float* _
   const int32_t lo = offsets[i], hi = offsets[i + 1];
   for (int c = cx; c < C; c += 64) {
     const float g = dout[i * lddo + c];
-    float top = -__builtin_inff();
-    for (int32_t e = lo; e < hi; ++e) top = fmaxf(top, att[(int64_t)e * lda + c]);
-    float tot = 0.f;
-    for (int32_t e = lo; e < hi; ++e) tot += __expf(att[(int64_t)e * lda + c] - top);
-    const float inv = 1.0f / (tot + 1e-16f);
-    float dot = 0.f;  // sum_e w_e * dL/dw_e
-    for (int32_t e = lo; e < hi; ++e)
-      dot += __expf(att[(int64_t)e * lda + c] - top) * inv * msg[(int64_t)e * ldm + c] * g;
-    for (int32_t e = lo; e < hi; ++e) {
-      const float w = __expf(att[(int64_t)e * lda + c] - top) * inv;
+    SoftAcc s = {-__builtin_inff(), 0.f, 0.f};
+    int32_t e = lo;
+    for (; e + 4 <= hi; e += 4) {
+      float a[4], v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = att[(int64_t)(e + u) * lda + c];
+        v[u] = msg[(int64_t)(e + u) * ldm + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) soft_push(s, a[u], v[u]);
+    }
+    for (; e < hi; ++e) soft_push(s, att[(int64_t)e * lda + c], msg[(int64_t)e * ldm + c]);
+    const float inv = 1.0f / (s.tot + 1e-16f);
+    const float dot = s.acc * inv * g;  // sum_e w_e * msg_e * g
+    e = lo;
+    for (; e + 4 <= hi; e += 4) {
+      float a[4], v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = att[(int64_t)(e + u) * lda + c];
+        v[u] = msg[(int64_t)(e + u) * ldm + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float w = __expf(a[u] - s.top) * inv;
+        dmsg[(int64_t)(e + u) * lddm + c] = w * g;
+        datt[(int64_t)(e + u) * ldda + c] = w * (v[u] * g - dot);
+      }
+    }
+    for (; e < hi; ++e) {
+      const float w = __expf(att[(int64_t)e * lda + c] - s.top) * inv;
       dmsg[(int64_t)e * lddm + c] = w * g;
       datt[(int64_t)e * ldda + c] = w * (msg[(int64_t)e * ldm + c] * g - dot);
     }
@@ -728,7 +911,8 @@ int ccn_pn_edge_apply(const float* px, int64_t ldpx, const float* wp, int64_t ld
   CCN_REQUIRE(px && wp && pos_src && pos_dst && src && dst && Z && E > 0 && CCN_SMALL_INT(Co) && ldpx >= Co &&
                   ldwp >= 3 && ldz >= Co,
               "pn_edge_apply: bad arguments");
-  hipLaunchKernelGGL(pn_edge_apply_kernel, dim3(row_blocks(E)), dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp,
+  hipLaunchKernelGGL(pn_edge_apply_kernel, dim3((unsigned)((E + 4 * PN_APPLY_EDGES - 1) / (4 * PN_APPLY_EDGES))),
+                     dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp,
                      bias, pos_src, pos_dst, src, dst, E, (int)Co, radius, scale, shift, act, slope, Z, ldz);
   CCN_LAUNCH_OK("pn_edge_apply");
   return CCN_OK;
