@@ -166,10 +166,28 @@ __global__ void diff_concat_bwd_kernel(const float* __restrict__ x, int64_t ldx,
 }
 
 // ------------------------------------------------------------------ A4: shifted rows
-// one wave per output row; lanes stride over the channels of each tap (256 contiguous bytes per access)
+// Element-parallel: thread -> (row i, q = tap*C + c).  Row i of the shifted-row matrix is the contiguous span
+// x[(i - taps/2)*C ...] with the taps that leave the curve zeroed, so reads and writes are both coalesced whatever C
+// is (the narrow first layers, C = 8 / 32, would leave most of a wave idle with one row per wave).
 __global__ __launch_bounds__(256) void im2col_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                          const int32_t* __restrict__ seg, int64_t rows, int C,
                                                          int taps, float* __restrict__ col, int64_t ldcol) {
+  const int W = taps * C;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows * W) return;
+  // 32-bit division whenever the element count allows it (a 64-bit one costs more than the copy itself)
+  const int64_t i = rows * W < 0xffffffffLL ? (int64_t)((uint32_t)t / (uint32_t)W) : t / W;
+  const int q = (int)(t - i * W);
+  const int tap = (int)((uint32_t)q / (uint32_t)C), c = q - tap * C;
+  const int64_t j = i + tap - taps / 2;
+  const bool ok = j >= 0 && j < rows && (seg == nullptr || seg[j] == seg[i]);
+  col[i * ldcol + q] = ok ? x[j * ldx + c] : 0.0f;
+}
+
+// wide rows: one wave per output row, lanes stride over the channels of each tap (256 contiguous bytes per access)
+__global__ __launch_bounds__(256) void im2col_fwd_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                              const int32_t* __restrict__ seg, int64_t rows, int C,
+                                                              int taps, float* __restrict__ col, int64_t ldcol) {
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 4 + ry;
   if (i >= rows) return;
@@ -184,18 +202,17 @@ __global__ __launch_bounds__(256) void im2col_fwd_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void im2col_bwd_kernel(const float* __restrict__ dcol, int64_t ldcol,
                                                          const int32_t* __restrict__ seg, int64_t rows, int C,
                                                          int taps, float* __restrict__ dx, int64_t lddx) {
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int64_t j = (int64_t)blockIdx.x * 4 + ry;
-  if (j >= rows) return;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows * C) return;
+  const int64_t j = rows * C < 0xffffffffLL ? (int64_t)((uint32_t)t / (uint32_t)C) : t / C;
+  const int c = (int)(t - j * C);
   const int32_t me = seg ? seg[j] : 0;
-  for (int c = cx; c < C; c += 64) {
-    float acc = 0.0f;
-    for (int tap = 0; tap < taps; ++tap) {
-      const int64_t i = j - tap + taps / 2;  // output row whose tap `tap` read x[j]
-      if (i >= 0 && i < rows && (seg == nullptr || seg[i] == me)) acc += dcol[i * ldcol + tap * C + c];
-    }
-    dx[j * lddx + c] = acc;
+  float acc = 0.0f;
+  for (int tap = 0; tap < taps; ++tap) {
+    const int64_t i = j - tap + taps / 2;  // output row whose tap `tap` read x[j]
+    if (i >= 0 && i < rows && (seg == nullptr || seg[i] == me)) acc += dcol[i * ldcol + tap * C + c];
   }
+  dx[j * lddx + c] = acc;
 }
 
 __global__ void gather_rows_kernel(const float* __restrict__ src, int64_t lds_, const int64_t* __restrict__ index,
@@ -602,8 +619,12 @@ int ccn_im2col_fwd(const float* x, int64_t ldx, const int32_t* seg, int64_t rows
                   ldcol >= taps * C,
               "im2col_fwd: bad arguments");
   if (rows == 0) return CCN_OK;
-  hipLaunchKernelGGL(im2col_fwd_kernel, dim3(ccn_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, seg, rows,
-                     (int)C, (int)taps, col, ldcol);
+  if (C >= 64)
+    hipLaunchKernelGGL(im2col_fwd_rows_kernel, dim3(ccn_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, seg,
+                       rows, (int)C, (int)taps, col, ldcol);
+  else
+    hipLaunchKernelGGL(im2col_fwd_kernel, dim3(ccn_blocks(rows * taps * C, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       ldx, seg, rows, (int)C, (int)taps, col, ldcol);
   CCN_LAUNCH_OK("im2col_fwd");
   return CCN_OK;
 }
@@ -614,7 +635,7 @@ int ccn_im2col_bwd(const float* dcol, int64_t ldcol, const int32_t* seg, int64_t
                   ldcol >= taps * C,
               "im2col_bwd: bad arguments");
   if (rows == 0) return CCN_OK;
-  hipLaunchKernelGGL(im2col_bwd_kernel, dim3(ccn_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream, dcol, ldcol, seg,
+  hipLaunchKernelGGL(im2col_bwd_kernel, dim3(ccn_blocks(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, dcol, ldcol, seg,
                      rows, (int)C, (int)taps, dx, lddx);
   CCN_LAUNCH_OK("im2col_bwd");
   return CCN_OK;

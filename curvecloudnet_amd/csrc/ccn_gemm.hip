@@ -886,6 +886,97 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
   }
 }
 
+// float4 form of the above for 16-byte aligned operands with C % 4 == 0: a wave instruction covers 4 rows x 64
+// columns (lane = 16*row + column quad) and two such groups are in flight per lane, which is what it takes to keep
+// HBM busy from 128-row workgroups (the scalar form reaches 3.5 TB/s, this one streams at the BN-apply rate).
+template <int MODE>
+__global__ __launch_bounds__(256) void col_partial_vec_kernel(const float* __restrict__ X, int64_t ldx,
+                                                              const float* __restrict__ Y, int64_t ldy, int64_t rows,
+                                                              int64_t C, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, int act, float slope,
+                                                              double* __restrict__ partial) {
+  __shared__ double red[4][64][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cq = lane & 15, rsub = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS;
+  const int64_t r1 = r0 + RED_ROWS < rows ? r0 + RED_ROWS : rows;
+  for (int64_t c0 = 0; c0 < C; c0 += 64) {
+    const int64_t c = c0 + 4 * cq;
+    const bool in = c < C;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    float4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc, mu = sc, rs = sc;
+    if (MODE == 1 && in) {
+      sc = *reinterpret_cast<const float4*>(scale + c);
+      sh = *reinterpret_cast<const float4*>(shift + c);
+      mu = *reinterpret_cast<const float4*>(mean + c);
+      rs = *reinterpret_cast<const float4*>(rstd + c);
+    }
+    if (in) {
+      for (int64_t r = r0 + wave * 4 + rsub; r < r1; r += 32) {
+        const int64_t rb = r + 16;
+        const bool two = rb < r1;
+        float4 xa = *reinterpret_cast<const float4*>(X + r * ldx + c), xb = {0.f, 0.f, 0.f, 0.f};
+        float4 ya = {0.f, 0.f, 0.f, 0.f}, yb = ya;
+        if (two) xb = *reinterpret_cast<const float4*>(X + rb * ldx + c);
+        if (MODE == 1) {
+          ya = *reinterpret_cast<const float4*>(Y + r * ldy + c);
+          if (two) yb = *reinterpret_cast<const float4*>(Y + rb * ldy + c);
+        }
+        const float* xs[2] = {reinterpret_cast<const float*>(&xa), reinterpret_cast<const float*>(&xb)};
+        const float* ys[2] = {reinterpret_cast<const float*>(&ya), reinterpret_cast<const float*>(&yb)};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          if (t == 1 && !two) break;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (MODE == 0) {
+              s1[k] += (double)xs[t][k];
+            } else {
+              const float y = ys[t][k];
+              const float g = xs[t][k] * act_grad(y * (&sc.x)[k] + (&sh.x)[k], act, slope);
+              s1[k] += (double)g;
+              s2[k] += (double)(g * ((y - (&mu.x)[k]) * (&rs.x)[k]));
+            }
+          }
+        }
+      }
+    }
+    // fold the 4 row sub-groups of the wave (lanes l, l^16, l^32, l^48), then the 4 waves through LDS
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      s1[k] += __shfl_xor(s1[k], 16, 64);
+      s1[k] += __shfl_xor(s1[k], 32, 64);
+      s2[k] += __shfl_xor(s2[k], 16, 64);
+      s2[k] += __shfl_xor(s2[k], 32, 64);
+    }
+    if (rsub == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        red[wave][4 * cq + k][0] = s1[k];
+        red[wave][4 * cq + k][1] = s2[k];
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && c0 + lane < C) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a += red[w][lane][0];
+        b += red[w][lane][1];
+      }
+      partial[(int64_t)blockIdx.x * 2 * C + c0 + lane] = a;
+      partial[(int64_t)blockIdx.x * 2 * C + C + c0 + lane] = b;
+    }
+    __syncthreads();
+  }
+}
+
+static inline bool col_vec_ok(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t C) {
+  return C % 4 == 0 && lda % 4 == 0 && ((uintptr_t)a % 16) == 0 && (b == nullptr || (ldb % 4 == 0 && ((uintptr_t)b % 16) == 0));
+}
+
 // Two-level deterministic reduction of the partial rows: sums[w] = sum_p partial[p][w], w < width.
 // Level 1: grid (width/64, slices): every workgroup folds `per_slice` consecutive partial rows into the
 // first row of its slice (in place).  Level 2: one workgroup per 64 columns adds the slice heads.
@@ -1201,8 +1292,12 @@ int ccn_bn_act_bwd_reduce(const float* dZ, int64_t lddz, const float* Y, int64_t
   CCN_REQUIRE(dZ && Y && scale && shift && mean && rstd && sums && rows > 0 && C > 0, "bn_act_bwd_reduce: bad arguments");
   const int64_t nparts = ccn_stats_rows(rows);
   double* partial = sums + 2 * C;
-  hipLaunchKernelGGL(col_partial_kernel<1>, dim3((unsigned)nparts), dim3(256), 0, s, dZ, lddz, Y, ldy, rows, C, scale,
-                     shift, mean, rstd, act, slope, partial);
+  if (col_vec_ok(dZ, lddz, Y, ldy, C) && ((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)rstd) % 16 == 0)
+    hipLaunchKernelGGL(col_partial_vec_kernel<1>, dim3((unsigned)nparts), dim3(256), 0, s, dZ, lddz, Y, ldy, rows, C,
+                       scale, shift, mean, rstd, act, slope, partial);
+  else
+    hipLaunchKernelGGL(col_partial_kernel<1>, dim3((unsigned)nparts), dim3(256), 0, s, dZ, lddz, Y, ldy, rows, C, scale,
+                       shift, mean, rstd, act, slope, partial);
   launch_col_reduce(partial, nparts, 2 * C, sums, s);
   CCN_LAUNCH_OK("bn_act_bwd_reduce");
   return CCN_OK;
@@ -1227,9 +1322,14 @@ int ccn_colsum(const float* X, int64_t ldx, int64_t rows, int64_t C, double* acc
   CCN_REQUIRE(X && acc && out && rows > 0 && C > 0 && ldx >= C, "colsum: bad arguments");
   const int64_t nparts = ccn_stats_rows(rows);
   double* partial = acc + 2 * C;
-  hipLaunchKernelGGL(col_partial_kernel<0>, dim3((unsigned)nparts), dim3(256), 0, s, X, ldx, (const float*)nullptr,
-                     (int64_t)0, rows, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, 0, 0.f, partial);
+  if (col_vec_ok(X, ldx, nullptr, 0, C))
+    hipLaunchKernelGGL(col_partial_vec_kernel<0>, dim3((unsigned)nparts), dim3(256), 0, s, X, ldx, (const float*)nullptr,
+                       (int64_t)0, rows, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, 0, 0.f, partial);
+  else
+    hipLaunchKernelGGL(col_partial_kernel<0>, dim3((unsigned)nparts), dim3(256), 0, s, X, ldx, (const float*)nullptr,
+                       (int64_t)0, rows, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, 0, 0.f, partial);
   launch_col_reduce(partial, nparts, 2 * C, acc, s);
   hipLaunchKernelGGL(colsum_out_kernel, dim3(ccn_blocks(C, 128)), dim3(128), 0, s, acc, C, out);
   CCN_LAUNCH_OK("colsum");
