@@ -21,7 +21,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from curvecloudnet_amd import _lib                                              # noqa: E402
+from curvecloudnet_amd import _lib, ops                                         # noqa: E402
 from curvecloudnet_amd.model import ModelBase, segmentation_loss               # noqa: E402
 from curvecloudnet_amd.parallel import FlatAdam, GradientAllReduce, init_process_group_from_env  # noqa: E402
 from curvecloudnet_amd.synth import make_batch, to_device                      # noqa: E402
@@ -29,15 +29,18 @@ from curvecloudnet_amd import configs as ref_configs                           #
 from tests.util import hotpath_config                                          # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
 def gemm_label(name, ints, nulls=()):
     """(kernel symbol as rocprofv3 prints it, flops) of a GEMM launch; mirrors the dispatch in csrc/ccn_gemm.hip."""
-    if name not in ("gemm_nt", "gemm_nn", "gemm_tn"):
+    if name not in ("gemm_nt", "gemm_nn", "gemm_tn", "gemm_nt_bf16"):
         return None, 0.0
     ld_a, ld_b, _, m, n, k = ints[:6]
     flops = 2.0 * m * n * k
+    if name == "gemm_nt_bf16":
+        return "gemm_bf16_kernel<128, %d, 4>" % (32 if n <= 32 else (64 if n <= 64 else 128)), flops
     aligned = ld_a % 4 == 0 and ld_b % 4 == 0
     if name == "gemm_nt":
         bn = 32 if n <= 32 else (64 if n <= 64 else 128)
@@ -164,6 +167,9 @@ def main():
     ap.add_argument("--curves", type=int, default=2048, help="curves per cloud (2048 ~ 50k points; 4900 ~ 120k)")
     ap.add_argument("--mixed-lengths", action="store_true", help="log-normal curve lengths (BASELINE configs[4])")
     ap.add_argument("--width", type=float, default=1.0)
+    ap.add_argument("--mlp-dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="bf16: forward / data-gradient products of the MLP and conv layers on the bf16 MFMA path "
+                         "(BASELINE configs 3 and 5); the headline metric is quoted in fp32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -178,6 +184,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    ops.set_mlp_dtype(args.mlp_dtype)
     make_cfg, in_dim, n_classes, net_desc = NETWORKS[args.config]
     cfg = make_cfg(width=args.width)
     kw = {k: v for k, v in cfg.items() if k != "type"}
@@ -227,7 +234,8 @@ def main():
     result = {
         "metric": "point-clouds/sec fwd+bwd @50k pts", "value": world * b * args.steps / elapsed, "unit": "clouds/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.mlp_dtype == "fp32" else "bf16 products, f32 accumulate / storage", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1] shape: %d clouds/GPU x %d curves (~%dk points each, %d points "
                                "on rank 0), fp32 curve-conv + HIP FRNN + MFMA MLP stack; network = %s at width x%g; "
                                "fwd + mean-NLL + bwd + Adam"
@@ -243,8 +251,9 @@ def main():
         if top["flops"] > 0:
             achieved = top["flops"] / (top["ms"] * 1e-3) / 1e12
             tr = pmc_traffic(name)
-            result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                                  "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+            peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_F32_MFMA_TFLOPS
+            result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak,
+                                  "unit": "TFLOP/s", "frac": achieved / peak,
                                   "traffic": tr["bytes_per_launch"] if tr else None, "traffic_source": tr,
                                   "flops_per_launch": top["flops"] / top["launches"],
                                   "kernel": name, "avg_launch_ms": top["ms"] / top["launches"],

@@ -384,6 +384,105 @@ __global__ __launch_bounds__(GEMM_TPB) void gemm_fast_kernel(const float* __rest
 }
 
 
+// ------------------------------------------------------------------ bf16 MFMA variant of Y = A W^T (BASELINE configs 3 / 5)
+// Operands stay fp32 in HBM; a K slice is staged through registers exactly like gemm_fast_kernel, rounded to bf16
+// (v_cvt_pk_bf16_f32, round-to-nearest-even) ONCE per element on its way into LDS, and multiplied with
+// v_mfma_f32_32x32x16_bf16 into fp32 accumulators (bias = initial accumulator value, BatchNorm statistics of the
+// fp32 result in the epilogue, as in the fp32 kernels).  LDS rows hold 32 bf16 + 8 of padding (80 bytes): a lane's
+// fragment for k-step s is ONE 16-byte read at chunk 2s+h (k = 16s + 8h .. +7, the instruction's own operand
+// layout -- no K permutation needed), conflict-free across 16 lanes at the 20-bank row stride.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+constexpr int BF_LD = BK + 8;  // bf16 elements per LDS row
+
+template <int ROWS>
+__device__ __forceinline__ void tile_store_bf16(__bf16* __restrict__ lds, const float4 (&regs)[Tile<ROWS, KC>::PER_THREAD]) {
+#pragma unroll
+  for (int it = 0; it < Tile<ROWS, KC>::PER_THREAD; ++it) {
+    const int slot = threadIdx.x + it * GEMM_TPB;
+    const int r = slot >> 3, kq = slot & 7;
+    bf16x4 v;
+    v[0] = (__bf16)regs[it].x;
+    v[1] = (__bf16)regs[it].y;
+    v[2] = (__bf16)regs[it].z;
+    v[3] = (__bf16)regs[it].w;
+    *reinterpret_cast<bf16x4*>(lds + r * BF_LD + kq * 4) = v;
+  }
+}
+
+template <int BM, int BN, int WM>
+__global__ __launch_bounds__(GEMM_TPB) void gemm_bf16_kernel(const float* __restrict__ A, int64_t lda,
+                                                             const float* __restrict__ B, int64_t ldb,
+                                                             const float* __restrict__ bias, float* __restrict__ C,
+                                                             int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                                             double* __restrict__ colstats) {
+  constexpr int WN = 4 / WM;
+  constexpr int WCOLS = BN / WN;
+  constexpr int NT = WCOLS / 32;
+  constexpr int AE = BM * BF_LD, BE = BN * BF_LD;  // bf16 elements per tile
+  static_assert(BM == 32 * WM && NT >= 1, "tile shape");
+  static_assert((AE + BE) * 2 * 2 >= WM * BN * 2 * 8, "epilogue scratch fits");
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (AE + BE)];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int i = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
+
+  f32x16 acc[NT];
+  acc_init<NT>(acc, bias, n0 + wn * WCOLS, N, i);
+
+  FastLoader<BM, KC> la;
+  FastLoader<BN, KC> lb;
+  la.init(A, lda, m0, M);
+  lb.init(B, ldb, n0, N);
+  float4 ra[Tile<BM, KC>::PER_THREAD], rb[Tile<BN, KC>::PER_THREAD];
+  if (BK <= K) {
+    la.load_full(0, ra);
+    lb.load_full(0, rb);
+  } else {
+    la.load_tail(0, K, ra);
+    lb.load_tail(0, K, rb);
+  }
+  tile_store_bf16<BM>(lds, ra);
+  tile_store_bf16<BN>(lds + AE, rb);
+  __syncthreads();
+  int buf = 0;
+  for (int64_t k0 = 0; k0 < K; k0 += BK) {
+    const __bf16* As = lds + buf * (AE + BE);
+    const __bf16* Bs = As + AE;
+    const int64_t kn = k0 + BK;
+    if (kn < K) {  // next slice in flight while this one is multiplied
+      if (kn + BK <= K) {
+        la.load_full(kn, ra);
+        lb.load_full(kn, rb);
+      } else {
+        la.load_tail(kn, K, ra);
+        lb.load_tail(kn, K, rb);
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(As + (wm * 32 + i) * BF_LD + (2 * st + h) * 8);
+      bf16x8 b8[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        b8[t] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WCOLS + t * 32 + i) * BF_LD + (2 * st + h) * 8);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8[t], acc[t], 0, 0, 0);
+    }
+    if (kn < K) {
+      __bf16* An = lds + (buf ^ 1) * (AE + BE);
+      tile_store_bf16<BM>(An, ra);
+      tile_store_bf16<BN>(An + AE, rb);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  gemm_epilogue<BM, BN, WM, EPI_STORE, NT>(acc, reinterpret_cast<float*>(lds), bias, C, ldc, M, N, m0, n0, wm, wn, i, h,
+                                           colstats);
+}
+
 // ------------------------------------------------------------------ LDS-DMA pipeline (Y = A W^T, both operands KC)
 // 256 x BN tile, 8 waves (one 32-row band each), BK = 32.  Tiles reach LDS with global_load_lds_dwordx4
 // (no VGPR staging): one wave instruction copies 8 rows x 128 B into a linear 1 KiB span, so the tile rows are
@@ -1128,6 +1227,30 @@ int ccn_gemm_use_dma(int on) {
 
 int ccn_gemm_force_generic(int on) {
   g_force_generic = on != 0;
+  return CCN_OK;
+}
+
+int ccn_gemm_nt_bf16(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                     int64_t M, int64_t N, int64_t K, double* colstats, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(A && W && Y, "gemm_nt_bf16: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, "gemm_nt_bf16: bad sizes M=%lld N=%lld K=%lld",
+              (long long)M, (long long)N, (long long)K);
+  CCN_REQUIRE(aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && lda >= 4 && ldw >= 4,
+              "gemm_nt_bf16: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+  if (M == 0) return CCN_OK;
+  const int64_t gm = (M + 127) / 128;
+  CCN_REQUIRE(gm <= 2147483647LL, "gemm_nt_bf16: grid too large");
+  if (N <= 32)
+    hipLaunchKernelGGL((gemm_bf16_kernel<128, 32, 4>), dim3((unsigned)gm, (unsigned)((N + 31) / 32)), dim3(GEMM_TPB), 0, s,
+                       A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats);
+  else if (N <= 64)
+    hipLaunchKernelGGL((gemm_bf16_kernel<128, 64, 4>), dim3((unsigned)gm, (unsigned)((N + 63) / 64)), dim3(GEMM_TPB), 0, s,
+                       A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats);
+  else
+    hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 4>), dim3((unsigned)gm, (unsigned)((N + 127) / 128)), dim3(GEMM_TPB), 0,
+                       s, A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats);
+  CCN_LAUNCH_OK("gemm_nt_bf16");
   return CCN_OK;
 }
 

@@ -4,6 +4,7 @@ PyTorch supplies device memory, streams and autograd bookkeeping only; every ari
 the hot path is a ``ccn_*`` kernel launch.  Reference call sites are cited per operator.
 """
 import ctypes
+import os
 
 import torch
 
@@ -254,6 +255,34 @@ def _aligned_weight(weight):
     return wp
 
 
+_MLP_DTYPE = os.environ.get("CCN_MLP_DTYPE", "fp32")
+
+
+def set_mlp_dtype(name):
+    """"fp32" (default): exact fp32 MFMA products.  "bf16": the forward and data-gradient products of every
+    Linear / conv layer (``LinearBNAct``) round their operands to bf16 inside the GEMM and accumulate in fp32
+    (``ccn_gemm_nt_bf16``, BASELINE configs 3 and 5); weights, activations, BatchNorm statistics and the weight
+    gradients stay fp32.  Also settable with the environment variable CCN_MLP_DTYPE."""
+    global _MLP_DTYPE
+    if name not in ("fp32", "bf16"):
+        raise ValueError("mlp dtype must be 'fp32' or 'bf16'")
+    _MLP_DTYPE = name
+
+
+def mlp_dtype():
+    return _MLP_DTYPE
+
+
+def _aligned_rows(t):
+    """A copy with a 16-byte aligned, multiple-of-4 leading dimension when ``t`` does not have one already (the bf16
+    kernel and the LDS-DMA kernels only take such operands; everything the step modules produce already qualifies)."""
+    if _ld(t) % 4 == 0 and t.data_ptr() % 16 == 0:
+        return t
+    out = _rows(t.size(0), t.size(1), t.device)
+    out.copy_(t)
+    return out
+
+
 class LinearBNAct(torch.autograd.Function):
     """y = act(BN(x W^T + b)) with batch statistics taken in the GEMM epilogue.
 
@@ -274,8 +303,11 @@ class LinearBNAct(torch.autograd.Function):
         y = _rows(m, n, dev)
         has_bn = gamma is not None
         ctx.has_bn, ctx.act, ctx.training, ctx.has_bias = has_bn, ACT[act], bool(training), bias is not None
+        gemm_nt = ctx.gemm_nt = "gemm_nt_bf16" if _MLP_DTYPE == "bf16" else "gemm_nt"
+        if gemm_nt == "gemm_nt_bf16":
+            x = _aligned_rows(x)
         if not has_bn:
-            call("gemm_nt", ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, None)
+            call(gemm_nt, ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, None)
             ctx.save_for_backward(x, w)
             return y
         par = torch.empty((4, n), dtype=torch.float32, device=dev)      # scale, shift, mean, rstd
@@ -283,11 +315,11 @@ class LinearBNAct(torch.autograd.Function):
             if m < 2:
                 raise ValueError("Expected more than 1 value per channel when training")
             stats = _stats_buffer(m, n, dev)
-            call("gemm_nt", ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats))
+            call(gemm_nt, ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats))
             call("bn_finalize", ptr(stats), m, n, ptr(gamma), ptr(beta), float(eps), float(momentum),
                  ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
         else:
-            call("gemm_nt", ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, None)
+            call(gemm_nt, ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, None)
             call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), n,
                  ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
         z = _rows(m, n, dev)
@@ -323,7 +355,9 @@ class LinearBNAct(torch.autograd.Function):
             # index, which is the fastest tile layout (the weight transpose is a few KB..MB)
             wt = _rows(k, n, dev, zero=(n % 4 != 0))
             wt.copy_(w[:, :k].t())
-            call("gemm_nt", ptr(dy), _ld(dy), ptr(wt), _ld(wt), None, ptr(dx), _ld(dx), m, k, n, None)
+            if ctx.gemm_nt == "gemm_nt_bf16":
+                dy = _aligned_rows(dy)
+            call(ctx.gemm_nt, ptr(dy), _ld(dy), ptr(wt), _ld(wt), None, ptr(dx), _ld(dx), m, k, n, None)
         dw = _rows(n, k, dev, zero=True)
         call("gemm_tn", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
         db = None

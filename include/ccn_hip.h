@@ -139,7 +139,12 @@ int64_t ccn_stats_rows(int64_t rows); /* partial-statistics rows a reduction ove
 int ccn_gemm_use_dma(int on);       /* A/B hook: 0 = register-staged kernels only, 2 = LDS-DMA without the persistent tile loop, 1 = default */
 int ccn_gemm_force_generic(int on); /* test hook: route every GEMM through the unaligned-operand kernel */
 int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
-                int64_t M, int64_t N, int64_t K, double* colstats, void* stream); /* Y = A W^T + b */
+                int64_t M, int64_t N, int64_t K, double* colstats, void* stream);
+/* bf16 MFMA form of ccn_gemm_nt (BASELINE configs 3 / 5, "bf16 MLP MFMA path"): same arguments and outputs; A and W are
+ * read as fp32 and rounded to bf16 (round to nearest even) inside the kernel, products accumulate in fp32
+ * (v_mfma_f32_32x32x16_bf16), bias / Y / colstats stay fp32.  Requires 16-byte aligned A, W and lda, ldw % 4 == 0. */
+int ccn_gemm_nt_bf16(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                     int64_t M, int64_t N, int64_t K, double* colstats, void* stream); /* Y = A W^T + b */
 int ccn_gemm_nn(const float* dY, int64_t lddy, const float* W, int64_t ldw, float* dX, int64_t lddx, int64_t M,
                 int64_t N, int64_t K, void* stream);                              /* dX = dY W      */
 int ccn_gemm_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,

@@ -94,6 +94,58 @@ def feature_diffs(x, point2curveidx, batch):
 # --------------------------------------------------------------------------------------
 
 
+# --------------------------------------------------------------------------------------
+# bf16 MLP mode (BASELINE configs 3 / 5): emulation of "operands rounded to bf16, fp32 accumulation" for the
+# forward and data-gradient products; weight gradients use the unrounded fp32 operands.
+# --------------------------------------------------------------------------------------
+MLP_DTYPE = "fp32"
+
+
+def set_mlp_dtype(name):
+    global MLP_DTYPE
+    assert name in ("fp32", "bf16")
+    MLP_DTYPE = name
+
+
+def _bf16(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _LinearBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        y = _bf16(x) @ _bf16(w).t()
+        return y if b is None else y + b
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        return _bf16(g) @ _bf16(w), g.t() @ x, (g.sum(0) if ctx.has_bias else None)
+
+
+class _Conv1dBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, pad):
+        ctx.save_for_backward(x, w)
+        ctx.pad, ctx.has_bias = pad, b is not None
+        return F.conv1d(_bf16(x), _bf16(w), b, stride=1, padding=pad)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        dx = torch.nn.grad.conv1d_input(x.shape, _bf16(w), _bf16(g), stride=1, padding=ctx.pad)
+        dw = torch.nn.grad.conv1d_weight(x, w.shape, g, stride=1, padding=ctx.pad)
+        return dx, dw, (g.sum(dim=(0, 2)) if ctx.has_bias else None), None
+
+
+def linear(x, lin):
+    if MLP_DTYPE == "bf16":
+        return _LinearBF16.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
 class SymmetricConv1d(nn.Module):
     """Conv weights store the centre tap and one side; the other side mirrors it
     (ref fast_conv1d.py:148-187).  Parameter names/shapes match the reference's ``_ConvNd``."""
@@ -117,7 +169,10 @@ class SymmetricConv1d(nn.Module):
 
     def forward(self, seq):                           # seq: (L, C_in) one zero-padded sequence
         w = self.full_weight()
-        y = F.conv1d(seq.t().unsqueeze(0), w, self.bias, stride=1, padding=w.size(2) // 2)
+        if MLP_DTYPE == "bf16":
+            y = _Conv1dBF16.apply(seq.t().unsqueeze(0), w, self.bias, w.size(2) // 2)
+        else:
+            y = F.conv1d(seq.t().unsqueeze(0), w, self.bias, stride=1, padding=w.size(2) // 2)
         return y.squeeze(0).t()
 
 
@@ -480,9 +535,9 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for lin, norm in zip(self.lins, self.norms):
-            x = F.dropout(self.act(norm(lin(x))), p=self.dropout, training=self.training)
+            x = F.dropout(self.act(norm(linear(x, lin))), p=self.dropout, training=self.training)
         if self.plain_last:
-            x = F.dropout(self.lins[-1](x), p=self.dropout, training=self.training)
+            x = F.dropout(linear(x, self.lins[-1]), p=self.dropout, training=self.training)
         return x
 
 
