@@ -98,11 +98,8 @@ __global__ __launch_bounds__(QUERY_TPB) void grid_query_kernel(
   const int tid = threadIdx.x;
   const int64_t b = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + tid;
-  if (i >= P1) return;
-  int64_t* out_i = idx_out + (b * P1 + i) * K;
-  float* out_d = dist_out ? dist_out + (b * P1 + i) * K : nullptr;
   int have = 0;
-  if (i < lengths1[b]) {
+  if (i < P1 && i < lengths1[b]) {
     const float* q = q_pts + (b * P1 + i) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     const float r = radius[b];
@@ -110,44 +107,76 @@ __global__ __launch_bounds__(QUERY_TPB) void grid_query_kernel(
     const int3 cq = cell_of(qx, qy, qz, inv_cell_of(r));
     const uint32_t mask = (uint32_t)(T - 1);
     const int32_t* starts = cell_start + b * T;
-    for (int dz = -1; dz <= 1; ++dz)
-      for (int dy = -1; dy <= 1; ++dy)
-        for (int dx = -1; dx <= 1; ++dx) {
-          const int cx = cq.x + dx, cy = cq.y + dy, cz = cq.z + dz;
-          const uint32_t h = bucket_of(cx, cy, cz, mask);
-          const int32_t lo = starts[h], hi = starts[h + 1];
-          for (int32_t s = lo; s < hi; ++s) {
-            const int4 c = sorted_cell[s];
-            if (c.x != cx || c.y != cy || c.z != cz) continue;
-            const float4 p = sorted_pts[s];
-            const float d2 = ccn_sqdist3(p.x - qx, p.y - qy, p.z - qz);
-            if (!(d2 < r2)) continue;
-            const int j = __float_as_int(p.w);
-            if (have == K) {
-              const float wd = best_d[(K - 1) * QUERY_TPB + tid];
-              if (!(d2 < wd || (d2 == wd && j < best_i[(K - 1) * QUERY_TPB + tid]))) continue;
-            }
-            int slot = have < K ? have : K - 1;
-            while (slot > 0) {
-              const float pd = best_d[(slot - 1) * QUERY_TPB + tid];
-              const int pi = best_i[(slot - 1) * QUERY_TPB + tid];
-              if (!(pd > d2 || (pd == d2 && pi > j))) break;
-              best_d[slot * QUERY_TPB + tid] = pd;
-              best_i[slot * QUERY_TPB + tid] = pi;
-              --slot;
-            }
-            best_d[slot * QUERY_TPB + tid] = d2;
-            best_i[slot * QUERY_TPB + tid] = j;
-            if (have < K) ++have;
+    // Phase 1: the 27 bucket ranges, all loads in flight together.  Every point within r of the query lies in one of
+    // the 27 cells, hence in one of these buckets; a bucket shared by two of the cells (hash collision) is visited
+    // once, and points of colliding far-away cells fail the distance test -- so the exact-cell table need not be
+    // read and the accepted set is exactly {d2 < r*r}.
+    int32_t lo[27], hi[27];
+    uint32_t hs[27];
+#pragma unroll
+    for (int c = 0; c < 27; ++c) {
+      const int dx = c % 3 - 1, dy = (c / 3) % 3 - 1, dz = c / 9 - 1;
+      hs[c] = bucket_of(cq.x + dx, cq.y + dy, cq.z + dz, mask);
+      lo[c] = starts[hs[c]];
+      hi[c] = starts[hs[c] + 1];
+    }
+#pragma unroll
+    for (int c = 1; c < 27; ++c) {
+      bool dup = false;
+#pragma unroll
+      for (int e = 0; e < c; ++e) dup |= hs[e] == hs[c];
+      if (dup) hi[c] = lo[c];
+    }
+    // Phase 2: candidates, two point records in flight
+#pragma unroll 1
+    for (int c = 0; c < 27; ++c) {
+      for (int32_t s = lo[c]; s < hi[c]; s += 2) {
+        const float4 p0 = sorted_pts[s];
+        const bool two = s + 1 < hi[c];
+        const float4 p1 = two ? sorted_pts[s + 1] : p0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (u == 1 && !two) break;
+          const float4 p = u == 0 ? p0 : p1;
+          const float d2 = ccn_sqdist3(p.x - qx, p.y - qy, p.z - qz);
+          if (!(d2 < r2)) continue;
+          const int j = __float_as_int(p.w);
+          if (have == K) {
+            const float wd = best_d[(K - 1) * QUERY_TPB + tid];
+            if (!(d2 < wd || (d2 == wd && j < best_i[(K - 1) * QUERY_TPB + tid]))) continue;
           }
+          int slot = have < K ? have : K - 1;
+          while (slot > 0) {
+            const float pd = best_d[(slot - 1) * QUERY_TPB + tid];
+            const int pi = best_i[(slot - 1) * QUERY_TPB + tid];
+            if (!(pd > d2 || (pd == d2 && pi > j))) break;
+            best_d[slot * QUERY_TPB + tid] = pd;
+            best_i[slot * QUERY_TPB + tid] = pi;
+            --slot;
+          }
+          best_d[slot * QUERY_TPB + tid] = d2;
+          best_i[slot * QUERY_TPB + tid] = j;
+          if (have < K) ++have;
         }
+      }
+    }
   }
-  for (int s = 0; s < K; ++s) {
-    const bool ok = s < have;
-    out_i[s] = ok ? (int64_t)best_i[s * QUERY_TPB + tid] : -1;
-    if (out_d) out_d[s] = ok ? best_d[s * QUERY_TPB + tid] : -1.0f;
+  // The block's results form one contiguous (queries x K) span of the outputs: written cooperatively so that
+  // consecutive lanes store consecutive elements (a row per thread would scatter 8-byte stores K*8 bytes apart).
+  __shared__ int have_s[QUERY_TPB];
+  have_s[tid] = have;
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x;
+  const int64_t nq = P1 - i0 < QUERY_TPB ? P1 - i0 : QUERY_TPB;
+  int64_t* out_i = idx_out + (b * P1 + i0) * K;
+  float* out_d = dist_out ? dist_out + (b * P1 + i0) * K : nullptr;
+  for (int64_t e = tid; e < nq * K; e += QUERY_TPB) {
+    const int qq = (int)(e / K), sl = (int)(e - (int64_t)qq * K);
+    const bool ok = sl < have_s[qq];
+    out_i[e] = ok ? (int64_t)best_i[sl * QUERY_TPB + qq] : -1;
+    if (out_d) out_d[e] = ok ? best_d[sl * QUERY_TPB + qq] : -1.0f;
   }
-  if (count_out) count_out[b * P1 + i] = have;
+  if (count_out && i < P1) count_out[b * P1 + i] = have;
 }
 
 // ------------------------------------------------------------------ dense idx -> CSR edge list

@@ -82,6 +82,157 @@ __global__ __launch_bounds__(KNN_TPB) void knn_points_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------- grid-accelerated exact kNN (large clouds)
+// The exhaustive kernel above costs P1*P2 distance evaluations per cloud (1e10 per call at the benchmark size).
+// For large clouds the K nearest neighbours are searched with the FRNN hash grid at a per-cloud radius derived from
+// the point density; a query whose K-th neighbour was not found inside that radius is recomputed exhaustively, so
+// the result is the exact kNN for every query (same distance arithmetic and (d2, index) order as above).
+__device__ __forceinline__ float knn_weight(const float* __restrict__ src, int64_t j, float qx, float qy, float qz) {
+  // the reference recomputes the weight as 1 / clamp(sum((x - y)^2), 1e-16)  (point_ops.py:334-336)
+  const float dx = src[3 * j] - qx, dy = src[3 * j + 1] - qy, dz = src[3 * j + 2] - qz;
+  const float d2 = (dx * dx + dy * dy) + dz * dz;
+  return __frcp_rn(d2 < 1e-16f ? 1e-16f : d2);
+}
+
+// r[b] = scale * cbrt(bounding-box volume / points) of the source cloud (extents floored at 1 % of the largest)
+__global__ __launch_bounds__(256) void knn_cloud_radius_kernel(const float* __restrict__ src,
+                                                               const int64_t* __restrict__ s_ptr, float scale,
+                                                               float* __restrict__ radius) {
+  __shared__ float red[6][256];
+  const int64_t b = blockIdx.x, s0 = s_ptr[b], ns = s_ptr[b + 1] - s0;
+  float lo[3] = {__builtin_inff(), __builtin_inff(), __builtin_inff()}, hi[3] = {-lo[0], -lo[0], -lo[0]};
+  for (int64_t j = threadIdx.x; j < ns; j += 256)
+    for (int d = 0; d < 3; ++d) {
+      const float v = src[3 * (s0 + j) + d];
+      lo[d] = fminf(lo[d], v);
+      hi[d] = fmaxf(hi[d], v);
+    }
+  for (int d = 0; d < 3; ++d) {
+    red[d][threadIdx.x] = lo[d];
+    red[3 + d][threadIdx.x] = hi[d];
+  }
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w)
+      for (int d = 0; d < 3; ++d) {
+        red[d][threadIdx.x] = fminf(red[d][threadIdx.x], red[d][threadIdx.x + w]);
+        red[3 + d][threadIdx.x] = fmaxf(red[3 + d][threadIdx.x], red[3 + d][threadIdx.x + w]);
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float e[3], big = 0.f;
+    for (int d = 0; d < 3; ++d) {
+      e[d] = ns > 0 ? red[3 + d][0] - red[d][0] : 0.f;
+      big = fmaxf(big, e[d]);
+    }
+    float vol = 1.f;
+    for (int d = 0; d < 3; ++d) vol *= fmaxf(e[d], 0.01f * big);
+    const float r = scale * cbrtf(vol / (float)(ns > 0 ? ns : 1));
+    radius[b] = (r > 0.f && r < 1e30f) ? r : 1.0f;
+  }
+}
+
+// FRNN result (B, P1, K) of cloud-local indices -> packed neighbour table + weights; flag = 1 where the search radius
+// did not hold min(K, source points) neighbours (those rows are rewritten by the exhaustive kernel below).
+__global__ void knn_from_grid_kernel(const int64_t* __restrict__ idx, const float* __restrict__ q,
+                                     const int64_t* __restrict__ q_ptr, const float* __restrict__ src,
+                                     const int64_t* __restrict__ s_ptr, int64_t P1, int K, int64_t* __restrict__ nbr,
+                                     float* __restrict__ weight, int32_t* __restrict__ flag) {
+  const int64_t b = blockIdx.y, iq = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t q0 = q_ptr[b], nq = q_ptr[b + 1] - q0;
+  if (iq >= nq) return;
+  const int64_t s0 = s_ptr[b], ns = s_ptr[b + 1] - s0;
+  const float qx = q[3 * (q0 + iq)], qy = q[3 * (q0 + iq) + 1], qz = q[3 * (q0 + iq) + 2];
+  const int64_t* row = idx + (b * P1 + iq) * K;
+  int found = 0;
+  for (int t = 0; t < K; ++t) {
+    const int64_t j = row[t];
+    if (j >= 0) ++found;
+    nbr[(q0 + iq) * K + t] = j >= 0 ? s0 + j : -1;
+    weight[(q0 + iq) * K + t] = j >= 0 ? knn_weight(src, s0 + j, qx, qy, qz) : 0.f;
+  }
+  flag[q0 + iq] = found < (ns < K ? (int)ns : K) ? 1 : 0;
+}
+
+__global__ void scatter_flagged_kernel(const int32_t* __restrict__ flag, const int32_t* __restrict__ offsets, int64_t n,
+                                       int64_t* __restrict__ list) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag[i]) list[offsets[i]] = i;
+}
+
+// exhaustive search for the listed queries only: one WAVE per query (the list is short, so a thread per query would
+// leave the chip idle and pay the full latency of a 25k-point scan per thread).  Lane l visits sources l, l+64, ...
+// in index order and keeps its own ascending top-K; the K results are then drawn by K wave-wide minima over the
+// lanes' list heads, ordered by (d2, index) -- the same order the sequential scan produces.
+__global__ __launch_bounds__(KNN_TPB) void knn_points_list_kernel(const float* __restrict__ q,
+                                                                  const int64_t* __restrict__ q_ptr,
+                                                                  const float* __restrict__ src,
+                                                                  const int64_t* __restrict__ s_ptr, int B, int K,
+                                                                  const int64_t* __restrict__ list,
+                                                                  const int64_t* __restrict__ count,
+                                                                  int64_t* __restrict__ nbr, float* __restrict__ weight) {
+  const int lane = threadIdx.x & 63;
+  const int64_t t = (int64_t)blockIdx.x * (KNN_TPB / 64) + (threadIdx.x >> 6);
+  if (t >= count[0]) return;
+  const int64_t iq = list[t];
+  int b = 0;
+  while (b + 1 < B && q_ptr[b + 1] <= iq) ++b;
+  const int64_t s0 = s_ptr[b], ns = s_ptr[b + 1] - s0;
+  const float qx = q[3 * iq], qy = q[3 * iq + 1], qz = q[3 * iq + 2];
+  float bd[KNN_MAXK];
+  int64_t bi[KNN_MAXK];
+  float worst = __builtin_inff();
+#pragma unroll
+  for (int u = 0; u < KNN_MAXK; ++u) {
+    bd[u] = __builtin_inff();
+    bi[u] = -1;
+  }
+  for (int64_t j = lane; j < ns; j += 64) {
+    float cd = ccn_sqdist3(src[3 * (s0 + j)] - qx, src[3 * (s0 + j) + 1] - qy, src[3 * (s0 + j) + 2] - qz);
+    if (!(cd < worst)) continue;
+    int64_t ci = s0 + j;
+#pragma unroll
+    for (int u = 0; u < KNN_MAXK; ++u) {
+      if (u < K) {
+        const bool sw = cd < bd[u];
+        const float td = bd[u];
+        const int64_t ti = bi[u];
+        bd[u] = sw ? cd : td;
+        bi[u] = sw ? ci : ti;
+        cd = sw ? td : cd;
+        ci = sw ? ti : ci;
+        if (u == K - 1) worst = bd[u];
+      }
+    }
+  }
+  for (int r = 0; r < K; ++r) {
+    // wave-wide minimum of the list heads by (d2, index); exhausted lists offer (inf, -1) and lose to any real entry
+    float md = bd[0];
+    int64_t mi = bi[0];
+    for (int off = 32; off > 0; off >>= 1) {
+      const float od = __shfl_xor(md, off, 64);
+      const int64_t oi = __shfl_xor(mi, off, 64);
+      const bool take = oi >= 0 && (mi < 0 || od < md || (od == md && oi < mi));
+      md = take ? od : md;
+      mi = take ? oi : mi;
+    }
+    if (mi >= 0 && bi[0] == mi) {  // the winning lane pops its head
+#pragma unroll
+      for (int u = 0; u + 1 < KNN_MAXK; ++u) {
+        bd[u] = bd[u + 1];
+        bi[u] = bi[u + 1];
+      }
+      bd[KNN_MAXK - 1] = __builtin_inff();
+      bi[KNN_MAXK - 1] = -1;
+    }
+    if (lane == 0) {
+      nbr[iq * K + r] = mi;
+      weight[iq * K + r] = mi >= 0 ? knn_weight(src, mi, qx, qy, qz) : 0.f;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- ball query (pytorch3d.ops.ball_query)
 // first K points (index order) with d2 < r*r, -1 padded; one query per thread, sources through LDS tiles
 __global__ __launch_bounds__(KNN_TPB) void ball_query_kernel(const float* __restrict__ q,
@@ -259,6 +410,88 @@ __global__ __launch_bounds__(FPS_TPB) void fps_kernel(const float* __restrict__ 
   }
 }
 
+// Register-resident form for clouds of at most PPT*1024 points: each thread owns PPT points (coordinates and running
+// minimum distance in registers), so an iteration touches no global memory; the arg-max reduction carries the
+// winner's coordinates with it (wave shuffles, then the 16 per-wave entries through a double-buffered LDS table),
+// which leaves ONE barrier per selected sample.  Same arithmetic and tie rule as fps_kernel.
+struct FpsBest {
+  float v;
+  int i;
+  float x, y, z;
+};
+__device__ __forceinline__ void fps_take(FpsBest& a, const FpsBest& o) {
+  if (o.v > a.v || (o.v == a.v && o.i < a.i)) a = o;
+}
+__device__ __forceinline__ FpsBest fps_shfl(const FpsBest& a, int off) {
+  FpsBest o;
+  o.v = __shfl_xor(a.v, off, 64);
+  o.i = __shfl_xor(a.i, off, 64);
+  o.x = __shfl_xor(a.x, off, 64);
+  o.y = __shfl_xor(a.y, off, 64);
+  o.z = __shfl_xor(a.z, off, 64);
+  return o;
+}
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_TPB) void fps_reg_kernel(const float* __restrict__ pos,
+                                                          const int64_t* __restrict__ cloud_ptr,
+                                                          const int64_t* __restrict__ start,
+                                                          const int64_t* __restrict__ out_ptr,
+                                                          int64_t* __restrict__ out) {
+  __shared__ FpsBest red[2][FPS_TPB / 64];
+  const int64_t b = blockIdx.x;
+  const int64_t p0 = cloud_ptr[b];
+  const int n = (int)(cloud_ptr[b + 1] - p0);
+  const int64_t o0 = out_ptr[b];
+  const int keep = (int)(out_ptr[b + 1] - o0);
+  if (n <= 0 || keep <= 0) return;
+  const float* p = pos + 3 * p0;
+  float px[PPT], py[PPT], pz[PPT], md[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int i = threadIdx.x + k * FPS_TPB;
+    const bool in = i < n;
+    px[k] = in ? p[3 * i] : 0.f;
+    py[k] = in ? p[3 * i + 1] : 0.f;
+    pz[k] = in ? p[3 * i + 2] : 0.f;
+    md[k] = in ? __builtin_inff() : -2.f;  // never the maximum
+  }
+  int cur = (int)start[b];
+  cur = cur < 0 ? 0 : (cur >= n ? n - 1 : cur);
+  float cx = p[3 * cur], cy = p[3 * cur + 1], cz = p[3 * cur + 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int it = 0; it < keep; ++it) {
+    if (threadIdx.x == 0) out[o0 + it] = p0 + cur;
+    FpsBest best = {-1.f, 0x7fffffff, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      const float m = md[k] < 0.f ? md[k] : fminf(md[k], d2);
+      md[k] = m;
+      if (m > best.v) {  // k (hence the point index) increases: strict > keeps the smallest index
+        best.v = m;
+        best.i = threadIdx.x + k * FPS_TPB;
+        best.x = px[k];
+        best.y = py[k];
+        best.z = pz[k];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) fps_take(best, fps_shfl(best, off));
+    FpsBest* tab = red[it & 1];
+    if (lane == 0) tab[wave] = best;
+    __syncthreads();
+    FpsBest all = tab[lane & (FPS_TPB / 64 - 1)];
+#pragma unroll
+    for (int off = FPS_TPB / 128; off > 0; off >>= 1) fps_take(all, fps_shfl(all, off));
+    cur = all.i;
+    cx = all.x;
+    cy = all.y;
+    cz = all.z;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -271,6 +504,47 @@ int ccn_knn_points(const float* q, const int64_t* q_ptr, const float* src, const
   hipLaunchKernelGGL(knn_points_kernel, dim3(ccn_blocks(max_q, KNN_TPB), (unsigned)B), dim3(KNN_TPB), 0,
                      (hipStream_t)stream, q, q_ptr, src, s_ptr, (int)K, nbr, weight);
   CCN_LAUNCH_OK("knn_points");
+  return CCN_OK;
+}
+
+int ccn_knn_cloud_radius(const float* src, const int64_t* s_ptr, int64_t B, float scale, float* radius, void* stream) {
+  CCN_REQUIRE(src && s_ptr && radius && B > 0 && B < 65536 && scale > 0.f, "knn_cloud_radius: bad arguments");
+  hipLaunchKernelGGL(knn_cloud_radius_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, src, s_ptr, scale,
+                     radius);
+  CCN_LAUNCH_OK("knn_cloud_radius");
+  return CCN_OK;
+}
+
+int ccn_knn_from_grid(const int64_t* idx, const float* q, const int64_t* q_ptr, const float* src, const int64_t* s_ptr,
+                      int64_t B, int64_t P1, int64_t K, int64_t* nbr, float* weight, int32_t* flag, void* stream) {
+  CCN_REQUIRE(idx && q && q_ptr && src && s_ptr && nbr && weight && flag && B > 0 && B < 65536 && P1 > 0 && K >= 1 &&
+                  K <= KNN_MAXK,
+              "knn_from_grid: bad arguments");
+  hipLaunchKernelGGL(knn_from_grid_kernel, dim3(ccn_blocks(P1, 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, idx,
+                     q, q_ptr, src, s_ptr, P1, (int)K, nbr, weight, flag);
+  CCN_LAUNCH_OK("knn_from_grid");
+  return CCN_OK;
+}
+
+int ccn_scatter_flagged(const int32_t* flag, const int32_t* offsets, int64_t n, int64_t* list, void* stream) {
+  CCN_REQUIRE(flag && offsets && list && n >= 0, "scatter_flagged: bad arguments");
+  if (n == 0) return CCN_OK;
+  hipLaunchKernelGGL(scatter_flagged_kernel, dim3(ccn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, flag, offsets,
+                     n, list);
+  CCN_LAUNCH_OK("scatter_flagged");
+  return CCN_OK;
+}
+
+int ccn_knn_points_list(const float* q, const int64_t* q_ptr, const float* src, const int64_t* s_ptr, int64_t B,
+                        int64_t K, const int64_t* list, const int64_t* count, int64_t max_count, int64_t* nbr,
+                        float* weight, void* stream) {
+  CCN_REQUIRE(q && q_ptr && src && s_ptr && list && count && nbr && weight && B > 0 && B < 65536 && K >= 1 &&
+                  K <= KNN_MAXK && max_count >= 0,
+              "knn_points_list: bad arguments");
+  if (max_count == 0) return CCN_OK;
+  hipLaunchKernelGGL(knn_points_list_kernel, dim3(ccn_blocks(max_count, KNN_TPB / 64)), dim3(KNN_TPB), 0, (hipStream_t)stream,
+                     q, q_ptr, src, s_ptr, (int)B, (int)K, list, count, nbr, weight);
+  CCN_LAUNCH_OK("knn_points_list");
   return CCN_OK;
 }
 
@@ -323,10 +597,17 @@ int ccn_voxel_argmin(const float* score, const int64_t* voxel_of, int64_t n, int
 }
 
 int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, const int64_t* out_ptr, int64_t B,
-            float* mind, int64_t* out, void* stream) {
+            int64_t max_cloud, float* mind, int64_t* out, void* stream) {
   CCN_REQUIRE(pos && cloud_ptr && start && out_ptr && mind && out && B > 0, "fps: bad arguments");
-  hipLaunchKernelGGL(fps_kernel, dim3((unsigned)B), dim3(FPS_TPB), 0, (hipStream_t)stream, pos, cloud_ptr, start, out_ptr,
-                     mind, out);
+  hipStream_t s = (hipStream_t)stream;
+  if (max_cloud > 0 && max_cloud <= 4 * FPS_TPB)
+    hipLaunchKernelGGL(fps_reg_kernel<4>, dim3((unsigned)B), dim3(FPS_TPB), 0, s, pos, cloud_ptr, start, out_ptr, out);
+  else if (max_cloud > 0 && max_cloud <= 8 * FPS_TPB)
+    hipLaunchKernelGGL(fps_reg_kernel<8>, dim3((unsigned)B), dim3(FPS_TPB), 0, s, pos, cloud_ptr, start, out_ptr, out);
+  else if (max_cloud > 0 && max_cloud <= 16 * FPS_TPB)
+    hipLaunchKernelGGL(fps_reg_kernel<16>, dim3((unsigned)B), dim3(FPS_TPB), 0, s, pos, cloud_ptr, start, out_ptr, out);
+  else
+    hipLaunchKernelGGL(fps_kernel, dim3((unsigned)B), dim3(FPS_TPB), 0, s, pos, cloud_ptr, start, out_ptr, mind, out);
   CCN_LAUNCH_OK("fps");
   return CCN_OK;
 }

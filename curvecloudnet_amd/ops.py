@@ -736,14 +736,39 @@ class SGMax(torch.autograd.Function):
 # section 8(f) rows: exact kNN interpolation, voxel and farthest-point sampling
 # --------------------------------------------------------------------------------------
 
+KNN_GRID_MIN_POINTS = 4096     # source clouds below this size are searched exhaustively (ccn_knn_points)
+KNN_GRID_SCALE = 1.5           # search radius = scale * cbrt(bounding-box volume / points); <= 0 disables the grid path
+
+
 def knn_points_packed(pos_q, topo_q, pos_s, topo_s, k):
     """pytorch3d.ops.knn_points semantics on packed clouds: (nbr (Nq,k) packed source index, weight)."""
     pos_q, pos_s = _pos(pos_q), _pos(pos_s)
     nq, dev = pos_q.size(0), pos_q.device
     nbr = torch.empty((nq, k), dtype=torch.int64, device=dev)
     w = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    call("knn_points", ptr(pos_q), ptr(topo_q.cloud_ptr), ptr(pos_s), ptr(topo_s.cloud_ptr), topo_q.num_clouds,
-         topo_q.max_cloud, k, ptr(nbr), ptr(w))
+    b = topo_q.num_clouds
+    if topo_s.max_cloud < KNN_GRID_MIN_POINTS or KNN_GRID_SCALE <= 0:
+        call("knn_points", ptr(pos_q), ptr(topo_q.cloud_ptr), ptr(pos_s), ptr(topo_s.cloud_ptr), b, topo_q.max_cloud, k,
+             ptr(nbr), ptr(w))
+        return nbr, w
+    # large clouds: hash-grid search at a density-derived radius, exhaustive recomputation of the queries it missed
+    radius = torch.empty(b, dtype=torch.float32, device=dev)
+    call("knn_cloud_radius", ptr(pos_s), ptr(topo_s.cloud_ptr), b, float(KNN_GRID_SCALE), ptr(radius))
+    qp, _ = to_batch_padded(pos_q, topo_q)
+    sp, _ = to_batch_padded(pos_s, topo_s)
+    idx = fast_knn(qp, sp, topo_q.lengths, topo_s.lengths, k, radius)
+    flag = torch.empty(nq + 1, dtype=torch.int32, device=dev)
+    call("knn_from_grid", ptr(idx), ptr(pos_q), ptr(topo_q.cloud_ptr), ptr(pos_s), ptr(topo_s.cloud_ptr), b, idx.size(1),
+         k, ptr(nbr), ptr(w), ptr(flag))
+    offsets = torch.empty(nq + 1, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int64, device=dev)
+    ws = workspace(lib().ccn_exclusive_scan_workspace_bytes(nq), dev)
+    call("exclusive_scan_i32", ptr(flag), nq, ptr(offsets), ptr(total), ptr(ws), ws.numel())
+    missed = torch.empty(nq, dtype=torch.int64, device=dev)
+    call("scatter_flagged", ptr(flag), ptr(offsets), nq, ptr(missed))
+    call("knn_points_list", ptr(pos_q), ptr(topo_q.cloud_ptr), ptr(pos_s), ptr(topo_s.cloud_ptr), b, k, ptr(missed),
+         ptr(total), nq, ptr(nbr), ptr(w))
+    knn_points_packed.last_missed = total          # device scalar, for tests / diagnostics
     return nbr, w
 
 
@@ -789,7 +814,8 @@ def fps(pos, topo, ratio, start=None):
     mind = torch.empty(topo.n, dtype=torch.float32, device=dev)
     out = torch.empty(total, dtype=torch.int64, device=dev)
     start_d, out_ptr_d = start.to(dev), out_ptr.to(dev)     # named: must outlive the asynchronous launch
-    call("fps", ptr(pos), ptr(topo.cloud_ptr), ptr(start_d), ptr(out_ptr_d), topo.num_clouds, ptr(mind), ptr(out))
+    call("fps", ptr(pos), ptr(topo.cloud_ptr), ptr(start_d), ptr(out_ptr_d), topo.num_clouds, topo.max_cloud, ptr(mind),
+         ptr(out))
     return torch.sort(out)[0]
 
 

@@ -233,6 +233,18 @@ int ccn_seg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const i
  * fewer than K points), weight = 1 / clamp(|x - y|^2, 1e-16).  q_ptr / s_ptr: int64 (B+1) cloud offsets. */
 int ccn_knn_points(const float* q, const int64_t* q_ptr, const float* src, const int64_t* s_ptr, int64_t B,
                    int64_t max_q, int64_t K, int64_t* nbr, float* weight, void* stream);
+/* Grid-accelerated form of ccn_knn_points for large clouds (same results): ccn_knn_cloud_radius gives a per-cloud search
+ * radius from the source density, ccn_frnn_grid_build / ccn_frnn_query find the K nearest inside it, ccn_knn_from_grid
+ * converts the (B,P1,K) cloud-local result into the packed table + weights and flags the queries that found fewer than
+ * min(K, sources); those are listed (ccn_exclusive_scan_i32 over the flags + ccn_scatter_flagged) and recomputed
+ * exhaustively by ccn_knn_points_list (count: device int64 = number of listed queries, max_count = list capacity). */
+int ccn_knn_cloud_radius(const float* src, const int64_t* s_ptr, int64_t B, float scale, float* radius, void* stream);
+int ccn_knn_from_grid(const int64_t* idx, const float* q, const int64_t* q_ptr, const float* src, const int64_t* s_ptr,
+                      int64_t B, int64_t P1, int64_t K, int64_t* nbr, float* weight, int32_t* flag, void* stream);
+int ccn_scatter_flagged(const int32_t* flag, const int32_t* offsets, int64_t n, int64_t* list, void* stream);
+int ccn_knn_points_list(const float* q, const int64_t* q_ptr, const float* src, const int64_t* s_ptr, int64_t B,
+                        int64_t K, const int64_t* list, const int64_t* count, int64_t max_count, int64_t* nbr,
+                        float* weight, void* stream);
 /* ball_query: pytorch3d.ops.ball_query as called at point_ops.py:81 (SA with use_fast_knn: False): padded
  * (B,P,3) inputs, idx (B,P1,K) int64 = the first K points2 in index order with d2 < r*r, -1 padded. */
 int ccn_ball_query(const float* points1, const int64_t* lengths1, const float* points2, const int64_t* lengths2,
@@ -282,9 +294,10 @@ int ccn_voxel_keys(const float* pos, const int64_t* batch, const float* rnd, int
 int ccn_voxel_argmin(const float* score, const int64_t* voxel_of, int64_t n, int64_t num_voxels, int64_t* scratch,
                      int64_t* idx, void* stream);
 /* sample_farthest_points (point_ops.py:57-70): per cloud out_ptr[b+1]-out_ptr[b] samples starting at start[b];
- * out = packed point indices in selection order; mind: float scratch (n). */
+ * out = packed point indices in selection order; mind: float scratch (n); max_cloud: largest cloud size (clouds of up
+ * to 16384 points are processed register-resident, 0 = unknown). */
 int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, const int64_t* out_ptr, int64_t B,
-            float* mind, int64_t* out, void* stream);
+            int64_t max_cloud, float* mind, int64_t* out, void* stream);
 
 /* Dataset-side curve splitter (src/data/kitti_dataset.py:73-92 with beam == NULL,
  * src/data/nuscenes_dataset.py:101-118 on the beam-sorted sweep): curve_idx[0] = 0, a new curve starts at i where

@@ -310,3 +310,30 @@ def test_lovasz_loss_on_device():
         grad, = torch.autograd.grad(out, probas)
         assert abs(float(out) - float(g[key + ".loss"])) < 1e-5
         assert float((grad.cpu() - t(g[key + ".grad"])).abs().max()) < 1e-6
+
+
+def test_grid_knn_equals_exhaustive_knn():
+    """The hash-grid path of knn_points_packed (large clouds) returns exactly what the exhaustive kernel returns:
+    same neighbours in the same order, same weights -- including the queries the density radius misses."""
+    from curvecloudnet_amd import ops
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([0, 1])
+    pos, batch = d.pos.to(DEV), d.batch.to(DEV)
+    keep = torch.arange(0, pos.size(0), 2, device=DEV)
+    far = torch.tensor([[40.0, 40.0, 5.0], [-35.0, 20.0, -4.0]], device=DEV)      # isolated queries: forced misses
+    pos_q = torch.cat([pos[batch == 0], far[:1], pos[batch == 1], far[1:]])
+    batch_q = torch.cat([batch[batch == 0], batch[:1] * 0, batch[batch == 1], batch[:1] * 0 + 1])
+    topo_q = ops.CurveTopology(batch_q, torch.zeros_like(batch_q))
+    topo_s = ops.CurveTopology(batch[keep], torch.zeros_like(batch[keep]))
+    assert topo_s.max_cloud >= ops.KNN_GRID_MIN_POINTS
+    for k in (1, 3, 8):
+        nbr_g, w_g = ops.knn_points_packed(pos_q, topo_q, pos[keep], topo_s, k)
+        missed = int(ops.knn_points_packed.last_missed.item())
+        scale, ops.KNN_GRID_SCALE = ops.KNN_GRID_SCALE, 0.0
+        try:
+            nbr_e, w_e = ops.knn_points_packed(pos_q, topo_q, pos[keep], topo_s, k)
+        finally:
+            ops.KNN_GRID_SCALE = scale
+        assert torch.equal(nbr_g, nbr_e) and torch.equal(w_g, w_e)
+        print("k=%d: %d of %d queries recomputed exhaustively" % (k, missed, pos_q.size(0)))
+        assert 2 <= missed < pos_q.size(0) // 4
