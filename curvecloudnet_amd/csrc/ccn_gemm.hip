@@ -725,6 +725,11 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
   constexpr int NA = GL_BM / 8 / 8;
   constexpr int NB = BN >= 64 ? BN / 64 : 1;
   __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
+  // per-wave BatchNorm partial sums of the finished tile ([8 waves][BN][2] fp32, sums over the wave's 32 rows).  A
+  // table of its own instead of a recycled stage: no barrier is then needed before it is written, and it is read out
+  // (fp64 across the 4 waves of each 128-row half) after the FIRST slice barrier of the next tile, so the statistics
+  // add no workgroup barrier at all to the tile loop (two extra barriers per tile cost 13 % at K = 256).
+  __shared__ float stat_part[8 * BN * 2];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -779,6 +784,28 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
   issue_next();
   issue_next();
 
+  int64_t stat_tile = -1;  // tile whose statistics wait in stat_part
+  auto stats_readout = [&]() {
+    const int64_t pm = stat_tile / gn, pn0 = (stat_tile % gn) * BN;
+    for (int e = threadIdx.x; e < 2 * BN; e += GL_TPB) {
+      const int half = e / BN, c = e - half * BN;
+      const int64_t n = pn0 + c;
+      const int64_t prow = pm * 2 + half;
+      if (n < N && prow * 128 < M) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          s1 += (double)stat_part[((half * 4 + w) * BN + c) * 2];
+          s2 += (double)stat_part[((half * 4 + w) * BN + c) * 2 + 1];
+        }
+        double* dst = colstats + prow * 2 * N;
+        dst[n] = s1;
+        dst[N + n] = s2;
+      }
+    }
+    stat_tile = -1;
+  };
+
   int64_t g = 0;       // slices computed so far
   int64_t landed = 0;  // slices [0, landed) are known to be in LDS for this wave
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -798,6 +825,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
       }
       __builtin_amdgcn_s_barrier();
       issue_next();
+      if (u == 0 && stat_tile >= 0) stats_readout();
       const uint32_t stage_b = lds_base + (uint32_t)((g % 3) * STAGE * 4);
       f32x4 fa[2], fb[2][NT];
       lds_read_frag<NT>(stage_b + a_off, stage_b + b_off, 0, h, swz, fa[0], fb[0]);
@@ -823,53 +851,39 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
     // ---- tile epilogue.  Everything issued so far (<= 2 slices of the next tile) is waited for first.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     landed = gi;
-    double* stat_lds = reinterpret_cast<double*>(lds + ((g + 2) % 3) * STAGE);  // the stage just consumed
-    if (colstats != nullptr) __builtin_amdgcn_s_barrier();                     // every wave is done reading it
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int ncol = t * 32 + i;
       const int64_t n = n0 + ncol;
-      double s1 = 0.0, s2 = 0.0;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m < M && n < N) {
           const float v = acc[t][r];
           C[m * ldc + n] = v;
-          if (colstats != nullptr) {
-            s1 += (double)v;
-            s2 += (double)v * (double)v;
-          }
+          s1 += v;
+          s2 += v * v;
         }
       }
       if (colstats != nullptr) {
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
         if (h == 0) {
-          stat_lds[(wave * BN + ncol) * 2] = s1;
-          stat_lds[(wave * BN + ncol) * 2 + 1] = s2;
+          stat_part[(wave * BN + ncol) * 2] = s1;
+          stat_part[(wave * BN + ncol) * 2 + 1] = s2;
         }
       }
     }
     if (colstats != nullptr) {
-      __syncthreads();
-      for (int e = threadIdx.x; e < 2 * BN; e += GL_TPB) {
-        const int half = e / BN, c = e - half * BN;
-        const int64_t n = n0 + c;
-        const int64_t prow = (tile / gn) * 2 + half;
-        if (n < N && prow * 128 < M) {
-          double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            s1 += stat_lds[((half * 4 + w) * BN + c) * 2];
-            s2 += stat_lds[((half * 4 + w) * BN + c) * 2 + 1];
-          }
-          double* dst = colstats + prow * 2 * N;
-          dst[n] = s1;
-          dst[N + n] = s2;
-        }
-      }
+      stat_tile = tile;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // table written before this wave reaches the next barrier
     }
+  }
+  if (stat_tile >= 0) {  // statistics of the last tile
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stats_readout();
   }
 }
 
@@ -1262,8 +1276,11 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
               (long long)M, (long long)N, (long long)K);
   if (M == 0) return CCN_OK;
   int rc;
+  // short K, or fewer than two rounds of 256-row tiles over the 256 CUs: the register-staged kernels (128-row tiles,
+  // several workgroups per CU) win -- measured 95 / 101 vs 84 / 89 TFLOP/s at M = 10550 / 35151
   const bool dma_ok = aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && lda >= 4 && ldw >= 4 &&
-                      !g_force_generic && g_use_glds && M >= 1024 && K >= 128;  // short K: the multi-workgroup-per-CU kernels win
+                      !g_force_generic && g_use_glds && M >= 1024 && K >= 128 &&
+                      ((M + GL_BM - 1) / GL_BM) * ((N + 127) / 128) >= 512;
   if (dma_ok && bias == nullptr && K % BK == 0 && g_use_persistent &&
       ((M + GL_BM - 1) / GL_BM) * ((N + 127) / 128) >= 512) {
     if (N <= 32)

@@ -58,9 +58,11 @@ def test_linear_plain_fwd_bwd(M, K, N):
         _close(a, r, 5e-5, name)
 
 
-@pytest.mark.parametrize("M,K,N", [(3000, 67, 20), (4100, 256, 64), (2500, 134, 192), (1024, 32, 128)])
+@pytest.mark.parametrize("M,K,N", [(3000, 67, 20), (131500, 256, 64), (131200, 134, 192), (70000, 160, 300)])
 def test_gemm_dma_pipeline_matches_register_staged_kernel(M, K, N):
-    """Y = X W^T + b with BatchNorm partial statistics: LDS-DMA pipeline kernel vs the register-staged kernel."""
+    """Y = X W^T + b with BatchNorm partial statistics: LDS-DMA pipeline kernel (taken for K >= 128 and >= 512 tiles of
+    256 x 128; the bias keeps it off the persistent form; K = 134 / 160 exercise the K tail) vs the register-staged
+    kernel (first shape: both runs are the staged kernel)."""
     from curvecloudnet_amd import _lib
     from curvecloudnet_amd._lib import call, lib, ptr
     from curvecloudnet_amd.ops import _ld, _rows
@@ -103,7 +105,9 @@ def test_gemm_persistent_dma_kernel(M, K, N):
         finally:
             lib().ccn_gemm_use_dma(1)
     assert torch.equal(outs[0][0], outs[1][0])                  # same per-element fma order
-    assert torch.equal(outs[0][1], outs[1][1])
+    # the persistent kernel sums a wave's 32 rows in fp32 before going to fp64, the other one is fp64 throughout
+    ref_stats = outs[1][1]
+    assert float((outs[0][1] - ref_stats).abs().max()) <= 2e-6 * float(ref_stats.abs().max())
     _close(outs[0][0], x.cpu() @ w.cpu().t(), 5e-5, "vs torch")
 
 

@@ -46,3 +46,32 @@ buckets = [0, 0, 0, 0]
 for g, _, _ in gaps:
     buckets[0 if g < 5e3 else 1 if g < 5e4 else 2 if g < 5e5 else 3] += g
 print("idle by gap size: <5us %.1f ms, 5-50us %.1f ms, 50-500us %.1f ms, >500us %.1f ms" % tuple(b / 1e6 for b in buckets))
+
+# ---- per-queue view: how long is the busiest (feature) queue idle, and what runs on the other queues meanwhile
+by_q = defaultdict(list)
+for s_, e_, name, q in rows:
+    by_q[q].append((s_, e_, name))
+main_q = max(by_q, key=lambda q: sum(e - s for s, e, _ in by_q[q]))
+iv = sorted(by_q[main_q])
+gaps_main = []
+cur_e = iv[0][1]
+for s_, e_, name in iv[1:]:
+    if s_ > cur_e:
+        gaps_main.append((cur_e, s_, name))
+    cur_e = max(cur_e, e_)
+tot_gap = sum(b - a for a, b, _ in gaps_main)
+print("feature queue %s: idle %.1f ms of %.1f ms window (%d gaps)" % (main_q, tot_gap / 1e6, span / 1e6, len(gaps_main)))
+others = sorted((s_, e_, name) for q in by_q if q != main_q for s_, e_, name in by_q[q])
+blame = defaultdict(float)
+for a, b, nxt in gaps_main:
+    if b - a < 20e3:
+        continue
+    for s_, e_, name in others:
+        if e_ <= a:
+            continue
+        if s_ >= b:
+            break
+        blame[name[:60]] += min(e_, b) - max(s_, a)
+print("kernels on the other queues running during feature-queue gaps > 20 us:")
+for name, t_ in sorted(blame.items(), key=lambda kv: -kv[1])[:15]:
+    print("  %8.2f ms  %s" % (t_ / 1e6, name))
