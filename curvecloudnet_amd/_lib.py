@@ -17,6 +17,7 @@ HEADER_PATH = os.path.join(_ROOT, "include", "ccn_hip.h")
 
 _CTYPES = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
+    "double": ctypes.c_double,
 }
 
 

@@ -339,6 +339,281 @@ __global__ __launch_bounds__(TPB) void sg_edge_bwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------ A15 on COMPACT rows
+// In the dense layout every point owns K+1 rows, but a slot whose FRNN entry is -1 carries no neighbour: its first-layer
+// value is S[i] whatever the slot, so all empty slots of a point are the SAME row through the whole per-row MLP, and so
+// are all rows of the padding points (value `0`).  They matter only through the BatchNorm statistics (quirk Q4), which
+// are sums.  The compact layout keeps the real rows (self + found neighbours, grouped by point), ONE representative
+// row per point that has empty slots (weight = number of empty slots) and ONE row for all padding rows (weight = their
+// count); every reduction over rows takes the weights into account, so the result equals the dense computation
+// while the GEMMs run over 23-85 % of the rows (KITTI bench levels).
+//   rows [0, E): real, point p owns [grp_ptr[p], grp_ptr[p+1]) (self first, then the neighbours in FRNN order)
+//   rows [E, E+Ne): representatives, rep_row[p] = row of point p or -1;  row E+Ne: padding row;  row_w: weights of [E, R)
+__global__ void cg_count_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ cloud_ptr, int64_t Nmax,
+                                int K, int32_t* __restrict__ cnt, int32_t* __restrict__ has_rep) {
+  const int64_t b = blockIdx.y, i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
+  if (i >= len) return;
+  const int64_t* row = idx + (b * Nmax + i) * K;
+  int found = 0;
+  for (int s = 0; s < K; ++s) found += row[s] >= 0;
+  cnt[base + i] = 1 + found;
+  has_rep[base + i] = found < K;
+}
+
+__global__ void cg_fill_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ cloud_ptr, int64_t Nmax, int K,
+                               const int32_t* __restrict__ grp_ptr, const int32_t* __restrict__ rep_off, int64_t E,
+                               int32_t* __restrict__ row_src, int32_t* __restrict__ rep_row, float* __restrict__ row_w) {
+  const int64_t b = blockIdx.y, i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
+  if (i >= len) return;
+  const int64_t p = base + i;
+  const int64_t* row = idx + (b * Nmax + i) * K;
+  int32_t at = grp_ptr[p];
+  row_src[at++] = (int32_t)p;
+  int found = 0;
+  for (int s = 0; s < K; ++s) {
+    const int64_t j = row[s];
+    if (j >= 0) {
+      row_src[at++] = (int32_t)(base + j);
+      ++found;
+    }
+  }
+  if (found < K) {
+    const int32_t r = rep_off[p];
+    rep_row[p] = (int32_t)E + r;
+    row_w[r] = (float)(K - found);
+  } else {
+    rep_row[p] = -1;
+  }
+}
+
+// the sources of one point's real rows across the wave (lane s = row s of the group, groups have <= 64 rows)
+__device__ __forceinline__ int cg_src(int v, int s) { return __builtin_amdgcn_readlane(v, s); }
+
+// MODE 0: weighted column sums of y and y^2;  MODE 1: of g and g*xhat (g = dZ * act'(y*scale+shift)).
+// "Point" N is the padding pseudo-point: no real rows, representative row E+Ne with y = 0.
+template <int MODE>
+__global__ __launch_bounds__(TPB) void cg_edge_stats_kernel(
+    const float* __restrict__ ps, int64_t ldps, const int32_t* __restrict__ grp_ptr, const int32_t* __restrict__ row_src,
+    const int32_t* __restrict__ rep_row, const float* __restrict__ row_w, int64_t N, int64_t E, int64_t Ne, int Co,
+    const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope, int pts,
+    double* __restrict__ partial) {
+  __shared__ double red[4][64][2];
+  CCN_LANES;
+  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * pts;
+  const int c = blockIdx.y * 64 + cx, cc = c < Co ? c : Co - 1;
+  double s1 = 0.0, s2 = 0.0;
+  float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
+  if (MODE == 1) {
+    sc = scale[cc];
+    sh = shift[cc];
+    mu = mean[cc];
+    rs = rstd[cc];
+  }
+  for (int t = 0; t < pts; ++t) {
+    const int64_t p = first + t;
+    if (p > N) break;
+    const bool pad = p == N;
+    const int32_t g0 = pad ? 0 : grp_ptr[p], cnt = pad ? 0 : grp_ptr[p + 1] - g0;
+    const int32_t rrow = pad ? (int32_t)(E + Ne) : rep_row[p];
+    const int mysrc = cx < cnt ? row_src[g0 + cx] : 0;
+    const float si = pad ? 0.f : ps[p * ldps + Co + cc];
+    for (int s0 = 0; s0 < cnt; s0 += SG_UNROLL) {
+      float pv[SG_UNROLL], dz[SG_UNROLL];
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u) {
+        const int sidx = s0 + u;
+        const bool ok = sidx < cnt;
+        const int j = cg_src(mysrc, sidx & 63);
+        pv[u] = ok ? ps[(int64_t)j * ldps + cc] : 0.f;
+        if (MODE == 1) dz[u] = ok ? dZ[(int64_t)(g0 + sidx) * lddz + cc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u) {
+        if (s0 + u >= cnt) continue;
+        const float y = pv[u] + si;
+        if (MODE == 0) {
+          s1 += (double)y;
+          s2 += (double)y * (double)y;
+        } else {
+          const float g = dz[u] * edge_act_grad(y * sc + sh, act, slope);
+          s1 += (double)g;
+          s2 += (double)(g * ((y - mu) * rs));
+        }
+      }
+    }
+    if (rrow >= 0) {
+      const double w = (double)row_w[rrow - E];
+      const float y = si;
+      if (MODE == 0) {
+        s1 += w * (double)y;
+        s2 += w * (double)y * (double)y;
+      } else {
+        const float g = dZ[(int64_t)rrow * lddz + cc] * edge_act_grad(y * sc + sh, act, slope);
+        s1 += w * (double)g;
+        s2 += w * (double)(g * ((y - mu) * rs));
+      }
+    }
+  }
+  red[ry][cx][0] = s1;
+  red[ry][cx][1] = s2;
+  __syncthreads();
+  if (ry == 0 && c < Co) {
+    double a = 0.0, b2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      a += red[w][cx][0];
+      b2 += red[w][cx][1];
+    }
+    partial[(int64_t)blockIdx.x * 2 * Co + c] = a;
+    partial[(int64_t)blockIdx.x * 2 * Co + Co + c] = b2;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void cg_edge_apply_kernel(
+    const float* __restrict__ ps, int64_t ldps, const int32_t* __restrict__ grp_ptr, const int32_t* __restrict__ row_src,
+    const int32_t* __restrict__ rep_row, int64_t N, int64_t E, int64_t Ne, int Co, const float* __restrict__ scale,
+    const float* __restrict__ shift, int act, float slope, float* __restrict__ Z, int64_t ldz) {
+  CCN_LANES;
+  const int64_t p = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (p > N) return;
+  const bool pad = p == N;
+  const int32_t g0 = pad ? 0 : grp_ptr[p], cnt = pad ? 0 : grp_ptr[p + 1] - g0;
+  const int32_t rrow = pad ? (int32_t)(E + Ne) : rep_row[p];
+  const int mysrc = cx < cnt ? row_src[g0 + cx] : 0;
+  for (int c0 = 0; c0 < Co; c0 += 64) {
+    const int c = c0 + cx, cc = c < Co ? c : Co - 1;
+    const float si = pad ? 0.f : ps[p * ldps + Co + cc];
+    const float sc = scale ? scale[cc] : 1.f, sh = shift ? shift[cc] : 0.f;
+    for (int s0 = 0; s0 < cnt; s0 += SG_UNROLL) {
+      float pv[SG_UNROLL];
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u) {
+        const int j = cg_src(mysrc, (s0 + u) & 63);
+        pv[u] = s0 + u < cnt ? ps[(int64_t)j * ldps + cc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u)
+        if (s0 + u < cnt && c < Co) Z[(int64_t)(g0 + s0 + u) * ldz + c] = edge_act((pv[u] + si) * sc + sh, act, slope);
+    }
+    if (rrow >= 0 && c < Co) Z[(int64_t)rrow * ldz + c] = edge_act(si * sc + sh, act, slope);
+  }
+}
+
+// dPS must be zero on entry.  dS[p] is owned by point p (plain store), dP[src] is accumulated atomically.
+__global__ __launch_bounds__(TPB) void cg_edge_bwd_kernel(
+    const float* __restrict__ ps, int64_t ldps, const int32_t* __restrict__ grp_ptr, const int32_t* __restrict__ row_src,
+    const int32_t* __restrict__ rep_row, const float* __restrict__ row_w, int64_t N, int64_t E, int Co,
+    const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope,
+    const double* __restrict__ sums, double count, int training, float* __restrict__ dps, int64_t lddps) {
+  CCN_LANES;
+  const int64_t p = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (p >= N) return;  // the padding row feeds nothing upstream
+  const int32_t g0 = grp_ptr[p], cnt = grp_ptr[p + 1] - g0;
+  const int32_t rrow = rep_row[p];
+  const int mysrc = cx < cnt ? row_src[g0 + cx] : 0;
+  const float inv_n = (float)(1.0 / count);
+  for (int c0 = 0; c0 < Co; c0 += 64) {
+    const int c = c0 + cx, cc = c < Co ? c : Co - 1;
+    const float si = ps[p * ldps + Co + cc];
+    const float sc = scale ? scale[cc] : 1.f, sh = shift ? shift[cc] : 0.f;
+    const float mu = mean ? mean[cc] : 0.f, rs = rstd ? rstd[cc] : 0.f;
+    const float m1 = (training && sums) ? (float)sums[cc] * inv_n : 0.f;
+    const float m2 = (training && sums) ? (float)sums[Co + cc] * inv_n : 0.f;
+    float ds = 0.f;
+    for (int s0 = 0; s0 < cnt; s0 += SG_UNROLL) {
+      float pv[SG_UNROLL], dz[SG_UNROLL];
+      int jj[SG_UNROLL];
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u) {
+        const bool ok = s0 + u < cnt;
+        jj[u] = cg_src(mysrc, (s0 + u) & 63);
+        pv[u] = ok ? ps[(int64_t)jj[u] * ldps + cc] : 0.f;
+        dz[u] = ok ? dZ[(int64_t)(g0 + s0 + u) * lddz + cc] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u) {
+        if (s0 + u >= cnt) continue;
+        const float y = pv[u] + si;
+        const float g = dz[u] * edge_act_grad(y * sc + sh, act, slope);
+        const float dy = (training && sums) ? sc * (g - m1 - (y - mu) * rs * m2) : sc * g;
+        ds += dy;
+        if (c < Co) atomicAdd(&dps[(int64_t)jj[u] * lddps + c], dy);
+      }
+    }
+    if (rrow >= 0) {
+      const float y = si;
+      const float g = dZ[(int64_t)rrow * lddz + cc] * edge_act_grad(y * sc + sh, act, slope);
+      const float dy = (training && sums) ? sc * (g - m1 - (y - mu) * rs * m2) : sc * g;
+      ds += row_w[rrow - E] * dy;
+    }
+    if (c < Co) dps[p * lddps + Co + c] = ds;
+  }
+}
+
+// masked max over a point's real rows; the empty slots of the dense layout enter as the constant -1e2 (dgcnn.py:187-189)
+__global__ __launch_bounds__(TPB) void cg_max_fwd_kernel(const float* __restrict__ f, int64_t ldf,
+                                                         const int32_t* __restrict__ grp_ptr,
+                                                         const int32_t* __restrict__ rep_row, int64_t N, int C,
+                                                         float* __restrict__ out, int64_t ldo, int32_t* __restrict__ arg) {
+  CCN_LANES;
+  const int64_t p = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (p >= N) return;
+  const int32_t g0 = grp_ptr[p], cnt = grp_ptr[p + 1] - g0;
+  const bool has_empty = rep_row[p] >= 0;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + cx, cc = c < C ? c : C - 1;
+    float best = f[(int64_t)g0 * ldf + cc];  // the self row always exists
+    int at = 0;
+    for (int s0 = 1; s0 < cnt; s0 += SG_UNROLL) {
+      float v[SG_UNROLL];
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u) v[u] = s0 + u < cnt ? f[(int64_t)(g0 + s0 + u) * ldf + cc] : -__builtin_inff();
+#pragma unroll
+      for (int u = 0; u < SG_UNROLL; ++u)
+        if (s0 + u < cnt && v[u] > best) {
+          best = v[u];
+          at = s0 + u;
+        }
+    }
+    if (has_empty && -1e2f > best) {
+      best = -1e2f;
+      at = -1;
+    }
+    if (c < C) {
+      out[p * ldo + c] = best;
+      arg[p * C + c] = at;
+    }
+  }
+}
+
+// df rows of the point: the argmax row gets the gradient, the others (and the representative) zero; wave N clears
+// the padding row
+__global__ __launch_bounds__(TPB) void cg_max_bwd_kernel(const float* __restrict__ dout, int64_t lddo,
+                                                         const int32_t* __restrict__ arg,
+                                                         const int32_t* __restrict__ grp_ptr,
+                                                         const int32_t* __restrict__ rep_row, int64_t N, int64_t R, int C,
+                                                         float* __restrict__ df, int64_t lddf) {
+  CCN_LANES;
+  const int64_t p = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (p > N) return;
+  if (p == N) {
+    for (int c = cx; c < C; c += 64) df[(R - 1) * lddf + c] = 0.f;
+    return;
+  }
+  const int32_t g0 = grp_ptr[p], cnt = grp_ptr[p + 1] - g0;
+  const int32_t rrow = rep_row[p];
+  for (int c = cx; c < C; c += 64) {
+    const int at = arg[p * C + c];
+    const float g = dout[p * lddo + c];
+    for (int s = 0; s < cnt; ++s) df[(int64_t)(g0 + s) * lddf + c] = s == at ? g : 0.f;
+    if (rrow >= 0) df[(int64_t)rrow * lddf + c] = 0.f;
+  }
+}
+
 // ------------------------------------------------------------------ A13, algebraic form of the first message layer
 // W [x_j ; (p_j - p_i)/r] + b = PX[j] + Wp (p_j - p_i)/r + b with the per-point product PX = X Wx^T (N_src rows
 // instead of E edge rows); the 3-column position part is evaluated per edge from the relative position itself
@@ -866,6 +1141,113 @@ int ccn_sg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const in
   hipLaunchKernelGGL(sg_max_bwd_kernel, dim3(row_blocks(B * Nmax)), dim3(TPB), 0, (hipStream_t)stream, dout, lddo, arg,
                      cloud_ptr, B, Nmax, (int)K, (int)C, df, lddf);
   CCN_LAUNCH_OK("sg_max_bwd");
+  return CCN_OK;
+}
+
+// ---- compact SGCNN rows
+int ccn_cg_count(const int64_t* idx, const int64_t* cloud_ptr, int64_t B, int64_t Nmax, int64_t K, int32_t* cnt,
+                 int32_t* has_rep, void* stream) {
+  CCN_REQUIRE(idx && cloud_ptr && cnt && has_rep && B > 0 && B < 65536 && Nmax > 0 && K >= 1 && K <= 63,
+              "cg_count: bad arguments (K <= 63)");
+  hipLaunchKernelGGL(cg_count_kernel, dim3(ccn_blocks(Nmax, 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, idx,
+                     cloud_ptr, Nmax, (int)K, cnt, has_rep);
+  CCN_LAUNCH_OK("cg_count");
+  return CCN_OK;
+}
+
+int ccn_cg_fill(const int64_t* idx, const int64_t* cloud_ptr, int64_t B, int64_t Nmax, int64_t K, const int32_t* grp_ptr,
+                const int32_t* rep_off, int64_t E, int32_t* row_src, int32_t* rep_row, float* row_w, void* stream) {
+  CCN_REQUIRE(idx && cloud_ptr && grp_ptr && rep_off && row_src && rep_row && row_w && B > 0 && B < 65536 && Nmax > 0 &&
+                  K >= 1 && K <= 63 && E > 0 && E < 2147483647LL,
+              "cg_fill: bad arguments");
+  hipLaunchKernelGGL(cg_fill_kernel, dim3(ccn_blocks(Nmax, 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream, idx,
+                     cloud_ptr, Nmax, (int)K, grp_ptr, rep_off, E, row_src, rep_row, row_w);
+  CCN_LAUNCH_OK("cg_fill");
+  return CCN_OK;
+}
+
+static int cg_pts(int64_t N, int64_t Co) {
+  const int64_t chunks = (Co + 63) / 64;
+  int64_t pts = (N + 1) * chunks / (4 * 2048);
+  if (pts > SG_PTS_MAX) pts = SG_PTS_MAX;
+  if (pts < 1) pts = 1;
+  return (int)pts;
+}
+
+int64_t ccn_cg_edge_stats_rows(int64_t N, int64_t Co) {
+  const int pts = cg_pts(N, Co);
+  return (N + 1 + 4 * pts - 1) / (4 * pts);
+}
+
+int ccn_cg_edge_stats(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
+                      const int32_t* rep_row, const float* row_w, int64_t N, int64_t E, int64_t Ne, int64_t Co,
+                      double* partial, void* stream) {
+  CCN_REQUIRE(ps && grp_ptr && row_src && rep_row && row_w && partial && N > 0 && CCN_SMALL_INT(Co) && ldps >= 2 * Co,
+              "cg_edge_stats: bad arguments");
+  hipLaunchKernelGGL(cg_edge_stats_kernel<0>, dim3((unsigned)ccn_cg_edge_stats_rows(N, Co), (unsigned)((Co + 63) / 64)),
+                     dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr, row_src, rep_row, row_w, N, E, Ne, (int)Co,
+                     (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, 0, 0.f, cg_pts(N, Co), partial);
+  CCN_LAUNCH_OK("cg_edge_stats");
+  return CCN_OK;
+}
+
+int ccn_cg_edge_apply(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
+                      const int32_t* rep_row, int64_t N, int64_t E, int64_t Ne, int64_t Co, const float* scale,
+                      const float* shift, int act, float slope, float* Z, int64_t ldz, void* stream) {
+  CCN_REQUIRE(ps && grp_ptr && row_src && rep_row && Z && N > 0 && CCN_SMALL_INT(Co) && ldps >= 2 * Co && ldz >= Co,
+              "cg_edge_apply: bad arguments");
+  hipLaunchKernelGGL(cg_edge_apply_kernel, dim3(row_blocks(N + 1)), dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr,
+                     row_src, rep_row, N, E, Ne, (int)Co, scale, shift, act, slope, Z, ldz);
+  CCN_LAUNCH_OK("cg_edge_apply");
+  return CCN_OK;
+}
+
+int ccn_cg_edge_bwd_stats(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
+                          const int32_t* rep_row, const float* row_w, int64_t N, int64_t E, int64_t Ne, int64_t Co,
+                          const float* dZ, int64_t lddz, const float* scale, const float* shift, const float* mean,
+                          const float* rstd, int act, float slope, double* partial, void* stream) {
+  CCN_REQUIRE(ps && grp_ptr && row_src && rep_row && row_w && dZ && scale && shift && mean && rstd && partial && N > 0 &&
+                  CCN_SMALL_INT(Co) && ldps >= 2 * Co && lddz >= Co,
+              "cg_edge_bwd_stats: bad arguments");
+  hipLaunchKernelGGL(cg_edge_stats_kernel<1>, dim3((unsigned)ccn_cg_edge_stats_rows(N, Co), (unsigned)((Co + 63) / 64)),
+                     dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr, row_src, rep_row, row_w, N, E, Ne, (int)Co, dZ,
+                     lddz, scale, shift, mean, rstd, act, slope, cg_pts(N, Co), partial);
+  CCN_LAUNCH_OK("cg_edge_bwd_stats");
+  return CCN_OK;
+}
+
+int ccn_cg_edge_bwd(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src, const int32_t* rep_row,
+                    const float* row_w, int64_t N, int64_t E, int64_t Co, const float* dZ, int64_t lddz,
+                    const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                    const double* sums, double count, int training, float* dps, int64_t lddps, void* stream) {
+  CCN_REQUIRE(ps && grp_ptr && row_src && rep_row && row_w && dZ && dps && N > 0 && CCN_SMALL_INT(Co) && ldps >= 2 * Co &&
+                  lddz >= Co && lddps >= 2 * Co && count > 0,
+              "cg_edge_bwd: bad arguments");
+  hipLaunchKernelGGL(cg_edge_bwd_kernel, dim3(row_blocks(N)), dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr,
+                     row_src, rep_row, row_w, N, E, (int)Co, dZ, lddz, scale, shift, mean, rstd, act, slope, sums, count,
+                     training, dps, lddps);
+  CCN_LAUNCH_OK("cg_edge_bwd");
+  return CCN_OK;
+}
+
+int ccn_cg_max_fwd(const float* f, int64_t ldf, const int32_t* grp_ptr, const int32_t* rep_row, int64_t N, int64_t C,
+                   float* out, int64_t ldo, int32_t* arg, void* stream) {
+  CCN_REQUIRE(f && grp_ptr && rep_row && out && arg && N > 0 && CCN_SMALL_INT(C) && ldf >= C && ldo >= C,
+              "cg_max_fwd: bad arguments");
+  hipLaunchKernelGGL(cg_max_fwd_kernel, dim3(row_blocks(N)), dim3(TPB), 0, (hipStream_t)stream, f, ldf, grp_ptr, rep_row, N,
+                     (int)C, out, ldo, arg);
+  CCN_LAUNCH_OK("cg_max_fwd");
+  return CCN_OK;
+}
+
+int ccn_cg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const int32_t* grp_ptr, const int32_t* rep_row,
+                   int64_t N, int64_t R, int64_t C, float* df, int64_t lddf, void* stream) {
+  CCN_REQUIRE(dout && arg && grp_ptr && rep_row && df && N > 0 && R > N && CCN_SMALL_INT(C) && lddo >= C && lddf >= C,
+              "cg_max_bwd: bad arguments");
+  hipLaunchKernelGGL(cg_max_bwd_kernel, dim3(row_blocks(N + 1)), dim3(TPB), 0, (hipStream_t)stream, dout, lddo, arg,
+                     grp_ptr, rep_row, N, R, (int)C, df, lddf);
+  CCN_LAUNCH_OK("cg_max_bwd");
   return CCN_OK;
 }
 

@@ -999,6 +999,63 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
   }
 }
 
+// Row-weighted form (compact SGCNN rows: a representative row stands for `w` identical rows of the dense layout).
+// MODE 0: (sum w*x, sum w*x^2)   MODE 1: (sum w*g, sum w*g*xhat)
+template <int MODE>
+__global__ __launch_bounds__(256) void col_partial_w_kernel(const float* __restrict__ X, int64_t ldx,
+                                                            const float* __restrict__ Y, int64_t ldy,
+                                                            const float* __restrict__ w, int64_t rows, int64_t C,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int act, float slope,
+                                                            double* __restrict__ partial) {
+  __shared__ double red[4][64][2];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS;
+  const int64_t r1 = r0 + RED_ROWS < rows ? r0 + RED_ROWS : rows;
+  for (int64_t c0 = 0; c0 < C; c0 += 64) {
+    const int64_t c = c0 + cx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+      float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
+      if (MODE == 1) {
+        sc = scale[c];
+        sh = shift[c];
+        mu = mean[c];
+        rs = rstd[c];
+      }
+      for (int64_t r = r0 + ry; r < r1; r += 4) {
+        const double wr = (double)w[r];
+        const float xv = X[r * ldx + c];
+        if (MODE == 0) {
+          s1 += wr * (double)xv;
+          s2 += wr * (double)xv * (double)xv;
+        } else {
+          const float y = Y[r * ldy + c];
+          const float g = xv * act_grad(y * sc + sh, act, slope);
+          s1 += wr * (double)g;
+          s2 += wr * (double)(g * ((y - mu) * rs));
+        }
+      }
+    }
+    red[ry][cx][0] = s1;
+    red[ry][cx][1] = s2;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        a += red[k][cx][0];
+        b += red[k][cx][1];
+      }
+      partial[(int64_t)blockIdx.x * 2 * C + c] = a;
+      partial[(int64_t)blockIdx.x * 2 * C + C + c] = b;
+    }
+    __syncthreads();
+  }
+}
+
 // float4 form of the above for 16-byte aligned operands with C % 4 == 0: a wave instruction covers 4 rows x 64
 // columns (lane = 16*row + column quad) and two such groups are in flight per lane, which is what it takes to keep
 // HBM busy from 128-row workgroups (the scalar form reaches 3.5 TB/s, this one streams at the BN-apply rate).
@@ -1203,10 +1260,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ Y, int64_t ldy, int64_t rows, int C,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ rstd, int act, float slope, const double* __restrict__ sums, int training,
-    float* __restrict__ dY, int64_t lddy, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    float* __restrict__ dY, int64_t lddy, float* __restrict__ dgamma, float* __restrict__ dbeta, float inv_n) {
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int64_t r0 = (int64_t)blockIdx.x * 32;
-  const float inv_n = 1.0f / (float)rows;
   for (int c = cx; c < C; c += 64) {
     const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
     const float m1 = (float)sums[c] * inv_n, m2 = (float)sums[C + c] * inv_n;
@@ -1451,8 +1507,52 @@ int ccn_bn_act_bwd_apply(const float* dZ, int64_t lddz, const float* Y, int64_t 
               "bn_act_bwd_apply: bad arguments");
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ccn_blocks(rows, 32)), dim3(256), 0, (hipStream_t)stream, dZ, lddz,
                      Y, ldy, rows, (int)C, scale, shift, mean, rstd, act, slope, sums, training, dY, lddy, dgamma,
-                     dbeta);
+                     dbeta, 1.0f / (float)rows);
   CCN_LAUNCH_OK("bn_act_bwd_apply");
+  return CCN_OK;
+}
+
+// ---- row-weighted BatchNorm pieces (compact SGCNN rows; `count` = sum of all row weights = rows of the dense layout)
+int ccn_colstats_weighted(const float* X, int64_t ldx, const float* w, int64_t rows, int64_t C, double* acc,
+                          void* stream) {
+  // acc: 2*C totals (sum w*x, sum w*x^2) followed by [ccn_stats_rows(rows)][2*C] doubles of scratch
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(X && w && acc && rows > 0 && C > 0 && ldx >= C, "colstats_weighted: bad arguments");
+  const int64_t nparts = ccn_stats_rows(rows);
+  double* partial = acc + 2 * C;
+  hipLaunchKernelGGL(col_partial_w_kernel<0>, dim3((unsigned)nparts), dim3(256), 0, s, X, ldx, (const float*)nullptr,
+                     (int64_t)0, w, rows, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, 0, 0.f, partial);
+  launch_col_reduce(partial, nparts, 2 * C, acc, s);
+  CCN_LAUNCH_OK("colstats_weighted");
+  return CCN_OK;
+}
+
+int ccn_bn_act_bwd_reduce_weighted(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, const float* w,
+                                   int64_t rows, int64_t C, const float* scale, const float* shift, const float* mean,
+                                   const float* rstd, int act, float slope, double* sums, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(dZ && Y && w && scale && shift && mean && rstd && sums && rows > 0 && C > 0,
+              "bn_act_bwd_reduce_weighted: bad arguments");
+  const int64_t nparts = ccn_stats_rows(rows);
+  double* partial = sums + 2 * C;
+  hipLaunchKernelGGL(col_partial_w_kernel<1>, dim3((unsigned)nparts), dim3(256), 0, s, dZ, lddz, Y, ldy, w, rows, C,
+                     scale, shift, mean, rstd, act, slope, partial);
+  launch_col_reduce(partial, nparts, 2 * C, sums, s);
+  CCN_LAUNCH_OK("bn_act_bwd_reduce_weighted");
+  return CCN_OK;
+}
+
+int ccn_bn_act_bwd_apply_count(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C,
+                               const float* scale, const float* shift, const float* mean, const float* rstd, int act,
+                               float slope, const double* sums, double count, int training, float* dY, int64_t lddy,
+                               float* dgamma, float* dbeta, void* stream) {
+  CCN_REQUIRE(dZ && Y && scale && shift && mean && rstd && sums && dY && rows > 0 && C > 0 && count > 0,
+              "bn_act_bwd_apply_count: bad arguments");
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ccn_blocks(rows, 32)), dim3(256), 0, (hipStream_t)stream, dZ, lddz,
+                     Y, ldy, rows, (int)C, scale, shift, mean, rstd, act, slope, sums, training, dY, lddy, dgamma,
+                     dbeta, (float)(1.0 / count));
+  CCN_LAUNCH_OK("bn_act_bwd_apply_count");
   return CCN_OK;
 }
 

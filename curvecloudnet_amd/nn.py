@@ -43,11 +43,18 @@ class MLP(nn.Module):
     def out_channels(self):
         return self.channel_list[-1]
 
-    def forward(self, x, start=0):
-        """``start`` > 0 resumes after the first ``start`` layers (a caller computed them in fused form)."""
+    def forward(self, x, start=0, tail=None):
+        """``start`` > 0 resumes after the first ``start`` layers (a caller computed them in fused form).
+        ``tail`` = (first weighted row, weights, total count): the rows from that index on stand for several identical
+        rows each (compact SGCNN rows, ops.LinearBNActTail); the final plain layer needs no weights."""
         n_hidden = len(self.norms)
         for idx, (lin, norm) in enumerate(zip(self.lins, self.norms)):
             if idx < start:
+                continue
+            if tail is not None:
+                if lin.bias is not None or self.dropout > 0.0:
+                    raise NotImplementedError("weighted rows: bias / dropout layers")
+                x = ops.linear_bn_act_tail(x, lin.weight, norm.module, self.training, self.act, *tail)
                 continue
             x = ops.linear_bn_act(x, lin.weight, lin.bias, norm.module, self.training, self.act)
             if self.dropout > 0.0:

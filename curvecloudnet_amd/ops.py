@@ -966,3 +966,214 @@ def pn_edge_layer(px, wp, bias, pos_src, pos_dst, edges, radius, bn, training, a
     return PNEdgeLayer.apply(px, wp, bias, pos_src, pos_dst, edges.col, edges.row, radius, bn.weight, bn.bias,
                              bn.running_mean, bn.running_var, use_batch_stats, act, bn.eps,
                              bn.momentum if bn.momentum is not None else 0.1)
+
+
+# --------------------------------------------------------------------------------------
+# A15 on compact rows: the dense SGCNN computation without its duplicate rows (see ccn_hip.h, "COMPACT rows")
+# --------------------------------------------------------------------------------------
+
+class SGCompact:
+    """Row structure of one SGCNN call: real rows grouped by point, one weighted representative per point with empty
+    FRNN slots, one weighted row for all padding rows.  Index-only: built inside a geometry block."""
+
+    def __init__(self, nbr, topo):
+        b, nmax, k = nbr.shape
+        n, dev = topo.n, nbr.device
+        cnt = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        has = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        call("cg_count", ptr(nbr), ptr(topo.cloud_ptr), b, nmax, k, ptr(cnt), ptr(has))
+        self.grp_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        rep_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        totals = torch.empty(2, dtype=torch.int64, device=dev)
+        ws = workspace(lib().ccn_exclusive_scan_workspace_bytes(n), dev)
+        call("exclusive_scan_i32", ptr(cnt), n, ptr(self.grp_ptr), ptr(totals[0:1]), ptr(ws), ws.numel())
+        call("exclusive_scan_i32", ptr(has), n, ptr(rep_off), ptr(totals[1:2]), ptr(ws), ws.numel())
+        e, ne = (int(v) for v in totals.tolist())
+        self.n, self.k, self.e, self.ne = n, k, e, ne
+        self.rows = e + ne + 1
+        self.count = float(b * nmax * (k + 1))                    # rows of the dense layout = sum of all weights
+        self.row_src = torch.empty(e, dtype=torch.int32, device=dev)
+        self.rep_row = torch.empty(n, dtype=torch.int32, device=dev)
+        self.row_w = torch.empty(ne + 1, dtype=torch.float32, device=dev)
+        call("cg_fill", ptr(nbr), ptr(topo.cloud_ptr), b, nmax, k, ptr(self.grp_ptr), ptr(rep_off), e, ptr(self.row_src),
+             ptr(self.rep_row), ptr(self.row_w))
+        self.row_w[ne:].fill_(float((b * nmax - n) * (k + 1)))    # the padding row stands for all padding rows
+
+    def tensors(self):
+        return (self.grp_ptr, self.row_src, self.rep_row, self.row_w)
+
+
+class CGEdgeLayer(torch.autograd.Function):
+    """``SGEdgeLayer`` on compact rows: same values for the real rows, BatchNorm statistics identical to the dense
+    B*Nmax*(K+1)-row computation (weighted representatives), output (E + Ne + 1, Co)."""
+
+    @staticmethod
+    def forward(ctx, ps, grp_ptr, row_src, rep_row, row_w, dims, gamma, beta, running_mean, running_var, training, act,
+                eps, momentum):
+        ps = _mat(ps)
+        n, e, ne, count = dims
+        co = ps.size(1) // 2
+        dev = ps.device
+        has_bn = gamma is not None
+        ctx.has_bn, ctx.act, ctx.training, ctx.dims = has_bn, ACT[act], bool(training), dims
+        idx = (ptr(grp_ptr), ptr(row_src), ptr(rep_row))
+        par = None
+        if has_bn:
+            par = torch.empty((4, co), dtype=torch.float32, device=dev)
+            if training:
+                nparts = lib().ccn_cg_edge_stats_rows(n, co)
+                partial = torch.empty((nparts + 1) * 2 * co, dtype=torch.float64, device=dev)
+                call("cg_edge_stats", ptr(ps), _ld(ps), *idx, ptr(row_w), n, e, ne, co, ptr(partial))
+                call("bn_finalize_n", ptr(partial), nparts, int(count), co, ptr(gamma), ptr(beta), float(eps),
+                     float(momentum), ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                     ptr(par[3]))
+            else:
+                call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), co,
+                     ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        z = _rows(e + ne + 1, co, dev)
+        call("cg_edge_apply", ptr(ps), _ld(ps), *idx, n, e, ne, co, ptr(par[0]) if has_bn else None,
+             ptr(par[1]) if has_bn else None, ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
+        ctx.save_for_backward(ps, grp_ptr, row_src, rep_row, row_w, par if has_bn else ps.new_empty(0))
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        ps, grp_ptr, row_src, rep_row, row_w, par = ctx.saved_tensors
+        g = _mat(g)
+        n, e, ne, count = ctx.dims
+        co = ps.size(1) // 2
+        dev = g.device
+        idx = (ptr(grp_ptr), ptr(row_src), ptr(rep_row))
+        sums = dgamma = dbeta = None
+        pp = [None] * 4
+        if ctx.has_bn:
+            pp = [ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3])]
+            nparts = lib().ccn_cg_edge_stats_rows(n, co)
+            partial = torch.empty((nparts + 1) * 2 * co, dtype=torch.float64, device=dev)
+            call("cg_edge_bwd_stats", ptr(ps), _ld(ps), *idx, ptr(row_w), n, e, ne, co, ptr(g), _ld(g), *pp, ctx.act,
+                 LEAKY_SLOPE, ptr(partial))
+            sums = partial[nparts * 2 * co:]
+            call("reduce_partials", ptr(partial), nparts, 2 * co, ptr(sums))
+            dbeta, dgamma = sums[:co].float(), sums[co:].float()
+        dps = _rows(ps.size(0), 2 * co, dev, zero=True)
+        call("cg_edge_bwd", ptr(ps), _ld(ps), *idx, ptr(row_w), n, e, co, ptr(g), _ld(g), *pp, ctx.act, LEAKY_SLOPE,
+             ptr(sums) if sums is not None else None, float(count), 1 if (ctx.training and ctx.has_bn) else 0, ptr(dps),
+             _ld(dps))
+        return dps, None, None, None, None, None, dgamma, dbeta, None, None, None, None, None, None
+
+
+def cg_edge_layer(ps, comp, bn, training, act):
+    dims = (comp.n, comp.e, comp.ne, comp.count)
+    if bn is None:
+        return CGEdgeLayer.apply(ps, *comp.tensors(), dims, None, None, None, None, False, None, 0.0, 0.0)
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    use_batch_stats = training or not bn.track_running_stats
+    return CGEdgeLayer.apply(ps, *comp.tensors(), dims, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                             use_batch_stats, act, bn.eps, bn.momentum if bn.momentum is not None else 0.1)
+
+
+class LinearBNActTail(torch.autograd.Function):
+    """``LinearBNAct`` (no bias) over rows whose tail [tail:] carries weights: BatchNorm statistics, its backward
+    reductions and the weight gradient count row r of the tail ``w[r - tail]`` times (total ``count`` rows)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, act, eps, momentum, tail, w, count):
+        x = _mat(x)
+        m, k = x.shape
+        n = weight.size(0)
+        dev = x.device
+        wt = _aligned_weight(weight.detach())
+        ctx.act, ctx.training, ctx.tail, ctx.count = ACT[act], bool(training), int(tail), float(count)
+        gemm_nt = ctx.gemm_nt = "gemm_nt_bf16" if _MLP_DTYPE == "bf16" else "gemm_nt"
+        if gemm_nt == "gemm_nt_bf16":
+            x = _aligned_rows(x)
+        y = _rows(m, n, dev)
+        t = m - tail
+        xt, yt = x[tail:], y[tail:]
+        par = torch.empty((4, n), dtype=torch.float32, device=dev)
+        if training:
+            nparts = lib().ccn_stats_rows(tail)
+            stats = torch.empty((nparts + 2) * 2 * n, dtype=torch.float64, device=dev)
+            call(gemm_nt, ptr(x), _ld(x), ptr(wt), _ld(wt), None, ptr(y), _ld(y), tail, n, k, ptr(stats))
+            call(gemm_nt, ptr(xt), _ld(x), ptr(wt), _ld(wt), None, ptr(yt), _ld(y), t, n, k, None)
+            acc = torch.empty((lib().ccn_stats_rows(t) + 1) * 2 * n, dtype=torch.float64, device=dev)
+            call("colstats_weighted", ptr(yt), _ld(y), ptr(w), t, n, ptr(acc))
+            stats[nparts * 2 * n:(nparts + 1) * 2 * n].copy_(acc[:2 * n])          # one more partial row
+            call("bn_finalize_n", ptr(stats), nparts + 1, int(count), n, ptr(gamma), ptr(beta), float(eps),
+                 float(momentum), ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        else:
+            call(gemm_nt, ptr(x), _ld(x), ptr(wt), _ld(wt), None, ptr(y), _ld(y), m, n, k, None)
+            call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), n,
+                 ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        z = _rows(m, n, dev)
+        call("bn_act_fwd", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
+        ctx.save_for_backward(x, wt, y, par, w)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wt, y, par, w = ctx.saved_tensors
+        g = _mat(g)
+        dev = g.device
+        m, n = y.shape
+        k = x.size(1)
+        tail = ctx.tail
+        t = m - tail
+        pp = (ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        sums = _stats_buffer(tail, n, dev)
+        call("bn_act_bwd_reduce", ptr(g), _ld(g), ptr(y), _ld(y), tail, n, *pp, ctx.act, LEAKY_SLOPE, ptr(sums))
+        sums_t = _stats_buffer(t, n, dev)
+        gt, yt = g[tail:], y[tail:]
+        call("bn_act_bwd_reduce_weighted", ptr(gt), _ld(g), ptr(yt), _ld(y), ptr(w), t, n, *pp, ctx.act, LEAKY_SLOPE,
+             ptr(sums_t))
+        sums[:2 * n].add_(sums_t[:2 * n])
+        dy = _rows(m, n, dev)
+        dgb = torch.empty((2, n), dtype=torch.float32, device=dev)
+        call("bn_act_bwd_apply_count", ptr(g), _ld(g), ptr(y), _ld(y), m, n, *pp, ctx.act, LEAKY_SLOPE, ptr(sums),
+             ctx.count, 1 if ctx.training else 0, ptr(dy), _ld(dy), ptr(dgb[0]), ptr(dgb[1]))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _rows(m, k, dev)
+            wtt = _rows(k, n, dev, zero=(n % 4 != 0))
+            wtt.copy_(wt[:, :k].t())
+            call(ctx.gemm_nt, ptr(dy), _ld(dy), ptr(wtt), _ld(wtt), None, ptr(dx), _ld(dx), m, k, n, None)
+        dw = _rows(n, k, dev, zero=True)
+        call("gemm_tn", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), tail, n, k)
+        dyt = _rows(t, n, dev)
+        torch.mul(dy[tail:], w[:, None], out=dyt)
+        xt = x[tail:]
+        call("gemm_tn", ptr(dyt), _ld(dyt), ptr(xt), _ld(x), ptr(dw), _ld(dw), t, n, k)
+        return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None
+
+
+def linear_bn_act_tail(x, weight, bn, training, act, tail, w, count):
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    use_batch_stats = training or not bn.track_running_stats
+    return LinearBNActTail.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats, act,
+                                 bn.eps, bn.momentum if bn.momentum is not None else 0.1, tail, w, count)
+
+
+class CGMax(torch.autograd.Function):
+    """``SGMax`` on compact rows (ref dgcnn.py:181,187-189,206)."""
+
+    @staticmethod
+    def forward(ctx, f, grp_ptr, rep_row, n):
+        f = _mat(f)
+        c = f.size(1)
+        out = _rows(n, c, f.device)
+        arg = torch.empty((n, c), dtype=torch.int32, device=f.device)
+        call("cg_max_fwd", ptr(f), _ld(f), ptr(grp_ptr), ptr(rep_row), n, c, ptr(out), _ld(out), ptr(arg))
+        ctx.save_for_backward(arg, grp_ptr, rep_row)
+        ctx.shape = (n, f.size(0), c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        arg, grp_ptr, rep_row = ctx.saved_tensors
+        g = _mat(g)
+        n, rows, c = ctx.shape
+        df = _rows(rows, c, g.device)
+        call("cg_max_bwd", ptr(g), _ld(g), ptr(arg), ptr(grp_ptr), ptr(rep_row), n, rows, c, ptr(df), _ld(df))
+        return df, None, None, None

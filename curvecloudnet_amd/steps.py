@@ -410,6 +410,7 @@ class SGCNNLayer(nn.Module):
         self.attend_nn, self.aggr_type = attend_nn, aggr_type
         self.use_fast_knn, self.use_sparse_feat_agg = use_fast_knn, use_sparse_feat_agg
         self.force_edge_gemm = False        # tests: run the literal gather + GEMM formulation
+        self.compact_rows = os.environ.get("CCN_SG_COMPACT", "1") != "0"   # dense path without its duplicate rows
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
         x = _with_xyz(x, pos, self.with_xyz)
@@ -429,14 +430,30 @@ class SGCNNLayer(nn.Module):
             return out, pos, batch, point2curveidx
         if not self.use_fast_knn or self.aggr_type != "max":
             raise NotImplementedError("dense SGCNN path: only the FRNN + max configuration the shipped configs use")
+        lin0 = self.nn.lins[0]
+        algebraic = lin0.bias is None and self.nn.dropout == 0.0 and not self.force_edge_gemm
+        compact = (algebraic and self.compact_rows and self.k <= 63
+                   and all(l.bias is None for l in self.nn.lins[:len(self.nn.norms)]))
         with _geometry(kwargs) as geo:
             topo = _topology(batch, point2curveidx, kwargs, curves=False)
             padded, _ = ops.to_batch_padded(pos, topo)
             radius = 0.25 if self.r is None else self.r
             nbr = ops.fast_knn(padded, padded, topo.lengths, topo.lengths, self.k, radius)
-            geo.publish(topo, nbr)
-        lin0 = self.nn.lins[0]
-        if lin0.bias is None and self.nn.dropout == 0.0 and not self.force_edge_gemm:
+            comp = ops.SGCompact(nbr, topo) if compact else None
+            geo.publish(topo, nbr, comp.tensors() if compact else None)
+        if compact:
+            # dense computation without its duplicate rows: every empty FRNN slot of a point (and every padding row) is the
+            # same row through the whole MLP; they are kept once, with their multiplicity as weight in all reductions
+            c = x.size(1)
+            w = lin0.weight
+            ps = ops.linear_bn_act(x, torch.cat([w[:, :c] - w[:, c:], w[:, c:]], dim=0), None, None, False, None)
+            hidden0 = len(self.nn.norms) > 0
+            feat = ops.cg_edge_layer(ps, comp, self.nn.norms[0].module if hidden0 else None, self.training,
+                                     self.nn.act if hidden0 else None)
+            feat = self.nn(feat, start=1, tail=(comp.e, comp.row_w, comp.count))
+            out = ops.CGMax.apply(feat, comp.grp_ptr, comp.rep_row, topo.n)
+            return out, pos, batch, point2curveidx
+        if algebraic:
             # first layer in algebraic form: two per-point products + a gather-add instead of a GEMM over
             # 21x the rows (ops.SGEdgeLayer); exact up to fp32 re-association
             c = x.size(1)

@@ -249,6 +249,48 @@ int ccn_knn_points_list(const float* q, const int64_t* q_ptr, const float* src, 
  * (B,P,3) inputs, idx (B,P1,K) int64 = the first K points2 in index order with d2 < r*r, -1 padded. */
 int ccn_ball_query(const float* points1, const int64_t* lengths1, const float* points2, const int64_t* lengths2,
                    int64_t B, int64_t P1, int64_t P2, int64_t K, float radius, int64_t* idx, void* stream);
+/* ---- SGCNN dense path on COMPACT rows (dgcnn.py:158-207, same result as the B*Nmax*(K+1)-row computation).
+ * A dense slot whose FRNN entry is -1 has the same first-layer value S[i] whatever the slot, and so have all rows of the
+ * padding points: they only enter the BatchNorm statistics (quirk Q4).  Layout: rows [0,E) real (point p owns
+ * [grp_ptr[p], grp_ptr[p+1]): self, then its neighbours in FRNN order; row_src = packed source point), rows [E,E+Ne) one
+ * representative per point with empty slots (rep_row[p] = its row or -1, weight = number of empty slots), row E+Ne = all
+ * padding rows (weight set by the caller); row_w holds the Ne+1 weights.  cg_count -> two ccn_exclusive_scan_i32 ->
+ * cg_fill build it; the cg_edge_* kernels are the weighted counterparts of ccn_sg_edge_*; ccn_colstats_weighted /
+ * ccn_bn_act_bwd_reduce_weighted / ccn_bn_act_bwd_apply_count carry the weights through the following layers
+ * (count = B*Nmax*(K+1) = sum of all weights); cg_max is the masked max over the real rows (+ the -1e2 of empty slots). */
+int ccn_cg_count(const int64_t* idx, const int64_t* cloud_ptr, int64_t B, int64_t Nmax, int64_t K, int32_t* cnt,
+                 int32_t* has_rep, void* stream);
+int ccn_cg_fill(const int64_t* idx, const int64_t* cloud_ptr, int64_t B, int64_t Nmax, int64_t K, const int32_t* grp_ptr,
+                const int32_t* rep_off, int64_t E, int32_t* row_src, int32_t* rep_row, float* row_w, void* stream);
+int64_t ccn_cg_edge_stats_rows(int64_t N, int64_t Co);
+int ccn_cg_edge_stats(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
+                      const int32_t* rep_row, const float* row_w, int64_t N, int64_t E, int64_t Ne, int64_t Co,
+                      double* partial, void* stream);
+int ccn_cg_edge_apply(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
+                      const int32_t* rep_row, int64_t N, int64_t E, int64_t Ne, int64_t Co, const float* scale,
+                      const float* shift, int act, float slope, float* Z, int64_t ldz, void* stream);
+int ccn_cg_edge_bwd_stats(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
+                          const int32_t* rep_row, const float* row_w, int64_t N, int64_t E, int64_t Ne, int64_t Co,
+                          const float* dZ, int64_t lddz, const float* scale, const float* shift, const float* mean,
+                          const float* rstd, int act, float slope, double* partial, void* stream);
+int ccn_cg_edge_bwd(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src, const int32_t* rep_row,
+                    const float* row_w, int64_t N, int64_t E, int64_t Co, const float* dZ, int64_t lddz,
+                    const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                    const double* sums, double count, int training, float* dps, int64_t lddps, void* stream);
+int ccn_cg_max_fwd(const float* f, int64_t ldf, const int32_t* grp_ptr, const int32_t* rep_row, int64_t N, int64_t C,
+                   float* out, int64_t ldo, int32_t* arg, void* stream);
+int ccn_cg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const int32_t* grp_ptr, const int32_t* rep_row,
+                   int64_t N, int64_t R, int64_t C, float* df, int64_t lddf, void* stream);
+int ccn_colstats_weighted(const float* X, int64_t ldx, const float* w, int64_t rows, int64_t C, double* acc,
+                          void* stream);
+int ccn_bn_act_bwd_reduce_weighted(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, const float* w,
+                                   int64_t rows, int64_t C, const float* scale, const float* shift, const float* mean,
+                                   const float* rstd, int act, float slope, double* sums, void* stream);
+int ccn_bn_act_bwd_apply_count(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C,
+                               const float* scale, const float* shift, const float* mean, const float* rstd, int act,
+                               float slope, const double* sums, double count, int training, float* dY, int64_t lddy,
+                               float* dgamma, float* dbeta, void* stream);
+
 /* PointNetConv2 first message layer in algebraic form (point_conv.py:35-93; local_nn.lins[0].weight = [Wx | Wp]):
  *   y[e] = PX[src[e]] + Wp (pos_src[src[e]] - pos_dst[dst[e]]) / radius + bias,   PX = X Wx^T  (N_src x Co, one GEMM over the
  * source points instead of the E edge rows; radius <= 0: no division), followed by BatchNorm over the E edges + activation.

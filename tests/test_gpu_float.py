@@ -603,3 +603,31 @@ def test_bf16_model_tracks_emulation_and_fp32(bf16_mode, which):
         assert e_emul < 5e-2        # measured 2.5e-2 (6.8e-2 to the fp32 mode)
     out_b.square().mean().backward()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in mine.parameters())
+
+
+@pytest.mark.parametrize("ids,k,r", [([2, 3], 12, 0.05), ([0], 20, 0.02), ([4, 5, 6], 8, 0.5)])
+def test_sgcnn_compact_rows_match_dense_rows(ids, k, r):
+    """The compact-row SGCNN path (real rows + weighted representatives of the empty slots / padding rows) against the
+    dense B*Nmax*(K+1)-row path: outputs, every gradient and the BatchNorm running statistics."""
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch(ids, n_curves=50 if len(ids) > 1 else 300)
+    c = 21
+    torch.manual_seed(0)
+    mod = steps.SGCNNLayer(MLP([2 * (c + 3), 40, 32, 24], bias=False), k, r=r, with_xyz=True).to(DEV).train()
+    x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4)).to(DEV)
+    cot = torch.randn(d.pos.size(0), 24, generator=torch.Generator().manual_seed(5)).to(DEV)
+    res, stats = [], []
+    for compact in (True, False):
+        mod.compact_rows = compact
+        for bn in mod.nn.norms:
+            bn.module.reset_running_stats()
+        xi = x.clone().requires_grad_(True)
+        out = mod(xi, d.pos.to(DEV), d.batch.to(DEV), d.curve_idxs.to(DEV))[0]
+        res.append([out.detach()] + list(torch.autograd.grad((out * cot).sum(), [xi] + list(mod.parameters()))))
+        stats.append([b.detach().clone().float() for b in mod.buffers()])
+    for a, b in zip(*res):
+        _close(a, b, 1e-4, "compact vs dense")
+    for a, b in zip(*stats):
+        _close(a, b, 1e-5, "running statistics")
