@@ -170,6 +170,9 @@ def main():
     ap.add_argument("--mlp-dtype", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: forward / data-gradient products of the MLP and conv layers on the bf16 MFMA path "
                          "(BASELINE configs 3 and 5); the headline metric is quoted in fp32")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="compute each step's sampling / neighbour search inside its own forward instead of during the "
+                         "previous step's backward pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -199,11 +202,20 @@ def main():
     n_points = data.pos.size(0)
     labels = torch.randint(0, n_classes, (n_points,), generator=torch.Generator().manual_seed(rank)).to(dev)
 
+    staged = {"plan": None}
+
     def step():
         sync.zero_grad()
-        torch.manual_seed(7)                                 # fixes the CurveFPS phase draws
-        loss = segmentation_loss(model(data), labels)
+        plan = staged["plan"]
+        if plan is None:
+            torch.manual_seed(7)                             # fixes the CurveFPS phase draws
+        loss = segmentation_loss(model(data, plan=plan), labels)
         loss.backward()
+        if not args.no_pipeline:
+            # the next batch's sampling / neighbour search is queued on the side stream while this batch's backward pass
+            # (already queued) runs: what a training loop does with the loader's next batch (ModelBase.prepare)
+            torch.manual_seed(7)
+            staged["plan"] = model.prepare(data)
         sync.finish()
         opt.step()
         return loss
@@ -238,8 +250,10 @@ def main():
         "dtype": "f32" if args.mlp_dtype == "fp32" else "bf16 products, f32 accumulate / storage", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1] shape: %d clouds/GPU x %d curves (~%dk points each, %d points "
                                "on rank 0), fp32 curve-conv + HIP FRNN + MFMA MLP stack; network = %s at width x%g; "
-                               "fwd + mean-NLL + bwd + Adam"
-                               % (b, args.curves, round(n_points / b / 1000), n_points, net_desc, args.width),
+                               "fwd + mean-NLL + bwd + Adam%s"
+                               % (b, args.curves, round(n_points / b / 1000), n_points, net_desc, args.width,
+                                  "" if args.no_pipeline else
+                                  "; the next step's sampling / neighbour search runs during this step's backward"),
                    "network": args.config, "parameters": sum(p.numel() for p in model.parameters()),
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                    "clouds_per_gpu": b, "points_per_cloud": n_points // b, "parallelism": "dp%d" % world,

@@ -8,6 +8,7 @@ resolution level are built once and shared by every step at that level.
 """
 import math
 import os
+from types import SimpleNamespace
 
 import torch
 import torch.nn as nn
@@ -37,7 +38,7 @@ def _walk_tensors(obj, depth=0):
     elif isinstance(obj, (list, tuple)):
         for o in obj:
             yield from _walk_tensors(o, depth)
-    elif isinstance(obj, (ops.CurveTopology, ops.EdgeList)) and depth < 2:
+    elif isinstance(obj, (ops.CurveTopology, ops.EdgeList, ops.SGCompact, SimpleNamespace)) and depth < 3:
         for o in vars(obj).values():
             yield from _walk_tensors(o, depth + 1)
 
@@ -49,8 +50,8 @@ class _GeometryBlock:
     ``geo.publish(...)``: the main stream then waits for the block's event and the allocator is told that
     those tensors are in use on the main stream too."""
 
-    def __init__(self, ctx):
-        self.ctx, self._scope = ctx, None
+    def __init__(self, ctx, defer=False):
+        self.ctx, self._scope, self.defer, self.event = ctx, None, defer, None
 
     def __enter__(self):
         ctx = self.ctx
@@ -71,9 +72,10 @@ class _GeometryBlock:
 
     def __exit__(self, et, ev, tb):
         if self._scope is not None:
-            done = self.ctx.side.record_event()
+            self.event = self.ctx.side.record_event()
             self._scope.__exit__(et, ev, tb)
-            self.ctx.main.wait_event(done)
+            if not self.defer:          # deferred blocks (geometry prepass): the consumer waits on .event itself
+                self.ctx.main.wait_event(self.event)
         return False
 
 
@@ -81,7 +83,7 @@ class ForwardContext:
     """Per-forward state: the ``CurveTopology`` cache for the (batch, curve-id) pairs seen, and the
     side stream the geometry blocks run on."""
 
-    def __init__(self, num_clouds=None, device=None):
+    def __init__(self, num_clouds=None, device=None, inputs_ready=False):
         self.num_clouds = num_clouds
         self._topo = {}
         self._zeros = {}
@@ -91,10 +93,11 @@ class ForwardContext:
             if self.side is not None:
                 self.main = torch.cuda.current_stream(device)
                 self.stress = mode == "stress"
-                self.side.wait_stream(self.main)          # the level-0 inputs were produced on the main stream
+                if not inputs_ready:
+                    self.side.wait_stream(self.main)      # the level-0 inputs were produced on the main stream
 
-    def geometry(self):
-        return _GeometryBlock(self)
+    def geometry(self, defer=False):
+        return _GeometryBlock(self, defer)
 
     def topology(self, batch, p2c, curves=True):
         """curves=False: only the cloud tables are needed (levels whose points were re-ordered by voxel
@@ -184,15 +187,21 @@ class SymmetricCurve1DConvFastV1(nn.Module):
         self.with_xyz, self.with_diff = with_xyz, with_diff
         self.conv_modules, self.norm_modules = _conv_stack(feat_dims, kernel_size, bias, with_diff, True)
 
-    def forward(self, x, pos, batch, point2curveidx, **kwargs):
-        with _geometry(kwargs) as geo:
-            topo = geo.publish(_topology(batch, point2curveidx, kwargs))
+    def geometry(self, pos, batch, point2curveidx, kwargs):
+        return SimpleNamespace(topo=_topology(batch, point2curveidx, kwargs), out=(pos, batch, point2curveidx))
+
+    def features(self, x, pos, g):
         x = _with_xyz(x, pos, self.with_xyz)
         for conv, norm in zip(self.conv_modules, self.norm_modules):
             if self.with_diff:
-                x = ops.DiffConcat.apply(x, topo.cid)
-            x = _conv_bn_act(x, topo.cid, self.kernel_size, conv, norm, self.training)
-        return x, pos, batch, point2curveidx
+                x = ops.DiffConcat.apply(x, g.topo.cid)
+            x = _conv_bn_act(x, g.topo.cid, self.kernel_size, conv, norm, self.training)
+        return x
+
+    def forward(self, x, pos, batch, point2curveidx, **kwargs):
+        with _geometry(kwargs) as geo:
+            g = geo.publish(self.geometry(pos, batch, point2curveidx, kwargs))
+        return (self.features(x, pos, g),) + g.out
 
 
 class SymmetricCurve1DConvV2(nn.Module):
@@ -207,20 +216,26 @@ class SymmetricCurve1DConvV2(nn.Module):
         self.with_xyz, self.with_diff = with_xyz, with_diff
         self.conv_modules, self.norm_modules = _conv_stack(feat_dims, kernel_size, bias, with_diff, False)
 
-    def forward(self, x, pos, batch, point2curveidx, **kwargs):
+    def geometry(self, pos, batch, point2curveidx, kwargs):
         pad = (self.kernel_size // 2) * (len(self.feat_dims) - 1) if self.kernel_size > 1 else 0
-        with _geometry(kwargs) as geo:
-            topo = _topology(batch, point2curveidx, kwargs)
-            rows = torch.arange(topo.n, device=pos.device) + pad * (topo.cid.long() + 1)
-            geo.publish(topo, rows)
+        topo = _topology(batch, point2curveidx, kwargs)
+        rows = torch.arange(topo.n, device=pos.device) + pad * (topo.cid.long() + 1)
+        return SimpleNamespace(topo=topo, rows=rows, n_rows=topo.n + (topo.num_curves + 1) * pad,
+                               out=(pos, batch, point2curveidx))
+
+    def features(self, x, pos, g):
         x = _with_xyz(x, pos, self.with_xyz)
-        n_rows = topo.n + (topo.num_curves + 1) * pad
         if self.with_diff:
-            x = ops.DiffConcat.apply(x, topo.cid)
-        seq = ops.ScatterRows.apply(x, rows, n_rows)
+            x = ops.DiffConcat.apply(x, g.topo.cid)
+        seq = ops.ScatterRows.apply(x, g.rows, g.n_rows)
         for conv, norm in zip(self.conv_modules, self.norm_modules):
             seq = _conv_bn_act(seq, None, self.kernel_size, conv, norm, self.training)
-        return ops.gather_rows(seq, rows), pos, batch, point2curveidx
+        return ops.gather_rows(seq, g.rows)
+
+    def forward(self, x, pos, batch, point2curveidx, **kwargs):
+        with _geometry(kwargs) as geo:
+            g = geo.publish(self.geometry(pos, batch, point2curveidx, kwargs))
+        return (self.features(x, pos, g),) + g.out
 
 
 # --------------------------------------------------------------------------------------
@@ -308,25 +323,30 @@ class SAModule(nn.Module):
         self.conv = PointNetConv2(nn, add_self_loops=False, aggr_type=aggr_type, attend_nn=attend_nn,
                                   normalize_radius=self.normalize_radius)
 
+    def geometry(self, pos, batch, point2curveidx, kwargs):
+        topo = _topology(batch, point2curveidx, kwargs, curves=self.downsample_type == "curve-fps")
+        if self.downsample_type == "random":
+            idx = torch.sort(torch.randperm(pos.size(0))[: int(pos.size(0) * self.ratio)])[0].to(pos.device)
+        elif self.downsample_type == "curve-fps":
+            idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
+        elif self.downsample_type == "voxel":
+            idx = ops.voxel_fps(pos, batch, self.voxel_size)
+        else:
+            idx = ops.fps(pos, topo, self.ratio)
+        pos_q, batch_q = pos[idx], batch[idx]
+        p2c_q = None if point2curveidx is None else point2curveidx[idx]
+        topo_q = _topology(batch_q, p2c_q, kwargs, curves=False)
+        edges = ops.frnn_edges(pos_q, topo_q, pos, topo, self.knn, self.r,
+                               operation="knn" if self.use_fast_knn else "ball-group")
+        return SimpleNamespace(edges=edges, out=(pos_q, batch_q, p2c_q))
+
+    def features(self, x, pos, g):
+        return self.conv((x, None), (pos, g.out[0]), g.edges)
+
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
         with _geometry(kwargs) as geo:
-            topo = _topology(batch, point2curveidx, kwargs, curves=self.downsample_type == "curve-fps")
-            if self.downsample_type == "random":
-                idx = torch.sort(torch.randperm(pos.size(0))[: int(pos.size(0) * self.ratio)])[0].to(pos.device)
-            elif self.downsample_type == "curve-fps":
-                idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
-            elif self.downsample_type == "voxel":
-                idx = ops.voxel_fps(pos, batch, self.voxel_size)
-            else:
-                idx = ops.fps(pos, topo, self.ratio)
-            pos_q, batch_q = pos[idx], batch[idx]
-            p2c_q = None if point2curveidx is None else point2curveidx[idx]
-            topo_q = _topology(batch_q, p2c_q, kwargs, curves=False)
-            edges = ops.frnn_edges(pos_q, topo_q, pos, topo, self.knn, self.r,
-                                   operation="knn" if self.use_fast_knn else "ball-group")
-            geo.publish(pos_q, batch_q, p2c_q, edges)
-        x = self.conv((x, None), (pos, pos_q), edges)
-        return x, pos_q, batch_q, p2c_q
+            g = geo.publish(self.geometry(pos, batch, point2curveidx, kwargs))
+        return (self.features(x, pos, g),) + g.out
 
 
 class CurveSAModule(nn.Module):
@@ -341,18 +361,22 @@ class CurveSAModule(nn.Module):
         self.conv = PointNetConv2(nn, add_self_loops=False, global_nn=global_nn, aggr_type=aggr_type,
                                   attend_nn=attend_nn, normalize_radius=self.normalize_radius)
 
-    def forward(self, x, pos, batch, point2curveidx, **kwargs):
+    def geometry(self, pos, batch, point2curveidx, kwargs):
         if not self.use_curve_fps:
             raise NotImplementedError("the shipped configs always set use_curve_fps (ref pointnet2.py:165-168)")
-        with _geometry(kwargs) as geo:
-            topo = _topology(batch, point2curveidx, kwargs)
-            idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
-            edges = ops.radius_1d_group_subset(pos, idx, topo, self.r)
-            pos_q, batch_q, p2c_q = pos[idx], batch[idx], point2curveidx[idx]
-            geo.publish(idx, edges, pos_q, batch_q, p2c_q)
+        topo = _topology(batch, point2curveidx, kwargs)
+        idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
+        edges = ops.radius_1d_group_subset(pos, idx, topo, self.r)
+        return SimpleNamespace(edges=edges, out=(pos[idx], batch[idx], point2curveidx[idx], None, idx))
+
+    def features(self, x, pos, g):
         x = _with_xyz(x, pos[:, :3], self.with_xyz)
-        x = self.conv((x, None), (pos, pos_q), edges)
-        return x, pos_q, batch_q, p2c_q, None, idx
+        return self.conv((x, None), (pos, g.out[0]), g.edges)
+
+    def forward(self, x, pos, batch, point2curveidx, **kwargs):
+        with _geometry(kwargs) as geo:
+            g = geo.publish(self.geometry(pos, batch, point2curveidx, kwargs))
+        return (self.features(x, pos, g),) + g.out
 
 
 def _fp_concat(x, x_skip, pos_skip, with_xyz):
@@ -371,27 +395,35 @@ class FPModule(nn.Module):
         super().__init__()
         self.k, self.nn, self.with_xyz = k, nn, with_xyz
 
+    def geometry(self, pos, batch, pos_skip, batch_skip, point2curveidx, point2curveidx_skip, kwargs):
+        topo_x = _topology(batch, point2curveidx, kwargs, curves=False)
+        topo_y = _topology(batch_skip, point2curveidx_skip, kwargs, curves=False)
+        nbr, w = ops.knn_points_packed(pos_skip, topo_y, pos, topo_x, self.k)
+        return SimpleNamespace(nbr=nbr, w=w, out=(pos_skip, batch_skip, point2curveidx_skip))
+
+    def features(self, x, x_skip, g):
+        x = ops.CurveInterp.apply(x, g.nbr, g.w)
+        return self.nn(_fp_concat(x, x_skip, g.out[0], self.with_xyz))
+
     def forward(self, x, pos, batch, x_skip, pos_skip, batch_skip, point2curveidx=None, point2curveidx_skip=None,
                 **kwargs):
         with _geometry(kwargs) as geo:
-            topo_x = _topology(batch, point2curveidx, kwargs, curves=False)
-            topo_y = _topology(batch_skip, point2curveidx_skip, kwargs, curves=False)
-            nbr, w = geo.publish(*ops.knn_points_packed(pos_skip, topo_y, pos, topo_x, self.k))
-        x = ops.CurveInterp.apply(x, nbr, w)
-        x = self.nn(_fp_concat(x, x_skip, pos_skip, self.with_xyz))
-        return x, pos_skip, batch_skip, point2curveidx_skip
+            g = geo.publish(self.geometry(pos, batch, pos_skip, batch_skip, point2curveidx, point2curveidx_skip, kwargs))
+        return (self.features(x, x_skip, g),) + g.out
 
 
 class CurveFPModule(FPModule):
     """ref pointnet2.py:184-205: interpolate along curves from the sampled points, concat skip, MLP."""
 
+    def geometry(self, idx, pos_skip, batch_skip, point2curveidx_skip, kwargs):
+        topo = _topology(batch_skip, point2curveidx_skip, kwargs)
+        nbr, w = ops.knn_1d_group_superset_dense(pos_skip, idx, topo, self.k)
+        return SimpleNamespace(nbr=nbr, w=w, out=(pos_skip, batch_skip, point2curveidx_skip))
+
     def forward(self, x, idx, x_skip, pos_skip, batch_skip, point2curveidx_skip=None, **kwargs):
         with _geometry(kwargs) as geo:
-            topo = _topology(batch_skip, point2curveidx_skip, kwargs)
-            nbr, w = geo.publish(*ops.knn_1d_group_superset_dense(pos_skip, idx, topo, self.k))
-        x = ops.CurveInterp.apply(x, nbr, w)
-        x = self.nn(_fp_concat(x, x_skip, pos_skip, self.with_xyz))
-        return x, pos_skip, batch_skip, point2curveidx_skip
+            g = geo.publish(self.geometry(idx, pos_skip, batch_skip, point2curveidx_skip, kwargs))
+        return (self.features(x, x_skip, g),) + g.out
 
 
 # --------------------------------------------------------------------------------------
@@ -412,36 +444,44 @@ class SGCNNLayer(nn.Module):
         self.force_edge_gemm = False        # tests: run the literal gather + GEMM formulation
         self.compact_rows = os.environ.get("CCN_SG_COMPACT", "1") != "0"   # dense path without its duplicate rows
 
-    def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
-        x = _with_xyz(x, pos, self.with_xyz)
-        if self.use_sparse_feat_agg:
-            # ref dgcnn.py:209-246 forward_slow: edge list from FRNN / exact kNN, message nn([x_i, x_j - x_i]),
-            # per-query max or softmax-attention over the CSR groups (BatchNorm sees the real edges only)
-            if self.aggr_type not in ("max", "attend"):
-                raise NotImplementedError("aggr_type=%r" % self.aggr_type)
-            with _geometry(kwargs) as geo:
-                topo = _topology(batch, point2curveidx, kwargs, curves=False)
-                edges = geo.publish(ops.frnn_edges(pos, topo, pos, topo, self.k, self.r, accel_knn=self.use_fast_knn))
-            msg = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row))
-            if self.aggr_type == "max":
-                out = ops.SegMax.apply(msg, edges.offsets, edges.num_dst)
-            else:
-                out = ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst)
-            return out, pos, batch, point2curveidx
-        if not self.use_fast_knn or self.aggr_type != "max":
-            raise NotImplementedError("dense SGCNN path: only the FRNN + max configuration the shipped configs use")
+    def _mode(self):
         lin0 = self.nn.lins[0]
         algebraic = lin0.bias is None and self.nn.dropout == 0.0 and not self.force_edge_gemm
         compact = (algebraic and self.compact_rows and self.k <= 63
                    and all(l.bias is None for l in self.nn.lins[:len(self.nn.norms)]))
-        with _geometry(kwargs) as geo:
-            topo = _topology(batch, point2curveidx, kwargs, curves=False)
-            padded, _ = ops.to_batch_padded(pos, topo)
-            radius = 0.25 if self.r is None else self.r
-            nbr = ops.fast_knn(padded, padded, topo.lengths, topo.lengths, self.k, radius)
-            comp = ops.SGCompact(nbr, topo) if compact else None
-            geo.publish(topo, nbr, comp.tensors() if compact else None)
-        if compact:
+        return algebraic, compact
+
+    def geometry(self, pos, batch, point2curveidx, kwargs):
+        topo = _topology(batch, point2curveidx, kwargs, curves=False)
+        out = (pos, batch, point2curveidx)
+        if self.use_sparse_feat_agg:
+            # ref dgcnn.py:209-246 forward_slow: edge list from FRNN / exact kNN
+            if self.aggr_type not in ("max", "attend"):
+                raise NotImplementedError("aggr_type=%r" % self.aggr_type)
+            edges = ops.frnn_edges(pos, topo, pos, topo, self.k, self.r, accel_knn=self.use_fast_knn)
+            return SimpleNamespace(edges=edges, out=out)
+        if not self.use_fast_knn or self.aggr_type != "max":
+            raise NotImplementedError("dense SGCNN path: only the FRNN + max configuration the shipped configs use")
+        padded, _ = ops.to_batch_padded(pos, topo)
+        radius = 0.25 if self.r is None else self.r
+        nbr = ops.fast_knn(padded, padded, topo.lengths, topo.lengths, self.k, radius)
+        comp = ops.SGCompact(nbr, topo) if self._mode()[1] else None
+        return SimpleNamespace(topo=topo, nbr=nbr, comp=comp, out=out)
+
+    def features(self, x, pos, g):
+        x = _with_xyz(x, pos, self.with_xyz)
+        if self.use_sparse_feat_agg:
+            # message nn([x_i, x_j - x_i]), per-query max or softmax-attention over the CSR groups (BatchNorm sees the
+            # real edges only)
+            edges = g.edges
+            msg = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row))
+            if self.aggr_type == "max":
+                return ops.SegMax.apply(msg, edges.offsets, edges.num_dst)
+            return ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst)
+        topo, nbr, comp = g.topo, g.nbr, g.comp
+        algebraic, _ = self._mode()
+        lin0 = self.nn.lins[0]
+        if comp is not None:
             # dense computation without its duplicate rows: every empty FRNN slot of a point (and every padding row) is the
             # same row through the whole MLP; they are kept once, with their multiplicity as weight in all reductions
             c = x.size(1)
@@ -451,8 +491,7 @@ class SGCNNLayer(nn.Module):
             feat = ops.cg_edge_layer(ps, comp, self.nn.norms[0].module if hidden0 else None, self.training,
                                      self.nn.act if hidden0 else None)
             feat = self.nn(feat, start=1, tail=(comp.e, comp.row_w, comp.count))
-            out = ops.CGMax.apply(feat, comp.grp_ptr, comp.rep_row, topo.n)
-            return out, pos, batch, point2curveidx
+            return ops.CGMax.apply(feat, comp.grp_ptr, comp.rep_row, topo.n)
         if algebraic:
             # first layer in algebraic form: two per-point products + a gather-add instead of a GEMM over
             # 21x the rows (ops.SGEdgeLayer); exact up to fp32 re-association
@@ -465,13 +504,19 @@ class SGCNNLayer(nn.Module):
             feat = self.nn(feat, start=1)
         else:
             feat = self.nn(ops.SGGather.apply(x, nbr, topo.cloud_ptr))
-        out = ops.SGMax.apply(feat, nbr, topo.cloud_ptr, topo.n)
-        return out, pos, batch, point2curveidx
+        return ops.SGMax.apply(feat, nbr, topo.cloud_ptr, topo.n)
+
+    def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
+        with _geometry(kwargs) as geo:
+            g = geo.publish(self.geometry(pos, batch, point2curveidx, kwargs))
+        return (self.features(x, pos, g),) + g.out
 
 
 class _DynamicEdgeConv(nn.Module):
     """ref dgcnn.py:16-95 DynamicEdgeConv: the neighbourhood is searched between FEATURE vectors, message
     nn([x_i, x_j - x_i]), max over each query's neighbours (empty groups give 0)."""
+
+    geometry_needs_features = True      # no position-only prepass for a model that contains this step
 
     def _search(self, feats, topo):
         raise NotImplementedError
@@ -528,16 +573,20 @@ class GlobalSAModule(nn.Module):
         if self.pooling != "max":
             raise NotImplementedError("Pooling strategy %s not implemented!" % self.pooling)
 
+    def geometry(self, pos, batch, point2curveidx, kwargs):
+        topo = _topology(batch, point2curveidx, kwargs, curves=False)
+        first = topo.cloud_ptr[:-1]
+        return SimpleNamespace(offsets=topo.cloud_ptr.to(torch.int32), num_clouds=topo.num_clouds,
+                               out=(pos[first], batch[first], None if point2curveidx is None else point2curveidx[first]))
+
+    def features(self, x, pos, g):
+        f = self.nn(ops.cat_cols([x, pos]))
+        return ops.SegMax.apply(f, g.offsets, g.num_clouds)
+
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
         with _geometry(kwargs) as geo:
-            topo = _topology(batch, point2curveidx, kwargs, curves=False)
-            offsets = topo.cloud_ptr.to(torch.int32)
-            first = topo.cloud_ptr[:-1]
-            out = (pos[first], batch[first], None if point2curveidx is None else point2curveidx[first])
-            geo.publish(offsets, out)
-        f = self.nn(ops.cat_cols([x, pos]))
-        f = ops.SegMax.apply(f, offsets, topo.num_clouds)
-        return (f,) + out
+            g = geo.publish(self.geometry(pos, batch, point2curveidx, kwargs))
+        return (self.features(x, pos, g),) + g.out
 
 
 # --------------------------------------------------------------------------------------

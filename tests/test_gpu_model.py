@@ -190,9 +190,9 @@ def test_remaining_reference_configs_match_oracle(which):
 
 
 def test_geometry_stream_modes_agree(monkeypatch):
-    """The position-only work runs on a side stream (steps.ForwardContext.geometry).  Three runs of the
-    same model and input -- side stream off, on, and on with the side stream artificially delayed at every
-    block -- must give bit-identical logits (the forward has no atomics) and the same gradients up to the
+    """The position-only work runs on a side stream (steps.ForwardContext.geometry), either step by step inside
+    forward or ahead of it (ModelBase.prepare).  Runs of the same model and input -- side stream off, on, on with the
+    side stream artificially delayed at every block, and prepared ahead with the delay -- must give bit-identical logits (the forward has no atomics) and the same gradients up to the
     atomic-add order of the weight-gradient kernels.  A missing stream dependency fails the stress run."""
     from curvecloudnet_amd import configs
     from curvecloudnet_amd.model import build_model, segmentation_loss
@@ -202,11 +202,16 @@ def test_geometry_stream_modes_agree(monkeypatch):
     data = batch_to(make_batch([3, 4], n_curves=160), DEV)
     y = _labels(data.pos.size(0), 20, 8).to(DEV)
     runs = {}
-    for mode in ("0", "1", "stress", "stress"):
-        monkeypatch.setenv("CCN_GEOMETRY_STREAM", mode)
+    for mode in ("0", "1", "stress", "stress", "prepared"):
+        monkeypatch.setenv("CCN_GEOMETRY_STREAM", "stress" if mode == "prepared" else mode)
         model.zero_grad(set_to_none=True)
         torch.manual_seed(11)
-        out = model(data)
+        if mode == "prepared":       # ModelBase.prepare: all position-only work first, features afterwards
+            plan = model.prepare(data)
+            assert plan is not None
+            out = model(data, plan=plan)
+        else:
+            out = model(data)
         segmentation_loss(out, y).backward()
         torch.cuda.synchronize()
         grads = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
