@@ -902,6 +902,7 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static bool g_force_generic = false;  // test hook (ccn_gemm_force_generic)
 static bool g_use_glds = true;        // test / A-B hook (ccn_gemm_use_dma)
 static bool g_use_persistent = true;  // A-B hook (ccn_gemm_use_dma(2) = DMA without the persistent tile loop)
+static int64_t g_dma_min_k = 64;      // DMA kernels from this K on (A-B hook: ccn_gemm_use_dma(k >= 32) sets it)
 
 template <int BM, int BN, int WM, int ALAY, int BLAY, int EPI>
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
@@ -1290,6 +1291,12 @@ extern "C" {
 int64_t ccn_stats_rows(int64_t rows) { return (rows + RED_ROWS - 1) / RED_ROWS; }
 
 int ccn_gemm_use_dma(int on) {
+  if (on >= 32) {  // threshold experiment: DMA kernels from K >= on
+    g_dma_min_k = on;
+    g_use_glds = g_use_persistent = true;
+    return CCN_OK;
+  }
+  g_dma_min_k = 64;
   g_use_glds = on != 0;
   g_use_persistent = on == 1;
   return CCN_OK;
@@ -1332,10 +1339,11 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
               (long long)M, (long long)N, (long long)K);
   if (M == 0) return CCN_OK;
   int rc;
-  // short K, or fewer than two rounds of 256-row tiles over the 256 CUs: the register-staged kernels (128-row tiles,
-  // several workgroups per CU) win -- measured 95 / 101 vs 84 / 89 TFLOP/s at M = 10550 / 35151
+  // K < 64, or fewer than two rounds of 256-row tiles over the 256 CUs: the register-staged kernels (128-row tiles,
+  // several workgroups per CU) win -- measured 95 / 101 vs 84 / 89 TFLOP/s at M = 10550 / 35151; from K = 64 on the
+  // persistent DMA kernel is ahead (K = 64: 70 vs 62, K = 96: 91 vs 82 TFLOP/s over 1.3 M rows)
   const bool dma_ok = aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && lda >= 4 && ldw >= 4 &&
-                      !g_force_generic && g_use_glds && M >= 1024 && K >= 128 &&
+                      !g_force_generic && g_use_glds && M >= 1024 && K >= g_dma_min_k &&
                       ((M + GL_BM - 1) / GL_BM) * ((N + 127) / 128) >= 512;
   if (dma_ok && bias == nullptr && K % BK == 0 && g_use_persistent &&
       ((M + GL_BM - 1) / GL_BM) * ((N + 127) / 128) >= 512) {

@@ -58,9 +58,10 @@ def test_linear_plain_fwd_bwd(M, K, N):
         _close(a, r, 5e-5, name)
 
 
-@pytest.mark.parametrize("M,K,N", [(3000, 67, 20), (131500, 256, 64), (131200, 134, 192), (70000, 160, 300)])
+@pytest.mark.parametrize("M,K,N", [(3000, 67, 20), (131500, 256, 64), (131200, 134, 192), (70000, 160, 300),
+                                   (140000, 64, 100), (135000, 96, 128), (133000, 72, 64)])
 def test_gemm_dma_pipeline_matches_register_staged_kernel(M, K, N):
-    """Y = X W^T + b with BatchNorm partial statistics: LDS-DMA pipeline kernel (taken for K >= 128 and >= 512 tiles of
+    """Y = X W^T + b with BatchNorm partial statistics: LDS-DMA pipeline kernel (taken for K >= 64 and >= 512 tiles of
     256 x 128; the bias keeps it off the persistent form; K = 134 / 160 exercise the K tail) vs the register-staged
     kernel (first shape: both runs are the staged kernel)."""
     from curvecloudnet_amd import _lib
@@ -85,7 +86,8 @@ def test_gemm_dma_pipeline_matches_register_staged_kernel(M, K, N):
     _close(outs[0][0], F.linear(x.cpu(), w.cpu(), b.cpu()), 5e-5, "vs torch")
 
 
-@pytest.mark.parametrize("M,K,N", [(140000, 128, 128), (270001, 64 + 64, 64), (150000, 256, 192), (300000, 160, 20)])
+@pytest.mark.parametrize("M,K,N", [(140000, 128, 128), (270001, 64 + 64, 64), (150000, 256, 192), (300000, 160, 20),
+                                   (300000, 64, 128), (280000, 96, 64), (140000, 64, 33)])
 def test_gemm_persistent_dma_kernel(M, K, N):
     """No bias, K % 32 == 0, >= 512 tiles: the persistent LDS-DMA kernel (tiles streamed through one ring) against
     the one-tile-per-workgroup DMA kernel and torch; statistics partial rows included."""

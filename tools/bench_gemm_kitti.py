@@ -4,7 +4,7 @@ import torch
 from curvecloudnet_amd._lib import call, ptr, lib
 from curvecloudnet_amd.ops import _rows, _ld
 
-SHAPES = [(1342781, 256, 256), (67368, 1024, 1024), (224448, 512, 512), (4408488, 64, 64), (1652112, 128, 128),
+SHAPES = [(1342781, 64, 128), (2341754, 64, 64), (1342781, 96, 128), (1342781, 256, 256), (67368, 1024, 1024), (224448, 512, 512), (4408488, 64, 64), (1652112, 128, 128),
           (10550, 1024, 1024), (35151, 512, 512)]
 dev = "cuda"
 
