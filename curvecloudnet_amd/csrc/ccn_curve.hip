@@ -215,6 +215,36 @@ __global__ __launch_bounds__(256) void im2col_bwd_kernel(const float* __restrict
   dx[j * lddx + c] = acc;
 }
 
+// Convolution as "product first, shift-add second" (layers with C_in >> C_out on the zero-separated V2 sequence):
+// P = X W_all^T holds, per row, the contribution of that row to each tap of each output channel (taps*C_out columns
+// instead of the taps*C_in columns of the shifted-row matrix); Y[i][co] = b[co] + sum_tap P[i + tap - h][tap*C_out + co].
+__global__ __launch_bounds__(256) void shift_add_fwd_kernel(const float* __restrict__ P, int64_t ldp,
+                                                            const float* __restrict__ bias, int64_t rows, int Co, int taps,
+                                                            float* __restrict__ Y, int64_t ldy) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows * Co) return;
+  const int64_t i = rows * Co < 0xffffffffLL ? (int64_t)((uint32_t)t / (uint32_t)Co) : t / Co;
+  const int co = (int)(t - i * Co);
+  float acc = bias ? bias[co] : 0.f;
+  for (int tap = 0; tap < taps; ++tap) {
+    const int64_t j = i + tap - taps / 2;
+    if (j >= 0 && j < rows) acc += P[j * ldp + tap * Co + co];
+  }
+  Y[i * ldy + co] = acc;
+}
+
+__global__ __launch_bounds__(256) void shift_add_bwd_kernel(const float* __restrict__ dY, int64_t lddy, int64_t rows, int Co,
+                                                            int taps, float* __restrict__ dP, int64_t lddp) {
+  const int W = taps * Co;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows * W) return;
+  const int64_t j = rows * W < 0xffffffffLL ? (int64_t)((uint32_t)t / (uint32_t)W) : t / W;
+  const int q = (int)(t - j * W);
+  const int tap = (int)((uint32_t)q / (uint32_t)Co), co = q - tap * Co;
+  const int64_t i = j - tap + taps / 2;  // the output row that read P[j] through tap `tap`
+  dP[j * lddp + q] = (i >= 0 && i < rows) ? dY[i * lddy + co] : 0.f;
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ src, int64_t lds_, const int64_t* __restrict__ index,
                                    int64_t m, int64_t C, float* __restrict__ dst, int64_t ldd) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -638,6 +668,30 @@ int ccn_im2col_bwd(const float* dcol, int64_t ldcol, const int32_t* seg, int64_t
   hipLaunchKernelGGL(im2col_bwd_kernel, dim3(ccn_blocks(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, dcol, ldcol, seg,
                      rows, (int)C, (int)taps, dx, lddx);
   CCN_LAUNCH_OK("im2col_bwd");
+  return CCN_OK;
+}
+
+int ccn_shift_add_fwd(const float* P, int64_t ldp, const float* bias, int64_t rows, int64_t Co, int64_t taps, float* Y,
+                      int64_t ldy, void* stream) {
+  CCN_REQUIRE(P && Y && rows >= 0 && Co > 0 && Co < (1 << 20) && taps >= 1 && (taps & 1) && taps < 64 &&
+                  ldp >= taps * Co && ldy >= Co,
+              "shift_add_fwd: bad arguments");
+  if (rows == 0) return CCN_OK;
+  hipLaunchKernelGGL(shift_add_fwd_kernel, dim3(ccn_blocks(rows * Co, 256)), dim3(256), 0, (hipStream_t)stream, P, ldp,
+                     bias, rows, (int)Co, (int)taps, Y, ldy);
+  CCN_LAUNCH_OK("shift_add_fwd");
+  return CCN_OK;
+}
+
+int ccn_shift_add_bwd(const float* dY, int64_t lddy, int64_t rows, int64_t Co, int64_t taps, float* dP, int64_t lddp,
+                      void* stream) {
+  CCN_REQUIRE(dY && dP && rows >= 0 && Co > 0 && Co < (1 << 20) && taps >= 1 && (taps & 1) && taps < 64 &&
+                  lddp >= taps * Co && lddy >= Co,
+              "shift_add_bwd: bad arguments");
+  if (rows == 0) return CCN_OK;
+  hipLaunchKernelGGL(shift_add_bwd_kernel, dim3(ccn_blocks(rows * taps * Co, 256)), dim3(256), 0, (hipStream_t)stream, dY,
+                     lddy, rows, (int)Co, (int)taps, dP, lddp);
+  CCN_LAUNCH_OK("shift_add_bwd");
   return CCN_OK;
 }
 

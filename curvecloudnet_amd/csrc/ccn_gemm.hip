@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(256) void col_partial_w_kernel(const float* __restr
         rs = rstd[c];
       }
       for (int64_t r = r0 + ry; r < r1; r += 4) {
-        const double wr = (double)w[r];
+        const double wr = w ? (double)w[r] : 1.0;
         const float xv = X[r * ldx + c];
         if (MODE == 0) {
           s1 += wr * (double)xv;
@@ -1525,7 +1525,7 @@ int ccn_colstats_weighted(const float* X, int64_t ldx, const float* w, int64_t r
                           void* stream) {
   // acc: 2*C totals (sum w*x, sum w*x^2) followed by [ccn_stats_rows(rows)][2*C] doubles of scratch
   hipStream_t s = (hipStream_t)stream;
-  CCN_REQUIRE(X && w && acc && rows > 0 && C > 0 && ldx >= C, "colstats_weighted: bad arguments");
+  CCN_REQUIRE(X && acc && rows > 0 && C > 0 && ldx >= C, "colstats_weighted: bad arguments");   // w == NULL: weights 1
   const int64_t nparts = ccn_stats_rows(rows);
   double* partial = acc + 2 * C;
   hipLaunchKernelGGL(col_partial_w_kernel<0>, dim3((unsigned)nparts), dim3(256), 0, s, X, ldx, (const float*)nullptr,

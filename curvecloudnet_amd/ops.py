@@ -1177,3 +1177,69 @@ class CGMax(torch.autograd.Function):
         df = _rows(rows, c, g.device)
         call("cg_max_bwd", ptr(g), _ld(g), ptr(arg), ptr(grp_ptr), ptr(rep_row), n, rows, c, ptr(df), _ld(df))
         return df, None, None, None
+
+
+class ShiftAddBNAct(torch.autograd.Function):
+    """Second half of a curve-conv layer computed as "product first, shift-add second" (see ccn_shift_add_fwd):
+    y = shift_add(P) + b, BatchNorm over the rows (batch statistics in training mode), activation."""
+
+    @staticmethod
+    def forward(ctx, p, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum, taps):
+        p = _mat(p)
+        m = p.size(0)
+        n = p.size(1) // taps
+        dev = p.device
+        ctx.act, ctx.training, ctx.taps, ctx.has_bias, ctx.ldp = ACT[act], bool(training), taps, bias is not None, p.size(1)
+        y = _rows(m, n, dev)
+        call("shift_add_fwd", ptr(p), _ld(p), ptr(bias), m, n, taps, ptr(y), _ld(y))
+        par = torch.empty((4, n), dtype=torch.float32, device=dev)
+        if training:
+            if m < 2:
+                raise ValueError("Expected more than 1 value per channel when training")
+            acc = _stats_buffer(m, n, dev)
+            call("colstats_weighted", ptr(y), _ld(y), None, m, n, ptr(acc))
+            # acc[0:2n] holds the totals: finalise from that single row
+            call("bn_finalize_n", ptr(acc), 1, m, n, ptr(gamma), ptr(beta), float(eps), float(momentum), ptr(running_mean),
+                 ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        else:
+            call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), n,
+                 ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        z = _rows(m, n, dev)
+        call("bn_act_fwd", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
+        ctx.save_for_backward(y, par)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        y, par = ctx.saved_tensors
+        g = _mat(g)
+        dev = g.device
+        m, n = y.shape
+        pp = (ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        sums = _stats_buffer(m, n, dev)
+        call("bn_act_bwd_reduce", ptr(g), _ld(g), ptr(y), _ld(y), m, n, *pp, ctx.act, LEAKY_SLOPE, ptr(sums))
+        dy = _rows(m, n, dev)
+        dgb = torch.empty((2, n), dtype=torch.float32, device=dev)
+        call("bn_act_bwd_apply", ptr(g), _ld(g), ptr(y), _ld(y), m, n, *pp, ctx.act, LEAKY_SLOPE, ptr(sums),
+             1 if ctx.training else 0, ptr(dy), _ld(dy), ptr(dgb[0]), ptr(dgb[1]))
+        dp = _rows(m, ctx.ldp, dev)
+        call("shift_add_bwd", ptr(dy), _ld(dy), m, n, ctx.taps, ptr(dp), _ld(dp))
+        db = None
+        if ctx.has_bias:
+            acc = _stats_buffer(m, n, dev)
+            db = torch.empty(n, dtype=torch.float32, device=dev)
+            call("colsum", ptr(dy), _ld(dy), m, n, ptr(acc), ptr(db))
+        return dp, db, dgb[0], dgb[1], None, None, None, None, None, None, None
+
+
+def conv_rows_bn_act(x, gemm_weight, bias, bn, training, act, taps):
+    """One conv + BatchNorm + activation layer on an unsegmented row sequence (V2 layout) for C_in >= 2*C_out:
+    P = X W_all^T over the rows, then the shift-add; ``gemm_weight`` is the (C_out, taps*C_in) shifted-row matrix."""
+    co, cin = gemm_weight.size(0), gemm_weight.size(1) // taps
+    w_all = gemm_weight.view(co, taps, cin).permute(1, 0, 2).reshape(taps * co, cin)
+    p = linear_bn_act(x, w_all, None, None, False, None)
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    use_batch_stats = training or not bn.track_running_stats
+    return ShiftAddBNAct.apply(p, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats, act, bn.eps,
+                               bn.momentum if bn.momentum is not None else 0.1, taps)

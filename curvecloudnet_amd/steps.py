@@ -171,8 +171,15 @@ def _conv_stack(feat_dims, kernel_size, bias, with_diff, diff_every_layer):
 
 
 def _conv_bn_act(x, seg, taps, conv, norm, training):
+    if seg is None and taps > 1 and x.size(1) >= 2 * conv.out_channels and CONV_SHIFT_ADD:
+        # many more input than output channels on the unsegmented V2 sequence: product first (taps*C_out columns per row),
+        # shift-add second, instead of materialising the taps*C_in-column shifted-row matrix
+        return ops.conv_rows_bn_act(x, conv.gemm_weight(), conv.bias, norm, training, "leaky_relu", taps)
     col = ops.Im2Col.apply(x, seg, taps)
     return ops.linear_bn_act(col, conv.gemm_weight(), conv.bias, norm, training, "leaky_relu")
+
+
+CONV_SHIFT_ADD = os.environ.get("CCN_CONV_SHIFT_ADD", "1") != "0"
 
 
 class SymmetricCurve1DConvFastV1(nn.Module):

@@ -113,6 +113,15 @@ int ccn_interp_fwd(const float* x, int64_t ldx, const int64_t* nbr, const float*
 int ccn_interp_bwd(const float* dy, int64_t lddy, const int64_t* nbr, const float* weight, int64_t n, int64_t k,
                    int64_t C, float* dx, int64_t lddx, void* stream);
 
+/* Symmetric curve convolution on the zero-separated V2 sequence (fast_conv1d.py:60-73) for layers with many more input
+ * than output channels, as "product first, shift-add second": P = X W_all^T (W_all: taps*C_out x C_in, one GEMM) and
+ * Y[i][co] = bias[co] + sum_tap P[i + tap - taps/2][tap*C_out + co] (rows outside the sequence contribute 0).  bwd: the
+ * gather dP[j][tap*C_out + co] = dY[j - tap + taps/2][co].  Replaces the (rows x taps*C_in) shifted-row matrix. */
+int ccn_shift_add_fwd(const float* P, int64_t ldp, const float* bias, int64_t rows, int64_t Co, int64_t taps, float* Y,
+                      int64_t ldy, void* stream);
+int ccn_shift_add_bwd(const float* dY, int64_t lddy, int64_t rows, int64_t Co, int64_t taps, float* dP, int64_t lddp,
+                      void* stream);
+
 /* ---- A11: point_ops.py:459 frnn.frnn_grid_points (third_party/FRNN: grid build + radius query) ---
  * points: (B, P, 3) float32 zero padded, lengths int64 (B), r float32 (B).  idx: (B, P1, K) int64, the
  * <=K nearest points2 with d2 < r*r ascending by (d2, index), -1 padded; rows >= lengths1 are -1.
@@ -281,6 +290,7 @@ int ccn_cg_max_fwd(const float* f, int64_t ldf, const int32_t* grp_ptr, const in
                    float* out, int64_t ldo, int32_t* arg, void* stream);
 int ccn_cg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const int32_t* grp_ptr, const int32_t* rep_row,
                    int64_t N, int64_t R, int64_t C, float* df, int64_t lddf, void* stream);
+/* w == NULL: all weights 1 (plain column sums of x and x^2) */
 int ccn_colstats_weighted(const float* X, int64_t ldx, const float* w, int64_t rows, int64_t C, double* acc,
                           void* stream);
 int ccn_bn_act_bwd_reduce_weighted(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, const float* w,

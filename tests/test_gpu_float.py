@@ -633,3 +633,31 @@ def test_sgcnn_compact_rows_match_dense_rows(ids, k, r):
         _close(a, b, 1e-4, "compact vs dense")
     for a, b in zip(*stats):
         _close(a, b, 1e-5, "running statistics")
+
+
+def test_conv_shift_add_matches_shifted_row_gemm():
+    """V2 conv layers with C_in >= 2*C_out: "product first, shift-add second" against the shifted-row (im2col) GEMM --
+    outputs, gradients of input / weights / BatchNorm parameters, running statistics."""
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([1, 2], n_curves=70)
+    torch.manual_seed(0)
+    mod = steps.SymmetricCurve1DConvV2([37, 16, 8, 12], 5, with_xyz=True, with_diff=True).to(DEV).train()
+    x = torch.randn(d.pos.size(0), 34, generator=torch.Generator().manual_seed(4)).to(DEV)
+    cot = torch.randn(d.pos.size(0), 12, generator=torch.Generator().manual_seed(5)).to(DEV)
+    res, stats = [], []
+    for flag in (True, False):
+        steps.CONV_SHIFT_ADD = flag
+        try:
+            for bn in mod.norm_modules:
+                bn.reset_running_stats()
+            xi = x.clone().requires_grad_(True)
+            out = mod(xi, d.pos.to(DEV), d.batch.to(DEV), d.curve_idxs.to(DEV))[0]
+            res.append([out.detach()] + list(torch.autograd.grad((out * cot).sum(), [xi] + list(mod.parameters()))))
+            stats.append([b.detach().clone().float() for b in mod.buffers()])
+        finally:
+            steps.CONV_SHIFT_ADD = True
+    for a, b in zip(*res):
+        _close(a, b, 1e-4, "shift-add vs shifted-row GEMM")
+    for a, b in zip(*stats):
+        _close(a, b, 1e-5, "running statistics")
