@@ -3,7 +3,6 @@ section of the YAMLs, same state-dict keys) and runs its skip-connection state m
 (ref src/models/base.py:16-215).
 """
 import copy
-import os
 
 import torch
 import torch.nn.functional as F

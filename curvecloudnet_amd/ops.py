@@ -3,12 +3,10 @@
 PyTorch supplies device memory, streams and autograd bookkeeping only; every arithmetic step on
 the hot path is a ``ccn_*`` kernel launch.  Reference call sites are cited per operator.
 """
-import ctypes
 import os
 
 import torch
 
-from . import _lib
 from ._lib import call, lib, ptr, require_gpu, workspace
 
 ACT = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2}
