@@ -35,10 +35,13 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 def gemm_label(name, ints, nulls=()):
     """(kernel symbol as rocprofv3 prints it, flops) of a GEMM launch; mirrors the dispatch in csrc/ccn_gemm.hip."""
-    if name not in ("gemm_nt", "gemm_nn", "gemm_tn", "gemm_nt_bf16"):
+    if name not in ("gemm_nt", "gemm_nn", "gemm_tn", "gemm_nt_bf16", "gemm_tn_bf16"):
         return None, 0.0
     ld_a, ld_b, _, m, n, k = ints[:6]
     flops = 2.0 * m * n * k
+    if name == "gemm_tn_bf16":
+        bm, bn = (64 if n <= 64 else 128), (64 if k <= 64 else 128)
+        return "gemm_bf16_tn_kernel<%d, %d, %d>" % (bm, bn, bm // 32), flops
     if name == "gemm_nt_bf16":
         return "gemm_bf16_kernel<128, %d, 4>" % (32 if n <= 32 else (64 if n <= 64 else 128)), flops
     aligned = ld_a % 4 == 0 and ld_b % 4 == 0

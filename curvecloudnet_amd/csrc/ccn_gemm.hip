@@ -483,6 +483,102 @@ __global__ __launch_bounds__(GEMM_TPB) void gemm_bf16_kernel(const float* __rest
                                            colstats);
 }
 
+// bf16 weight gradient: C[M x N] += A^T B with both operands stored contraction-major (A: (k, r) at p[k*lda + r], i.e.
+// dW += dY^T X with the sample index as k).  A thread's float4 holds 4 consecutive rows r at ONE k, so the rounded
+// values are scattered into the same [row][k] bf16 LDS image the NT kernel uses (4 two-byte writes per float4); the
+// multiply loop and the fragment reads are then identical.  The reduction over k is split across blockIdx.z and
+// accumulated with fp32 atomics like the fp32 kernel.
+template <int ROWS>
+__device__ __forceinline__ void tile_store_bf16_mc(__bf16* __restrict__ lds,
+                                                   const float4 (&regs)[Tile<ROWS, MC>::PER_THREAD]) {
+  constexpr int Q = ROWS / 4;
+#pragma unroll
+  for (int it = 0; it < Tile<ROWS, MC>::PER_THREAD; ++it) {
+    const int slot = threadIdx.x + it * GEMM_TPB;
+    const int kk = slot / Q, rq = slot - kk * Q;
+    __bf16* dst = lds + (4 * rq) * BF_LD + kk;
+    dst[0] = (__bf16)regs[it].x;
+    dst[BF_LD] = (__bf16)regs[it].y;
+    dst[2 * BF_LD] = (__bf16)regs[it].z;
+    dst[3 * BF_LD] = (__bf16)regs[it].w;
+  }
+}
+
+template <int BM, int BN, int WM>
+__global__ __launch_bounds__(GEMM_TPB) void gemm_bf16_tn_kernel(const float* __restrict__ A, int64_t lda,
+                                                                const float* __restrict__ B, int64_t ldb,
+                                                                float* __restrict__ C, int64_t ldc, int64_t M, int64_t N,
+                                                                int64_t K, int64_t kchunk) {
+  constexpr int WN = 4 / WM;
+  constexpr int WCOLS = BN / WN;
+  constexpr int NT = WCOLS / 32;
+  constexpr int AE = BM * BF_LD, BE = BN * BF_LD;
+  static_assert(BM == 32 * WM && NT >= 1, "tile shape");
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (AE + BE)];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int i = lane & 31, h = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+
+  f32x16 acc[NT];
+  acc_init<NT>(acc, nullptr, n0 + wn * WCOLS, N, i);
+
+  FastLoader<BM, MC> la;
+  FastLoader<BN, MC> lb;
+  la.init(A, lda, m0, M);
+  lb.init(B, ldb, n0, N);
+  float4 ra[Tile<BM, MC>::PER_THREAD], rb[Tile<BN, MC>::PER_THREAD];
+  if (kbeg < kend) {
+    if (kbeg + BK <= kend) {
+      la.load_full(kbeg, ra);
+      lb.load_full(kbeg, rb);
+    } else {
+      la.load_tail(kbeg, kend, ra);
+      lb.load_tail(kbeg, kend, rb);
+    }
+    tile_store_bf16_mc<BM>(lds, ra);
+    tile_store_bf16_mc<BN>(lds + AE, rb);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+    const __bf16* As = lds + buf * (AE + BE);
+    const __bf16* Bs = As + AE;
+    const int64_t kn = k0 + BK;
+    if (kn < kend) {
+      if (kn + BK <= kend) {
+        la.load_full(kn, ra);
+        lb.load_full(kn, rb);
+      } else {
+        la.load_tail(kn, kend, ra);
+        lb.load_tail(kn, kend, rb);
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const bf16x8 a8 = *reinterpret_cast<const bf16x8*>(As + (wm * 32 + i) * BF_LD + (2 * st + h) * 8);
+      bf16x8 b8[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        b8[t] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WCOLS + t * 32 + i) * BF_LD + (2 * st + h) * 8);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8[t], acc[t], 0, 0, 0);
+    }
+    if (kn < kend) {
+      __bf16* An = lds + (buf ^ 1) * (AE + BE);
+      tile_store_bf16_mc<BM>(An, ra);
+      tile_store_bf16_mc<BN>(An + AE, rb);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+  gemm_epilogue<BM, BN, WM, EPI_ATOMIC, NT>(acc, reinterpret_cast<float*>(lds), nullptr, C, ldc, M, N, m0, n0, wm, wn, i, h,
+                                            nullptr);
+}
+
 // ------------------------------------------------------------------ LDS-DMA pipeline (Y = A W^T, both operands KC)
 // 256 x BN tile, 8 waves (one 32-row band each), BK = 32.  Tiles reach LDS with global_load_lds_dwordx4
 // (no VGPR staging): one wave instruction copies 8 rows x 128 B into a linear 1 KiB span, so the tile rows are
@@ -1286,6 +1382,27 @@ __global__ void colsum_out_kernel(const double* __restrict__ sums, int64_t C, fl
 
 }  // namespace
 
+template <int BM, int BN, int WM>
+static int launch_bf16_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                          int64_t N, int64_t K, hipStream_t s) {
+  // output N x K, contraction over the M rows split across ~2048 workgroups
+  const int64_t gm = (N + BM - 1) / BM, gn = (K + BN - 1) / BN;
+  int64_t ksplit = (2048 + gm * gn - 1) / (gm * gn);
+  const int64_t max_split = (M + 4 * BK - 1) / (4 * BK);
+  if (ksplit > max_split) ksplit = max_split;
+  if (ksplit < 1) ksplit = 1;
+  int64_t kchunk = (M + ksplit - 1) / ksplit;
+  kchunk = (kchunk + BK - 1) / BK * BK;
+  const int64_t gz = (M + kchunk - 1) / kchunk;
+  if (gm > 2147483647LL || gn > 65535 || gz > 65535) {
+    ccn_set_error("gemm_tn_bf16: grid too large");
+    return CCN_ERR_ARG;
+  }
+  hipLaunchKernelGGL((gemm_bf16_tn_kernel<BM, BN, WM>), dim3((unsigned)gm, (unsigned)gn, (unsigned)gz), dim3(GEMM_TPB), 0, s,
+                     dY, lddy, X, ldx, dW, lddw, N, K, M, kchunk);
+  return CCN_OK;
+}
+
 extern "C" {
 
 int64_t ccn_stats_rows(int64_t rows) { return (rows + RED_ROWS - 1) / RED_ROWS; }
@@ -1421,6 +1538,26 @@ int ccn_gemm_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, floa
   }
   if (rc) return rc;
   CCN_LAUNCH_OK("gemm_tn");
+  return CCN_OK;
+}
+
+int ccn_gemm_tn_bf16(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                     int64_t N, int64_t K, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(dY && X && dW, "gemm_tn_bf16: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "gemm_tn_bf16: bad sizes");
+  CCN_REQUIRE(aligned16(dY) && aligned16(X) && lddy % 4 == 0 && ldx % 4 == 0 && lddy >= 4 && ldx >= 4,
+              "gemm_tn_bf16: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+  if (M == 0) return CCN_OK;
+  int rc;
+  if (N <= 64)
+    rc = K <= 64 ? launch_bf16_tn<64, 64, 2>(dY, lddy, X, ldx, dW, lddw, M, N, K, s)
+                 : launch_bf16_tn<64, 128, 2>(dY, lddy, X, ldx, dW, lddw, M, N, K, s);
+  else
+    rc = K <= 64 ? launch_bf16_tn<128, 64, 4>(dY, lddy, X, ldx, dW, lddw, M, N, K, s)
+                 : launch_bf16_tn<128, 128, 4>(dY, lddy, X, ldx, dW, lddw, M, N, K, s);
+  if (rc) return rc;
+  CCN_LAUNCH_OK("gemm_tn_bf16");
   return CCN_OK;
 }
 

@@ -259,8 +259,9 @@ _MLP_DTYPE = os.environ.get("CCN_MLP_DTYPE", "fp32")
 def set_mlp_dtype(name):
     """"fp32" (default): exact fp32 MFMA products.  "bf16": the forward and data-gradient products of every
     Linear / conv layer (``LinearBNAct``) round their operands to bf16 inside the GEMM and accumulate in fp32
-    (``ccn_gemm_nt_bf16``, BASELINE configs 3 and 5); weights, activations, BatchNorm statistics and the weight
-    gradients stay fp32.  Also settable with the environment variable CCN_MLP_DTYPE."""
+    (``ccn_gemm_nt_bf16``, BASELINE configs 3 and 5), and so do the weight-gradient products (``ccn_gemm_tn_bf16``);
+    weights, activations, gradients and BatchNorm statistics are stored and reduced in fp32.  Also settable with the
+    environment variable CCN_MLP_DTYPE."""
     global _MLP_DTYPE
     if name not in ("fp32", "bf16"):
         raise ValueError("mlp dtype must be 'fp32' or 'bf16'")
@@ -357,7 +358,11 @@ class LinearBNAct(torch.autograd.Function):
                 dy = _aligned_rows(dy)
             call(ctx.gemm_nt, ptr(dy), _ld(dy), ptr(wt), _ld(wt), None, ptr(dx), _ld(dx), m, k, n, None)
         dw = _rows(n, k, dev, zero=True)
-        call("gemm_tn", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
+        if ctx.gemm_nt == "gemm_nt_bf16":
+            dy = _aligned_rows(dy)
+            call("gemm_tn_bf16", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
+        else:
+            call("gemm_tn", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
         db = None
         if ctx.has_bias:
             acc = _stats_buffer(m, n, dev)
@@ -1137,11 +1142,12 @@ class LinearBNActTail(torch.autograd.Function):
             wtt.copy_(wt[:, :k].t())
             call(ctx.gemm_nt, ptr(dy), _ld(dy), ptr(wtt), _ld(wtt), None, ptr(dx), _ld(dx), m, k, n, None)
         dw = _rows(n, k, dev, zero=True)
-        call("gemm_tn", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), tail, n, k)
+        gemm_tn = "gemm_tn_bf16" if ctx.gemm_nt == "gemm_nt_bf16" else "gemm_tn"
+        call(gemm_tn, ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), tail, n, k)
         dyt = _rows(t, n, dev)
         torch.mul(dy[tail:], w[:, None], out=dyt)
         xt = x[tail:]
-        call("gemm_tn", ptr(dyt), _ld(dyt), ptr(xt), _ld(x), ptr(dw), _ld(dw), t, n, k)
+        call("gemm_tn", ptr(dyt), _ld(dyt), ptr(xt), _ld(x), ptr(dw), _ld(dw), t, n, k)       # few rows: fp32
         return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None
 
 

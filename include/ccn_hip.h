@@ -157,7 +157,10 @@ int ccn_gemm_nt_bf16(const float* A, int64_t lda, const float* W, int64_t ldw, c
 int ccn_gemm_nn(const float* dY, int64_t lddy, const float* W, int64_t ldw, float* dX, int64_t lddx, int64_t M,
                 int64_t N, int64_t K, void* stream);                              /* dX = dY W      */
 int ccn_gemm_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
-                int64_t N, int64_t K, void* stream); /* dW += dY^T X (dW pre-zeroed by caller) */
+                int64_t N, int64_t K, void* stream);
+/* bf16 MFMA form of ccn_gemm_tn (bf16 MLP mode): dW += bf16(dY)^T bf16(X), fp32 accumulation; 16-byte aligned operands. */
+int ccn_gemm_tn_bf16(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                     int64_t N, int64_t K, void* stream); /* dW += dY^T X (dW pre-zeroed by caller) */
 
 int ccn_bn_finalize(const double* colstats, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
                     float momentum, float* running_mean, float* running_var, float* scale, float* shift,

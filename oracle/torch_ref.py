@@ -96,7 +96,7 @@ def feature_diffs(x, point2curveidx, batch):
 
 # --------------------------------------------------------------------------------------
 # bf16 MLP mode (BASELINE configs 3 / 5): emulation of "operands rounded to bf16, fp32 accumulation" for the
-# forward and data-gradient products; weight gradients use the unrounded fp32 operands.
+# forward, data-gradient and weight-gradient products.
 # --------------------------------------------------------------------------------------
 MLP_DTYPE = "fp32"
 
@@ -122,7 +122,7 @@ class _LinearBF16(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        return _bf16(g) @ _bf16(w), g.t() @ x, (g.sum(0) if ctx.has_bias else None)
+        return _bf16(g) @ _bf16(w), _bf16(g).t() @ _bf16(x), (g.sum(0) if ctx.has_bias else None)
 
 
 class _Conv1dBF16(torch.autograd.Function):
@@ -136,7 +136,7 @@ class _Conv1dBF16(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         dx = torch.nn.grad.conv1d_input(x.shape, _bf16(w), _bf16(g), stride=1, padding=ctx.pad)
-        dw = torch.nn.grad.conv1d_weight(x, w.shape, g, stride=1, padding=ctx.pad)
+        dw = torch.nn.grad.conv1d_weight(_bf16(x), w.shape, _bf16(g), stride=1, padding=ctx.pad)
         return dx, dw, (g.sum(dim=(0, 2)) if ctx.has_bias else None), None
 
 
