@@ -272,6 +272,30 @@ def mlp_dtype():
     return _MLP_DTYPE
 
 
+def _has_main_grad(weight):
+    return getattr(weight, "_ccn_main_grad", None) is not None and weight.is_leaf and weight.requires_grad
+
+
+def _main_grad(weight, n, k):
+    """The parameter's gradient-bucket view (parallel.GradientAllReduce) if the weight gradient can be accumulated
+    straight into it: an fp32 (n, k) row-major view.  The weight-gradient product accumulates with atomics anyway, so
+    writing there saves the zero-fill of a temporary and autograd's add."""
+    if weight is None:
+        return None
+    g = getattr(weight, "_ccn_main_grad", None)
+    if g is None or g.dtype != torch.float32 or tuple(g.shape) != (n, k) or not g.is_contiguous() or not g.is_cuda:
+        return None
+    return g
+
+
+def _main_grad_done(weight):
+    """Tell the gradient all-reduce that this parameter's gradient is complete (autograd is given no tensor for it)."""
+    ready = getattr(weight, "_ccn_grad_ready", None)
+    if ready is not None:
+        ready()
+    return None
+
+
 def _aligned_rows(t):
     """A copy with a 16-byte aligned, multiple-of-4 leading dimension when ``t`` does not have one already (the bf16
     kernel and the LDS-DMA kernels only take such operands; everything the step modules produce already qualifies)."""
@@ -303,6 +327,7 @@ class LinearBNAct(torch.autograd.Function):
         has_bn = gamma is not None
         ctx.has_bn, ctx.act, ctx.training, ctx.has_bias = has_bn, ACT[act], bool(training), bias is not None
         gemm_nt = ctx.gemm_nt = "gemm_nt_bf16" if _MLP_DTYPE == "bf16" else "gemm_nt"
+        ctx.main_grad_of = weight if _has_main_grad(weight) else None
         if gemm_nt == "gemm_nt_bf16":
             x = _aligned_rows(x)
         if not has_bn:
@@ -357,12 +382,17 @@ class LinearBNAct(torch.autograd.Function):
             if ctx.gemm_nt == "gemm_nt_bf16":
                 dy = _aligned_rows(dy)
             call(ctx.gemm_nt, ptr(dy), _ld(dy), ptr(wt), _ld(wt), None, ptr(dx), _ld(dx), m, k, n, None)
-        dw = _rows(n, k, dev, zero=True)
-        if ctx.gemm_nt == "gemm_nt_bf16":
-            dy = _aligned_rows(dy)
-            call("gemm_tn_bf16", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
-        else:
-            call("gemm_tn", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            into = _main_grad(ctx.main_grad_of, n, k)
+            dw = into if into is not None else _rows(n, k, dev, zero=True)
+            if ctx.gemm_nt == "gemm_nt_bf16":
+                dy = _aligned_rows(dy)
+                call("gemm_tn_bf16", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
+            else:
+                call("gemm_tn", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
+            if into is not None:
+                dw = _main_grad_done(ctx.main_grad_of)
         db = None
         if ctx.has_bias:
             acc = _stats_buffer(m, n, dev)
@@ -1088,6 +1118,7 @@ class LinearBNActTail(torch.autograd.Function):
         dev = x.device
         wt = _aligned_weight(weight.detach())
         ctx.act, ctx.training, ctx.tail, ctx.count = ACT[act], bool(training), int(tail), float(count)
+        ctx.main_grad_of = weight if _has_main_grad(weight) else None
         gemm_nt = ctx.gemm_nt = "gemm_nt_bf16" if _MLP_DTYPE == "bf16" else "gemm_nt"
         if gemm_nt == "gemm_nt_bf16":
             x = _aligned_rows(x)
@@ -1141,13 +1172,16 @@ class LinearBNActTail(torch.autograd.Function):
             wtt = _rows(k, n, dev, zero=(n % 4 != 0))
             wtt.copy_(wt[:, :k].t())
             call(ctx.gemm_nt, ptr(dy), _ld(dy), ptr(wtt), _ld(wtt), None, ptr(dx), _ld(dx), m, k, n, None)
-        dw = _rows(n, k, dev, zero=True)
+        into = _main_grad(ctx.main_grad_of, n, k)
+        dw = into if into is not None else _rows(n, k, dev, zero=True)
         gemm_tn = "gemm_tn_bf16" if ctx.gemm_nt == "gemm_nt_bf16" else "gemm_tn"
         call(gemm_tn, ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), tail, n, k)
         dyt = _rows(t, n, dev)
         torch.mul(dy[tail:], w[:, None], out=dyt)
         xt = x[tail:]
         call("gemm_tn", ptr(dyt), _ld(dyt), ptr(xt), _ld(x), ptr(dw), _ld(dw), t, n, k)       # few rows: fp32
+        if into is not None:
+            dw = _main_grad_done(ctx.main_grad_of)
         return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None
 
 

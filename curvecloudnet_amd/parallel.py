@@ -71,6 +71,11 @@ class GradientAllReduce:
         off = 0
         for p in plist:
             p.grad = flat[off: off + p.numel()].view_as(p)
+            # the HIP layers add a weight gradient straight into this view (ops.LinearBNAct: the product already
+            # accumulates with atomics) instead of returning a tensor for autograd to add -- one launch per layer
+            # instead of three (zero-fill, product, add); they report completion through _ccn_grad_ready
+            p._ccn_main_grad = p.grad
+            p._ccn_grad_ready = (lambda q=p: self._on_grad(q)) if self.world > 1 else None
             off += p.numel()
             self._bucket_of[p] = len(self.buckets)
         self.buckets.append((flat, list(plist)))
@@ -115,6 +120,7 @@ class GradientAllReduce:
             for p in plist:        # re-attach in case an optimizer replaced .grad
                 if p.grad is None or p.grad.data_ptr() != flat[off: off + p.numel()].data_ptr():
                     p.grad = flat[off: off + p.numel()].view_as(p)
+                    p._ccn_main_grad = p.grad
                 off += p.numel()
 
     @property
