@@ -1357,7 +1357,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
     const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ Y, int64_t ldy, int64_t rows, int C,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ rstd, int act, float slope, const double* __restrict__ sums, int training,
-    float* __restrict__ dY, int64_t lddy, float* __restrict__ dgamma, float* __restrict__ dbeta, float inv_n) {
+    float* __restrict__ dY, int64_t lddy, float* __restrict__ dgamma, float* __restrict__ dbeta, float inv_n,
+    int acc_params) {
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int64_t r0 = (int64_t)blockIdx.x * 32;
   for (int c = cx; c < C; c += 64) {
@@ -1368,9 +1369,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(
       const float g = dZ[r * lddz + c] * act_grad(y * sc + sh, act, slope);
       dY[r * lddy + c] = training ? sc * (g - m1 - (y - mu) * rs * m2) : sc * g;
     }
-    if (blockIdx.x == 0 && ry == 0) {
-      if (dgamma) dgamma[c] = (float)sums[C + c];
-      if (dbeta) dbeta[c] = (float)sums[c];
+    if (blockIdx.x == 0 && ry == 0) {  // acc_params: add into the caller's gradient buffers (gradient-bucket views)
+      if (dgamma) dgamma[c] = (acc_params ? dgamma[c] : 0.f) + (float)sums[C + c];
+      if (dbeta) dbeta[c] = (acc_params ? dbeta[c] : 0.f) + (float)sums[c];
     }
   }
 }
@@ -1652,7 +1653,7 @@ int ccn_bn_act_bwd_apply(const float* dZ, int64_t lddz, const float* Y, int64_t 
               "bn_act_bwd_apply: bad arguments");
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ccn_blocks(rows, 32)), dim3(256), 0, (hipStream_t)stream, dZ, lddz,
                      Y, ldy, rows, (int)C, scale, shift, mean, rstd, act, slope, sums, training, dY, lddy, dgamma,
-                     dbeta, 1.0f / (float)rows);
+                     dbeta, 1.0f / (float)rows, 0);
   CCN_LAUNCH_OK("bn_act_bwd_apply");
   return CCN_OK;
 }
@@ -1692,12 +1693,20 @@ int ccn_bn_act_bwd_apply_count(const float* dZ, int64_t lddz, const float* Y, in
                                const float* scale, const float* shift, const float* mean, const float* rstd, int act,
                                float slope, const double* sums, double count, int training, float* dY, int64_t lddy,
                                float* dgamma, float* dbeta, void* stream) {
+  return ccn_bn_act_bwd_apply_ex(dZ, lddz, Y, ldy, rows, C, scale, shift, mean, rstd, act, slope, sums, count, training, 0,
+                                 dY, lddy, dgamma, dbeta, stream);
+}
+
+int ccn_bn_act_bwd_apply_ex(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C,
+                            const float* scale, const float* shift, const float* mean, const float* rstd, int act,
+                            float slope, const double* sums, double count, int training, int accumulate_params,
+                            float* dY, int64_t lddy, float* dgamma, float* dbeta, void* stream) {
   CCN_REQUIRE(dZ && Y && scale && shift && mean && rstd && sums && dY && rows > 0 && C > 0 && count > 0,
-              "bn_act_bwd_apply_count: bad arguments");
+              "bn_act_bwd_apply_ex: bad arguments");
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(ccn_blocks(rows, 32)), dim3(256), 0, (hipStream_t)stream, dZ, lddz,
                      Y, ldy, rows, (int)C, scale, shift, mean, rstd, act, slope, sums, training, dY, lddy, dgamma,
-                     dbeta, (float)(1.0 / count));
-  CCN_LAUNCH_OK("bn_act_bwd_apply_count");
+                     dbeta, (float)(1.0 / count), accumulate_params);
+  CCN_LAUNCH_OK("bn_act_bwd_apply_ex");
   return CCN_OK;
 }
 

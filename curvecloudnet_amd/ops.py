@@ -288,6 +288,13 @@ def _main_grad(weight, n, k):
     return g
 
 
+def _main_grad_vec(p, n):
+    g = getattr(p, "_ccn_main_grad", None) if p is not None else None
+    if g is None or g.dtype != torch.float32 or tuple(g.shape) != (n,) or not g.is_contiguous() or not g.is_cuda:
+        return None
+    return g
+
+
 def _main_grad_done(weight):
     """Tell the gradient all-reduce that this parameter's gradient is complete (autograd is given no tensor for it)."""
     ready = getattr(weight, "_ccn_grad_ready", None)
@@ -328,6 +335,7 @@ class LinearBNAct(torch.autograd.Function):
         ctx.has_bn, ctx.act, ctx.training, ctx.has_bias = has_bn, ACT[act], bool(training), bias is not None
         gemm_nt = ctx.gemm_nt = "gemm_nt_bf16" if _MLP_DTYPE == "bf16" else "gemm_nt"
         ctx.main_grad_of = weight if _has_main_grad(weight) else None
+        ctx.bn_refs = (gamma, beta) if has_bn and _has_main_grad(gamma) and _has_main_grad(beta) else None
         if gemm_nt == "gemm_nt_bf16":
             x = _aligned_rows(x)
         if not has_bn:
@@ -362,11 +370,21 @@ class LinearBNAct(torch.autograd.Function):
             call("bn_act_bwd_reduce", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
                  ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums))
             dy = _rows(m, n, dev)
-            dgb = torch.empty((2, n), dtype=torch.float32, device=dev)
-            call("bn_act_bwd_apply", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
-                 ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums), 1 if ctx.training else 0, ptr(dy), _ld(dy),
-                 ptr(dgb[0]), ptr(dgb[1]))
-            dgamma, dbeta = dgb[0], dgb[1]
+            refs = ctx.bn_refs
+            gview = _main_grad_vec(refs[0], n) if refs else None
+            bview = _main_grad_vec(refs[1], n) if refs else None
+            if gview is not None and bview is not None and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]:
+                # BatchNorm parameter gradients added straight into their gradient-bucket views
+                call("bn_act_bwd_apply_ex", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                     ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums), float(m), 1 if ctx.training else 0, 1, ptr(dy), _ld(dy),
+                     ptr(gview), ptr(bview))
+                dgamma, dbeta = _main_grad_done(refs[0]), _main_grad_done(refs[1])
+            else:
+                dgb = torch.empty((2, n), dtype=torch.float32, device=dev)
+                call("bn_act_bwd_apply", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                     ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums), 1 if ctx.training else 0, ptr(dy), _ld(dy),
+                     ptr(dgb[0]), ptr(dgb[1]))
+                dgamma, dbeta = dgb[0], dgb[1]
         else:
             x, w = ctx.saved_tensors
             dy, dgamma, dbeta = g, None, None

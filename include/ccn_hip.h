@@ -303,6 +303,11 @@ int ccn_bn_act_bwd_apply_count(const float* dZ, int64_t lddz, const float* Y, in
                                const float* scale, const float* shift, const float* mean, const float* rstd, int act,
                                float slope, const double* sums, double count, int training, float* dY, int64_t lddy,
                                float* dgamma, float* dbeta, void* stream);
+/* same, accumulate_params != 0: dgamma / dbeta are ADDED to the given buffers (the parameters' gradient-bucket views) */
+int ccn_bn_act_bwd_apply_ex(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C,
+                            const float* scale, const float* shift, const float* mean, const float* rstd, int act,
+                            float slope, const double* sums, double count, int training, int accumulate_params,
+                            float* dY, int64_t lddy, float* dgamma, float* dbeta, void* stream);
 
 /* PointNetConv2 first message layer in algebraic form (point_conv.py:35-93; local_nn.lins[0].weight = [Wx | Wp]):
  *   y[e] = PX[src[e]] + Wp (pos_src[src[e]] - pos_dst[dst[e]]) / radius + bias,   PX = X Wx^T  (N_src x Co, one GEMM over the
