@@ -661,3 +661,35 @@ def test_conv_shift_add_matches_shifted_row_gemm():
         _close(a, b, 1e-4, "shift-add vs shifted-row GEMM")
     for a, b in zip(*stats):
         _close(a, b, 1e-5, "running statistics")
+
+
+def test_sgcnn_compact_rows_edge_cases():
+    """Compact-row SGCNN at the corners: a radius that gives every slot a neighbour (no representative rows), a radius
+    that gives none (every point: self + one representative), and a batch with a one-point cloud (padding rows)."""
+    from oracle import torch_ref as R
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([7, 8], n_curves=12)
+    pos = torch.cat([d.pos, d.pos[:1] + 5.0])                       # third cloud: a single isolated point
+    batch = torch.cat([d.batch, torch.full((1,), 2, dtype=torch.long)])
+    curve = torch.cat([d.curve_idxs, torch.zeros(1, dtype=torch.long)])
+    c = 5
+    x = torch.randn(pos.size(0), c, generator=torch.Generator().manual_seed(4))
+    for k, r in ((4, 50.0), (6, 1e-6), (10, 0.02)):
+        ref, mine = _pair(lambda: R.SGCNNLayer(R.MLP([2 * (c + 3), 16, 12], bias=False), k, r=r, with_xyz=True),
+                          lambda: steps.SGCNNLayer(MLP([2 * (c + 3), 16, 12], bias=False), k, r=r, with_xyz=True))
+        assert mine.compact_rows
+        _run_pair(ref, mine, [x, pos, batch, curve], seed=0)
+
+
+def test_conv_shift_add_short_sequences():
+    """Shift-add convolution when whole curves are shorter than the kernel (rows outside the sequence contribute 0)."""
+    from oracle import torch_ref as R
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([9], n_curves=3, lengths=[1, 2, 4])
+    ref, mine = _pair(lambda: R.SymmetricCurve1DConvV2([40, 8, 6], 7, with_xyz=True, with_diff=True),
+                      lambda: steps.SymmetricCurve1DConvV2([40, 8, 6], 7, with_xyz=True, with_diff=True))
+    x = torch.randn(d.pos.size(0), 37, generator=torch.Generator().manual_seed(4))
+    _run_pair(ref, mine, [x, d.pos, d.batch, d.curve_idxs], seed=0)

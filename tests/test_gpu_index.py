@@ -337,3 +337,26 @@ def test_grid_knn_equals_exhaustive_knn():
         assert torch.equal(nbr_g, nbr_e) and torch.equal(w_g, w_e)
         print("k=%d: %d of %d queries recomputed exhaustively" % (k, missed, pos_q.size(0)))
         assert 2 <= missed < pos_q.size(0) // 4
+
+
+def test_grid_knn_with_fewer_sources_than_k():
+    """Clouds whose source set is smaller than K: the table is -1 padded exactly like the exhaustive kernel's, whichever
+    path a cloud takes (the size threshold is lowered so that the grid path runs on these small clouds)."""
+    from curvecloudnet_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    pos_s = torch.rand(2 + 900, 3, generator=gen).to(DEV)
+    batch_s = torch.cat([torch.zeros(2, dtype=torch.long), torch.ones(900, dtype=torch.long)]).to(DEV)
+    pos_q = torch.rand(700, 3, generator=gen).to(DEV)
+    batch_q = torch.cat([torch.zeros(300, dtype=torch.long), torch.ones(400, dtype=torch.long)]).to(DEV)
+    topo_s = ops.CurveTopology(batch_s, torch.zeros_like(batch_s))
+    topo_q = ops.CurveTopology(batch_q, torch.zeros_like(batch_q))
+    keep = ops.KNN_GRID_MIN_POINTS
+    try:
+        ops.KNN_GRID_MIN_POINTS = 1
+        nbr_g, w_g = ops.knn_points_packed(pos_q, topo_q, pos_s, topo_s, 3)
+        ops.KNN_GRID_MIN_POINTS = 10 ** 9
+        nbr_e, w_e = ops.knn_points_packed(pos_q, topo_q, pos_s, topo_s, 3)
+    finally:
+        ops.KNN_GRID_MIN_POINTS = keep
+    assert torch.equal(nbr_g, nbr_e) and torch.equal(w_g, w_e)
+    assert bool((nbr_e[:300, 2] == -1).all()) and bool((nbr_e[:300, :2] >= 0).all()) and bool((nbr_e[300:] >= 2).all())
