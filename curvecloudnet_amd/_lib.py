@@ -78,13 +78,14 @@ def check(rc, what):
         raise RuntimeError("libccn_hip %s failed (%d): %s" % (what, rc, lib().ccn_last_error().decode()))
 
 
-PROFILE = None   # bench.py sets this to a list to time every launch with HIP events on the launch stream
+PROFILE = None          # bench.py sets this to a list to time launches with HIP events on the launch stream
+PROFILE_ONLY = None     # optional name prefix: only these entry points are timed (events cost ~1.5 us each on the GPU)
 
 
 def call(name, *args):
     """Invoke ``ccn_<name>`` on the current torch stream (appended as the last argument)."""
     fn = getattr(lib(), "ccn_" + name)
-    if PROFILE is None:
+    if PROFILE is None or (PROFILE_ONLY is not None and not name.startswith(PROFILE_ONLY)):
         check(fn(*args, stream()), name)
         return
     # torch.cuda.Event records on torch's current stream, which is exactly the stream passed to the kernel
