@@ -5,8 +5,9 @@
 //   cell_start  int32 [B*T + 1]   exclusive prefix of bucket populations, T = pow2 >= 2*P2 buckets per cloud
 //   cell_fill   int32 [B*T]       bucket populations (build) / scatter cursors
 //   sorted_pts  float4[B*P2]      (x, y, z, original index) grouped by bucket -> coalesced candidate reads
-//   sorted_cell int4  [B*P2]      integer cell of every sorted point (exact-cell filter: hash collisions and
-//                                 two neighbour cells sharing a bucket can never produce a duplicate)
+// A query reads the (at most 27, de-duplicated) buckets of the cells around it; points of other cells that hash into
+// the same buckets are rejected by the distance test, and a bucket shared by two of the 27 cells is read once, so no
+// per-point cell table is needed and no candidate is seen twice.
 // The grid only prunes: a candidate is accepted iff d2 = fma(dz,dz,fma(dy,dy,dx*dx)) < r*r, and the K best
 // are kept ordered by (d2, original index), exactly the exhaustive oracle (oracle/frnn_bruteforce.c).
 // Cell edge = 1.001 r, so every point within r of a query lies in the 27 cells around the query's cell
@@ -23,7 +24,6 @@ struct GridView {
   int32_t* cell_start;
   int32_t* cell_fill;
   float4* sorted_pts;
-  int4* sorted_cell;
   void* scan_scratch;
   int64_t T;
 };
@@ -37,7 +37,7 @@ __host__ int64_t table_size(int64_t P2) {
 __host__ size_t grid_bytes(int64_t B, int64_t P2) {
   const int64_t T = table_size(P2);
   return ccn_align256((size_t)(B * T + 1) * 4) + ccn_align256((size_t)(B * T) * 4) +
-         ccn_align256((size_t)(B * P2) * 16) * 2 + ccn_scan_scratch_bytes(B * T + 1) + 1024;
+         ccn_align256((size_t)(B * P2) * 16) + ccn_scan_scratch_bytes(B * T + 1) + 1024;
 }
 
 __host__ bool carve(void* grid, size_t bytes, int64_t B, int64_t P2, GridView* g) {
@@ -46,7 +46,6 @@ __host__ bool carve(void* grid, size_t bytes, int64_t B, int64_t P2, GridView* g
   g->cell_start = a.take<int32_t>(B * g->T + 1);
   g->cell_fill = a.take<int32_t>(B * g->T);
   g->sorted_pts = a.take<float4>(B * P2);
-  g->sorted_cell = a.take<int4>(B * P2);
   g->scan_scratch = a.take<char>(ccn_scan_scratch_bytes(B * g->T + 1));
   return a.ok();
 }
@@ -67,8 +66,7 @@ __global__ __launch_bounds__(BUILD_TPB) void grid_insert_kernel(const float* __r
                                                                 const float* __restrict__ radius, int64_t P2,
                                                                 int64_t T, const int32_t* __restrict__ cell_start,
                                                                 int32_t* __restrict__ cell_fill,
-                                                                float4* __restrict__ sorted_pts,
-                                                                int4* __restrict__ sorted_cell) {
+                                                                float4* __restrict__ sorted_pts) {
   const int64_t b = blockIdx.y;
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= lengths[b]) return;
@@ -81,7 +79,6 @@ __global__ __launch_bounds__(BUILD_TPB) void grid_insert_kernel(const float* __r
   } else {
     const int32_t at = cell_start[slot] + atomicAdd(&cell_fill[slot], 1);
     sorted_pts[at] = make_float4(x, y, z, __int_as_float((int)j));
-    sorted_cell[at] = make_int4(c.x, c.y, c.z, 0);
   }
 }
 
@@ -90,7 +87,7 @@ __global__ __launch_bounds__(BUILD_TPB) void grid_insert_kernel(const float* __r
 __global__ __launch_bounds__(QUERY_TPB) void grid_query_kernel(
     const float* __restrict__ q_pts, const int64_t* __restrict__ lengths1, const float* __restrict__ radius,
     int64_t P1, int K, int64_t T, const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted_pts,
-    const int4* __restrict__ sorted_cell, int64_t* __restrict__ idx_out, float* __restrict__ dist_out,
+    int64_t* __restrict__ idx_out, float* __restrict__ dist_out,
     int32_t* __restrict__ count_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   float* best_d = (float*)lds_raw;                       // [K][QUERY_TPB]
@@ -234,12 +231,12 @@ int ccn_frnn_grid_build(const float* points2, const int64_t* lengths2, const flo
   CCN_HIP(hipMemsetAsync(g.cell_fill, 0, (size_t)cells * 4, s), "frnn_grid_build");
   dim3 gridDim_(ccn_blocks(P2, BUILD_TPB), (unsigned)B);
   hipLaunchKernelGGL(grid_insert_kernel<false>, gridDim_, dim3(BUILD_TPB), 0, s, points2, lengths2, r, P2, g.T,
-                     (const int32_t*)nullptr, g.cell_fill, (float4*)nullptr, (int4*)nullptr);
+                     (const int32_t*)nullptr, g.cell_fill, (float4*)nullptr);
   int rc = ccn_scan_i32(g.cell_fill, g.cell_start, cells, false, g.cell_start + cells, g.scan_scratch, s);
   if (rc) return rc;
   CCN_HIP(hipMemsetAsync(g.cell_fill, 0, (size_t)cells * 4, s), "frnn_grid_build");
   hipLaunchKernelGGL(grid_insert_kernel<true>, gridDim_, dim3(BUILD_TPB), 0, s, points2, lengths2, r, P2, g.T,
-                     g.cell_start, g.cell_fill, g.sorted_pts, g.sorted_cell);
+                     g.cell_start, g.cell_fill, g.sorted_pts);
   CCN_LAUNCH_OK("frnn_grid_build");
   return CCN_OK;
 }
@@ -254,7 +251,7 @@ int ccn_frnn_query(const float* points1, const int64_t* lengths1, const float* r
   const size_t lds = (size_t)K * QUERY_TPB * 8;
   dim3 gridDim_(ccn_blocks(P1, QUERY_TPB), (unsigned)B);
   hipLaunchKernelGGL(grid_query_kernel, gridDim_, dim3(QUERY_TPB), lds, (hipStream_t)stream, points1, lengths1, r, P1,
-                     (int)K, g.T, g.cell_start, g.sorted_pts, g.sorted_cell, idx, dist2, count);
+                     (int)K, g.T, g.cell_start, g.sorted_pts, idx, dist2, count);
   CCN_LAUNCH_OK("frnn_query");
   return CCN_OK;
 }
