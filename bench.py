@@ -48,8 +48,7 @@ def gemm_label(name, ints, nulls=()):
     if name == "gemm_nt":
         bn = 32 if n <= 32 else (64 if n <= 64 else 128)
         if aligned and m >= 1024 and k >= 64 and ((m + 255) // 256) * ((n + 127) // 128) >= 512:
-            no_bias = 4 in nulls                               # gemm_nt(A, lda, W, ldw, bias, ...)
-            if no_bias and k % 32 == 0:
+            if k % 32 == 0:
                 return "gemm_glds_persistent_kernel<%d>" % bn, flops
             return "gemm_glds_kernel<%d>" % bn, flops
         kern = "gemm_fast_kernel" if aligned else "gemm_kernel"

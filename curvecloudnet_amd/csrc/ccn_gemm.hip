@@ -802,7 +802,7 @@ int launch_glds(const float* A, int64_t lda, const float* W, int64_t ldw, const 
 
 
 // ------------------------------------------------------------------ persistent form of the LDS-DMA kernel
-// One workgroup per CU walks the output tiles (K % 32 == 0, no bias).  The K slices of consecutive tiles form ONE
+// One workgroup per CU walks the output tiles (K % 32 == 0).  The K slices of consecutive tiles form ONE
 // stream through the 3-stage ring, so the DMA of the next tile's first two slices is already in flight while the
 // current tile is finished, and the epilogue's global stores (issued and forgotten) drain under the next tile's
 // MFMAs: with a single 8-wave workgroup per CU nothing else could hide the pipeline fill or the 128 KiB of
@@ -813,6 +813,7 @@ int launch_glds(const float* A, int64_t lda, const float* W, int64_t ldw, const 
 template <int BN>
 __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const float* __restrict__ A, int64_t lda,
                                                                       const float* __restrict__ B, int64_t ldb,
+                                                                      const float* __restrict__ bias,
                                                                       float* __restrict__ C, int64_t ldc, int64_t M,
                                                                       int64_t N, int64_t K, int64_t tiles, int64_t gn,
                                                                       double* __restrict__ colstats) {
@@ -907,10 +908,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t m0 = (tile / gn) * GL_BM, n0 = (tile % gn) * BN;
     f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    acc_init<NT>(acc, bias, n0, N, i);  // bias (or 0) as the initial accumulator value
 
     for (int u = 0; u < T; ++u, ++g) {
       if (g >= landed) {
@@ -984,13 +982,13 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
 }
 
 template <int BN>
-int launch_glds_persistent(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M,
-                           int64_t N, int64_t K, double* colstats, hipStream_t s) {
+int launch_glds_persistent(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y,
+                           int64_t ldy, int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s) {
   const int64_t gm = (M + GL_BM - 1) / GL_BM, gn = (N + BN - 1) / BN;
   const int64_t tiles = gm * gn;
   const int64_t grid = tiles < 256 ? tiles : 256;  // one workgroup per CU (147 KB of LDS each)
-  hipLaunchKernelGGL((gemm_glds_persistent_kernel<BN>), dim3((unsigned)grid), dim3(GL_TPB), 0, s, A, lda, W, ldw, Y,
-                     ldy, M, N, K, tiles, gn, colstats);
+  hipLaunchKernelGGL((gemm_glds_persistent_kernel<BN>), dim3((unsigned)grid), dim3(GL_TPB), 0, s, A, lda, W, ldw, bias,
+                     Y, ldy, M, N, K, tiles, gn, colstats);
   return CCN_OK;
 }
 
@@ -1463,14 +1461,13 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
   const bool dma_ok = aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && lda >= 4 && ldw >= 4 &&
                       !g_force_generic && g_use_glds && M >= 1024 && K >= g_dma_min_k &&
                       ((M + GL_BM - 1) / GL_BM) * ((N + 127) / 128) >= 512;
-  if (dma_ok && bias == nullptr && K % BK == 0 && g_use_persistent &&
-      ((M + GL_BM - 1) / GL_BM) * ((N + 127) / 128) >= 512) {
+  if (dma_ok && K % BK == 0 && g_use_persistent) {
     if (N <= 32)
-      rc = launch_glds_persistent<32>(A, lda, W, ldw, Y, ldy, M, N, K, colstats, s);
+      rc = launch_glds_persistent<32>(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s);
     else if (N <= 64)
-      rc = launch_glds_persistent<64>(A, lda, W, ldw, Y, ldy, M, N, K, colstats, s);
+      rc = launch_glds_persistent<64>(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s);
     else
-      rc = launch_glds_persistent<128>(A, lda, W, ldw, Y, ldy, M, N, K, colstats, s);
+      rc = launch_glds_persistent<128>(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s);
     if (rc) return rc;
     CCN_LAUNCH_OK("gemm_nt");
     return CCN_OK;

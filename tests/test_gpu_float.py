@@ -62,7 +62,7 @@ def test_linear_plain_fwd_bwd(M, K, N):
                                    (140000, 64, 100), (135000, 96, 128), (133000, 72, 64)])
 def test_gemm_dma_pipeline_matches_register_staged_kernel(M, K, N):
     """Y = X W^T + b with BatchNorm partial statistics: LDS-DMA pipeline kernel (taken for K >= 64 and >= 512 tiles of
-    256 x 128; the bias keeps it off the persistent form; K = 134 / 160 exercise the K tail) vs the register-staged
+    256 x 128: the persistent form when K % 32 == 0, else the one-tile-per-workgroup form with its K tail) vs the register-staged
     kernel (first shape: both runs are the staged kernel)."""
     from curvecloudnet_amd import _lib
     from curvecloudnet_amd._lib import call, lib, ptr
