@@ -87,6 +87,7 @@ class ForwardContext:
         self.num_clouds = num_clouds
         self._topo = {}
         self._zeros = {}
+        self.sg_tables = {}       # (positions, K, radius) -> FRNN table + compact rows, shared by the SGCNN steps of a level
         self.side, self.main, self.stress = None, None, False
         if device is not None:
             self.side, mode = _geometry_stream(device)
@@ -469,11 +470,20 @@ class SGCNNLayer(nn.Module):
             return SimpleNamespace(edges=edges, out=out)
         if not self.use_fast_knn or self.aggr_type != "max":
             raise NotImplementedError("dense SGCNN path: only the FRNN + max configuration the shipped configs use")
-        padded, _ = ops.to_batch_padded(pos, topo)
         radius = 0.25 if self.r is None else self.r
-        nbr = ops.fast_knn(padded, padded, topo.lengths, topo.lengths, self.k, radius)
-        comp = ops.SGCompact(nbr, topo) if self._mode()[1] else None
-        return SimpleNamespace(topo=topo, nbr=nbr, comp=comp, out=out)
+        compact = self._mode()[1]
+        # the decoder revisits every level with the same K and radius as the encoder (and two consecutive steps share
+        # the deepest level): the neighbour table and its compact-row structure are computed once per forward
+        ctx = kwargs.get("_ccn_ctx")
+        key = (pos.data_ptr(), pos.size(0), self.k, float(radius), compact)
+        hit = ctx.sg_tables.get(key) if ctx is not None else None
+        if hit is None:
+            padded, _ = ops.to_batch_padded(pos, topo)
+            nbr = ops.fast_knn(padded, padded, topo.lengths, topo.lengths, self.k, radius)
+            hit = (nbr, ops.SGCompact(nbr, topo) if compact else None, pos)      # pos kept alive with the entry
+            if ctx is not None:
+                ctx.sg_tables[key] = hit
+        return SimpleNamespace(topo=topo, nbr=hit[0], comp=hit[1], out=out)
 
     def features(self, x, pos, g):
         x = _with_xyz(x, pos, self.with_xyz)
