@@ -810,7 +810,7 @@ int launch_glds(const float* A, int64_t lda, const float* W, int64_t ldw, const 
 // vmcnt retires loads, stores and LDS-DMA in issue order, so the counted waits are arranged as follows: before
 // the stores every DMA issued so far is waited for (it is at least one compute phase old) and remembered as
 // landed; the next two slices then need no wait, and later counted waits see the stores as the oldest entries.
-template <int BN>
+template <int BN, int STAGES>
 __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const float* __restrict__ A, int64_t lda,
                                                                       const float* __restrict__ B, int64_t ldb,
                                                                       const float* __restrict__ bias,
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
   constexpr int AF = GL_BM * BK, BF = BN * BK, STAGE = AF + BF;
   constexpr int NA = GL_BM / 8 / 8;
   constexpr int NB = BN >= 64 ? BN / 64 : 1;
-  __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];
+  __shared__ __attribute__((aligned(16))) float lds[STAGES * STAGE];
   // per-wave BatchNorm partial sums of the finished tile ([8 waves][BN][2] fp32, sums over the wave's 32 rows).  A
   // table of its own instead of a recycled stage: no barrier is then needed before it is written, and it is read out
   // (fp64 across the 4 waves of each 128-row half) after the FIRST slice barrier of the next tile, so the statistics
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
         b_src[j] = B + row * ldb + 4 * (lc ^ ((r >> 1) & 7));
       }
     }
-    float* st = lds + (gi % 3) * STAGE;
+    float* st = lds + (gi % STAGES) * STAGE;
     const int64_t k0 = (int64_t)it_u * BK;
 #pragma unroll
     for (int j = 0; j < NA; ++j) glds16(a_src[j] + k0, st + (8 * (wave * NA + j)) * BK);
@@ -878,8 +878,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
       it_tile += gridDim.x;
     }
   };
-  issue_next();
-  issue_next();
+  for (int pre = 0; pre < STAGES - 1; ++pre) issue_next();  // the DMA runs STAGES-1 slices ahead of the compute
 
   int64_t stat_tile = -1;  // tile whose statistics wait in stat_part
   auto stats_readout = [&]() {
@@ -920,7 +919,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
       __builtin_amdgcn_s_barrier();
       issue_next();
       if (u == 0 && stat_tile >= 0) stats_readout();
-      const uint32_t stage_b = lds_base + (uint32_t)((g % 3) * STAGE * 4);
+      const uint32_t stage_b = lds_base + (uint32_t)((g % STAGES) * STAGE * 4);
       f32x4 fa[2], fb[2][NT];
       lds_read_frag<NT>(stage_b + a_off, stage_b + b_off, 0, h, swz, fa[0], fb[0]);
 #pragma unroll
@@ -945,19 +944,34 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
     // ---- tile epilogue.  Everything issued so far (<= 2 slices of the next tile) is waited for first.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     landed = gi;
+    // Interior tiles (all but the last tile row / column) store without per-element bounds tests: 16*NT stores per lane
+    // with a compare, a branch and a 64-bit multiply-add each made the epilogue ~8.5k cycles per tile (measured 4.2 us
+    // per tile whatever K), a quarter of a K = 128 tile.
+    const bool interior = m0 + GL_BM <= M && n0 + BN <= N;
+    float* const crow = C + (m0 + wave * 32 + 4 * h) * ldc + n0 + i;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int ncol = t * 32 + i;
       const int64_t n = n0 + ncol;
       float s1 = 0.f, s2 = 0.f;
+      if (interior) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < M && n < N) {
+        for (int r = 0; r < 16; ++r) {
           const float v = acc[t][r];
-          C[m * ldc + n] = v;
+          crow[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc + t * 32] = v;
           s1 += v;
           s2 += v * v;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < M && n < N) {
+            const float v = acc[t][r];
+            C[m * ldc + n] = v;
+            s1 += v;
+            s2 += v * v;
+          }
         }
       }
       if (colstats != nullptr) {
@@ -987,7 +1001,8 @@ int launch_glds_persistent(const float* A, int64_t lda, const float* W, int64_t 
   const int64_t gm = (M + GL_BM - 1) / GL_BM, gn = (N + BN - 1) / BN;
   const int64_t tiles = gm * gn;
   const int64_t grid = tiles < 256 ? tiles : 256;  // one workgroup per CU (147 KB of LDS each)
-  hipLaunchKernelGGL((gemm_glds_persistent_kernel<BN>), dim3((unsigned)grid), dim3(GL_TPB), 0, s, A, lda, W, ldw, bias,
+  // (a 256 x 256 tile with a 2-stage ring was tried: +2 % at N = 512, -6 % where it leaves few tiles, 12 spilled VGPRs)
+  hipLaunchKernelGGL((gemm_glds_persistent_kernel<BN, 3>), dim3((unsigned)grid), dim3(GL_TPB), 0, s, A, lda, W, ldw, bias,
                      Y, ldy, M, N, K, tiles, gn, colstats);
   return CCN_OK;
 }
