@@ -56,7 +56,7 @@ def gemm_label(name, ints, nulls=()):
     if name == "gemm_nn":
         bn = 32 if k <= 32 else (64 if k <= 64 else 128)
         return "gemm_fast_kernel<128, %d, 4, 0, 1, 0>" % bn, flops
-    tile = "32, 128, 1" if n <= 32 else ("64, 64, 2" if k <= 64 else "64, 128, 2")
+    tile = "32, 128, 1" if n <= 32 else ("64, 64, 2" if k <= 64 else ("128, 128, 4" if n > 64 and m >= 50000 else "64, 128, 2"))
     return "gemm_fast_kernel<%s, 1, 1, 1, true>" % tile, flops
 
 

@@ -1546,6 +1546,9 @@ int ccn_gemm_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, floa
   } else {
     if (K <= 64)
       rc = launch_gemm<64, 64, 2, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s);
+    else if (N > 64 && M >= 50000)  // 128 x 128 tiles once the row split alone fills the chip: 112 -> 121 TFLOP/s at
+                                    // M = 1.3 M, K = N = 256 (but 112 -> 105 at M = 10 k, where the 64-row tile stays)
+      rc = launch_gemm<128, 128, 4, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s);
     else
       rc = launch_gemm<64, 128, 2, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s);
   }
