@@ -272,6 +272,57 @@ def mlp_dtype():
     return _MLP_DTYPE
 
 
+_WGRAD_STREAMS = {}
+_WGRAD_PENDING = set()
+
+
+def _wgrad_stream(device):
+    """Side stream for weight-gradient products that accumulate straight into a gradient bucket: nothing in the rest of
+    the backward pass consumes them, so they run concurrently with the (mostly HBM-bound) BatchNorm / gather passes and
+    data-gradient products of the layers below.  ``join_wgrad()`` orders the current stream behind them; it is called
+    by GradientAllReduce before a bucket is reduced, in finish() / zero_grad(), and by FlatAdam.step().
+    CCN_WGRAD_STREAM=0 keeps the products on the backward stream."""
+    if os.environ.get("CCN_WGRAD_STREAM", "1") == "0" or device.type != "cuda":
+        return None
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _WGRAD_STREAMS:
+        _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _WGRAD_STREAMS[key]
+
+
+def join_wgrad():
+    """Make the current stream wait for every weight-gradient product queued on the side stream."""
+    for key in list(_WGRAD_PENDING):
+        torch.cuda.current_stream(key).wait_stream(_WGRAD_STREAMS[key])
+        _WGRAD_PENDING.discard(key)
+
+
+class _WgradScope:
+    """``with _WgradScope(into, dy, x):`` runs the enclosed launches on the weight-gradient stream (when the product
+    goes into a gradient bucket), after everything queued so far on the current stream."""
+
+    def __init__(self, into, *operands):
+        self.ws = _wgrad_stream(into.device) if into is not None else None
+        self.operands = operands
+
+    def __enter__(self):
+        if self.ws is None:
+            return self
+        cur = torch.cuda.current_stream()
+        self.ws.wait_stream(cur)
+        for t in self.operands:
+            t.record_stream(self.ws)            # freed by autograd while the side stream may still read them
+        self.scope = torch.cuda.stream(self.ws)
+        self.scope.__enter__()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.ws is not None:
+            self.scope.__exit__(et, ev, tb)
+            _WGRAD_PENDING.add(self.ws.device.index)
+        return False
+
+
 def _has_main_grad(weight):
     return getattr(weight, "_ccn_main_grad", None) is not None and weight.is_leaf and weight.requires_grad
 
@@ -406,9 +457,9 @@ class LinearBNAct(torch.autograd.Function):
             dw = into if into is not None else _rows(n, k, dev, zero=True)
             if ctx.gemm_nt == "gemm_nt_bf16":
                 dy = _aligned_rows(dy)
-                call("gemm_tn_bf16", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
-            else:
-                call("gemm_tn", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
+            with _WgradScope(into, dy, x, dw):
+                call("gemm_tn_bf16" if ctx.gemm_nt == "gemm_nt_bf16" else "gemm_tn", ptr(dy), _ld(dy), ptr(x), _ld(x),
+                     ptr(dw), _ld(dw), m, n, k)
             if into is not None:
                 dw = _main_grad_done(ctx.main_grad_of)
         db = None
@@ -1193,11 +1244,12 @@ class LinearBNActTail(torch.autograd.Function):
         into = _main_grad(ctx.main_grad_of, n, k)
         dw = into if into is not None else _rows(n, k, dev, zero=True)
         gemm_tn = "gemm_tn_bf16" if ctx.gemm_nt == "gemm_nt_bf16" else "gemm_tn"
-        call(gemm_tn, ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), tail, n, k)
         dyt = _rows(t, n, dev)
         torch.mul(dy[tail:], w[:, None], out=dyt)
         xt = x[tail:]
-        call("gemm_tn", ptr(dyt), _ld(dyt), ptr(xt), _ld(x), ptr(dw), _ld(dw), t, n, k)       # few rows: fp32
+        with _WgradScope(into, dy, x, dyt, dw):
+            call(gemm_tn, ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), tail, n, k)
+            call("gemm_tn", ptr(dyt), _ld(dyt), ptr(xt), _ld(x), ptr(dw), _ld(dw), t, n, k)   # few rows: fp32
         if into is not None:
             dw = _main_grad_done(ctx.main_grad_of)
         return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None

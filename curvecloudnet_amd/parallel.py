@@ -13,6 +13,11 @@ import torch
 import torch.distributed as dist
 
 
+def _join_wgrad():
+    from .ops import join_wgrad         # (ops imports torch only; no cycle)
+    join_wgrad()
+
+
 def init_process_group_from_env(backend=None):
     """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,11 +101,13 @@ class GradientAllReduce:
         b = self._bucket_of[p]
         self._pending[b] += 1
         if self._pending[b] == len(self.buckets[b][1]):
+            _join_wgrad()           # weight gradients of the HIP layers may still be running on their side stream
             self._handles.append(dist.all_reduce(self.buckets[b][0], op=dist.ReduceOp.SUM, group=self.group,
                                                  async_op=True))
 
     def finish(self):
         """Call after ``loss.backward()``: waits for the collectives and averages over ranks."""
+        _join_wgrad()
         if self.world > 1:
             # buckets whose parameters did not all receive a gradient this step are reduced here
             for b, (flat, plist) in enumerate(self.buckets):
@@ -114,6 +121,7 @@ class GradientAllReduce:
         self._pending = [0] * len(self.buckets)
 
     def zero_grad(self):
+        _join_wgrad()
         for flat, plist in self.buckets:
             flat.zero_()
             off = 0
@@ -160,6 +168,7 @@ class FlatAdam:
     @torch.no_grad()
     def step(self):
         from ._lib import call, ptr
+        _join_wgrad()
         self.steps += 1
         for (gflat, _), (pflat, m, v) in zip(self.sync.buckets, self.state):
             call("adam_step", ptr(pflat), ptr(gflat), ptr(m), ptr(v), gflat.numel(), float(self.lr), float(self.betas[0]),
