@@ -279,8 +279,8 @@ _WGRAD_PENDING = set()
 def _wgrad_stream(device):
     """Side stream for weight-gradient products that accumulate straight into a gradient bucket: nothing in the rest of
     the backward pass consumes them, so they run concurrently with the (mostly HBM-bound) BatchNorm / gather passes and
-    data-gradient products of the layers below.  ``join_wgrad()`` orders the current stream behind them; it is called
-    by GradientAllReduce before a bucket is reduced, in finish() / zero_grad(), and by FlatAdam.step().
+    data-gradient products of the layers below.  ``join_wgrad()`` orders the current stream behind them; it runs as an
+    autograd end-of-backward callback, and GradientAllReduce calls it before a bucket is reduced during the pass.
     CCN_WGRAD_STREAM=0 keeps the products on the backward stream."""
     if os.environ.get("CCN_WGRAD_STREAM", "1") == "0" or device.type != "cuda":
         return None
@@ -319,6 +319,10 @@ class _WgradScope:
     def __exit__(self, et, ev, tb):
         if self.ws is not None:
             self.scope.__exit__(et, ev, tb)
+            if not _WGRAD_PENDING:
+                # end of this backward pass: order the backward stream behind the side stream, so that whoever reads
+                # .grad after loss.backward() needs no extra call (a stream wait, nothing blocks on the host)
+                torch.autograd.Variable._execution_engine.queue_callback(join_wgrad)
             _WGRAD_PENDING.add(self.ws.device.index)
         return False
 
