@@ -49,7 +49,7 @@ def gemm_label(name, ints, nulls=()):
         bn = 32 if n <= 32 else (64 if n <= 64 else 128)
         if aligned and m >= 1024 and k >= 64 and ((m + 255) // 256) * ((n + 127) // 128) >= 512:
             if k % 32 == 0:
-                return "gemm_glds_persistent_kernel<%d>" % bn, flops
+                return "gemm_glds_persistent_kernel<%d, 3>" % bn, flops
             return "gemm_glds_kernel<%d>" % bn, flops
         kern = "gemm_fast_kernel" if aligned else "gemm_kernel"
         return "%s<128, %d, 4, 0, 0, 0%s>" % (kern, bn, (", true" if k > 96 else ", false") if aligned else ""), flops

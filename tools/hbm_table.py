@@ -24,8 +24,9 @@ print("Sources: `%s` (--kernel-trace --stats of `python bench.py`) and `%s` (sep
 print("`--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE` passes of the same command; FETCH_SIZE doubled as")
 print("MI355X_MICROARCH.md prescribes for gfx950).  GB/s = (read + written bytes per launch) / average launch duration; HBM3E")
 print("spec peak 8000 GB/s.  MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); clock = GRBM_GUI_ACTIVE")
-print("/ 8 / duration in the (serialised) counter pass.  Durations come from the un-instrumented stats run, where the")
-print("position-only kernels overlap the feature kernels on a second stream.\n")
+print("/ 8 / duration in the (serialised) counter pass.  Durations come from the un-instrumented stats run, where kernels of")
+print("three streams overlap (position-only work, weight-gradient products, everything else): a kernel's GB/s here is what it")
+print("gets while sharing the chip, not its stand-alone rate (BN backward apply: 5.6 TB/s alone, 2.8 TB/s next to a GEMM).\n")
 print("| % GPU time | kernel | launches | avg us | read MB | written MB | GB/s | % of 8 TB/s | MFMA util | clock GHz |")
 print("|---|---|---|---|---|---|---|---|---|---|")
 for pct, short, calls, avg, rd, wr, gbs, util, clk in rows[:32]:
