@@ -239,11 +239,13 @@ def main():
         _lib.PROFILE, _lib.PROFILE_ONLY = [], "gemm_"
     ref_event = torch.cuda.Event(enable_timing=True)
     ref_event.record()
+    mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    device_mallocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - mallocs0
     records, _lib.PROFILE, _lib.PROFILE_ONLY = _lib.PROFILE, None, None
     full_records = None
     if records is not None and world == 1:
@@ -273,6 +275,8 @@ def main():
                                   "; the next step's sampling / neighbour search runs during this step's backward"),
                    "network": args.config, "parameters": sum(p.numel() for p in model.parameters()),
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                   "reserved_hbm_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
+                   "device_mallocs_in_timed_region": device_mallocs,
                    "clouds_per_gpu": b, "points_per_cloud": n_points // b, "parallelism": "dp%d" % world,
                    "loss": float(loss.detach())},
     }
