@@ -209,20 +209,31 @@ def main():
 
     staged = {"plan": None}
 
+    debug = os.environ.get("CCN_BENCH_DEBUG") == "1"
+
     def step():
+        marks = [time.perf_counter()]
         sync.zero_grad()
         plan = staged["plan"]
         if plan is None:
             torch.manual_seed(7)                             # fixes the CurveFPS phase draws
         loss = segmentation_loss(model(data, plan=plan), labels)
+        marks.append(time.perf_counter())
         loss.backward()
+        marks.append(time.perf_counter())
         if not args.no_pipeline:
             # the next batch's sampling / neighbour search is queued on the side stream while this batch's backward pass
             # (already queued) runs: what a training loop does with the loader's next batch (ModelBase.prepare)
             torch.manual_seed(7)
             staged["plan"] = model.prepare(data)
+        marks.append(time.perf_counter())
         sync.finish()
         opt.step()
+        if debug:
+            torch.cuda.synchronize()
+            marks.append(time.perf_counter())
+            print("rank %d host ms: forward %.1f backward %.1f prepare %.1f finish+opt+sync %.1f"
+                  % ((rank,) + tuple(1e3 * (b_ - a_) for a_, b_ in zip(marks[:-1], marks[1:]))), flush=True)
         return loss
 
     def barrier():

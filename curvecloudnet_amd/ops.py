@@ -287,6 +287,11 @@ def _wgrad_stream(device):
     CCN_WGRAD_STREAM=0 keeps the products on the backward stream."""
     if os.environ.get("CCN_WGRAD_STREAM", "1") == "0" or device.type != "cuda":
         return None
+    if (os.environ.get("CCN_WGRAD_STREAM") != "force" and torch.distributed.is_available()
+            and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
+        # With gradient collectives in flight the extra stream made a 2-rank rehearsal (gloo, both ranks on one GPU)
+        # 30x slower for reasons not understood yet; multi-rank runs keep the products on the backward stream.
+        return None
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _WGRAD_STREAMS:
         _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
