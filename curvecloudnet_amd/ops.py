@@ -289,8 +289,11 @@ def _wgrad_stream(device):
         return None
     if (os.environ.get("CCN_WGRAD_STREAM") != "force" and torch.distributed.is_available()
             and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
-        # With gradient collectives in flight the extra stream made a 2-rank rehearsal (gloo, both ranks on one GPU)
-        # 30x slower for reasons not understood yet; multi-rank runs keep the products on the backward stream.
+        # Multi-rank runs keep the products on the backward stream.  In the 2-rank rehearsal (gloo, BOTH ranks on one GPU)
+        # the extra stream made a step 3-30x slower, the more hardware queues were in play the worse (no geometry stream:
+        # 3x; GPU_MAX_HW_QUEUES=8: no progress) -- queue oversubscription of that one GPU by two processes plus gloo's copy
+        # streams, which a one-process-per-GPU run should not see, but that could not be checked on real RCCL here
+        # (CCN_WGRAD_STREAM=force enables it regardless).
         return None
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _WGRAD_STREAMS:
