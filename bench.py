@@ -237,8 +237,12 @@ def main():
         return loss
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
-            torch.distributed.barrier()
+            if torch.distributed.get_backend() == "nccl":
+                torch.distributed.barrier(device_ids=[local_rank])      # RCCL: name the device, no guessing
+            else:
+                torch.distributed.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
