@@ -288,11 +288,15 @@ def _wgrad_stream(device):
     if os.environ.get("CCN_WGRAD_STREAM", "1") == "0" or device.type != "cuda":
         return None
     if (os.environ.get("CCN_WGRAD_STREAM") != "force" and torch.distributed.is_available()
-            and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
+            and torch.distributed.is_initialized()
+            and (torch.distributed.get_world_size() > 1 or os.environ.get("CCN_SINGLE_RANK_GROUP"))):
         # Multi-rank runs keep the products on the backward stream.  In the 2-rank rehearsal (gloo, BOTH ranks on one GPU)
         # the extra stream made a step 3-30x slower, the more hardware queues were in play the worse (no geometry stream:
         # 3x; GPU_MAX_HW_QUEUES=8: no progress) -- queue oversubscription of that one GPU by two processes plus gloo's copy
-        # streams, which a one-process-per-GPU run should not see, but that could not be checked on real RCCL here
+        # streams.  A single process that owns its GPU and runs the same hooks over a one-rank RCCL group
+        # (CCN_SINGLE_RANK_GROUP=nccl) shows no such effect (65.4 vs 65.9 clouds/s with / without the stream: the join
+        # before every bucket's all-reduce removes the overlap, so there is nothing to gain either), but a one-rank group
+        # launches no RCCL kernels, so the stream stays off where it cannot be validated
         # (CCN_WGRAD_STREAM=force enables it regardless).
         return None
     key = device.index if device.index is not None else torch.cuda.current_device()

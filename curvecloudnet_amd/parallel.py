@@ -23,6 +23,12 @@ def init_process_group_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and os.environ.get("CCN_SINGLE_RANK_GROUP") and not dist.is_initialized():
+        # diagnostic (CCN_SINGLE_RANK_GROUP=nccl|gloo): a one-rank process group, so that the data-parallel code path
+        # (hooks, joins, one all_reduce call per bucket) can be timed by a single process that has the GPU to itself
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend=os.environ["CCN_SINGLE_RANK_GROUP"], rank=0, world_size=1)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -52,6 +58,8 @@ class GradientAllReduce:
     def __init__(self, module, bucket_bytes=25 * 1024 * 1024, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # CCN_SINGLE_RANK_GROUP (diagnostic, see init_process_group_from_env): hooks and collectives run with one rank too
+        self.reduces = self.world > 1 or (dist.is_initialized() and bool(os.environ.get("CCN_SINGLE_RANK_GROUP")))
         params = [p for p in module.parameters() if p.requires_grad]
         self.buckets = []          # (flat buffer, [params])
         self._bucket_of = {}
@@ -67,7 +75,7 @@ class GradientAllReduce:
         self._pending = [0] * len(self.buckets)
         self._handles = []
         self._quiet = False
-        if self.world > 1:
+        if self.reduces:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -80,7 +88,7 @@ class GradientAllReduce:
             # accumulates with atomics) instead of returning a tensor for autograd to add -- one launch per layer
             # instead of three (zero-fill, product, add); they report completion through _ccn_grad_ready
             p._ccn_main_grad = p.grad
-            p._ccn_grad_ready = (lambda q=p: self._on_grad(q)) if self.world > 1 else None
+            p._ccn_grad_ready = (lambda q=p: self._on_grad(q)) if self.reduces else None
             off += p.numel()
             self._bucket_of[p] = len(self.buckets)
         self.buckets.append((flat, list(plist)))
@@ -108,7 +116,7 @@ class GradientAllReduce:
     def finish(self):
         """Call after ``loss.backward()``: waits for the collectives and averages over ranks."""
         _join_wgrad()
-        if self.world > 1:
+        if self.reduces:
             # buckets whose parameters did not all receive a gradient this step are reduced here
             for b, (flat, plist) in enumerate(self.buckets):
                 if self._pending[b] != len(plist):
