@@ -35,10 +35,12 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 def gemm_label(name, ints, nulls=()):
     """(kernel symbol as rocprofv3 prints it, flops) of a GEMM launch; mirrors the dispatch in csrc/ccn_gemm.hip."""
-    if name not in ("gemm_nt", "gemm_nn", "gemm_tn", "gemm_nt_bf16", "gemm_tn_bf16"):
+    if name not in ("gemm_nt", "gemm_nn", "gemm_tn", "gemm_nt_bf16", "gemm_tn_bf16", "gemm_nt_x3"):
         return None, 0.0
     ld_a, ld_b, _, m, n, k = ints[:6]
     flops = 2.0 * m * n * k
+    if name == "gemm_nt_x3":
+        return "gemm_x3_kernel<%s>" % ("32, 4" if n <= 32 else ("64, 2" if n <= 64 else "128, 2")), flops
     if name == "gemm_tn_bf16":
         bm, bn = (64 if n <= 64 else 128), (64 if k <= 64 else 128)
         return "gemm_bf16_tn_kernel<%d, %d, %d>" % (bm, bn, bm // 32), flops
@@ -172,7 +174,7 @@ def main():
     ap.add_argument("--curves", type=int, default=2048, help="curves per cloud (2048 ~ 50k points; 4900 ~ 120k)")
     ap.add_argument("--mixed-lengths", action="store_true", help="log-normal curve lengths (BASELINE configs[4])")
     ap.add_argument("--width", type=float, default=1.0)
-    ap.add_argument("--mlp-dtype", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--mlp-dtype", choices=["fp32", "bf16", "bf16x3"], default="fp32",
                     help="bf16: forward / data-gradient products of the MLP and conv layers on the bf16 MFMA path "
                          "(BASELINE configs 3 and 5); the headline metric is quoted in fp32")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -281,7 +283,9 @@ def main():
         "metric": "point-clouds/sec fwd+bwd @50k pts", "value": world * b * args.steps / elapsed, "unit": "clouds/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.mlp_dtype == "fp32" else "bf16 products, f32 accumulate / storage", "data": "synthetic",
+        "dtype": {"fp32": "f32", "bf16": "bf16 products, f32 accumulate / storage",
+                  "bf16x3": "f32-grade products assembled from 3-way bf16 splits (6 bf16 MFMAs each; weight gradients "
+                            "on the f32 MFMA), f32 accumulate / storage"}[args.mlp_dtype], "data": "synthetic",
         "config": {"workload": "BASELINE configs[1] shape: %d clouds/GPU x %d curves (~%dk points each, %d points "
                                "on rank 0), fp32 curve-conv + HIP FRNN + MFMA MLP stack; network = %s at width x%g; "
                                "fwd + mean-NLL + bwd + Adam%s"
@@ -306,7 +310,9 @@ def main():
         if top["flops"] > 0:
             achieved = top["flops"] / (top["ms"] * 1e-3) / 1e12
             tr = pmc_traffic(name)
-            peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_F32_MFMA_TFLOPS
+            # the split product spends six bf16 MFMAs per algorithmic multiply-add
+            peak = (PEAK_BF16_MFMA_TFLOPS / 6.0 if "x3" in name else
+                    PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_F32_MFMA_TFLOPS)
             result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak,
                                   "unit": "TFLOP/s", "frac": achieved / peak,
                                   "traffic": tr["bytes_per_launch"] if tr else None, "traffic_source": tr,
@@ -328,7 +334,7 @@ def main():
             busy += cur_e - cur_s
             fam_flops = sum(gemm_label(r[0], r[1], r[4])[1] for r in records)
             fam = fam_flops / (busy * 1e-3) / 1e12
-            if world == 1 and os.environ.get("CCN_WGRAD_STREAM", "1") != "0":
+            if world == 1 and os.environ.get("CCN_WGRAD_STREAM", "1") != "0" and args.mlp_dtype == "fp32":
                 result["roofline"]["note"] = ("launch durations include the time this kernel shares the chip with the "
                                               "weight-gradient stream (ops._WgradScope); with CCN_WGRAD_STREAM=0 the same "
                                               "kernel measures 101.6 TFLOP/s (frac 0.646) and the step is 2.7 % slower")

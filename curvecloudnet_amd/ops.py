@@ -260,16 +260,41 @@ def set_mlp_dtype(name):
     """"fp32" (default): exact fp32 MFMA products.  "bf16": the forward and data-gradient products of every
     Linear / conv layer (``LinearBNAct``) round their operands to bf16 inside the GEMM and accumulate in fp32
     (``ccn_gemm_nt_bf16``, BASELINE configs 3 and 5), and so do the weight-gradient products (``ccn_gemm_tn_bf16``);
-    weights, activations, gradients and BatchNorm statistics are stored and reduced in fp32.  Also settable with the
-    environment variable CCN_MLP_DTYPE."""
+    weights, activations, gradients and BatchNorm statistics are stored and reduced in fp32.  "bf16x3": fp32-grade
+    products on the bf16 matrix cores -- every operand of a forward / data-gradient product is split exactly into three
+    bf16 terms and the product assembled from the six leading partial products (``ccn_gemm_nt_x3``: error below one
+    fp32 rounding per product, 2.7x fewer matrix-core cycles); weight gradients stay on the fp32 MFMA kernel.  Also
+    settable with the environment variable CCN_MLP_DTYPE."""
     global _MLP_DTYPE
-    if name not in ("fp32", "bf16"):
-        raise ValueError("mlp dtype must be 'fp32' or 'bf16'")
+    if name not in ("fp32", "bf16", "bf16x3"):
+        raise ValueError("mlp dtype must be 'fp32', 'bf16' or 'bf16x3'")
     _MLP_DTYPE = name
 
 
 def mlp_dtype():
     return _MLP_DTYPE
+
+
+_GEMM_NT = {"fp32": "gemm_nt", "bf16": "gemm_nt_bf16", "bf16x3": "gemm_nt_x3"}
+X3_MIN_K = 64            # below this a product is HBM-bound on either kernel
+
+
+def _nt_name():
+    return _GEMM_NT[_MLP_DTYPE]
+
+
+def _gemm_nt(name, x, w, bias, y, m, n, k, stats, xp=None, yp=None):
+    """Y = X W^T + b through the entry ``name``; ``xp`` / ``yp`` override the row pointers (a row offset into x / y)."""
+    xp = ptr(x) if xp is None else xp
+    yp = ptr(y) if yp is None else yp
+    if name == "gemm_nt_x3":
+        if k >= X3_MIN_K:
+            nb = lib().ccn_gemm_x3_workspace_bytes(n, k)
+            scratch = workspace(nb, x.device)     # the split weight; stream-ordered reuse by the caching allocator
+            call(name, xp, _ld(x), ptr(w), _ld(w), ptr(bias), yp, _ld(y), m, n, k, ptr(stats), ptr(scratch), nb)
+            return
+        name = "gemm_nt"
+    call(name, xp, _ld(x), ptr(w), _ld(w), ptr(bias), yp, _ld(y), m, n, k, ptr(stats))
 
 
 _WGRAD_STREAMS = {}
@@ -412,13 +437,13 @@ class LinearBNAct(torch.autograd.Function):
         y = _rows(m, n, dev)
         has_bn = gamma is not None
         ctx.has_bn, ctx.act, ctx.training, ctx.has_bias = has_bn, ACT[act], bool(training), bias is not None
-        gemm_nt = ctx.gemm_nt = "gemm_nt_bf16" if _MLP_DTYPE == "bf16" else "gemm_nt"
+        gemm_nt = ctx.gemm_nt = _nt_name()
         ctx.main_grad_of = weight if _has_main_grad(weight) else None
         ctx.bn_refs = (gamma, beta) if has_bn and _has_main_grad(gamma) and _has_main_grad(beta) else None
-        if gemm_nt == "gemm_nt_bf16":
+        if gemm_nt != "gemm_nt":
             x = _aligned_rows(x)
         if not has_bn:
-            call(gemm_nt, ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, None)
+            _gemm_nt(gemm_nt, x, w, bias, y, m, n, k, None)
             ctx.save_for_backward(x, w)
             return y
         par = torch.empty((4, n), dtype=torch.float32, device=dev)      # scale, shift, mean, rstd
@@ -426,11 +451,11 @@ class LinearBNAct(torch.autograd.Function):
             if m < 2:
                 raise ValueError("Expected more than 1 value per channel when training")
             stats = _stats_buffer(m, n, dev)
-            call(gemm_nt, ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats))
+            _gemm_nt(gemm_nt, x, w, bias, y, m, n, k, stats)
             call("bn_finalize", ptr(stats), m, n, ptr(gamma), ptr(beta), float(eps), float(momentum),
                  ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
         else:
-            call(gemm_nt, ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, None)
+            _gemm_nt(gemm_nt, x, w, bias, y, m, n, k, None)
             call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), n,
                  ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
         z = _rows(m, n, dev)
@@ -476,9 +501,9 @@ class LinearBNAct(torch.autograd.Function):
             # index, which is the fastest tile layout (the weight transpose is a few KB..MB)
             wt = _rows(k, n, dev, zero=(n % 4 != 0))
             wt.copy_(w[:, :k].t())
-            if ctx.gemm_nt == "gemm_nt_bf16":
+            if ctx.gemm_nt != "gemm_nt":
                 dy = _aligned_rows(dy)
-            call(ctx.gemm_nt, ptr(dy), _ld(dy), ptr(wt), _ld(wt), None, ptr(dx), _ld(dx), m, k, n, None)
+            _gemm_nt(ctx.gemm_nt, dy, wt, None, dx, m, k, n, None)
         dw = None
         if ctx.needs_input_grad[1]:
             into = _main_grad(ctx.main_grad_of, n, k)
@@ -1216,8 +1241,8 @@ class LinearBNActTail(torch.autograd.Function):
         wt = _aligned_weight(weight.detach())
         ctx.act, ctx.training, ctx.tail, ctx.count = ACT[act], bool(training), int(tail), float(count)
         ctx.main_grad_of = weight if _has_main_grad(weight) else None
-        gemm_nt = ctx.gemm_nt = "gemm_nt_bf16" if _MLP_DTYPE == "bf16" else "gemm_nt"
-        if gemm_nt == "gemm_nt_bf16":
+        gemm_nt = ctx.gemm_nt = _nt_name()
+        if gemm_nt != "gemm_nt":
             x = _aligned_rows(x)
         y = _rows(m, n, dev)
         t = m - tail
@@ -1226,15 +1251,15 @@ class LinearBNActTail(torch.autograd.Function):
         if training:
             nparts = lib().ccn_stats_rows(tail)
             stats = torch.empty((nparts + 2) * 2 * n, dtype=torch.float64, device=dev)
-            call(gemm_nt, ptr(x), _ld(x), ptr(wt), _ld(wt), None, ptr(y), _ld(y), tail, n, k, ptr(stats))
-            call(gemm_nt, ptr(xt), _ld(x), ptr(wt), _ld(wt), None, ptr(yt), _ld(y), t, n, k, None)
+            _gemm_nt(gemm_nt, x, wt, None, y, tail, n, k, stats)
+            _gemm_nt(gemm_nt, x, wt, None, y, t, n, k, None, xp=ptr(xt), yp=ptr(yt))
             acc = torch.empty((lib().ccn_stats_rows(t) + 1) * 2 * n, dtype=torch.float64, device=dev)
             call("colstats_weighted", ptr(yt), _ld(y), ptr(w), t, n, ptr(acc))
             stats[nparts * 2 * n:(nparts + 1) * 2 * n].copy_(acc[:2 * n])          # one more partial row
             call("bn_finalize_n", ptr(stats), nparts + 1, int(count), n, ptr(gamma), ptr(beta), float(eps),
                  float(momentum), ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
         else:
-            call(gemm_nt, ptr(x), _ld(x), ptr(wt), _ld(wt), None, ptr(y), _ld(y), m, n, k, None)
+            _gemm_nt(gemm_nt, x, wt, None, y, m, n, k, None)
             call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), n,
                  ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
         z = _rows(m, n, dev)
@@ -1268,7 +1293,7 @@ class LinearBNActTail(torch.autograd.Function):
             dx = _rows(m, k, dev)
             wtt = _rows(k, n, dev, zero=(n % 4 != 0))
             wtt.copy_(wt[:, :k].t())
-            call(ctx.gemm_nt, ptr(dy), _ld(dy), ptr(wtt), _ld(wtt), None, ptr(dx), _ld(dx), m, k, n, None)
+            _gemm_nt(ctx.gemm_nt, dy, wtt, None, dx, m, k, n, None)
         into = _main_grad(ctx.main_grad_of, n, k)
         dw = into if into is not None else _rows(n, k, dev, zero=True)
         gemm_tn = "gemm_tn_bf16" if ctx.gemm_nt == "gemm_nt_bf16" else "gemm_tn"

@@ -154,6 +154,14 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
  * (v_mfma_f32_32x32x16_bf16), bias / Y / colstats stay fp32.  Requires 16-byte aligned A, W and lda, ldw % 4 == 0. */
 int ccn_gemm_nt_bf16(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                      int64_t M, int64_t N, int64_t K, double* colstats, void* stream); /* Y = A W^T + b */
+/* fp32-grade form of ccn_gemm_nt on the bf16 matrix cores ("bf16x3" MLP mode): every operand is split exactly into three
+ * bf16 terms and the product assembled from the six leading partial products, accumulated in fp32 (dropped terms
+ * < 2^-23 |a b|).  Same arguments and outputs as ccn_gemm_nt plus caller-owned scratch for the split weight
+ * (ccn_gemm_x3_workspace_bytes(N, K) bytes, 16-byte aligned).  Requires 16-byte aligned A and lda % 4 == 0. */
+int64_t ccn_gemm_x3_workspace_bytes(int64_t N, int64_t K);
+int ccn_gemm_x3_knock(int k);
+int ccn_gemm_nt_x3(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                   int64_t M, int64_t N, int64_t K, double* colstats, void* wsplit, int64_t wsplit_bytes, void* stream);
 int ccn_gemm_nn(const float* dY, int64_t lddy, const float* W, int64_t ldw, float* dX, int64_t lddx, int64_t M,
                 int64_t N, int64_t K, void* stream);                              /* dX = dY W      */
 int ccn_gemm_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,

@@ -1,0 +1,115 @@
+"""The split-bf16 ("bf16x3") product: fp32-grade results from the bf16 matrix cores (csrc/ccn_gemm_x3.hip).
+
+Two kinds of checks: the raw C-ABI entry against an fp64 product next to the fp32 MFMA entry (its error must be of the
+same size), and the SAME fp32 parity tests the fp32 mode passes (layer against torch, assembled network against the
+oracle), re-run with the mode switched on and unchanged tolerances."""
+import pytest
+import torch
+
+from tests import test_gpu_float as TF
+from tests import test_gpu_model as TM
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture
+def x3_mode():
+    from curvecloudnet_amd import ops
+    old_min = ops.X3_MIN_K
+    ops.set_mlp_dtype("bf16x3")
+    ops.X3_MIN_K = 1                 # the test networks are narrow: send every product through the split kernel
+    yield ops
+    ops.set_mlp_dtype("fp32")
+    ops.X3_MIN_K = old_min
+
+
+@pytest.mark.parametrize("M,K,N,bias", [(1, 3, 2, True), (127, 6, 20, False), (128, 32, 32, True), (1000, 134, 64, True),
+                                        (333, 259, 128, False), (4097, 64, 192, True), (70, 515, 300, True),
+                                        (30000, 256, 256, True), (5000, 2051, 1024, False), (2049, 1024, 1027, True)])
+def test_x3_product_is_fp32_grade(M, K, N, bias):
+    """Error against the fp64 product, relative to sum_k |a||w| (the natural scale of rounding errors in a dot product):
+    the split product must be as accurate as the fp32 MFMA kernel (measured 3-5e-7 for both; plain bf16: 1e-3), and the
+    BatchNorm partial statistics it emits must match the fp32 kernel's."""
+    from curvecloudnet_amd._lib import call, lib, ptr
+    from curvecloudnet_amd.ops import _ld, _rows
+    gen = torch.Generator().manual_seed(M + K + N)
+    x = _rows(M, K, DEV)
+    x.copy_((torch.randn(M, K, generator=gen) * torch.logspace(-3, 3, K)[None, :]).to(DEV))   # wide dynamic range
+    w = _rows(N, K, DEV, zero=True)
+    w[:, :K].copy_((torch.randn(N, K, generator=gen) / K ** 0.5).to(DEV))
+    b = torch.randn(N, generator=gen).to(DEV) if bias else None
+    nparts = lib().ccn_stats_rows(M)
+    ys, stats = {}, {}
+    for name in ("gemm_nt", "gemm_nt_x3"):
+        y = _rows(M, N, DEV)
+        y.fill_(float("nan"))
+        st = torch.zeros((nparts + 1) * 2 * N, dtype=torch.float64, device=DEV)
+        extra = ()
+        if name == "gemm_nt_x3":
+            nb = lib().ccn_gemm_x3_workspace_bytes(N, K)
+            scratch = torch.empty(nb, dtype=torch.uint8, device=DEV)
+            extra = (ptr(scratch), nb)
+        call(name, ptr(x), _ld(x), ptr(w), _ld(w), ptr(b), ptr(y), _ld(y), M, N, K, ptr(st), *extra)
+        ys[name], stats[name] = y[:, :N].double().cpu(), st[: nparts * 2 * N].view(nparts, 2, N).sum(0).cpu()
+    xd, wd = x[:, :K].double().cpu(), w[:, :K].double().cpu()
+    ref = xd @ wd.t() + (b.double().cpu() if bias else 0.0)
+    scale = xd.abs() @ wd.abs().t() + (b.abs().double().cpu() if bias else 0.0)
+    e32 = float(((ys["gemm_nt"] - ref).abs() / scale).max())
+    e3 = float(((ys["gemm_nt_x3"] - ref).abs() / scale).max())
+    print("max error / sum|a||w|: fp32 MFMA %.3g, split bf16 %.3g" % (e32, e3))
+    assert torch.isfinite(ys["gemm_nt_x3"]).all()
+    assert e3 < 1e-6 and e3 < 2.0 * e32 + 1e-7
+    # column sums / sums of squares of Y (fp64 accumulation of fp32 values on both sides)
+    s32, s3 = stats["gemm_nt"], stats["gemm_nt_x3"]
+    ref_sq = (ref ** 2).sum(0)
+    assert float(((s3[1] - s32[1]).abs() / ref_sq.clamp_min(1e-30)).max()) < 1e-5
+    assert float((s3[0] - s32[0]).abs().max()) <= 1e-5 * float(scale.sum(0).max())
+
+
+def test_x3_rejects_bad_arguments():
+    from curvecloudnet_amd import _lib
+    from curvecloudnet_amd.ops import _ld, _rows
+    x, w, y = _rows(64, 64, DEV), _rows(64, 64, DEV), _rows(64, 64, DEV)
+    scratch = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    with pytest.raises(RuntimeError, match="scratch too small"):
+        _lib.call("gemm_nt_x3", _lib.ptr(x), _ld(x), _lib.ptr(w), _ld(w), None, _lib.ptr(y), _ld(y), 64, 64, 64, None,
+                  _lib.ptr(scratch), 1024)
+    assert _lib.lib().ccn_gemm_x3_workspace_bytes(64, 64) == 3 * 128 * 64 * 2
+    assert _lib.lib().ccn_gemm_x3_workspace_bytes(129, 33) == 3 * 256 * 64 * 2
+
+
+# ---- the fp32 parity tests, unchanged tolerances, with the split product underneath
+@pytest.mark.parametrize("M,K,N", [(1, 3, 2), (127, 6, 20), (1000, 134, 64), (333, 259, 128), (4097, 64, 192), (70, 515, 300)])
+def test_x3_linear_plain_fwd_bwd(x3_mode, M, K, N):
+    TF.test_linear_plain_fwd_bwd(M, K, N)
+
+
+@pytest.mark.parametrize("M,K,N,act,bias", [(500, 38, 64, "leaky_relu", False), (2000, 134, 64, "relu", False),
+                                             (129, 16, 40, "relu", True), (4100, 64, 256, "leaky_relu", True)])
+@pytest.mark.parametrize("training", [True, False])
+def test_x3_linear_bn_act_vs_torch(x3_mode, M, K, N, act, bias, training):
+    TF.test_linear_bn_act_vs_torch(M, K, N, act, bias, training)
+
+
+@pytest.mark.parametrize("ids,n_curves", [([0], 96), ([1, 2], 64)])
+def test_x3_model_forward_backward_matches_oracle(x3_mode, ids, n_curves):
+    TM.test_model_forward_backward_matches_oracle(ids, n_curves)
+
+
+def test_x3_full_kitti_config_matches_oracle(x3_mode):
+    TM.test_full_kitti_config_matches_oracle()
+
+
+def test_x3_mode_really_uses_the_split_kernel(x3_mode):
+    from curvecloudnet_amd import _lib
+    ops = x3_mode
+    x = torch.randn(300, 70, device=DEV)
+    lin = torch.nn.Linear(70, 40).to(DEV)
+    _lib.PROFILE = []
+    try:
+        ops.linear_bn_act(x, lin.weight, lin.bias, None, False, None)
+        names = [r[0] for r in _lib.PROFILE]
+    finally:
+        _lib.PROFILE = None
+    assert names == ["gemm_nt_x3"], names
