@@ -265,7 +265,335 @@ __global__ __launch_bounds__(X_TPB, 2) void gemm_x3_kernel(const float* __restri
   }
 }
 
+
+// ------------------------------------------------------------------ persistent LDS-DMA form (K % 32 == 0, many tiles)
+// One 8-wave workgroup per CU walks 256 x BN output tiles; wave w owns the 32-row band w.  The K slices of consecutive
+// tiles form one stream:
+//   A  fp32, 256 rows x 128 B per slice, copied by global_load_lds into a 3-stage ring two slices ahead (HBM latency);
+//      LDS chunk c (16 B) of row r holds global chunk c ^ ((r >> 1) & 7), so a lane's eight consecutive k (two 16-byte
+//      reads at chunks 4 st + 2 h + {0, 1}) are conflict-free.  The split into three bf16 terms happens in registers,
+//      between the MFMAs -- no bf16 image of A is ever written to LDS, and no second barrier per slice is needed;
+//   W  the three pre-split bf16 images, BN rows x 64 B each per slice, copied one slice ahead (they come from L2) into a
+//      2-stage ring; LDS chunk c of row r holds global chunk c ^ ((r >> 2) & 3): one ds_read_b128 per fragment,
+//      conflict-free.
+// vmcnt retires in issue order, so each iteration issues W(g+1) BEFORE A(g+2): waiting for slice g then leaves exactly
+// the four A copies of slice g+1 in flight.  The epilogue (stores issued and forgotten, BatchNorm partial sums parked in
+// an LDS table that is read out after the next tile's first barrier) is the one of gemm_glds_persistent_kernel.
 static int g_knock = 0;
+static bool g_use_persistent = true;
+constexpr int P_TPB = 512;
+constexpr int P_BM = 256;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, bf16x8& vh, bf16x8& vm, bf16x8& vl) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = e < 4 ? lo[e] : hi[e - 4];
+    __bf16 eh, em, el;
+    split3(x, eh, em, el);
+    vh[e] = eh;
+    vm[e] = em;
+    vl[e] = el;
+  }
+}
+
+template <int BN>
+__global__ __launch_bounds__(P_TPB) void gemm_x3_persistent_kernel(const float* __restrict__ A, int64_t lda,
+                                                                   const __bf16* __restrict__ Wimg, int64_t Np,
+                                                                   int64_t Kp, const float* __restrict__ bias,
+                                                                   float* __restrict__ C, int64_t ldc, int64_t M,
+                                                                   int64_t N, int64_t K, int64_t gm, int gn, int xcd_map,
+                                                                   double* __restrict__ colstats) {
+  constexpr int NT = BN / 32;
+  constexpr int A_ST = P_BM * XK;        // floats per A stage (32 KiB)
+  constexpr int B_ST = 3 * BN * 64;      // bytes per W stage
+  constexpr int NA = 4;                  // A copies per wave and slice (8 rows x 128 B each)
+  constexpr int B_GROUPS = 3 * BN / 16;  // 1-KiB copies (16 rows x 64 B) per W slice
+  constexpr int NB = (B_GROUPS + 7) / 8;
+  __shared__ __attribute__((aligned(16))) float ldsA[3 * A_ST];
+  __shared__ __attribute__((aligned(16))) unsigned char ldsB[2 * B_ST];
+  __shared__ float stat_part[8 * BN * 2];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const uint32_t ldsA_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ldsA;
+  const uint32_t ldsB_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ldsB;
+  const uint32_t a_row = (uint32_t)((wave * 32 + i) * 128);
+  const uint32_t a_swz = (uint32_t)((i >> 1) & 7);
+  const uint32_t b_row = (uint32_t)(i * 64);
+  const uint32_t b_swz = (uint32_t)((i >> 2) & 3);
+  const int T = (int)(K / XK);
+
+  // tile of step j for this workgroup.  xcd_map: the gn column tiles of one row block go to workgroups w, w + 8, ...
+  // (the same XCD, the same step), so A is read from HBM once and from that XCD's L2 by the others
+  const int rows_per_step = xcd_map ? (int)(gridDim.x / gn) : 0;
+  auto tile_at = [&](int64_t j, int64_t& m, int& n) -> bool {
+    if (xcd_map) {
+      const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+      n = slot % gn;
+      m = j * rows_per_step + (slot / gn) * 8 + xcd;
+    } else {
+      const int64_t tile = j * gridDim.x + blockIdx.x;
+      m = tile / gn;
+      n = (int)(tile - m * gn);
+    }
+    return m < gm;
+  };
+
+  // ---- issue cursors: A runs two slices ahead of the compute cursor, W one
+  const int lr8 = lane >> 3, lc8 = lane & 7;   // A copy: lane -> (row lane/8 of the 8-row group, 16-byte chunk lane%8)
+  const int lr4 = lane >> 2, lc4 = lane & 3;   // W copy: lane -> (row lane/4 of the 16-row group, chunk lane%4)
+  const float* a_src[NA];
+  const __bf16* b_src[NB];
+  int64_t ca_j = 0, ca_m = 0, cb_j = 0, cb_m = 0;
+  int ca_n = 0, cb_n = 0, ca_u = 0, cb_u = 0;
+  bool ca_live = tile_at(0, ca_m, ca_n), cb_live = tile_at(0, cb_m, cb_n);
+  int64_t issuedA = 0, issuedB = 0;
+  auto issue_a = [&]() {
+    if (!ca_live) return;
+    if (ca_u == 0) {
+#pragma unroll
+      for (int q = 0; q < NA; ++q) {
+        const int r = 8 * (wave * NA + q) + lr8;
+        int64_t row = ca_m * P_BM + r;
+        row = row < M ? row : M - 1;
+        a_src[q] = A + row * lda + 4 * (lc8 ^ ((r >> 1) & 7));
+      }
+    }
+    float* st = ldsA + (issuedA % 3) * A_ST;
+    const int64_t k0 = (int64_t)ca_u * XK;
+#pragma unroll
+    for (int q = 0; q < NA; ++q) glds16(a_src[q] + k0, st + (8 * (wave * NA + q)) * XK);
+    ++issuedA;
+    if (++ca_u == T) {
+      ca_u = 0;
+      ++ca_j;
+      ca_live = tile_at(ca_j, ca_m, ca_n);
+    }
+  };
+  auto issue_b = [&]() {
+    if (!cb_live) return;
+    if (cb_u == 0) {
+#pragma unroll
+      for (int q = 0; q < NB; ++q) {
+        const int gidx = (wave * NB + q) % B_GROUPS;   // (surplus copies repeat a group: same bytes, same place)
+        const int img = gidx / (BN / 16), rb = gidx - img * (BN / 16);
+        const int r = rb * 16 + lr4;
+        b_src[q] = Wimg + ((int64_t)img * Np + (int64_t)cb_n * BN + r) * Kp + 8 * (lc4 ^ ((r >> 2) & 3));
+      }
+    }
+    unsigned char* st = ldsB + (issuedB % 2) * B_ST;
+    const int64_t k0 = (int64_t)cb_u * XK;
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int gidx = (wave * NB + q) % B_GROUPS;
+      glds16(b_src[q] + k0, st + gidx * 1024);
+    }
+    ++issuedB;
+    if (++cb_u == T) {
+      cb_u = 0;
+      ++cb_j;
+      cb_live = tile_at(cb_j, cb_m, cb_n);
+    }
+  };
+  issue_b();
+  issue_a();
+  issue_a();
+
+  int64_t stat_m = -1;   // row block / column tile whose statistics wait in stat_part
+  int stat_n = 0;
+  auto stats_readout = [&]() {
+    for (int e = threadIdx.x; e < 2 * BN; e += P_TPB) {
+      const int half = e / BN, c = e - half * BN;
+      const int64_t n = (int64_t)stat_n * BN + c;
+      const int64_t prow = stat_m * 2 + half;
+      if (n < N && prow * 128 < M) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          s1 += (double)stat_part[((half * 4 + w) * BN + c) * 2];
+          s2 += (double)stat_part[((half * 4 + w) * BN + c) * 2 + 1];
+        }
+        double* dst = colstats + prow * 2 * N;
+        dst[n] = s1;
+        dst[N + n] = s2;
+      }
+    }
+    stat_m = -1;
+  };
+
+  // ---- compute.  Waves 0-3 (group 0) and 4-7 (group 1; wave w + 4 shares its SIMD with wave w) run half a slice apart:
+  // per slice, group 0 does  load/split(st 0) . MFMA(st 0) . load/split(st 1) . MFMA(st 1),  group 1 starts with the MFMAs
+  // of the fragments it loaded at the end of the PREVIOUS slice and ends with the loads of st 1 -- so while one wave of a
+  // SIMD reads LDS and splits its A fragment (vector work), the other one feeds the matrix core, with the one barrier per
+  // slice the ring needs anyway.  (Both groups in step left the matrix core idle for half the time: SQ_VALU_MFMA_BUSY 47 %.)
+  const bool late = wave >= 4;
+  int64_t g = 0, landedA = 0, landedB = 0;
+  f32x16 acc[NT];
+  f32x4 fb[NT][3];
+  bf16x8 ah, am, al;
+  auto acc_init = [&](int64_t n0) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int64_t n = n0 + t * 32 + i;
+      const float b = (bias != nullptr && n < N) ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = b;
+    }
+  };
+  // fragments of step st of the slice in ring position (sa, sb): A raw -> three bf16 terms, W images as they are
+  auto load_frags = [&](int sa, int sb, int st) {
+    const uint32_t aB = ldsA_base + (uint32_t)(sa * A_ST * 4) + a_row;
+    const uint32_t bB = ldsB_base + (uint32_t)(sb * B_ST) + b_row + 16u * ((uint32_t)(2 * st + h) ^ b_swz);
+    const uint32_t c0 = 16u * ((uint32_t)(4 * st + 2 * h) ^ a_swz), c1 = 16u * ((uint32_t)(4 * st + 2 * h + 1) ^ a_swz);
+    f32x4 a0, a1;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(aB + c0) : "memory");
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(aB + c1) : "memory");
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[t][sp]) : "v"(bB), "n"(sp * BN * 64 + t * 32 * 64) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * NT) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    split8(a0, a1, ah, am, al);       // under the latency of the W reads
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto products = [&]() {   // the 6 NT MFMAs of one step, smallest partial products first
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, fb[t][0]), bm = __builtin_bit_cast(bf16x8, fb[t][1]),
+                   bl = __builtin_bit_cast(bf16x8, fb[t][2]);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // tile epilogue.  Everything issued so far (slices of the next tile) is waited for first: vmcnt retires in order, and
+  // the stores below would otherwise sit in front of younger copies in every later counted wait.
+  auto epilogue = [&](int64_t em, int en) {
+    const int64_t m0 = em * P_BM, n0 = (int64_t)en * BN;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landedA = issuedA;
+    landedB = issuedB;
+    const bool interior = m0 + P_BM <= M && n0 + BN <= N;
+    float* const crow = C + (m0 + wave * 32 + 4 * h) * ldc + n0 + i;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int ncol = t * 32 + i;
+      const int64_t n = n0 + ncol;
+      float s1 = 0.f, s2 = 0.f;
+      if (interior) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[t][r];
+          crow[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc + t * 32] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < M && n < N) {
+            const float v = acc[t][r];
+            C[m * ldc + n] = v;
+            s1 += v;
+            s2 += v * v;
+          }
+        }
+      }
+      if (colstats != nullptr) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0) {
+          stat_part[(wave * BN + ncol) * 2] = s1;
+          stat_part[(wave * BN + ncol) * 2 + 1] = s2;
+        }
+      }
+    }
+    if (colstats != nullptr) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // table written before the next barrier
+  };
+
+  // One flat loop over this workgroup's slices plus a final drain pass; the epilogue of a tile runs at the start of the
+  // NEXT tile's first pass (after group 1 has issued the tile's last MFMAs), so there is one copy of it in the code.
+  int64_t tm = 0, pm = -1;   // current tile, finished tile whose epilogue is due
+  int tn = 0, pn = 0, u = 0;
+  int64_t j = 0;
+  bool have = tile_at(0, tm, tn);
+  bool pending = false;      // group 1: fragments of (previous slice, step 1) loaded, MFMAs not issued yet
+  if (!have) return;         // (the whole workgroup: no barrier has been executed yet)
+  for (;;) {
+    if (have && (g >= landedB || g >= landedA)) {
+      if (issuedA > g + 1)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (u == 1 && stat_m >= 0) stats_readout();   // parked by every wave before this barrier
+    if (late && pending) {
+      products();
+      pending = false;
+    }
+    if (u == 0 && pm >= 0) {
+      epilogue(pm, pn);
+      if (colstats != nullptr) {
+        stat_m = pm;
+        stat_n = pn;
+      }
+      pm = -1;
+    }
+    if (!have) break;
+    issue_b();   // (one at a time between the MFMA groups instead of in a burst here: tried, 5 % slower)
+    issue_a();
+    if (u == 0) acc_init((int64_t)tn * BN);
+    const int sa = (int)(g % 3), sb = (int)(g & 1);
+    load_frags(sa, sb, 0);
+    products();
+    load_frags(sa, sb, 1);
+    if (!late)
+      products();
+    else
+      pending = true;
+    ++g;
+    if (++u == T) {
+      u = 0;
+      pm = tm;
+      pn = tn;
+      ++j;
+      have = tile_at(j, tm, tn);
+    }
+  }
+  if (stat_m >= 0) {   // statistics of the last tile
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stats_readout();
+  }
+}
+
+template <int BN>
+void launch_x3_persistent(const float* A, int64_t lda, const __bf16* img, int64_t Np, int64_t Kp, const float* bias,
+                          float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s) {
+  const int64_t gm = (M + P_BM - 1) / P_BM;
+  const int gn = (int)((N + BN - 1) / BN);
+  const int xcd_map = (gn <= 32 && 32 % gn == 0 && !(g_knock & 128)) ? 1 : 0;
+  hipLaunchKernelGGL((gemm_x3_persistent_kernel<BN>), dim3(256), dim3(P_TPB), 0, s, A, lda, img, Np, Kp, bias, Y, ldy, M, N,
+                     K, gm, gn, xcd_map, colstats);
+}
+
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int BN, int WMW>
@@ -282,7 +610,7 @@ void launch_x3(const float* A, int64_t lda, const __bf16* img, int64_t Np, int64
 
 extern "C" {
 
-int ccn_gemm_x3_knock(int k) { g_knock = k; return 0; }
+int ccn_gemm_x3_knock(int k) { g_knock = k & ~16; g_use_persistent = !(k & 16); return 0; }
 int64_t ccn_gemm_x3_workspace_bytes(int64_t N, int64_t K) {
   if (N <= 0 || K <= 0) return 0;
   const int64_t Np = (N + X_NPAD - 1) / X_NPAD * X_NPAD, Kp = (K + XK - 1) / XK * XK;
@@ -306,6 +634,19 @@ int ccn_gemm_nt_x3(const float* A, int64_t lda, const float* W, int64_t ldw, con
   __bf16* img = reinterpret_cast<__bf16*>(wsplit);
   hipLaunchKernelGGL(x3_split_weights_kernel, dim3((unsigned)((Np * Kp + 255) / 256)), dim3(256), 0, s, W, ldw, N, K, Np,
                      Kp, img);
+  // many 256-row tiles and whole K slices: the persistent LDS-DMA kernel (one workgroup per CU, 256 CUs)
+  const bool persistent = g_use_persistent && K % XK == 0 && K >= 64 &&
+                          ((M + P_BM - 1) / P_BM) * ((N + 127) / 128) >= 512;
+  if (persistent) {
+    if (N <= 32)
+      launch_x3_persistent<32>(A, lda, img, Np, Kp, bias, Y, ldy, M, N, K, colstats, s);
+    else if (N <= 64)
+      launch_x3_persistent<64>(A, lda, img, Np, Kp, bias, Y, ldy, M, N, K, colstats, s);
+    else
+      launch_x3_persistent<128>(A, lda, img, Np, Kp, bias, Y, ldy, M, N, K, colstats, s);
+    CCN_LAUNCH_OK("gemm_nt_x3");
+    return CCN_OK;
+  }
   if (N <= 32)
     launch_x3<32, 4>(A, lda, img, Np, Kp, bias, Y, ldy, M, N, K, colstats, s);
   else if (N <= 64)

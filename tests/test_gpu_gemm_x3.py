@@ -26,7 +26,11 @@ def x3_mode():
 
 @pytest.mark.parametrize("M,K,N,bias", [(1, 3, 2, True), (127, 6, 20, False), (128, 32, 32, True), (1000, 134, 64, True),
                                         (333, 259, 128, False), (4097, 64, 192, True), (70, 515, 300, True),
-                                        (30000, 256, 256, True), (5000, 2051, 1024, False), (2049, 1024, 1027, True)])
+                                        (30000, 256, 256, True), (5000, 2051, 1024, False), (2049, 1024, 1027, True),
+                                        # >= 512 tiles of 256 x 128 and K % 32 == 0: the persistent LDS-DMA kernel
+                                        (140000, 64, 64, True), (70001, 256, 256, True), (131073, 96, 128, False),
+                                        (40000, 128, 512, True), (300000, 64, 20, True), (66000, 512, 1024, False),
+                                        (50100, 64, 384, True)])
 def test_x3_product_is_fp32_grade(M, K, N, bias):
     """Error against the fp64 product, relative to sum_k |a||w| (the natural scale of rounding errors in a dot product):
     the split product must be as accurate as the fp32 MFMA kernel (measured 3-5e-7 for both; plain bf16: 1e-3), and the
@@ -52,9 +56,10 @@ def test_x3_product_is_fp32_grade(M, K, N, bias):
             extra = (ptr(scratch), nb)
         call(name, ptr(x), _ld(x), ptr(w), _ld(w), ptr(b), ptr(y), _ld(y), M, N, K, ptr(st), *extra)
         ys[name], stats[name] = y[:, :N].double().cpu(), st[: nparts * 2 * N].view(nparts, 2, N).sum(0).cpu()
-    xd, wd = x[:, :K].double().cpu(), w[:, :K].double().cpu()
-    ref = xd @ wd.t() + (b.double().cpu() if bias else 0.0)
-    scale = xd.abs() @ wd.abs().t() + (b.abs().double().cpu() if bias else 0.0)
+    xd, wd = x[:, :K].double(), w[:, :K].double()          # fp64 on the GPU (rocBLAS): the reference product
+    ref = (xd @ wd.t() + (b.double() if bias else 0.0)).cpu()
+    scale = (xd.abs() @ wd.abs().t() + (b.abs().double() if bias else 0.0)).cpu()
+    del xd, wd
     e32 = float(((ys["gemm_nt"] - ref).abs() / scale).max())
     e3 = float(((ys["gemm_nt_x3"] - ref).abs() / scale).max())
     print("max error / sum|a||w|: fp32 MFMA %.3g, split bf16 %.3g" % (e32, e3))
