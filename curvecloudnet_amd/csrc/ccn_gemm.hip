@@ -840,7 +840,22 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
   // ---- issue cursor (runs two slices ahead of the compute cursor, across tile boundaries)
   const float* a_src[NA];
   const float* b_src[NB];
-  int64_t it_tile = blockIdx.x;
+  // Tile order.  With all 256 workgroups launched and gn dividing 32, the gn column tiles of one 256-row block go to
+  // workgroups w, w + 8, ... of the SAME step: those ids sit on one XCD, so the row block is read from HBM once and from
+  // that XCD's L2 by the other column tiles (measured on the split-bf16 twin of this kernel: 707 -> 379 MB read per
+  // launch at K = N = 256).  Otherwise tiles are dealt round-robin.
+  const int64_t gm_tiles = tiles / gn;
+  const bool xcd_map = gridDim.x == 256 && gn <= 32 && 32 % gn == 0;
+  auto tile_of = [&](int64_t j) -> int64_t {   // (>= tiles: this workgroup has no tile in step j)
+    if (xcd_map) {
+      const int64_t slot = blockIdx.x >> 3;
+      const int64_t m = j * (256 / gn) + (slot / gn) * 8 + (blockIdx.x & 7);
+      return m < gm_tiles ? m * gn + slot % gn : tiles;
+    }
+    return j * gridDim.x + blockIdx.x;
+  };
+  int64_t it_j = 0;
+  int64_t it_tile = tile_of(0);
   int it_u = 0;
   int64_t gi = 0;  // slices issued so far
   auto issue_next = [&]() {
@@ -875,7 +890,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
     ++gi;
     if (++it_u == T) {
       it_u = 0;
-      it_tile += gridDim.x;
+      it_tile = tile_of(++it_j);
     }
   };
   for (int pre = 0; pre < STAGES - 1; ++pre) issue_next();  // the DMA runs STAGES-1 slices ahead of the compute
@@ -904,7 +919,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
 
   int64_t g = 0;       // slices computed so far
   int64_t landed = 0;  // slices [0, landed) are known to be in LDS for this wave
-  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+  for (int64_t j = 0, tile; (tile = tile_of(j)) < tiles; ++j) {
     const int64_t m0 = (tile / gn) * GL_BM, n0 = (tile % gn) * BN;
     f32x16 acc[NT];
     acc_init<NT>(acc, bias, n0, N, i);  // bias (or 0) as the initial accumulator value
@@ -944,6 +959,8 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
     // ---- tile epilogue.  Everything issued so far (<= 2 slices of the next tile) is waited for first.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     landed = gi;
+    // (16-byte stores after a DPP quad transpose of the accumulators -- 16 instead of 64 store instructions per lane -- were
+    // tried and measured 2-5 % SLOWER: the epilogue is bound by the write path, not by the number of store instructions.)
     // Interior tiles (all but the last tile row / column) store without per-element bounds tests: 16*NT stores per lane
     // with a compare, a branch and a 64-bit multiply-add each made the epilogue ~8.5k cycles per tile (measured 4.2 us
     // per tile whatever K), a quarter of a K = 128 tile.

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(X_TPB, 2) void gemm_x3_kernel(const float* __restri
                                                            const __bf16* __restrict__ Wimg, int64_t Np, int64_t Kp,
                                                            const float* __restrict__ bias, float* __restrict__ C,
                                                            int64_t ldc, int64_t M, int64_t N, int64_t K, int64_t gm,
-                                                           int gn, double* __restrict__ colstats, int knock) {
+                                                           int gn, double* __restrict__ colstats) {
   constexpr int WNW = 4 / WMW;               // waves along N
   constexpr int AB = X_BM / (32 * WMW);      // 32-row blocks per wave
   constexpr int NT = BN / (32 * WNW);        // 32-column blocks per wave
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(X_TPB, 2) void gemm_x3_kernel(const float* __restri
   __syncthreads();
   for (int64_t k0 = 0; k0 < K; k0 += XK) {
     const bool has_next = k0 + XK < K;
-    if (has_next && !(knock & 1)) load_slice(k0 + XK);   // in flight during the MFMAs below
+    if (has_next) load_slice(k0 + XK);   // in flight during the MFMAs below
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       bf16x8 a[AB][3], b[NT][3];
@@ -195,7 +195,6 @@ __global__ __launch_bounds__(X_TPB, 2) void gemm_x3_kernel(const float* __restri
         for (int s = 0; s < 3; ++s)
           b[t][s] = *reinterpret_cast<const bf16x8*>(Bl + s * B_IMG + ((wn * NT + t) * 32 + i) * XLD + (2 * st + h) * 8);
       // smallest partial products first; consecutive MFMAs go to different accumulators
-      if (knock & 2) continue;
       constexpr int SA[6] = {2, 0, 1, 1, 0, 0};
       constexpr int SB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -208,14 +207,13 @@ __global__ __launch_bounds__(X_TPB, 2) void gemm_x3_kernel(const float* __restri
     }
     if (has_next) {
       __syncthreads();   // every wave is done reading this slice
-      if (!(knock & 4)) store_slice();
+      store_slice();
       __syncthreads();
     }
   }
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   double* stat_lds = reinterpret_cast<double*>(lds);   // [WMW][BN][2]
-  if (knock & 8) return;
   if (colstats != nullptr) __syncthreads();            // LDS is reused
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -279,8 +277,7 @@ __global__ __launch_bounds__(X_TPB, 2) void gemm_x3_kernel(const float* __restri
 // vmcnt retires in issue order, so each iteration issues W(g+1) BEFORE A(g+2): waiting for slice g then leaves exactly
 // the four A copies of slice g+1 in flight.  The epilogue (stores issued and forgotten, BatchNorm partial sums parked in
 // an LDS table that is read out after the next tile's first barrier) is the one of gemm_glds_persistent_kernel.
-static int g_knock = 0;
-static bool g_use_persistent = true;
+static bool g_use_persistent = true;   // A/B hook (ccn_gemm_x3_use_persistent)
 constexpr int P_TPB = 512;
 constexpr int P_BM = 256;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -588,7 +585,7 @@ void launch_x3_persistent(const float* A, int64_t lda, const __bf16* img, int64_
                           float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s) {
   const int64_t gm = (M + P_BM - 1) / P_BM;
   const int gn = (int)((N + BN - 1) / BN);
-  const int xcd_map = (gn <= 32 && 32 % gn == 0 && !(g_knock & 128)) ? 1 : 0;
+  const int xcd_map = (gn <= 32 && 32 % gn == 0) ? 1 : 0;
   hipLaunchKernelGGL((gemm_x3_persistent_kernel<BN>), dim3(256), dim3(P_TPB), 0, s, A, lda, img, Np, Kp, bias, Y, ldy, M, N,
                      K, gm, gn, xcd_map, colstats);
 }
@@ -603,14 +600,18 @@ void launch_x3(const float* A, int64_t lda, const __bf16* img, int64_t Np, int64
   const int gn = (int)((N + BN - 1) / BN);
   const int64_t grid = (gm + 7) / 8 * 8 * gn;
   hipLaunchKernelGGL((gemm_x3_kernel<BN, WMW>), dim3((unsigned)grid), dim3(X_TPB), 0, s, A, lda, img, Np, Kp, bias, Y, ldy,
-                     M, N, K, gm, gn, colstats, g_knock);
+                     M, N, K, gm, gn, colstats);
 }
 
 }  // namespace
 
 extern "C" {
 
-int ccn_gemm_x3_knock(int k) { g_knock = k & ~16; g_use_persistent = !(k & 16); return 0; }
+int ccn_gemm_x3_use_persistent(int on) {
+  g_use_persistent = on != 0;
+  return CCN_OK;
+}
+
 int64_t ccn_gemm_x3_workspace_bytes(int64_t N, int64_t K) {
   if (N <= 0 || K <= 0) return 0;
   const int64_t Np = (N + X_NPAD - 1) / X_NPAD * X_NPAD, Kp = (K + XK - 1) / XK * XK;

@@ -72,6 +72,35 @@ def test_x3_product_is_fp32_grade(M, K, N, bias):
     assert float((s3[0] - s32[0]).abs().max()) <= 1e-5 * float(scale.sum(0).max())
 
 
+@pytest.mark.parametrize("M,K,N", [(140000, 64, 64), (70001, 256, 256), (40000, 128, 512), (50100, 64, 384)])
+def test_x3_persistent_and_register_staged_kernels_agree(M, K, N):
+    """The two kernels behind ccn_gemm_nt_x3 (LDS-DMA persistent for many tiles, register-staged otherwise) on the same
+    operands: same partial products, different summation order over K slices only."""
+    from curvecloudnet_amd._lib import call, lib, ptr
+    from curvecloudnet_amd.ops import _ld, _rows
+    gen = torch.Generator().manual_seed(M + K)
+    x = _rows(M, K, DEV)
+    x.copy_(torch.randn(M, K, generator=gen).to(DEV))
+    w = _rows(N, K, DEV, zero=True)
+    w[:, :K].copy_((torch.randn(N, K, generator=gen) / K ** 0.5).to(DEV))
+    nb = lib().ccn_gemm_x3_workspace_bytes(N, K)
+    scratch = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    nparts = lib().ccn_stats_rows(M)
+    outs = []
+    try:
+        for on in (1, 0):
+            lib().ccn_gemm_x3_use_persistent(on)
+            y = _rows(M, N, DEV)
+            st = torch.zeros((nparts + 1) * 2 * N, dtype=torch.float64, device=DEV)
+            call("gemm_nt_x3", ptr(x), _ld(x), ptr(w), _ld(w), None, ptr(y), _ld(y), M, N, K, ptr(st), ptr(scratch), nb)
+            outs.append((y[:, :N].clone(), st[: nparts * 2 * N].clone()))
+    finally:
+        lib().ccn_gemm_x3_use_persistent(1)
+    (ya, sa), (yb, sb) = outs
+    assert float((ya - yb).abs().max()) < 2e-6 * max(1.0, float(yb.abs().max()))
+    assert float((sa - sb).abs().max()) < 1e-6 * max(1.0, float(sb.abs().max()))
+
+
 def test_x3_rejects_bad_arguments():
     from curvecloudnet_amd import _lib
     from curvecloudnet_amd.ops import _ld, _rows

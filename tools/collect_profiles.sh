@@ -1,12 +1,14 @@
 #!/bin/bash
 # Run ON the GPU box (under gpurun): rocprofv3 kernel statistics + separate PMC passes of the default bench command.
-# Usage: bash tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>_*  (copy what should be judged into profiles/)
+# Usage: bash tools/collect_profiles.sh <tag> [extra bench.py flags]   -> gpurun_out/<tag>_*  (copy what should be judged
+# into profiles/), e.g. "r01n_x3 --mlp-dtype bf16x3"
 set -o pipefail
 tag=${1:-rXX}
+shift
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-bench="python3 $repo/bench.py --no-cpu-baseline --no-kernel-timing"
+bench="python3 $repo/bench.py --no-cpu-baseline --no-kernel-timing $*"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o s -- $bench > $out/${tag}_stats_run.log 2>&1 || exit 1
 cp "$(find /tmp/p_stats -name '*kernel_stats.csv' | head -1)" $out/${tag}_kitti_kernel_stats.csv
 for pass in fetch:FETCH_SIZE write:WRITE_SIZE "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over one GEMM shape for the split-bf16 kernel: tools/_pmc_x3.sh M K N
+# PMC passes over one GEMM shape for the split-bf16 kernel: tools/pmc_gemm_x3.sh M K N
 cd /tmp && export TMPDIR=/tmp
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 export PYTHONPATH=$repo
@@ -16,7 +16,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = col
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
     if "x3" not in k: continue
-    k = k.split("(")[0][-60:]
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-60:]
     acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); 
 for k, d in acc.items():
     print(k, {c: "%.4g" % v for c, v in d.items()})
