@@ -61,6 +61,8 @@ def lib():
             fn.restype, fn.argtypes = restype, argtypes
         if handle.ccn_abi_version() != 1:
             raise RuntimeError("libccn_hip.so ABI version mismatch")
+        if os.environ.get("CCN_GEMM_DMA"):       # A/B hook of the GEMM dispatch (include/ccn_hip.h: ccn_gemm_use_dma)
+            handle.ccn_gemm_use_dma(int(os.environ["CCN_GEMM_DMA"]))
         _lib = handle
     return _lib
 

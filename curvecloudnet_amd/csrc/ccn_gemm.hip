@@ -816,7 +816,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
                                                                       const float* __restrict__ bias,
                                                                       float* __restrict__ C, int64_t ldc, int64_t M,
                                                                       int64_t N, int64_t K, int64_t tiles, int64_t gn,
-                                                                      double* __restrict__ colstats) {
+                                                                      int xcd_order, double* __restrict__ colstats) {
   constexpr int NT = BN / 32;
   constexpr int AF = GL_BM * BK, BF = BN * BK, STAGE = AF + BF;
   constexpr int NA = GL_BM / 8 / 8;
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
   // that XCD's L2 by the other column tiles (measured on the split-bf16 twin of this kernel: 707 -> 379 MB read per
   // launch at K = N = 256).  Otherwise tiles are dealt round-robin.
   const int64_t gm_tiles = tiles / gn;
-  const bool xcd_map = gridDim.x == 256 && gn <= 32 && 32 % gn == 0;
+  const bool xcd_map = xcd_order && gridDim.x == 256 && gn <= 32 && 32 % gn == 0;
   auto tile_of = [&](int64_t j) -> int64_t {   // (>= tiles: this workgroup has no tile in step j)
     if (xcd_map) {
       const int64_t slot = blockIdx.x >> 3;
@@ -1012,6 +1012,8 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
   }
 }
 
+static bool g_xcd_map = true;  // A-B hook (ccn_gemm_use_dma(3) = persistent kernel with round-robin tiles)
+
 template <int BN>
 int launch_glds_persistent(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y,
                            int64_t ldy, int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s) {
@@ -1020,7 +1022,7 @@ int launch_glds_persistent(const float* A, int64_t lda, const float* W, int64_t 
   const int64_t grid = tiles < 256 ? tiles : 256;  // one workgroup per CU (147 KB of LDS each)
   // (a 256 x 256 tile with a 2-stage ring was tried: +2 % at N = 512, -6 % where it leaves few tiles, 12 spilled VGPRs)
   hipLaunchKernelGGL((gemm_glds_persistent_kernel<BN, 3>), dim3((unsigned)grid), dim3(GL_TPB), 0, s, A, lda, W, ldw, bias,
-                     Y, ldy, M, N, K, tiles, gn, colstats);
+                     Y, ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats);
   return CCN_OK;
 }
 
@@ -1446,7 +1448,8 @@ int ccn_gemm_use_dma(int on) {
   }
   g_dma_min_k = 64;
   g_use_glds = on != 0;
-  g_use_persistent = on == 1;
+  g_use_persistent = on == 1 || on == 3;
+  g_xcd_map = on != 3;
   return CCN_OK;
 }
 
