@@ -305,7 +305,8 @@ __global__ __launch_bounds__(GEMM_TPB) void gemm_fast_kernel(const float* __rest
                                                              const float* __restrict__ B, int64_t ldb,
                                                              const float* __restrict__ bias, float* __restrict__ C,
                                                              int64_t ldc, int64_t M, int64_t N, int64_t K,
-                                                             int64_t kchunk, double* __restrict__ colstats) {
+                                                             int64_t kchunk, double* __restrict__ colstats,
+                                                             int xcd_order) {
   constexpr int WN = 4 / WM;
   constexpr int WCOLS = BN / WN;
   constexpr int NT = WCOLS / 32;
@@ -318,12 +319,25 @@ __global__ __launch_bounds__(GEMM_TPB) void gemm_fast_kernel(const float* __rest
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave % WM, wn = wave / WM;
   const int i = lane & 31, h = lane >> 5;
-  const int64_t m0 = (int64_t)blockIdx.x * BM, n0 = (int64_t)blockIdx.y * BN;
-  const int64_t kbeg = (int64_t)blockIdx.z * kchunk;
+  int64_t bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (EPI == EPI_ATOMIC && xcd_order) {
+    // one-dimensional launch of the split-K form: workgroup ids w, w + 8, w + 16, ... (one XCD, dispatched back to back)
+    // walk the output tiles of ONE K chunk, so the chunk's operand rows are read from HBM once and from that XCD's L2 by
+    // the other tiles (round-robin ids spread the tiles of a chunk over all eight XCDs, each fetching the rows again)
+    const int64_t tiles_m = (M + BM - 1) / BM, tpc = tiles_m * ((N + BN - 1) / BN);
+    const int64_t seq = bx >> 3;
+    bz = (seq / tpc) * 8 + (bx & 7);
+    const int64_t t = seq % tpc;
+    by = t / tiles_m;
+    bx = t - by * tiles_m;
+    if (bz * kchunk >= K) return;
+  }
+  const int64_t m0 = bx * BM, n0 = by * BN;
+  const int64_t kbeg = bz * kchunk;
   const int64_t kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
 
   f32x16 acc[NT];
-  acc_init<NT>(acc, (EPI == EPI_STORE && blockIdx.z == 0) ? bias : nullptr, n0 + wn * WCOLS, N, i);
+  acc_init<NT>(acc, (EPI == EPI_STORE && bz == 0) ? bias : nullptr, n0 + wn * WCOLS, N, i);
 
   FastLoader<BM, ALAY> la;
   FastLoader<BN, BLAY> lb;
@@ -1047,14 +1061,16 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const 
   }
   // fast path needs 16-byte aligned rows and at least one 16-byte group per row to clamp into
   const bool fast = a_vec && b_vec && lda >= 4 && ldb >= 4 && !g_force_generic;
+  // split-K (weight-gradient) products with several tiles per chunk: XCD-ordered one-dimensional grid (see the kernel)
+  const bool xcd_order = EPI == EPI_ATOMIC && g_xcd_map && gz >= 8 && gm * gn > 1 &&
+                         gm * gn * ((gz + 7) / 8 * 8) <= 2147483647LL;
+  const dim3 grid = xcd_order ? dim3((unsigned)(gm * gn * ((gz + 7) / 8 * 8))) : dim3((unsigned)gm, (unsigned)gn, (unsigned)gz);
   if (fast && kchunk > 96)
-    hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WM, ALAY, BLAY, EPI, true>),
-                       dim3((unsigned)gm, (unsigned)gn, (unsigned)gz), dim3(GEMM_TPB), 0, s, A, lda, B, ldb, bias, C, ldc,
-                       M, N, K, kchunk, colstats);
+    hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WM, ALAY, BLAY, EPI, true>), grid, dim3(GEMM_TPB), 0, s, A, lda, B, ldb,
+                       bias, C, ldc, M, N, K, kchunk, colstats, xcd_order ? 1 : 0);
   else if (fast)
-    hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WM, ALAY, BLAY, EPI, false>),
-                       dim3((unsigned)gm, (unsigned)gn, (unsigned)gz), dim3(GEMM_TPB), 0, s, A, lda, B, ldb, bias, C, ldc,
-                       M, N, K, kchunk, colstats);
+    hipLaunchKernelGGL((gemm_fast_kernel<BM, BN, WM, ALAY, BLAY, EPI, false>), grid, dim3(GEMM_TPB), 0, s, A, lda, B, ldb,
+                       bias, C, ldc, M, N, K, kchunk, colstats, xcd_order ? 1 : 0);
   else
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, ALAY, BLAY, EPI>), dim3((unsigned)gm, (unsigned)gn, (unsigned)gz),
                        dim3(GEMM_TPB), 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, kchunk, a_vec, b_vec, colstats);
