@@ -51,7 +51,11 @@ def gemm_label(name, ints, nulls=()):
     aligned = ld_a % 4 == 0 and ld_b % 4 == 0
     if name == "gemm_nt":
         bn = 32 if n <= 32 else (64 if n <= 64 else 128)
-        if aligned and m >= 1024 and k >= 64 and ((m + 255) // 256) * ((n + 127) // 128) >= 512:
+        base_ok = aligned and m >= 1024 and k >= 64
+        if (base_ok and n > 64 and k % 32 == 0 and os.environ.get("CCN_GEMM_DMA") != "4"
+                and ((m + 127) // 128) * ((n + 127) // 128) >= 128):
+            return "gemm_glds_pair_kernel", flops
+        if base_ok and ((m + 255) // 256) * ((n + 127) // 128) >= 512:
             if k % 32 == 0:
                 return "gemm_glds_persistent_kernel<%d, 3>" % bn, flops
             return "gemm_glds_kernel<%d>" % bn, flops

@@ -1028,6 +1028,215 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
 
 static bool g_xcd_map = true;  // A-B hook (ccn_gemm_use_dma(3) = persistent kernel with round-robin tiles)
 
+// ------------------------------------------------------------------ two independent workgroups per CU (N > 64)
+// The 8-wave persistent kernel above keeps ONE workgroup on a CU, so nothing runs while its waves store a finished tile
+// (3.65 us of a 36 us tile at K = 256, 19 % at K = 128).  Here a CU holds TWO 4-wave workgroups on 128 x 128 tiles (each
+// wave a 64 x 64 quadrant: one A and one B fragment read per four MFMAs instead of five per sixteen): they share nothing,
+// drift apart, and one's epilogue, pipeline refill and barrier waits run under the other's MFMAs.  64 KB of LDS each:
+// a two-stage LDS-DMA ring, the copy of slice g + 1 issued right after the barrier of slice g -- one slice of lead is
+// enough because the partner workgroup's compute phase lies in between as well.  Every iteration waits vmcnt(0): the
+// epilogue's stores are simply part of what is waited for (the partner computes meanwhile).
+constexpr int PR_TPB = 256;
+constexpr int PR_BM = 128, PR_BN = 128;
+
+__global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* __restrict__ A, int64_t lda,
+                                                                   const float* __restrict__ B, int64_t ldb,
+                                                                   const float* __restrict__ bias, float* __restrict__ C,
+                                                                   int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                                                   int64_t tiles, int64_t gn, int xcd_order,
+                                                                   double* __restrict__ colstats) {
+  constexpr int AF = PR_BM * BK, BF = PR_BN * BK, STAGE = AF + BF;
+  constexpr int NC = 4;  // LDS-DMA copies (8 rows x 128 B) per wave, slice and operand
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  __shared__ float stat_part[2 * PR_BN * 2];  // [wm][column][sum, sum of squares] of the finished tile
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int i = lane & 31, h = lane >> 5;
+  const int swz = (i >> 1) & 7;
+  const int lr = lane >> 3, lc = lane & 7;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+  const uint32_t a_off = (uint32_t)((wm * 64 + i) * BK * 4);            // A fragment row of block ab = 0 (ab adds 32 rows)
+  const uint32_t b_off = (uint32_t)((AF + (wn * 64 + i) * BK) * 4);     // B fragment row of block t = 0
+  const int T = (int)(K / BK);
+
+  const int64_t gm_tiles = tiles / gn;
+  const bool xcd_map = xcd_order && gridDim.x == 512 && gn <= 64 && 64 % gn == 0;
+  auto tile_of = [&](int64_t j) -> int64_t {   // as in the 8-wave kernel, with 64 workgroup slots per XCD
+    if (xcd_map) {
+      const int64_t slot = blockIdx.x >> 3;
+      const int64_t m = j * (512 / gn) + (slot / gn) * 8 + (blockIdx.x & 7);
+      return m < gm_tiles ? m * gn + slot % gn : tiles;
+    }
+    return j * gridDim.x + blockIdx.x;
+  };
+
+  // ---- issue cursor: one slice ahead of the compute cursor, across tile boundaries
+  const float* a_src[NC];
+  const float* b_src[NC];
+  int64_t it_j = 0, it_tile = tile_of(0), gi = 0;
+  int it_u = 0;
+  auto issue_next = [&]() {
+    if (it_tile >= tiles) return;
+    if (it_u == 0) {
+      const int64_t im0 = (it_tile / gn) * PR_BM, in0 = (it_tile % gn) * PR_BN;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const int r = 8 * (wave * NC + q) + lr;
+        int64_t row = im0 + r;
+        row = row < M ? row : M - 1;
+        a_src[q] = A + row * lda + 4 * (lc ^ ((r >> 1) & 7));
+        row = in0 + r;
+        row = row < N ? row : N - 1;
+        b_src[q] = B + row * ldb + 4 * (lc ^ ((r >> 1) & 7));
+      }
+    }
+    float* st = lds + (gi & 1) * STAGE;
+    const int64_t k0 = (int64_t)it_u * BK;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) glds16(a_src[q] + k0, st + (8 * (wave * NC + q)) * BK);
+#pragma unroll
+    for (int q = 0; q < NC; ++q) glds16(b_src[q] + k0, st + AF + (8 * (wave * NC + q)) * BK);
+    ++gi;
+    if (++it_u == T) {
+      it_u = 0;
+      it_tile = tile_of(++it_j);
+    }
+  };
+  issue_next();
+
+  int64_t stat_tile = -1;
+  auto stats_readout = [&]() {
+    const int64_t pm = stat_tile / gn, pn0 = (stat_tile % gn) * PR_BN;
+    for (int c = threadIdx.x; c < PR_BN; c += PR_TPB) {
+      const int64_t n = pn0 + c;
+      if (n < N) {
+        double* dst = colstats + pm * 2 * N;   // one partial row per 128-row block (ccn_stats_rows)
+        dst[n] = (double)stat_part[c * 2] + (double)stat_part[(PR_BN + c) * 2];
+        dst[N + n] = (double)stat_part[c * 2 + 1] + (double)stat_part[(PR_BN + c) * 2 + 1];
+      }
+    }
+    stat_tile = -1;
+  };
+
+  int64_t g = 0;
+  for (int64_t j = 0, tile; (tile = tile_of(j)) < tiles; ++j) {
+    const int64_t m0 = (tile / gn) * PR_BM, n0 = (tile % gn) * PR_BN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int64_t n = n0 + wn * 64 + t * 32 + i;
+      const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ab][t][r] = bv;
+    }
+
+    for (int u = 0; u < T; ++u, ++g) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice g has landed (and the previous tile's stores retired)
+      __builtin_amdgcn_s_barrier();
+      issue_next();
+      if (u == 0 && stat_tile >= 0) stats_readout();
+      const uint32_t stage_b = lds_base + (uint32_t)((g & 1) * STAGE * 4);
+      f32x4 fa[2][2], fb[2][2];   // [K group parity][block]
+      auto read_group = [&](int q, f32x4 (&da)[2], f32x4 (&db)[2]) {
+        const uint32_t ch = 16u * (uint32_t)((2 * q + h) ^ swz);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(da[0]) : "v"(stage_b + a_off + ch) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(da[1]) : "v"(stage_b + a_off + ch), "n"(32 * BK * 4) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(db[0]) : "v"(stage_b + b_off + ch) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(db[1]) : "v"(stage_b + b_off + ch), "n"(32 * BK * 4) : "memory");
+      };
+      read_group(0, fa[0], fb[0]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < 3) {
+          read_group(q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
+          asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][ab].x, fb[q & 1][t].x, acc[ab][t], 0, 0, 0);
+            acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][ab].y, fb[q & 1][t].y, acc[ab][t], 0, 0, 0);
+            acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][ab].z, fb[q & 1][t].z, acc[ab][t], 0, 0, 0);
+            acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][ab].w, fb[q & 1][t].w, acc[ab][t], 0, 0, 0);
+          }
+      }
+    }
+
+    // ---- tile epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+    const bool interior = m0 + PR_BM <= M && n0 + PR_BN <= N;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ncol = wn * 64 + t * 32 + i;
+      const int64_t n = n0 + ncol;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab) {
+        float* const crow = C + (m0 + wm * 64 + ab * 32 + 4 * h) * ldc + n;
+        if (interior) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[ab][t][r];
+            crow[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;
+            s1 += v;
+            s2 += v * v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * 64 + ab * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < M && n < N) {
+              const float v = acc[ab][t][r];
+              C[m * ldc + n] = v;
+              s1 += v;
+              s2 += v * v;
+            }
+          }
+        }
+      }
+      if (colstats != nullptr) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0) {
+          stat_part[(wm * PR_BN + ncol) * 2] = s1;
+          stat_part[(wm * PR_BN + ncol) * 2 + 1] = s2;
+        }
+      }
+    }
+    if (colstats != nullptr) {
+      stat_tile = tile;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // table written before this wave reaches the next barrier
+    }
+  }
+  if (stat_tile >= 0) {  // statistics of the last tile
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stats_readout();
+  }
+}
+
+static bool g_use_pair = true;  // A-B hook (ccn_gemm_use_dma(4) = the 8-wave persistent kernel for N > 64 as well)
+// from this many 128 x 128 tiles on (measured at 128 / 256 / 512 / 1024: 3168 x 2048 -> 1024 (200 tiles) 87 vs 80 TFLOP/s on
+// the register-staged kernel, 10550 x 1024 -> 1024 (664 tiles) 99 vs 84, 35151 x 512 -> 512 107 vs 88 on the 8-wave kernel)
+constexpr int64_t PAIR_MIN_TILES = 128;
+
+int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                     int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s) {
+  const int64_t gm = (M + PR_BM - 1) / PR_BM, gn = (N + PR_BN - 1) / PR_BN;
+  const int64_t tiles = gm * gn;
+  const int64_t grid = tiles < 512 ? tiles : 512;  // two workgroups per CU
+  hipLaunchKernelGGL(gemm_glds_pair_kernel, dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy, M, N, K,
+                     tiles, gn, g_xcd_map ? 1 : 0, colstats);
+  return CCN_OK;
+}
+
+
 template <int BN>
 int launch_glds_persistent(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y,
                            int64_t ldy, int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s) {
@@ -1464,8 +1673,9 @@ int ccn_gemm_use_dma(int on) {
   }
   g_dma_min_k = 64;
   g_use_glds = on != 0;
-  g_use_persistent = on == 1 || on == 3;
+  g_use_persistent = on == 1 || on == 3 || on == 4;
   g_xcd_map = on != 3;
+  g_use_pair = on != 4;
   return CCN_OK;
 }
 
@@ -1509,9 +1719,17 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
   // K < 64, or fewer than two rounds of 256-row tiles over the 256 CUs: the register-staged kernels (128-row tiles,
   // several workgroups per CU) win -- measured 95 / 101 vs 84 / 89 TFLOP/s at M = 10550 / 35151; from K = 64 on the
   // persistent DMA kernel is ahead (K = 64: 70 vs 62, K = 96: 91 vs 82 TFLOP/s over 1.3 M rows)
-  const bool dma_ok = aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && lda >= 4 && ldw >= 4 &&
-                      !g_force_generic && g_use_glds && M >= 1024 && K >= g_dma_min_k &&
-                      ((M + GL_BM - 1) / GL_BM) * ((N + 127) / 128) >= 512;
+  const bool base_ok = aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && lda >= 4 && ldw >= 4 &&
+                       !g_force_generic && g_use_glds && M >= 1024 && K >= g_dma_min_k;
+  const bool dma_ok = base_ok && ((M + GL_BM - 1) / GL_BM) * ((N + 127) / 128) >= 512;
+  // N > 64: two 4-wave workgroups per CU on 128 x 128 tiles
+  if (base_ok && N > 64 && K % BK == 0 && g_use_persistent && g_use_pair &&
+      ((M + PR_BM - 1) / PR_BM) * ((N + PR_BN - 1) / PR_BN) >= PAIR_MIN_TILES) {
+    rc = launch_glds_pair(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s);
+    if (rc) return rc;
+    CCN_LAUNCH_OK("gemm_nt");
+    return CCN_OK;
+  }
   if (dma_ok && K % BK == 0 && g_use_persistent) {
     if (N <= 32)
       rc = launch_glds_persistent<32>(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s);

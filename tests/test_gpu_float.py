@@ -97,7 +97,9 @@ def test_gemm_persistent_dma_kernel(M, K, N):
     x = _rows(M, K, DEV); x.copy_(torch.randn(M, K, generator=gen))
     w = _rows(N, K, DEV, zero=True); w.copy_(torch.randn(N, K, generator=gen) / K ** 0.5)
     outs = []
-    for mode in (1, 2):
+    # 1: default (N > 64: two 4-wave workgroups per CU on 128 x 128 tiles; else the 8-wave kernel), 4: the 8-wave kernel for
+    # every N, 3: its round-robin tile order, 2: one tile per workgroup
+    for mode in (1, 4, 3, 2):
         lib().ccn_gemm_use_dma(mode)
         try:
             y = _rows(M, N, DEV); y.fill_(float("nan"))
@@ -106,10 +108,11 @@ def test_gemm_persistent_dma_kernel(M, K, N):
             outs.append((y.clone(), stats[: lib().ccn_stats_rows(M) * 2 * N].clone()))
         finally:
             lib().ccn_gemm_use_dma(1)
-    assert torch.equal(outs[0][0], outs[1][0])                  # same per-element fma order
-    # the persistent kernel sums a wave's 32 rows in fp32 before going to fp64, the other one is fp64 throughout
-    ref_stats = outs[1][1]
-    assert float((outs[0][1] - ref_stats).abs().max()) <= 2e-6 * float(ref_stats.abs().max())
+    ref_stats = outs[-1][1]
+    for y, st in outs[:-1]:
+        assert torch.equal(y, outs[-1][0])                      # same per-element fma order
+        # the persistent kernels sum a wave's 32 / 64 rows in fp32 before going to fp64, the other one is fp64 throughout
+        assert float((st - ref_stats).abs().max()) <= 2e-6 * float(ref_stats.abs().max())
     _close(outs[0][0], x.cpu() @ w.cpu().t(), 5e-5, "vs torch")
 
 
