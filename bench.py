@@ -343,7 +343,8 @@ def main():
             if world == 1 and os.environ.get("CCN_WGRAD_STREAM", "1") != "0" and args.mlp_dtype == "fp32":
                 result["roofline"]["note"] = ("launch durations include the time this kernel shares the chip with the "
                                               "weight-gradient stream (ops._WgradScope); with CCN_WGRAD_STREAM=0 the same "
-                                              "kernel measures 101.6 TFLOP/s (frac 0.646) and the step is 2.7 % slower")
+                                              "kernel measures 105.8 TFLOP/s (frac 0.672) and the step is 2.3 % slower "
+                                              "(profiles/r01o_kitti_bench_nows.json)")
             result["roofline"]["all_gemm_launches"] = {
                 "achieved": fam, "frac": fam / peak, "busy_ms_per_step": busy / args.steps,
                 "note": "flops of every GEMM launch / union of their execution intervals (two streams overlap)"}
