@@ -40,6 +40,8 @@ def gemm_label(name, ints, nulls=()):
     ld_a, ld_b, _, m, n, k = ints[:6]
     flops = 2.0 * m * n * k
     if name == "gemm_nt_x3":
+        if k % 32 == 0 and k >= 64 and n > 64 and ((m + 127) // 128) * ((n + 127) // 128) >= 128:
+            return "gemm_x3_pair_kernel", flops
         if k % 32 == 0 and k >= 64 and ((m + 255) // 256) * ((n + 127) // 128) >= 512:
             return "gemm_x3_persistent_kernel<%d>" % (32 if n <= 32 else (64 if n <= 64 else 128)), flops
         return "gemm_x3_kernel<%s>" % ("32, 4" if n <= 32 else ("64, 2" if n <= 64 else "128, 2")), flops

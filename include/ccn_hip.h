@@ -159,7 +159,7 @@ int ccn_gemm_nt_bf16(const float* A, int64_t lda, const float* W, int64_t ldw, c
  * < 2^-23 |a b|).  Same arguments and outputs as ccn_gemm_nt plus caller-owned scratch for the split weight
  * (ccn_gemm_x3_workspace_bytes(N, K) bytes, 16-byte aligned).  Requires 16-byte aligned A and lda % 4 == 0. */
 int64_t ccn_gemm_x3_workspace_bytes(int64_t N, int64_t K);
-int ccn_gemm_x3_use_persistent(int on); /* A/B hook: 0 = the register-staged kernel for every shape, 1 = default */
+int ccn_gemm_x3_use_persistent(int on); /* A/B hook: 0 = the register-staged kernel for every shape, 2 = no paired 4-wave workgroups (8-wave persistent kernel for every N), 1 = default */
 int ccn_gemm_nt_x3(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                    int64_t M, int64_t N, int64_t K, double* colstats, void* wsplit, int64_t wsplit_bytes, void* stream);
 int ccn_gemm_nn(const float* dY, int64_t lddy, const float* W, int64_t ldw, float* dX, int64_t lddx, int64_t M,

@@ -72,10 +72,11 @@ def test_x3_product_is_fp32_grade(M, K, N, bias):
     assert float((s3[0] - s32[0]).abs().max()) <= 1e-5 * float(scale.sum(0).max())
 
 
-@pytest.mark.parametrize("M,K,N", [(140000, 64, 64), (70001, 256, 256), (40000, 128, 512), (50100, 64, 384)])
+@pytest.mark.parametrize("M,K,N", [(140000, 64, 64), (70001, 256, 256), (40000, 128, 512), (50100, 64, 384), (9000, 96, 1027),
+                                   (131073, 64, 65)])
 def test_x3_persistent_and_register_staged_kernels_agree(M, K, N):
-    """The two kernels behind ccn_gemm_nt_x3 (LDS-DMA persistent for many tiles, register-staged otherwise) on the same
-    operands: same partial products, different summation order over K slices only."""
+    """The kernels behind ccn_gemm_nt_x3 (paired 4-wave workgroups for N > 64, 8-wave LDS-DMA persistent for many tiles,
+    register-staged otherwise) on the same operands: same partial products, different summation order over K slices only."""
     from curvecloudnet_amd._lib import call, lib, ptr
     from curvecloudnet_amd.ops import _ld, _rows
     gen = torch.Generator().manual_seed(M + K)
@@ -88,7 +89,7 @@ def test_x3_persistent_and_register_staged_kernels_agree(M, K, N):
     nparts = lib().ccn_stats_rows(M)
     outs = []
     try:
-        for on in (1, 0):
+        for on in (1, 2, 0):
             lib().ccn_gemm_x3_use_persistent(on)
             y = _rows(M, N, DEV)
             st = torch.zeros((nparts + 1) * 2 * N, dtype=torch.float64, device=DEV)
@@ -96,9 +97,10 @@ def test_x3_persistent_and_register_staged_kernels_agree(M, K, N):
             outs.append((y[:, :N].clone(), st[: nparts * 2 * N].clone()))
     finally:
         lib().ccn_gemm_x3_use_persistent(1)
-    (ya, sa), (yb, sb) = outs
-    assert float((ya - yb).abs().max()) < 2e-6 * max(1.0, float(yb.abs().max()))
-    assert float((sa - sb).abs().max()) < 1e-6 * max(1.0, float(sb.abs().max()))
+    yb, sb = outs[-1]
+    for ya, sa in outs[:-1]:
+        assert float((ya - yb).abs().max()) < 2e-6 * max(1.0, float(yb.abs().max()))
+        assert float((sa - sb).abs().max()) < 1e-6 * max(1.0, float(sb.abs().max()))
 
 
 def test_x3_rejects_bad_arguments():

@@ -13,6 +13,9 @@ SHAPES = [  # (rows M, N, K)
 if len(sys.argv) > 1:
     SHAPES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
 dev = "cuda"
+import os
+if os.environ.get("X3_HOOK"):
+    lib().ccn_gemm_x3_use_persistent(int(os.environ["X3_HOOK"]))
 
 
 def timeit(fn, n=5):
