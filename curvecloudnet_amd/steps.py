@@ -28,7 +28,9 @@ def _geometry_stream(device):
         return None, mode
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _GEOMETRY_STREAMS:
-        _GEOMETRY_STREAMS[key] = torch.cuda.Stream(device=device)
+        # high priority: its kernels are short or latency-bound (sampling, neighbour search) and the host waits for their
+        # sizes; they should be dispatched ahead of the feature stream's long GEMMs, not queue behind them
+        _GEOMETRY_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1)
     return _GEOMETRY_STREAMS[key], mode
 
 
