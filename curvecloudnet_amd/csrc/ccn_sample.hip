@@ -345,16 +345,14 @@ __global__ void voxel_unpack_kernel(const unsigned long long* __restrict__ best,
 // one workgroup per cloud; every iteration updates the distance-to-chosen-set of all points and takes the
 // arg max (ties: smallest index).  d2 = (dx*dx + dy*dy) + dz*dz, matching the oracle.
 constexpr int FPS_TPB = 1024;
-constexpr int FPS_CLAIM_LDS = 96 * 1024;   // dynamic LDS a sampling workgroup claims to keep its CU to itself (see ccn_fps)
+constexpr int FPS_CLAIM_MAX = 96 * 1024;   // dynamic LDS a sampling workgroup claims to keep its CU to itself (see ccn_fps)
+static int g_fps_claim = FPS_CLAIM_MAX;    // A/B hook: ccn_fps_set_lds_claim
 
 __global__ __launch_bounds__(FPS_TPB) void fps_kernel(const float* __restrict__ pos,
                                                       const int64_t* __restrict__ cloud_ptr,
                                                       const int64_t* __restrict__ start,
                                                       const int64_t* __restrict__ out_ptr, float* __restrict__ mind,
                                                       int64_t* __restrict__ out) {
-  // K sequential arg-max rounds by ONE workgroup per cloud: pure latency.  When a throughput kernel of another stream
-  // shares the CU (the GEMM workgroups of the feature stream), these waves should win every issue arbitration.
-  __builtin_amdgcn_s_setprio(3);
   __shared__ float red_v[FPS_TPB / 64];
   __shared__ int red_i[FPS_TPB / 64];
   __shared__ int chosen;
@@ -442,9 +440,6 @@ __global__ __launch_bounds__(FPS_TPB) void fps_reg_kernel(const float* __restric
                                                           const int64_t* __restrict__ start,
                                                           const int64_t* __restrict__ out_ptr,
                                                           int64_t* __restrict__ out) {
-  // K sequential arg-max rounds by ONE workgroup per cloud: pure latency.  When a throughput kernel of another stream
-  // shares the CU (the GEMM workgroups of the feature stream), these waves should win every issue arbitration.
-  __builtin_amdgcn_s_setprio(3);
   __shared__ FpsBest red[2][FPS_TPB / 64];
   const int64_t b = blockIdx.x;
   const int64_t p0 = cloud_ptr[b];
@@ -603,6 +598,11 @@ int ccn_voxel_argmin(const float* score, const int64_t* voxel_of, int64_t n, int
   return CCN_OK;
 }
 
+int ccn_fps_set_lds_claim(int bytes) {
+  g_fps_claim = bytes < 0 ? 0 : (bytes > FPS_CLAIM_MAX ? FPS_CLAIM_MAX : bytes);
+  return CCN_OK;
+}
+
 int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, const int64_t* out_ptr, int64_t B,
             int64_t max_cloud, float* mind, int64_t* out, void* stream) {
   CCN_REQUIRE(pos && cloud_ptr && start && out_ptr && mind && out && B > 0, "fps: bad arguments");
@@ -613,21 +613,21 @@ int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, co
   // is the critical path there); a handful of the 256 CUs is all it takes.
   static bool claimed = false;
   if (!claimed) {
-    bool ok = hipFuncSetAttribute((const void*)fps_reg_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_LDS) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void*)fps_reg_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_LDS) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void*)fps_reg_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_LDS) == hipSuccess;
-    ok = ok && hipFuncSetAttribute((const void*)fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_LDS) == hipSuccess;
+    bool ok = hipFuncSetAttribute((const void*)fps_reg_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)fps_reg_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)fps_reg_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
     CCN_REQUIRE(ok, "fps: cannot raise the dynamic LDS limit");
     claimed = true;
   }
   if (max_cloud > 0 && max_cloud <= 4 * FPS_TPB)
-    hipLaunchKernelGGL(fps_reg_kernel<4>, dim3((unsigned)B), dim3(FPS_TPB), FPS_CLAIM_LDS, s, pos, cloud_ptr, start, out_ptr, out);
+    hipLaunchKernelGGL(fps_reg_kernel<4>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, out);
   else if (max_cloud > 0 && max_cloud <= 8 * FPS_TPB)
-    hipLaunchKernelGGL(fps_reg_kernel<8>, dim3((unsigned)B), dim3(FPS_TPB), FPS_CLAIM_LDS, s, pos, cloud_ptr, start, out_ptr, out);
+    hipLaunchKernelGGL(fps_reg_kernel<8>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, out);
   else if (max_cloud > 0 && max_cloud <= 16 * FPS_TPB)
-    hipLaunchKernelGGL(fps_reg_kernel<16>, dim3((unsigned)B), dim3(FPS_TPB), FPS_CLAIM_LDS, s, pos, cloud_ptr, start, out_ptr, out);
+    hipLaunchKernelGGL(fps_reg_kernel<16>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, out);
   else
-    hipLaunchKernelGGL(fps_kernel, dim3((unsigned)B), dim3(FPS_TPB), FPS_CLAIM_LDS, s, pos, cloud_ptr, start, out_ptr, mind, out);
+    hipLaunchKernelGGL(fps_kernel, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, mind, out);
   CCN_LAUNCH_OK("fps");
   return CCN_OK;
 }

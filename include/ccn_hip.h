@@ -364,6 +364,7 @@ int ccn_voxel_argmin(const float* score, const int64_t* voxel_of, int64_t n, int
 /* sample_farthest_points (point_ops.py:57-70): per cloud out_ptr[b+1]-out_ptr[b] samples starting at start[b];
  * out = packed point indices in selection order; mind: float scratch (n); max_cloud: largest cloud size (clouds of up
  * to 16384 points are processed register-resident, 0 = unknown). */
+int ccn_fps_set_lds_claim(int bytes); /* A/B hook: dynamic LDS a sampling workgroup claims to keep its CU free of GEMM workgroups (default and maximum 98304, 0 = none) */
 int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, const int64_t* out_ptr, int64_t B,
             int64_t max_cloud, float* mind, int64_t* out, void* stream);
 
