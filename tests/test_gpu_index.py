@@ -243,6 +243,25 @@ def test_fps_matches_oracle(ids, ratio):
     assert torch.equal(got.cpu(), want)
 
 
+def test_fps_lds_claim_does_not_change_the_samples():
+    """The sampling workgroups claim 96 KB of dynamic LDS they never touch (so that no GEMM workgroup shares their CU);
+    with and without the claim the sample indices are the same, on the register and on the global-memory variant."""
+    ops = _ops()
+    from curvecloudnet_amd import _lib
+    for n_curves, ratio in ((40, 0.25), (1500, 0.05)):        # ~1 k points (registers) and ~36 k points per cloud (global)
+        d = _synth([1, 2], n_curves=n_curves)
+        topo = ops.CurveTopology(d.batch.to(DEV), d.curve_idxs.to(DEV))
+        outs = []
+        try:
+            for claim in (98304, 0, 40000):
+                _lib.lib().ccn_fps_set_lds_claim(claim)
+                outs.append(ops.fps(d.pos.to(DEV), topo, ratio, start=torch.tensor([5, 17])).cpu())
+        finally:
+            _lib.lib().ccn_fps_set_lds_claim(98304)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert outs[0].numel() == int(torch.ceil(topo.lengths.cpu() * ratio).sum())
+
+
 def test_knn_points_matches_bruteforce():
     ops = _ops()
     from oracle import torch_ref as R
