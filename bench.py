@@ -13,20 +13,15 @@ all-reduce (N > 1, RCCL), Adam update.  Rank 0 prints ONE JSON line (contract in
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from curvecloudnet_amd import _lib, ops                                         # noqa: E402
-from curvecloudnet_amd.model import ModelBase, segmentation_loss               # noqa: E402
-from curvecloudnet_amd.parallel import FlatAdam, GradientAllReduce, init_process_group_from_env  # noqa: E402
-from curvecloudnet_amd.synth import make_batch, to_device                      # noqa: E402
-from curvecloudnet_amd import configs as ref_configs                           # noqa: E402
-from tests.util import hotpath_config                                          # noqa: E402
+torch = _lib = None                # bound in main(), after the self-launch decision
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
@@ -120,23 +115,66 @@ def summarise_profile(records, steps, write_shapes=True):
     return rows, total
 
 
-NETWORKS = {
-    # name: (config builder, in_dim, classes, description)
-    "kitti": (ref_configs.kitti_config, 4, 20, "the reference's kitti-curvecloudnet.yaml model section (33 steps, all levels)"),
-    "nuscenes": (ref_configs.nuscenes_config, 4, 17, "the reference's nuscenes-curvecloudnet.yaml model section"),
-    "a2d2": (ref_configs.a2d2_config, 4, 55, "the reference's audi-curvecloudnet.yaml model section"),
-    "shapenet-seg": (ref_configs.shapenet_seg_config, 3, 50, "the reference's shapenet-seg-curvecloudnet.yaml model section"),
-    "kortx": (lambda width=1.0: ref_configs.shapenet_seg_config(width, kortx=True), 3, 50,
-              "the reference's kortx-testsplit-curvecloudnet.yaml model section (k=7 curve convolutions, exact kNN K=30)"),
-    "hotpath": (hotpath_config, 4, 20,
-                "section-8a hot-path subset (conv1d-fast-v2, sa-geo, mlp, 2x sgcnn, skip, fp-geo, conv)"),
+NETWORK_NAMES = ("kitti", "nuscenes", "a2d2", "shapenet-seg", "kortx", "hotpath")
+
+
+def networks():
+    """name -> (config builder, in_dim, classes, description)"""
+    from curvecloudnet_amd import configs as ref_configs
+    return {
+        "kitti": (ref_configs.kitti_config, 4, 20, "the reference's kitti-curvecloudnet.yaml model section (33 steps, all levels)"),
+        "nuscenes": (ref_configs.nuscenes_config, 4, 17, "the reference's nuscenes-curvecloudnet.yaml model section"),
+        "a2d2": (ref_configs.a2d2_config, 4, 55, "the reference's audi-curvecloudnet.yaml model section"),
+        "shapenet-seg": (ref_configs.shapenet_seg_config, 3, 50, "the reference's shapenet-seg-curvecloudnet.yaml model section"),
+        "kortx": (lambda width=1.0: ref_configs.shapenet_seg_config(width, kortx=True), 3, 50,
+                  "the reference's kortx-testsplit-curvecloudnet.yaml model section (k=7 curve convolutions, exact kNN K=30)"),
+        "hotpath": (ref_configs.hotpath_config, 4, 20,
+                    "section-8a hot-path subset (conv1d-fast-v2, sa-geo, mlp, 2x sgcnn, skip, fp-geo, conv)"),
+    }
+
+
+# BASELINE.json `configs` presets (--baseline-config i): what each one fixes on this command line
+BASELINE_PRESETS = {
+    0: dict(config="shapenet-seg", clouds_per_gpu=1, curves=85, mixed_lengths=False, mlp_dtype="fp32"),    # ~2048 points
+    1: dict(config="kitti", clouds_per_gpu=8, curves=2048, mixed_lengths=False, mlp_dtype="fp32"),
+    2: dict(config="nuscenes", clouds_per_gpu=16, curves=1430, mixed_lengths=False, mlp_dtype="bf16"),      # ~35k points
+    3: dict(config="kitti", clouds_per_gpu=4, curves=4900, mixed_lengths=False, mlp_dtype="fp32"),          # ~120k points
+    4: dict(config="a2d2", clouds_per_gpu=8, curves=2048, mixed_lengths=True, mlp_dtype="fp16"),
 }
 
 
-def make_input(cloud_ids, in_dim, args):
+def workload_label(args):
+    """Which BASELINE.json configuration (if any) this command line is."""
+    a = args
+    if a.width != 1.0:
+        return "diagnostic (width x%g): not a BASELINE configuration" % a.width
+    if a.config == "kitti" and a.curves == 2048 and a.clouds_per_gpu == 8 and not a.mixed_lengths and a.mlp_dtype == "fp32":
+        return ("BASELINE metric shape = configs[1] (batch 8 x 2048-curve / ~50k-point clouds on 1 GPU, fp32 curve-conv + "
+                "HIP FRNN) through the reference's full KITTI model section")
+    if a.config == "kortx" and not a.mixed_lengths and a.mlp_dtype == "fp32":
+        return "BASELINE configs[1] network (kortx-testsplit model section, fp32) at %d clouds/GPU x %d curves" % (
+            a.clouds_per_gpu, a.curves)
+    if a.config == "nuscenes" and a.mlp_dtype == "bf16":
+        return "BASELINE configs[2] (nuScenes model section, bf16 MLP MFMA path) at %d clouds/GPU x %d curves" % (
+            a.clouds_per_gpu, a.curves)
+    if a.config == "kitti" and a.curves >= 4000 and a.mlp_dtype == "fp32":
+        return "BASELINE configs[3] per-GPU shape (KITTI model section, %d clouds/GPU x %d curves ~ 120k points)" % (
+            a.clouds_per_gpu, a.curves)
+    if a.config == "a2d2" and a.mixed_lengths:
+        return "BASELINE configs[4] (A2D2 model section, mixed curve lengths, %s products) at %d clouds/GPU" % (
+            a.mlp_dtype, a.clouds_per_gpu)
+    if a.config == "shapenet-seg":
+        return "BASELINE configs[0] network (shapenet-seg model section) at %d clouds/GPU x %d curves" % (
+            a.clouds_per_gpu, a.curves)
+    return "diagnostic: %s model section at %d clouds/GPU x %d curves%s, %s (not a BASELINE configuration)" % (
+        a.config, a.clouds_per_gpu, a.curves, " mixed lengths" if a.mixed_lengths else "", a.mlp_dtype)
+
+
+def make_input(cloud_ids, in_dim, args, curves=None):
     """Synthetic clouds in the layout the reference's datasets hand to the model: LiDAR sets carry reflectance in x
     (in_dim 4); the object sets have x=None, positions normalised to the unit ball and a category id per cloud."""
-    data = make_batch(cloud_ids, n_curves=args.curves, mixed_lengths=args.mixed_lengths)
+    from curvecloudnet_amd.synth import make_batch
+    data = make_batch(cloud_ids, n_curves=curves or args.curves, mixed_lengths=args.mixed_lengths)
     if in_dim == 3:
         data.x = None
         data.pos = data.pos / 3.0
@@ -144,53 +182,123 @@ def make_input(cloud_ids, in_dim, args):
     return data
 
 
-def cpu_baseline(cfg, in_dim, n_classes, args, seed, timed_steps=2):
-    """The oracle timed on the host: 1 cloud per step, forward + backward + Adam."""
-    from oracle import torch_ref as R
+def cpu_baseline(cfg, in_dim, n_classes, args, seed, points_per_cloud):
+    """The CPU oracle (oracle/torch_ref.py, kind "port") timed on this host's cores on a BOUNDED sample of the same
+    workload: ONE cloud of `--cpu-curves` curves (default a quarter of the benchmark cloud), same model section, same
+    width, full fp32.  Legs: forward only, and forward + backward + Adam (the metric's step); 1 warm-up + 3 timed
+    passes each, min and median reported.  `value` is scaled LINEARLY in the point count to the benchmark's cloud size
+    (the oracle's neighbour searches are exhaustive, i.e. super-linear: linear scaling flatters the CPU)."""
     import copy
+    import statistics
+    from oracle import torch_ref as R
     kw = {k: v for k, v in copy.deepcopy(cfg).items() if k != "type"}
     torch.manual_seed(seed)
     model = R.ModelBase(in_dim, n_classes, **kw).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    data = make_input([0], in_dim, args)
-    labels = torch.randint(0, n_classes, (data.pos.size(0),), generator=torch.Generator().manual_seed(1))
-    times = []
-    for it in range(1 + timed_steps):        # 1 warm-up + timed steps
+    data = make_input([0], in_dim, args, curves=args.cpu_curves)
+    n = data.pos.size(0)
+    labels = torch.randint(0, n_classes, (n,), generator=torch.Generator().manual_seed(1))
+    t_all = time.perf_counter()
+    fwd, full = [], []
+    for it in range(1 + args.cpu_steps):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            model(data)
+        fwd.append(time.perf_counter() - t0)
+    for it in range(1 + args.cpu_steps):
         t0 = time.perf_counter()
         opt.zero_grad()
         loss = R.segmentation_loss(model(data), labels)
         loss.backward()
         opt.step()
-        times.append(time.perf_counter() - t0)
-    best = min(times[1:])
-    return {"value": 1.0 / best, "unit": "clouds/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle/torch_ref.py ModelBase, 1 cloud (%d curves, %d points) per step, fwd+bwd+Adam, "
-                      "best of %d timed step(s) after 1 warm-up (%.1f s of CPU work)"
-                      % (args.curves, data.pos.size(0), timed_steps, sum(times))}
+        full.append(time.perf_counter() - t0)
+    fwd, full = fwd[1:], full[1:]
+    scale = n / float(points_per_cloud)           # fraction of a benchmark-size cloud per sample cloud
+    return {"value": scale / min(full), "unit": "clouds/s", "cores": torch.get_num_threads(), "kind": "port",
+            "value_median": scale / statistics.median(full),
+            "forward_only": {"value": scale / min(fwd), "value_median": scale / statistics.median(fwd), "unit": "clouds/s"},
+            "sample_step_s": {"fwd_bwd_adam": [round(t, 3) for t in full], "fwd": [round(t, 3) for t in fwd]},
+            "sample": "oracle/torch_ref.py ModelBase (%s, width x%g), 1 cloud of %d curves = %d points per step; legs: "
+                      "forward only, forward+backward+Adam; 1 warm-up + %d timed passes each; value = (sample points / "
+                      "%d benchmark points per cloud) / min step time, median alongside (%.0f s of CPU work in all)"
+                      % (args.config, args.width, args.cpu_curves, n, args.cpu_steps, points_per_cloud,
+                         time.perf_counter() - t_all)}
 
 
-def main():
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a torch.distributed launcher around it: start the N rank processes
+    here, as FRESH child processes (`python -m torch.distributed.run ... bench.py <same arguments>`), before this process
+    has made any GPU call -- it never does: it waits for the children and exits with their return code.  (A process that
+    has initialised the GPU must not exec or fork workers on this pool.)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=sorted(NETWORKS), default="kitti",
+    ap.add_argument("--baseline-config", type=int, choices=sorted(BASELINE_PRESETS), default=None,
+                    help="set --config / --clouds-per-gpu / --curves / --mixed-lengths / --mlp-dtype to BASELINE.json "
+                         "configs[i] (explicit flags given alongside still win)")
+    ap.add_argument("--config", choices=sorted(NETWORK_NAMES), default=None,
                     help="kitti (default): the reference's full KITTI model (33 steps, 28.8 M parameters); "
                          "hotpath: the section-8a subset without the voxel/FPS levels; the others: the remaining "
                          "shipped model sections")
-    ap.add_argument("--clouds-per-gpu", type=int, default=8)
-    ap.add_argument("--curves", type=int, default=2048, help="curves per cloud (2048 ~ 50k points; 4900 ~ 120k)")
-    ap.add_argument("--mixed-lengths", action="store_true", help="log-normal curve lengths (BASELINE configs[4])")
+    ap.add_argument("--clouds-per-gpu", type=int, default=None)
+    ap.add_argument("--curves", type=int, default=None, help="curves per cloud (2048 ~ 50k points; 4900 ~ 120k)")
+    ap.add_argument("--mixed-lengths", action="store_true", default=None,
+                    help="log-normal curve lengths (BASELINE configs[4])")
     ap.add_argument("--width", type=float, default=1.0)
-    ap.add_argument("--mlp-dtype", choices=["fp32", "bf16", "bf16x3"], default="fp32",
-                    help="bf16: forward / data-gradient products of the MLP and conv layers on the bf16 MFMA path "
-                         "(BASELINE configs 3 and 5); the headline metric is quoted in fp32")
+    ap.add_argument("--mlp-dtype", choices=["fp32", "bf16", "fp16", "bf16x3"], default=None,
+                    help="bf16 / fp16: forward / data-gradient / weight-gradient products of the MLP and conv layers on "
+                         "the 16-bit MFMA path (BASELINE configs 2 and 4); the headline metric is quoted in fp32")
+    ap.add_argument("--graph", action="store_true",
+                    help="forward-only throughput with the feature pass of a prepared plan captured in a hipGraph "
+                         "(BASELINE configs[4]); prints eager and replayed rates")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="compute each step's sampling / neighbour search inside its own forward instead of during the "
                          "previous step's backward pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-curves", type=int, default=None,
+                    help="curves of the CPU baseline's sample cloud (default: a quarter of --curves)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed passes per CPU-baseline leg")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
+    preset = BASELINE_PRESETS.get(args.baseline_config, {})
+    defaults = dict(config="kitti", clouds_per_gpu=8, curves=2048, mixed_lengths=False, mlp_dtype="fp32")
+    for k, dflt in defaults.items():
+        if getattr(args, k) is None:
+            setattr(args, k, preset.get(k, dflt))
+    if args.cpu_curves is None:
+        args.cpu_curves = max(16, args.curves // 4)
+    return args
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
+
+    global torch, _lib                      # (module-level helpers use them; the self-launching parent never imports torch)
+    import torch
+    from curvecloudnet_amd import _lib, ops
+    from curvecloudnet_amd.model import ModelBase, segmentation_loss
+    from curvecloudnet_amd.parallel import FlatAdam, GradientAllReduce, init_process_group_from_env
+    from curvecloudnet_amd.synth import to_device
 
     # CCN_DIST_BACKEND=gloo + CCN_FORCE_DEVICE=0 rehearse the N>1 code path with several ranks on ONE GPU
     rank, world, local_rank = init_process_group_from_env(backend=os.environ.get("CCN_DIST_BACKEND"))
@@ -203,7 +311,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     ops.set_mlp_dtype(args.mlp_dtype)
-    make_cfg, in_dim, n_classes, net_desc = NETWORKS[args.config]
+    make_cfg, in_dim, n_classes, net_desc = networks()[args.config]
     cfg = make_cfg(width=args.width)
     kw = {k: v for k, v in cfg.items() if k != "type"}
     torch.manual_seed(1234)                                  # identical replicas on every rank
@@ -292,13 +400,13 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"fp32": "f32", "bf16": "bf16 products, f32 accumulate / storage",
+                  "fp16": "fp16 products, f32 accumulate / storage",
                   "bf16x3": "f32-grade products assembled from 3-way bf16 splits (6 bf16 MFMAs each; weight gradients "
                             "on the f32 MFMA), f32 accumulate / storage"}[args.mlp_dtype], "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1] shape: %d clouds/GPU x %d curves (~%dk points each, %d points "
-                               "on rank 0), fp32 curve-conv + HIP FRNN + MFMA MLP stack; network = %s at width x%g; "
-                               "fwd + mean-NLL + bwd + Adam%s"
-                               % (b, args.curves, round(n_points / b / 1000), n_points, net_desc, args.width,
-                                  "" if args.no_pipeline else
+        "config": {"workload": "%s; %d clouds/GPU x %d curves (~%dk points each, %d points on rank 0); curve-conv + HIP "
+                               "FRNN + MFMA MLP stack; network = %s at width x%g; fwd + mean-NLL + bwd + Adam%s"
+                               % (workload_label(args), b, args.curves, round(n_points / b / 1000), n_points, net_desc,
+                                  args.width, "" if args.no_pipeline else
                                   "; the next step's sampling / neighbour search runs during this step's backward"),
                    "network": args.config, "parameters": sum(p.numel() for p in model.parameters()),
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
@@ -363,7 +471,7 @@ def main():
                 tf = " %7.1f TFLOP/s" % (t["flops"] / (t["ms"] * 1e-3) / 1e12) if t["flops"] else ""
                 f.write("%9.2f ms %5.1f%% %6d launches  %s%s\n" % (t["ms"], 100 * t["ms"] / total_ms, t["launches"], k, tf))
     if not args.no_cpu_baseline and world == 1:
-        result["cpu_baseline"] = cpu_baseline(cfg, in_dim, n_classes, args, 1234, timed_steps=2 if args.config == "hotpath" else 1)
+        result["cpu_baseline"] = cpu_baseline(cfg, in_dim, n_classes, args, 1234, n_points // b)
     print(json.dumps(result))
 
 

@@ -30,7 +30,21 @@ class MLP(nn.Module):
         if act not in ("relu", "leaky_relu"):
             raise NotImplementedError("activation %r" % (act,))
         self.channel_list = list(channel_list)
-        self.act, self.plain_last, self.dropout = act, plain_last, float(dropout)
+        self.act, self.plain_last = act, plain_last
+        # PyG 2.3.0: a scalar dropout becomes a per-layer list and the plain last layer is never dropped
+        # ([upstream, from memory of torch_geometric/nn/models/mlp.py]; every shipped config sets 0.0)
+        n_layers = len(channel_list) - 1
+        if isinstance(dropout, (int, float)):
+            drops = [float(dropout)] * n_layers
+            if plain_last and n_layers:
+                drops[-1] = 0.0
+        else:
+            drops = [float(d) for d in dropout]
+            if len(drops) != n_layers:
+                raise ValueError("Number of dropout values provided (%d) does not match the number of layers "
+                                 "specified (%d)" % (len(drops), n_layers))
+        self.dropouts = drops
+        self.dropout = max(drops) if drops else 0.0          # > 0: some layer drops (the fused first-layer forms check this)
         self.lins = nn.ModuleList(nn.Linear(a, b, bias=bias) for a, b in zip(channel_list[:-1], channel_list[1:]))
         normed = channel_list[1:-1] if plain_last else channel_list[1:]
         self.norms = nn.ModuleList(BatchNorm(c) for c in normed)
@@ -57,13 +71,13 @@ class MLP(nn.Module):
                 x = ops.linear_bn_act_tail(x, lin.weight, norm.module, self.training, self.act, *tail)
                 continue
             x = ops.linear_bn_act(x, lin.weight, lin.bias, norm.module, self.training, self.act)
-            if self.dropout > 0.0:
-                x = F.dropout(x, p=self.dropout, training=self.training)
+            if self.dropouts[idx] > 0.0:
+                x = F.dropout(x, p=self.dropouts[idx], training=self.training)
         if self.plain_last and start <= n_hidden:
             last = self.lins[-1]
             x = ops.linear_bn_act(x, last.weight, last.bias, None, self.training, None)
-            if self.dropout > 0.0:
-                x = F.dropout(x, p=self.dropout, training=self.training)
+            if self.dropouts[-1] > 0.0:
+                x = F.dropout(x, p=self.dropouts[-1], training=self.training)
         return x
 
     def __repr__(self):

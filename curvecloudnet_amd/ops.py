@@ -368,42 +368,74 @@ class _WgradScope:
     def __exit__(self, et, ev, tb):
         if self.ws is not None:
             self.scope.__exit__(et, ev, tb)
-            if not _WGRAD_PENDING:
-                # end of this backward pass: order the backward stream behind the side stream, so that whoever reads
-                # .grad after loss.backward() needs no extra call (a stream wait, nothing blocks on the host)
-                torch.autograd.Variable._execution_engine.queue_callback(join_wgrad)
+            # end of this backward pass: order the backward stream behind the side stream, so that whoever reads
+            # .grad after loss.backward() needs no extra call (a stream wait, nothing blocks on the host).  Queued by
+            # every scope (the callback is idempotent and costs a microsecond): a flag "already queued" would survive a
+            # backward pass that raised after a scope had run, and no later pass would then queue the join.
+            torch.autograd.Variable._execution_engine.queue_callback(join_wgrad)
             _WGRAD_PENDING.add(self.ws.device.index)
         return False
 
 
+def _bucket_view(p):
+    """The parameter's gradient-bucket view (parallel.GradientAllReduce) if ``p.grad`` still IS that view.  After an
+    optimizer's / module's ``zero_grad(set_to_none=True)`` the attribute is stale (``p.grad`` is None or another tensor):
+    the fused path is then off and autograd gets an ordinary gradient tensor, instead of sums piling up in a buffer
+    nobody reads or zeroes."""
+    if p is None:
+        return None
+    g = getattr(p, "_ccn_main_grad", None)
+    if g is None or not p.is_leaf or not p.requires_grad:
+        return None
+    if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+        return None
+    return g
+
+
 def _has_main_grad(weight):
-    return getattr(weight, "_ccn_main_grad", None) is not None and weight.is_leaf and weight.requires_grad
+    return _bucket_view(weight) is not None
 
 
 def _main_grad(weight, n, k):
-    """The parameter's gradient-bucket view (parallel.GradientAllReduce) if the weight gradient can be accumulated
-    straight into it: an fp32 (n, k) row-major view.  The weight-gradient product accumulates with atomics anyway, so
-    writing there saves the zero-fill of a temporary and autograd's add."""
-    if weight is None:
-        return None
-    g = getattr(weight, "_ccn_main_grad", None)
+    """The bucket view if the weight gradient can be accumulated straight into it: an fp32 (n, k) row-major view.  The
+    weight-gradient product accumulates anyway, so writing there saves the zero-fill of a temporary and autograd's add."""
+    g = _bucket_view(weight)
     if g is None or g.dtype != torch.float32 or tuple(g.shape) != (n, k) or not g.is_contiguous() or not g.is_cuda:
         return None
     return g
 
 
 def _main_grad_vec(p, n):
-    g = getattr(p, "_ccn_main_grad", None) if p is not None else None
+    g = _bucket_view(p)
     if g is None or g.dtype != torch.float32 or tuple(g.shape) != (n,) or not g.is_contiguous() or not g.is_cuda:
         return None
     return g
 
 
+def _main_grad_note(*params):
+    """Forward of a layer that will add these parameters' gradients into their bucket views itself: the all-reduce
+    counts the use, and reduces the bucket only after the matching backward (parallel.GradientAllReduce.note_use)."""
+    for p in params:
+        sync = getattr(p, "_ccn_sync", None) if p is not None else None
+        if sync is not None:
+            sync.note_use(p)
+
+
+def _main_grad_cancel(*params):
+    """A noted use turned out not to be fused (the bucket view went stale between forward and backward): autograd
+    accumulates this gradient and the post-accumulate hook reports it."""
+    for p in params:
+        sync = getattr(p, "_ccn_sync", None)
+        if sync is not None:
+            sync.use_cancelled(p)
+
+
 def _main_grad_done(weight):
-    """Tell the gradient all-reduce that this parameter's gradient is complete (autograd is given no tensor for it)."""
-    ready = getattr(weight, "_ccn_grad_ready", None)
-    if ready is not None:
-        ready()
+    """Tell the gradient all-reduce that this use of the parameter has queued its gradient (autograd is given no tensor
+    for it)."""
+    sync = getattr(weight, "_ccn_sync", None)
+    if sync is not None:
+        sync.use_done(weight)
     return None
 
 
@@ -438,8 +470,11 @@ class LinearBNAct(torch.autograd.Function):
         has_bn = gamma is not None
         ctx.has_bn, ctx.act, ctx.training, ctx.has_bias = has_bn, ACT[act], bool(training), bias is not None
         gemm_nt = ctx.gemm_nt = _nt_name()
-        ctx.main_grad_of = weight if _has_main_grad(weight) else None
-        ctx.bn_refs = (gamma, beta) if has_bn and _has_main_grad(gamma) and _has_main_grad(beta) else None
+        grad_on = torch.is_grad_enabled()
+        ctx.main_grad_of = weight if (grad_on and ctx.needs_input_grad[1] and _main_grad(weight, n, k) is not None) else None
+        ctx.bn_refs = ((gamma, beta) if has_bn and grad_on and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]
+                       and _main_grad_vec(gamma, n) is not None and _main_grad_vec(beta, n) is not None else None)
+        _main_grad_note(ctx.main_grad_of, *(ctx.bn_refs or ()))
         if gemm_nt != "gemm_nt":
             x = _aligned_rows(x)
         if not has_bn:
@@ -477,7 +512,9 @@ class LinearBNAct(torch.autograd.Function):
             refs = ctx.bn_refs
             gview = _main_grad_vec(refs[0], n) if refs else None
             bview = _main_grad_vec(refs[1], n) if refs else None
-            if gview is not None and bview is not None and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]:
+            if refs and (gview is None or bview is None):
+                _main_grad_cancel(*refs)        # the views went stale since forward: autograd accumulates instead
+            if gview is not None and bview is not None:
                 # BatchNorm parameter gradients added straight into their gradient-bucket views
                 call("bn_act_bwd_apply_ex", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
                      ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums), float(m), 1 if ctx.training else 0, 1, ptr(dy), _ld(dy),
@@ -507,6 +544,8 @@ class LinearBNAct(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             into = _main_grad(ctx.main_grad_of, n, k)
+            if into is None and ctx.main_grad_of is not None:
+                _main_grad_cancel(ctx.main_grad_of)
             dw = into if into is not None else _rows(n, k, dev, zero=True)
             if ctx.gemm_nt == "gemm_nt_bf16":
                 dy = _aligned_rows(dy)
@@ -1240,7 +1279,9 @@ class LinearBNActTail(torch.autograd.Function):
         dev = x.device
         wt = _aligned_weight(weight.detach())
         ctx.act, ctx.training, ctx.tail, ctx.count = ACT[act], bool(training), int(tail), float(count)
-        ctx.main_grad_of = weight if _has_main_grad(weight) else None
+        ctx.main_grad_of = weight if (torch.is_grad_enabled() and ctx.needs_input_grad[1]
+                                      and _main_grad(weight, n, k) is not None) else None
+        _main_grad_note(ctx.main_grad_of)
         gemm_nt = ctx.gemm_nt = _nt_name()
         if gemm_nt != "gemm_nt":
             x = _aligned_rows(x)
@@ -1295,6 +1336,8 @@ class LinearBNActTail(torch.autograd.Function):
             wtt.copy_(wt[:, :k].t())
             _gemm_nt(ctx.gemm_nt, dy, wtt, None, dx, m, k, n, None)
         into = _main_grad(ctx.main_grad_of, n, k)
+        if into is None and ctx.main_grad_of is not None:
+            _main_grad_cancel(ctx.main_grad_of)
         dw = into if into is not None else _rows(n, k, dev, zero=True)
         gemm_tn = "gemm_tn_bf16" if ctx.gemm_nt == "gemm_nt_bf16" else "gemm_tn"
         dyt = _rows(t, n, dev)

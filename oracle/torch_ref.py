@@ -527,17 +527,25 @@ class MLP(nn.Module):
     def __init__(self, channel_list, dropout=0.0, act="relu", norm="batch_norm", plain_last=True, bias=True, **kwargs):
         super().__init__()
         assert norm == "batch_norm"
-        self.channel_list, self.plain_last, self.dropout = list(channel_list), plain_last, dropout
+        self.channel_list, self.plain_last = list(channel_list), plain_last
+        n_layers = len(channel_list) - 1
+        if isinstance(dropout, (int, float)):           # PyG 2.3.0: per-layer list, the plain last layer is never dropped
+            self.dropout = [float(dropout)] * n_layers
+            if plain_last and n_layers:
+                self.dropout[-1] = 0.0
+        else:
+            self.dropout = [float(d) for d in dropout]
+            assert len(self.dropout) == n_layers
         self.act = {"relu": F.relu, "leaky_relu": F.leaky_relu}[act]
         self.lins = nn.ModuleList(nn.Linear(a, b, bias=bias) for a, b in zip(channel_list[:-1], channel_list[1:]))
         normed = channel_list[1:-1] if plain_last else channel_list[1:]
         self.norms = nn.ModuleList(_Norm(c) for c in normed)
 
     def forward(self, x):
-        for lin, norm in zip(self.lins, self.norms):
-            x = F.dropout(self.act(norm(linear(x, lin))), p=self.dropout, training=self.training)
+        for i, (lin, norm) in enumerate(zip(self.lins, self.norms)):
+            x = F.dropout(self.act(norm(linear(x, lin))), p=self.dropout[i], training=self.training)
         if self.plain_last:
-            x = F.dropout(linear(x, self.lins[-1]), p=self.dropout, training=self.training)
+            x = F.dropout(linear(x, self.lins[-1]), p=self.dropout[-1], training=self.training)
         return x
 
 

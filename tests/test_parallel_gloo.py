@@ -84,6 +84,137 @@ def test_gradient_allreduce_world2_matches_single_process():
     assert float((a - want).abs().max()) < 1e-6
 
 
+class _FusedLinear(torch.autograd.Function):
+    """CPU stand-in for the HIP layers' main-grad protocol (ops.LinearBNAct): the weight gradient is ADDED into the
+    bucket view by the layer itself, autograd gets None for it, and the all-reduce is told through note_use / use_done."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x)
+        ctx.w = w
+        w._ccn_sync.note_use(w)
+        return x @ w.detach().t()
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        w = ctx.w
+        w._ccn_main_grad.add_(g.t() @ x)
+        w._ccn_sync.use_done(w)
+        return g @ w.detach(), None
+
+
+class _TwoUse(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Parameter(torch.randn(5, 7))       # odd sizes: slots must still start 16-byte aligned
+        self.b = torch.nn.Parameter(torch.randn(3, 5))
+        self.c = torch.nn.Parameter(torch.randn(3))
+
+    def forward(self, x):
+        return _FusedLinear.apply(_FusedLinear.apply(x, self.a).relu(), self.b) + self.c
+
+
+def _worker_two_uses(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from curvecloudnet_amd.parallel import GradientAllReduce, init_process_group_from_env
+    init_process_group_from_env(backend="gloo")
+    torch.manual_seed(0)
+    model = _TwoUse()
+    sync = GradientAllReduce(model, bucket_bytes=64)            # one bucket per parameter or two
+    for flat, plist, offs in sync.buckets:
+        assert all(o % 4 == 0 for o in offs) and flat.numel() % 4 == 0
+        for p, o in zip(plist, offs):
+            assert p.grad.data_ptr() == flat[o:].data_ptr()
+    g = torch.Generator().manual_seed(10 + rank)
+    x1, x2 = torch.randn(6, 7, generator=g), torch.randn(4, 7, generator=g)
+    sync.zero_grad()
+    # the model runs TWICE before one backward pass: every fused parameter has two outstanding uses, and its bucket must
+    # be reduced after the second product, exactly once
+    (model(x1).square().mean() + model(x2).square().mean()).backward()
+    sync.finish()
+    assert sync.reduce_calls == len(sync.buckets), (sync.reduce_calls, len(sync.buckets))
+    flat = torch.cat([p.grad.flatten() for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        out.put([t.tolist() for t in gathered])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fused_gradients_with_two_uses_per_backward_world2():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_two_uses, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = torch.tensor(got[0]), torch.tensor(got[1])
+    assert torch.equal(a, b)
+    # reference: plain autograd on both ranks' inputs, averaged
+    want = 0
+    for rank in range(2):
+        torch.manual_seed(0)
+        m = _TwoUse()
+        g = torch.Generator().manual_seed(10 + rank)
+        x1, x2 = torch.randn(6, 7, generator=g), torch.randn(4, 7, generator=g)
+
+        def f(x):
+            return (x @ m.a.t()).relu() @ m.b.t() + m.c
+        (f(x1).square().mean() + f(x2).square().mean()).backward()
+        want = want + torch.cat([p.grad.flatten() for p in m.parameters()]) / 2
+    assert float((a - want).abs().max()) < 1e-6
+
+
+def test_late_gradient_after_reduce_raises():
+    """Accumulating over two backward passes WITHOUT no_sync() would leave the second pass un-reduced: it must raise."""
+    import pytest
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), CCN_SINGLE_RANK_GROUP="gloo")
+    from curvecloudnet_amd.parallel import GradientAllReduce
+    try:
+        dist.init_process_group(backend="gloo", rank=0, world_size=1)
+        m = torch.nn.Linear(3, 2)
+        sync = GradientAllReduce(m)
+        assert sync.reduces
+        sync.zero_grad()
+        m(torch.ones(4, 3)).sum().backward()
+        with pytest.raises(RuntimeError, match="no_sync"):
+            m(torch.ones(4, 3)).sum().backward()
+        sync.finish()
+        # the sanctioned form
+        sync.zero_grad()
+        with sync.no_sync():
+            m(torch.ones(4, 3)).sum().backward()
+        m(torch.ones(4, 3)).sum().backward()
+        sync.finish()
+        assert float(m.bias.grad[0]) == 8.0
+    finally:
+        os.environ.pop("CCN_SINGLE_RANK_GROUP", None)
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_bucket_slots_are_16_byte_aligned_for_the_shipped_configs():
+    """with use_bias=True the 55- / 50-class output bias used to push every weight behind it off 16-byte
+    alignment (a2d2: 33 of 61 Linear weights)."""
+    from curvecloudnet_amd import configs
+    from curvecloudnet_amd.model import build_model
+    from curvecloudnet_amd.parallel import GradientAllReduce
+    for cfg, in_dim, n_out in ((configs.a2d2_config(0.125), 4, 55), (configs.shapenet_seg_config(0.125), 3, 50)):
+        model = build_model(cfg, in_dim, n_out)
+        assert any(p.numel() % 4 for p in model.parameters())
+        sync = GradientAllReduce(model, bucket_bytes=1 << 16)
+        for flat, plist, offs in sync.buckets:
+            for p, o in zip(plist, offs):
+                assert o % 4 == 0 and (p.grad.data_ptr() - flat.data_ptr()) % 16 == 0
+
+
 def test_single_process_is_a_noop():
     from curvecloudnet_amd.parallel import GradientAllReduce
     m = torch.nn.Linear(3, 2)
@@ -92,4 +223,4 @@ def test_single_process_is_a_noop():
     m(torch.ones(4, 3)).sum().backward()
     sync.finish()
     assert m.weight.grad is not None and float(m.weight.grad.abs().sum()) > 0
-    assert sync.num_bytes == (6 + 2) * 4
+    assert sync.num_bytes == (8 + 4) * 4          # slots of 6 and 2 floats rounded up to 16-byte multiples

@@ -20,48 +20,7 @@ def t(a, device="cpu"):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
-def hotpath_config(width=1.0, with_sa=False):
-    """Reference-style ``model:`` dict restricted to the steps of SURVEY.md section 8(a).
-    width=1.0 gives the KITTI/nuScenes channel counts of App. A for those steps."""
-    def w(c):
-        return max(4, int(round(c * width)))
-    steps = [
-        {"step_name": "conv1d-fast-v2", "with_diff": True, "with_xyz": True},
-        {"step_name": "sa-geo", "curve_fps_arclen": 0.007, "use_curve_fps": True, "use_curve_knn": True,
-         "with_xyz": True, "aggr_type": "attend", "normalize_radius": True},
-        {"step_name": "mlp", "plain_last": False, "with_xyz": True},
-        {"step_name": "sgcnn", "with_xyz": True, "aggr_type": "max"},
-        "skip-connect",
-        {"step_name": "sgcnn", "with_xyz": True, "aggr_type": "max"},
-        "skip-connect",
-        {"step_name": "fp-geo", "with_xyz": True},
-        {"step_name": "conv1d-fast-v2", "with_diff": True, "with_xyz": True},
-        "skip-connect",
-    ]
-    feat_dims = [
-        [w(32), w(32), w(32)],
-        [w(64), w(128), w(192), w(256)],
-        [w(256), w(128), w(128), w(64)],
-        [w(64), w(64), w(64)],
-        [2 * w(64), w(128), w(128)],
-        [w(128), w(128)],
-        [2 * w(128), w(128), w(64)],
-        [w(64) + w(32) + 3, w(128), w(128)],
-        [w(32), w(32), w(32)],
-        [w(32) + w(128), w(128), w(64)],
-    ]
-    n = len(steps)
-    cfg = dict(
-        type="generic", use_bias=False, version=2.0, steps=steps, feat_dims=feat_dims,
-        out_mlp={"dims": [w(64), w(64)], "dropout": 0.0},
-        knn=[None, None, None, 20, None, 20, None, 3, None, None],
-        ratios=[None] * n,
-        radii=[None, 0.02, None, 0.04, None, 0.08, None, None, None, None],
-        num_skips=[None, None, None, None, 1, None, 1, None, None, 1],
-        kernel_sizes=[5, None, None, None, None, None, None, None, 5, None],
-        skip_connect_state_store=["conv1d-fast-v2", "sgcnn"],
-    )
-    return cfg
+from curvecloudnet_amd.configs import hotpath_config  # noqa: E402,F401  (lives in the package: bench.py uses it)
 
 
 def build_pair(cfg, in_dim, n_out, seed=0):
