@@ -30,10 +30,20 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 def gemm_label(name, ints, nulls=()):
     """(kernel symbol as rocprofv3 prints it, flops) of a GEMM launch; mirrors the dispatch in csrc/ccn_gemm.hip."""
-    if name not in ("gemm_nt", "gemm_nn", "gemm_tn", "gemm_nt_bf16", "gemm_tn_bf16", "gemm_nt_x3"):
+    if name not in ("gemm_nt", "gemm_nn", "gemm_tn", "gemm_tn_ws", "gemm_nt_bf16", "gemm_nt_f16", "gemm_tn_bf16", "gemm_nt_x3"):
         return None, 0.0
     ld_a, ld_b, _, m, n, k = ints[:6]
     flops = 2.0 * m * n * k
+    if name == "gemm_tn_ws":
+        def tile(d):
+            return 64 if (d <= 64 or 0 < d % 128 <= 64) else 128
+        if ld_a % 4 == 0 and ld_b % 4 == 0 and n > 32 and k > 32 and m >= 1024:
+            split = min(max(1, (512 + ((n + tile(n) - 1) // tile(n)) * ((k + tile(k) - 1) // tile(k)) - 1)
+                            // (((n + tile(n) - 1) // tile(n)) * ((k + tile(k) - 1) // tile(k)))), max(1, (m + 31) // 32 // 4))
+            return "gemm_tn_glds_kernel<%d, %d, %d>" % (tile(n), tile(k), 0 if split > 1 else 2), flops
+        name = "gemm_tn"
+    if name == "gemm_nt_f16":
+        return "gemm_bf16_kernel<128, %d, 4, true>" % (32 if n <= 32 else (64 if n <= 64 else 128)), flops
     if name == "gemm_nt_x3":
         if k % 32 == 0 and k >= 64 and n > 64 and ((m + 127) // 128) * ((n + 127) // 128) >= 128:
             return "gemm_x3_pair_kernel", flops
@@ -44,12 +54,12 @@ def gemm_label(name, ints, nulls=()):
         bm, bn = (64 if n <= 64 else 128), (64 if k <= 64 else 128)
         return "gemm_bf16_tn_kernel<%d, %d, %d>" % (bm, bn, bm // 32), flops
     if name == "gemm_nt_bf16":
-        return "gemm_bf16_kernel<128, %d, 4>" % (32 if n <= 32 else (64 if n <= 64 else 128)), flops
+        return "gemm_bf16_kernel<128, %d, 4, false>" % (32 if n <= 32 else (64 if n <= 64 else 128)), flops
     aligned = ld_a % 4 == 0 and ld_b % 4 == 0
     if name == "gemm_nt":
         bn = 32 if n <= 32 else (64 if n <= 64 else 128)
         base_ok = aligned and m >= 1024 and k >= 64
-        if (base_ok and n > 64 and k % 32 == 0 and os.environ.get("CCN_GEMM_DMA") != "4"
+        if (base_ok and n > 64 and os.environ.get("CCN_GEMM_DMA") != "4"
                 and ((m + 127) // 128) * ((n + 127) // 128) >= 128):
             return "gemm_glds_pair_kernel", flops
         if base_ok and ((m + 255) // 256) * ((n + 127) // 128) >= 512:

@@ -409,22 +409,44 @@ using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 constexpr int BF_LD = BK + 8;  // bf16 elements per LDS row
 
-template <int ROWS>
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+
+// F16 = false: bf16 image, true: fp16 image (same 2-byte layout; only the rounding and the MFMA opcode differ)
+template <int ROWS, bool F16 = false>
 __device__ __forceinline__ void tile_store_bf16(__bf16* __restrict__ lds, const float4 (&regs)[Tile<ROWS, KC>::PER_THREAD]) {
 #pragma unroll
   for (int it = 0; it < Tile<ROWS, KC>::PER_THREAD; ++it) {
     const int slot = threadIdx.x + it * GEMM_TPB;
     const int r = slot >> 3, kq = slot & 7;
-    bf16x4 v;
-    v[0] = (__bf16)regs[it].x;
-    v[1] = (__bf16)regs[it].y;
-    v[2] = (__bf16)regs[it].z;
-    v[3] = (__bf16)regs[it].w;
-    *reinterpret_cast<bf16x4*>(lds + r * BF_LD + kq * 4) = v;
+    if (F16) {
+      f16x4 v;
+      v[0] = (_Float16)regs[it].x;
+      v[1] = (_Float16)regs[it].y;
+      v[2] = (_Float16)regs[it].z;
+      v[3] = (_Float16)regs[it].w;
+      *reinterpret_cast<f16x4*>(lds + r * BF_LD + kq * 4) = v;
+    } else {
+      bf16x4 v;
+      v[0] = (__bf16)regs[it].x;
+      v[1] = (__bf16)regs[it].y;
+      v[2] = (__bf16)regs[it].z;
+      v[3] = (__bf16)regs[it].w;
+      *reinterpret_cast<bf16x4*>(lds + r * BF_LD + kq * 4) = v;
+    }
   }
 }
 
-template <int BM, int BN, int WM>
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const __bf16* a, const __bf16* b, f32x16 c) {
+  if (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(a), *reinterpret_cast<const f16x8*>(b), c, 0,
+                                                  0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(a), *reinterpret_cast<const bf16x8*>(b), c,
+                                                 0, 0, 0);
+}
+
+template <int BM, int BN, int WM, bool F16 = false>
 __global__ __launch_bounds__(GEMM_TPB) void gemm_bf16_kernel(const float* __restrict__ A, int64_t lda,
                                                              const float* __restrict__ B, int64_t ldb,
                                                              const float* __restrict__ bias, float* __restrict__ C,
@@ -458,8 +480,8 @@ __global__ __launch_bounds__(GEMM_TPB) void gemm_bf16_kernel(const float* __rest
     la.load_tail(0, K, ra);
     lb.load_tail(0, K, rb);
   }
-  tile_store_bf16<BM>(lds, ra);
-  tile_store_bf16<BN>(lds + AE, rb);
+  tile_store_bf16<BM, F16>(lds, ra);
+  tile_store_bf16<BN, F16>(lds + AE, rb);
   __syncthreads();
   int buf = 0;
   for (int64_t k0 = 0; k0 < K; k0 += BK) {
@@ -483,12 +505,13 @@ __global__ __launch_bounds__(GEMM_TPB) void gemm_bf16_kernel(const float* __rest
       for (int t = 0; t < NT; ++t)
         b8[t] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WCOLS + t * 32 + i) * BF_LD + (2 * st + h) * 8);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8[t], acc[t], 0, 0, 0);
+      for (int t = 0; t < NT; ++t)
+        acc[t] = mfma16<F16>(reinterpret_cast<const __bf16*>(&a8), reinterpret_cast<const __bf16*>(&b8[t]), acc[t]);
     }
     if (kn < K) {
       __bf16* An = lds + (buf ^ 1) * (AE + BE);
-      tile_store_bf16<BM>(An, ra);
-      tile_store_bf16<BN>(An + AE, rb);
+      tile_store_bf16<BM, F16>(An, ra);
+      tile_store_bf16<BN, F16>(An + AE, rb);
     }
     __syncthreads();
     buf ^= 1;
@@ -1058,7 +1081,9 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
   const uint32_t a_off = (uint32_t)((wm * 64 + i) * BK * 4);            // A fragment row of block ab = 0 (ab adds 32 rows)
   const uint32_t b_off = (uint32_t)((AF + (wn * 64 + i) * BK) * 4);     // B fragment row of block t = 0
-  const int T = (int)(K / BK);
+  const int T = (int)(K / BK);                      // full slices (LDS-DMA)
+  const int has_tail = (K % BK) != 0;               // K remainder: one more slice per tile, staged through registers
+  const int TT = T + has_tail;
 
   const int64_t gm_tiles = tiles / gn;
   const bool xcd_map = xcd_order && gridDim.x == 512 && gn <= 64 && 64 % gn == 0;
@@ -1075,11 +1100,13 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   const float* a_src[NC];
   const float* b_src[NC];
   int64_t it_j = 0, it_tile = tile_of(0), gi = 0;
+  int64_t im0 = 0, in0 = 0;
   int it_u = 0;
   auto issue_next = [&]() {
     if (it_tile >= tiles) return;
     if (it_u == 0) {
-      const int64_t im0 = (it_tile / gn) * PR_BM, in0 = (it_tile % gn) * PR_BN;
+      im0 = (it_tile / gn) * PR_BM;
+      in0 = (it_tile % gn) * PR_BN;
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
         const int r = 8 * (wave * NC + q) + lr;
@@ -1093,12 +1120,38 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     }
     float* st = lds + (gi & 1) * STAGE;
     const int64_t k0 = (int64_t)it_u * BK;
+    if (it_u < T) {
 #pragma unroll
-    for (int q = 0; q < NC; ++q) glds16(a_src[q] + k0, st + (8 * (wave * NC + q)) * BK);
+      for (int q = 0; q < NC; ++q) glds16(a_src[q] + k0, st + (8 * (wave * NC + q)) * BK);
 #pragma unroll
-    for (int q = 0; q < NC; ++q) glds16(b_src[q] + k0, st + AF + (8 * (wave * NC + q)) * BK);
+      for (int q = 0; q < NC; ++q) glds16(b_src[q] + k0, st + AF + (8 * (wave * NC + q)) * BK);
+    } else {
+      // K remainder (< 32 columns, e.g. the 3 xyz columns of a 259-wide concat): both operands through registers, zero
+      // filled beyond K, into the same swizzled image.  (Nothing else is in flight here: every iteration waits vmcnt(0).)
+#pragma unroll
+      for (int it = 0; it < 2 * PR_BM * 8 / PR_TPB; ++it) {
+        const int slot = threadIdx.x + it * PR_TPB;
+        const bool isA = slot < PR_BM * 8;
+        const int sl = isA ? slot : slot - PR_BM * 8;
+        const int r = sl >> 3, kq = sl & 7;
+        const float* p = isA ? A : B;
+        const int64_t ld = isA ? lda : ldb;
+        int64_t row = (isA ? im0 : in0) + r;
+        const int64_t lim = isA ? M : N;
+        row = row < lim ? row : lim - 1;
+        const int64_t k = k0 + kq * 4;
+        const int64_t kc = k <= ld - 4 ? k : ld - 4;      // (k > ld - 4 implies k >= K: everything is zeroed below)
+        float4 v = *reinterpret_cast<const float4*>(p + row * ld + kc);
+        v.x = k + 0 < K ? v.x : 0.f;
+        v.y = k + 1 < K ? v.y : 0.f;
+        v.z = k + 2 < K ? v.z : 0.f;
+        v.w = k + 3 < K ? v.w : 0.f;
+        *reinterpret_cast<float4*>(st + (isA ? 0 : AF) + r * BK + 4 * (kq ^ ((r >> 1) & 7))) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written before this wave reaches the next barrier
+    }
     ++gi;
-    if (++it_u == T) {
+    if (++it_u == TT) {
       it_u = 0;
       it_tile = tile_of(++it_j);
     }
@@ -1133,7 +1186,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
         for (int r = 0; r < 16; ++r) acc[ab][t][r] = bv;
     }
 
-    for (int u = 0; u < T; ++u, ++g) {
+    for (int u = 0; u < TT; ++u, ++g) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice g has landed (and the previous tile's stores retired)
       __builtin_amdgcn_s_barrier();
       issue_next();
@@ -1708,6 +1761,30 @@ int ccn_gemm_nt_bf16(const float* A, int64_t lda, const float* W, int64_t ldw, c
   return CCN_OK;
 }
 
+int ccn_gemm_nt_f16(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                    int64_t M, int64_t N, int64_t K, double* colstats, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(A && W && Y, "gemm_nt_f16: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, "gemm_nt_f16: bad sizes M=%lld N=%lld K=%lld",
+              (long long)M, (long long)N, (long long)K);
+  CCN_REQUIRE(aligned16(A) && aligned16(W) && lda % 4 == 0 && ldw % 4 == 0 && lda >= 4 && ldw >= 4,
+              "gemm_nt_f16: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+  if (M == 0) return CCN_OK;
+  const int64_t gm = (M + 127) / 128;
+  CCN_REQUIRE(gm <= 2147483647LL, "gemm_nt_f16: grid too large");
+  if (N <= 32)
+    hipLaunchKernelGGL((gemm_bf16_kernel<128, 32, 4, true>), dim3((unsigned)gm, (unsigned)((N + 31) / 32)), dim3(GEMM_TPB), 0,
+                       s, A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats);
+  else if (N <= 64)
+    hipLaunchKernelGGL((gemm_bf16_kernel<128, 64, 4, true>), dim3((unsigned)gm, (unsigned)((N + 63) / 64)), dim3(GEMM_TPB), 0,
+                       s, A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats);
+  else
+    hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 4, true>), dim3((unsigned)gm, (unsigned)((N + 127) / 128)), dim3(GEMM_TPB),
+                       0, s, A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats);
+  CCN_LAUNCH_OK("gemm_nt_f16");
+  return CCN_OK;
+}
+
 int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                 int64_t M, int64_t N, int64_t K, double* colstats, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -1723,7 +1800,8 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
                        !g_force_generic && g_use_glds && M >= 1024 && K >= g_dma_min_k;
   const bool dma_ok = base_ok && ((M + GL_BM - 1) / GL_BM) * ((N + 127) / 128) >= 512;
   // N > 64: two 4-wave workgroups per CU on 128 x 128 tiles
-  if (base_ok && N > 64 && K % BK == 0 && g_use_persistent && g_use_pair &&
+  // (K % 32 != 0 -- the widths made by the +3 xyz concat: 259, 262, 515, 1027, 2051 -- is handled inside the kernel)
+  if (base_ok && N > 64 && g_use_persistent && g_use_pair &&
       ((M + PR_BM - 1) / PR_BM) * ((N + PR_BN - 1) / PR_BN) >= PAIR_MIN_TILES) {
     rc = launch_glds_pair(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s);
     if (rc) return rc;

@@ -1,0 +1,358 @@
+// Weight-gradient product on the LDS-DMA pipeline:  dW[N x K] += dY[M x N]^T  X[M x K]   (fp32 MFMA, exact fma chains)
+//
+// Replaces autograd's weight gradient of F.linear / F.conv1d (reference fast_conv1d.py:183; PyG MLP as used at
+// base.py:90-125).  Both operands are CONTRACTION-MAJOR: the contraction index m is the row of dY and of X, so a 32-row
+// slice of either operand is 32 contiguous row pieces.  One workgroup (4 waves) owns one (output tile, row chunk) work item:
+//   * tile TN x TK of dW (TN, TK in {64, 128}); the M rows are split into `split` contiguous chunks of whole 32-row slices
+//   * a slice of both operands reaches LDS by LDS-DMA (global_load_lds_dwordx4, no VGPR staging) as a [32][TN] and a
+//     [32][TK] fp32 image: one wave instruction copies 64 lanes x 16 B = (256 / TN) rows of TN floats, linear in LDS,
+//     the per-lane global address supplies row and column; two-stage ring, slice u+1 in flight while slice u is multiplied
+//     (counted waits + raw s_barrier; two workgroups per CU, so one's waits sit under the other's MFMAs)
+//   * v_mfma_f32_32x32x2_f32: lane (i, h) supplies A[i][k = h] and B[k = h][i] for one step of TWO contraction rows.  With
+//     the images contraction-major, lane i reads 8 bytes at row 2s + h: the values of output rows n = 2i, 2i + 1 (and of
+//     output columns k = 2i, 2i + 1) -- i.e. the fragments of TWO MFMA tiles per operand in one conflict-free ds_read_b64.
+//     The wave's 64 x 64 quadrant is therefore an interleave of four 32 x 32 tiles (even/odd n x even/odd k); the epilogue
+//     undoes the interleave with 8-byte stores.
+//   * waves: (TN/64) x (TK/64) quadrants; with fewer than four quadrants the waves split the slice's 32 contraction rows
+//     between them (WC = 4 / quadrants) and their accumulators are summed through LDS once per work item
+//   * the partial tile of a work item goes to a caller-owned slab (plain 8-byte stores); ccn_tn_reduce adds the slabs of a
+//     tile to dW in chunk order: deterministic, and 4 * N * K * split bytes written once instead of one fp32 atomic per
+//     accumulator element (r01p: 61 MB of atomics per launch at 1.3 M x 256 x 256).  Without scratch (or split == 1)
+//     the accumulators are added to dW directly (atomics when split > 1).
+//   * XCD-aware work order: the tiles of one row chunk run on workgroup ids w, w + 8, ... (one XCD, dispatched back to
+//     back), so the chunk's rows are fetched from HBM once and re-read from that XCD's L2 by the other tiles.
+// Rows beyond M in the last slice: source rows are clamped (in bounds) and the dY fragment is zeroed for them.
+// Columns beyond N / K: source columns are clamped into the row; they only feed accumulator elements that are never stored.
+#include "ccn_common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+constexpr int TN_TPB = 256;
+constexpr int TN_SLICE = 32;   // contraction rows per slice
+
+__device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// EPI 0: slab store, 1: atomic add into dW, 2: plain add into dW (single owner)
+template <int TN, int TK, int EPI>
+__global__ __launch_bounds__(TN_TPB, 2) void gemm_tn_glds_kernel(const float* __restrict__ A, int64_t lda,
+                                                                 const float* __restrict__ B, int64_t ldb,
+                                                                 float* __restrict__ C, int64_t ldc, int64_t M, int64_t N,
+                                                                 int64_t K, int tiles_k, int tiles, int split,
+                                                                 int64_t slices_per_chunk, int64_t n_ids, int xcd_order,
+                                                                 float* __restrict__ slabs) {
+  constexpr int QN = TN / 64, QK = TK / 64, WC = 4 / (QN * QK);   // quadrants, waves sharing a quadrant
+  constexpr int STEPS = TN_SLICE / 2 / WC;                          // 2-row MFMA steps per wave and slice
+  constexpr int AF = TN_SLICE * TN, BF = TN_SLICE * TK, STAGE = AF + BF;
+  constexpr int RPI_A = 256 / TN, RPI_B = 256 / TK;                 // rows per DMA instruction
+  constexpr int NIA = TN_SLICE / RPI_A / 4, NIB = TN_SLICE / RPI_B / 4;   // DMA instructions per wave, slice, operand
+  // one LDS array (a second __shared__ object beside a DMA ring makes hipcc drain the queue before every ds_read)
+  constexpr int RED = QN * QK * (WC - 1) * 64 * 64;                 // cross-wave accumulator reduction (reuses the ring)
+  constexpr int LDS_FLOATS = 2 * STAGE > RED ? 2 * STAGE : RED;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int quad = wave / WC, wc = wave % WC;
+  const int wn = quad / QK, wk = quad % QK;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+  // this lane's fragment address inside a stage: row (wc * 2 * STEPS + h), columns wn*64 + 2i (A) / wk*64 + 2i (B)
+  const uint32_t a_off = (uint32_t)(((wc * 2 * STEPS + h) * TN + wn * 64 + 2 * i) * 4);
+  const uint32_t b_off = (uint32_t)((AF + (wc * 2 * STEPS + h) * TK + wk * 64 + 2 * i) * 4);
+  const int64_t total_slices = (M + TN_SLICE - 1) / TN_SLICE;
+
+  for (int64_t id = blockIdx.x; id < n_ids; id += gridDim.x) {
+    int64_t chunk, tile;
+    if (xcd_order) {
+      const int64_t slot = id >> 3;
+      chunk = (slot / tiles) * 8 + (id & 7);
+      tile = slot % tiles;
+    } else {
+      chunk = id / tiles;
+      tile = id % tiles;
+    }
+    if (chunk >= split) continue;
+    const int64_t s_beg = chunk * slices_per_chunk;
+    int64_t s_end = s_beg + slices_per_chunk;
+    if (s_end > total_slices) s_end = total_slices;
+    const int64_t n0 = (tile / tiles_k) * TN, k0 = (tile % tiles_k) * TK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ta][tb][r] = 0.f;
+
+    if (s_beg < s_end) {
+      // ---- per-lane DMA source columns (clamped into the row: lda, ldb are multiples of 4 and >= 4)
+      int64_t a_col[NIA], b_col[NIB];
+      int a_row[NIA], b_row[NIB];
+#pragma unroll
+      for (int q = 0; q < NIA; ++q) {
+        const int g = wave * NIA + q;
+        a_row[q] = g * RPI_A + lane / (TN / 4);
+        int64_t c = n0 + 4 * (lane % (TN / 4));
+        a_col[q] = c <= lda - 4 ? c : lda - 4;
+      }
+#pragma unroll
+      for (int q = 0; q < NIB; ++q) {
+        const int g = wave * NIB + q;
+        b_row[q] = g * RPI_B + lane / (TK / 4);
+        int64_t c = k0 + 4 * (lane % (TK / 4));
+        b_col[q] = c <= ldb - 4 ? c : ldb - 4;
+      }
+      auto issue = [&](int64_t s, int stage) {
+        float* st = lds + stage * STAGE;
+        const int64_t m0 = s * TN_SLICE;
+#pragma unroll
+        for (int q = 0; q < NIA; ++q) {
+          int64_t row = m0 + a_row[q];
+          row = row < M ? row : M - 1;
+          glds16(A + row * lda + a_col[q], st + (wave * NIA + q) * 256);
+        }
+#pragma unroll
+        for (int q = 0; q < NIB; ++q) {
+          int64_t row = m0 + b_row[q];
+          row = row < M ? row : M - 1;
+          glds16(B + row * ldb + b_col[q], st + AF + (wave * NIB + q) * 256);
+        }
+      };
+      __builtin_amdgcn_s_barrier();          // every wave is done with the previous item's LDS reads
+      issue(s_beg, 0);
+      int stage = 0;
+      for (int64_t s = s_beg; s < s_end; ++s, stage ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice s has landed (this wave's share)
+        __builtin_amdgcn_s_barrier();                      // ... and everybody else's; stage^1 is free again
+        if (s + 1 < s_end) issue(s + 1, stage ^ 1);
+        const uint32_t sb = lds_base + (uint32_t)(stage * STAGE * 4);
+        const int64_t rl64 = M - s * TN_SLICE;              // >= 32 except in the last slice of all
+        const int rows_left = rl64 < TN_SLICE ? (int)rl64 : TN_SLICE;
+        f32x2 fa[2], fb[2];
+        // fragment reads are inline asm (hipcc would otherwise wait for every pending LDS-DMA before a visible ds_read);
+        // step t+1 is read before the MFMAs of step t and waited for with a counted lgkmcnt
+        asm volatile("ds_read_b64 %0, %1" : "=v"(fa[0]) : "v"(sb + a_off) : "memory");
+        asm volatile("ds_read_b64 %0, %1" : "=v"(fb[0]) : "v"(sb + b_off) : "memory");
+#pragma unroll
+        for (int t = 0; t < STEPS; ++t) {
+          if (t + 1 < STEPS) {
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[(t + 1) & 1]) : "v"(sb + a_off), "n"((t + 1) * 2 * TN * 4) : "memory");
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb[(t + 1) & 1]) : "v"(sb + b_off), "n"((t + 1) * 2 * TK * 4) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          f32x2 a = fa[t & 1];
+          const f32x2 b = fb[t & 1];
+          if (rows_left < TN_SLICE && wc * 2 * STEPS + 2 * t + h >= rows_left) a = f32x2{0.f, 0.f};   // rows beyond M
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- waves that shared a quadrant: sum their accumulators into the wc == 0 wave through LDS
+    if (WC > 1) {
+      __builtin_amdgcn_s_barrier();   // all fragment reads of the last slice are done: the ring is free
+      float* red = lds;
+      if (wc > 0) {
+        float* dst = red + ((quad * (WC - 1) + (wc - 1)) * 64 * 64);
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[((ta * 2 + tb) * 16 + r) * 64 + lane] = acc[ta][tb][r];
+      }
+      __syncthreads();
+      if (wc == 0) {
+#pragma unroll
+        for (int w = 0; w < WC - 1; ++w) {
+          const float* src = red + ((quad * (WC - 1) + w) * 64 * 64);
+#pragma unroll
+          for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[ta][tb][r] += src[((ta * 2 + tb) * 16 + r) * 64 + lane];
+        }
+      }
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    // tile (ta, tb) holds output rows n = 2 * row + ta and columns k = 2 * col + tb of the quadrant.
+    if (wc == 0) {
+      if (EPI == 0) {
+        float* slab = slabs + ((int64_t)tile * split + chunk) * (TN * TK);
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int nl = wn * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + ta;
+            *reinterpret_cast<f32x2*>(slab + nl * TK + wk * 64 + 2 * i) = f32x2{acc[ta][0][r], acc[ta][1][r]};
+          }
+      } else {
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t n = n0 + wn * 64 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * h) + ta;
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+              const int64_t k = k0 + wk * 64 + 2 * i + tb;
+              if (n < N && k < K) {
+                if (EPI == 1)
+                  atomicAdd(&C[n * ldc + k], acc[ta][tb][r]);
+                else
+                  C[n * ldc + k] += acc[ta][tb][r];
+              }
+            }
+          }
+      }
+    }
+    if (WC > 1) __syncthreads();      // the reduction scratch is the ring: finish reading before the next item's DMA
+  }
+}
+
+// dW[n][k] += sum over the chunks of the tile's slabs, in chunk order (deterministic)
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slabs, int split, int tiles_k, int64_t N,
+                                                        int64_t K, float* __restrict__ C, int64_t ldc) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 of a tile row
+  const int64_t kq = (K + 3) / 4;
+  if (t >= N * kq) return;
+  const int64_t n = t / kq, k = (t - n * kq) * 4;
+  const int64_t tile = (n / TN) * tiles_k + k / TK;
+  const float* src = slabs + tile * split * (int64_t)(TN * TK) + (n % TN) * TK + (k % TK);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < split; ++c) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)c * (TN * TK));
+    s.x += v.x;
+    s.y += v.y;
+    s.z += v.z;
+    s.w += v.w;
+  }
+  float* dst = C + n * ldc + k;
+  dst[0] += s.x;
+  if (k + 1 < K) dst[1] += s.y;
+  if (k + 2 < K) dst[2] += s.z;
+  if (k + 3 < K) dst[3] += s.w;
+}
+
+struct TnPlan {
+  int tn, tk, tiles_n, tiles_k, tiles, split;
+  int64_t slices_per_chunk, n_ids, slab_floats;
+  bool xcd;
+};
+
+inline int pick_tile(int64_t d) {   // 128 unless the last 128-wide tile would be at most half used
+  if (d <= 64) return 64;
+  const int64_t rem = d % 128;
+  return (rem == 0 || rem > 64) ? 128 : 64;
+}
+
+inline TnPlan tn_plan(int64_t M, int64_t N, int64_t K) {
+  TnPlan p;
+  p.tn = pick_tile(N);
+  p.tk = pick_tile(K);
+  p.tiles_n = (int)((N + p.tn - 1) / p.tn);
+  p.tiles_k = (int)((K + p.tk - 1) / p.tk);
+  p.tiles = p.tiles_n * p.tiles_k;
+  const int64_t slices = (M + TN_SLICE - 1) / TN_SLICE;
+  // ~512 work items of at least 4 slices each (two workgroups per CU); more tiles than that: one chunk per tile
+  int64_t split = (512 + p.tiles - 1) / p.tiles;
+  if (split > slices / 4) split = slices / 4;
+  if (split < 1) split = 1;
+  p.slices_per_chunk = (slices + split - 1) / split;
+  split = (slices + p.slices_per_chunk - 1) / p.slices_per_chunk;
+  p.split = (int)split;
+  p.xcd = split >= 8 && p.tiles > 1;
+  p.n_ids = p.xcd ? (int64_t)p.tiles * ((split + 7) / 8 * 8) : (int64_t)p.tiles * split;
+  p.slab_floats = split > 1 ? (int64_t)p.tiles * split * p.tn * p.tk : 0;
+  return p;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <int TN, int TK>
+int launch_tn(const TnPlan& p, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw,
+              int64_t M, int64_t N, int64_t K, float* slabs, hipStream_t s) {
+  const int64_t grid = p.n_ids < 512 ? p.n_ids : 512;
+  if (p.split == 1)
+    hipLaunchKernelGGL((gemm_tn_glds_kernel<TN, TK, 2>), dim3((unsigned)grid), dim3(TN_TPB), 0, s, dY, lddy, X, ldx, dW, lddw,
+                       M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, (float*)nullptr);
+  else if (slabs == nullptr)
+    hipLaunchKernelGGL((gemm_tn_glds_kernel<TN, TK, 1>), dim3((unsigned)grid), dim3(TN_TPB), 0, s, dY, lddy, X, ldx, dW, lddw,
+                       M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, (float*)nullptr);
+  else {
+    hipLaunchKernelGGL((gemm_tn_glds_kernel<TN, TK, 0>), dim3((unsigned)grid), dim3(TN_TPB), 0, s, dY, lddy, X, ldx, dW, lddw,
+                       M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, slabs);
+    const int64_t work = N * ((K + 3) / 4);
+    hipLaunchKernelGGL((tn_reduce_kernel<TN, TK>), dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, slabs, p.split,
+                       p.tiles_k, N, K, dW, lddw);
+  }
+  return CCN_OK;
+}
+
+static bool g_tn_dma = true;   // A/B hook (ccn_gemm_tn_use_dma)
+
+}  // namespace
+
+extern "C" {
+
+int ccn_gemm_tn_use_dma(int on) {
+  g_tn_dma = on != 0;
+  return CCN_OK;
+}
+
+// The LDS-DMA kernel takes 16-byte aligned operands whose leading dimensions are multiples of 4, from N > 32 and K > 32
+// on (narrower outputs leave most of a 64-wide tile empty: the register-staged kernels keep those) and M >= 1024.
+static bool tn_dma_ok(const float* dY, int64_t lddy, const float* X, int64_t ldx, int64_t M, int64_t N, int64_t K) {
+  return g_tn_dma && aligned16(dY) && aligned16(X) && lddy % 4 == 0 && ldx % 4 == 0 && lddy >= 4 && ldx >= 4 && N > 32 &&
+         K > 32 && M >= 1024;
+}
+
+size_t ccn_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 32 || K <= 32 || M < 1024 || !g_tn_dma) return 0;
+  return (size_t)tn_plan(M, N, K).slab_floats * sizeof(float);
+}
+
+int ccn_gemm_tn_ws(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
+                   int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(dY && X && dW, "gemm_tn_ws: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "gemm_tn_ws: bad sizes");
+  if (M == 0) return CCN_OK;
+  if (!tn_dma_ok(dY, lddy, X, ldx, M, N, K)) return ccn_gemm_tn(dY, lddy, X, ldx, dW, lddw, M, N, K, stream);
+  const TnPlan p = tn_plan(M, N, K);
+  float* slabs = nullptr;
+  if (p.slab_floats > 0 && workspace != nullptr) {
+    CCN_REQUIRE(workspace_bytes >= (size_t)p.slab_floats * sizeof(float) && aligned16(workspace),
+                "gemm_tn_ws: workspace too small (%zu < %zu bytes) or unaligned", workspace_bytes,
+                (size_t)p.slab_floats * sizeof(float));
+    slabs = (float*)workspace;
+  }
+  int rc;
+  if (p.tn == 128 && p.tk == 128)
+    rc = launch_tn<128, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s);
+  else if (p.tn == 128)
+    rc = launch_tn<128, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s);
+  else if (p.tk == 128)
+    rc = launch_tn<64, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s);
+  else
+    rc = launch_tn<64, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s);
+  if (rc) return rc;
+  CCN_LAUNCH_OK("gemm_tn_ws");
+  return CCN_OK;
+}
+
+}  // extern "C"

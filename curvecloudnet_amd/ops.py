@@ -12,6 +12,19 @@ from ._lib import call, lib, ptr, require_gpu, workspace
 ACT = {None: 0, "none": 0, "relu": 1, "leaky_relu": 2}
 LEAKY_SLOPE = 0.01  # torch.nn.LeakyReLU default, the only slope the reference uses
 
+# Test hook: when set to a list, every max aggregation appends an (rows, C) int64 table naming, per output entry, the
+# SOURCE POINT whose value won (-1: the -1e2 fill of an empty slot / an empty group).  The parity tests compare these
+# tables with the oracle's to count arg-max flips on last-bit ties, and feed them back to the oracle so that gradients
+# are compared along identical routes.
+MAX_TRACE = None
+
+
+def _trace_max(arg, first, ids):
+    """arg (rows, C) position of the winner inside its group (-1: none); first (rows,) start of each group in ``ids``."""
+    pos = first.long()[:, None] + arg.long().clamp(min=0)
+    MAX_TRACE.append(torch.where(arg >= 0, ids.long()[pos.clamp(max=max(ids.numel() - 1, 0))],
+                                 torch.full((), -1, dtype=torch.int64, device=arg.device)).cpu())
+
 
 def _mat(t):
     """float32 2-D row-major matrix, possibly with a padded leading dimension (a column-slice view)."""
@@ -263,11 +276,14 @@ def set_mlp_dtype(name):
     weights, activations, gradients and BatchNorm statistics are stored and reduced in fp32.  "bf16x3": fp32-grade
     products on the bf16 matrix cores -- every operand of a forward / data-gradient product is split exactly into three
     bf16 terms and the product assembled from the six leading partial products (``ccn_gemm_nt_x3``: error below one
-    fp32 rounding per product, 2.7x fewer matrix-core cycles); weight gradients stay on the fp32 MFMA kernel.  Also
-    settable with the environment variable CCN_MLP_DTYPE."""
+    fp32 rounding per product, 2.7x fewer matrix-core cycles); weight gradients stay on the fp32 MFMA kernel.  "fp16"
+    (BASELINE configs[4], "fp16 features"): the FORWARD products round their operands to fp16 (``ccn_gemm_nt_f16``,
+    fp32 accumulation); the data- and weight-gradient products take the bf16 kernels, because gradient magnitudes fall
+    below fp16's normal range without loss scaling while bf16 keeps fp32's exponent.  Also settable with the
+    environment variable CCN_MLP_DTYPE."""
     global _MLP_DTYPE
-    if name not in ("fp32", "bf16", "bf16x3"):
-        raise ValueError("mlp dtype must be 'fp32', 'bf16' or 'bf16x3'")
+    if name not in ("fp32", "bf16", "fp16", "bf16x3"):
+        raise ValueError("mlp dtype must be 'fp32', 'bf16', 'fp16' or 'bf16x3'")
     _MLP_DTYPE = name
 
 
@@ -275,7 +291,8 @@ def mlp_dtype():
     return _MLP_DTYPE
 
 
-_GEMM_NT = {"fp32": "gemm_nt", "bf16": "gemm_nt_bf16", "bf16x3": "gemm_nt_x3"}
+_GEMM_NT = {"fp32": "gemm_nt", "bf16": "gemm_nt_bf16", "fp16": "gemm_nt_f16", "bf16x3": "gemm_nt_x3"}
+_GEMM_BWD = {"gemm_nt": "gemm_nt", "gemm_nt_bf16": "gemm_nt_bf16", "gemm_nt_f16": "gemm_nt_bf16", "gemm_nt_x3": "gemm_nt_x3"}
 X3_MIN_K = 64            # below this a product is HBM-bound on either kernel
 
 
@@ -449,6 +466,33 @@ def _aligned_rows(t):
     return out
 
 
+def gemm_tn(dy, x, into=None):
+    """dW (N, K) += dY (M, N)^T X (M, K): the weight-gradient product (ref: autograd of F.linear / F.conv1d at
+    fast_conv1d.py:183, PyG MLP at base.py:90-125).  ``into``: accumulation target (a gradient-bucket view); a zeroed
+    matrix otherwise.  Takes the LDS-DMA kernel when the operands qualify (ccn_gemm_tn_ws), with caller-owned scratch
+    for the per-workgroup partial tiles."""
+    dy, x = _mat(dy), _mat(x)
+    m, n = dy.shape
+    k = x.size(1)
+    if x.size(0) != m:
+        raise ValueError("gemm_tn: dY has %d rows, X has %d" % (m, x.size(0)))
+    dw = into if into is not None else _rows(n, k, dy.device, zero=True)
+    nb = lib().ccn_gemm_tn_workspace_bytes(m, n, k)
+    ws = workspace(nb, dy.device) if nb > 0 else None
+    call("gemm_tn_ws", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k, ptr(ws), nb)
+    return dw
+
+
+def _wgrad(gemm_nt, dy, x, dw, m, n, k):
+    """dW += dY^T X for the layer whose forward ran ``gemm_nt`` (bf16 / fp16 modes: bf16 products)."""
+    if gemm_nt in ("gemm_nt_bf16", "gemm_nt_f16"):
+        call("gemm_tn_bf16", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
+        return
+    nb = lib().ccn_gemm_tn_workspace_bytes(m, n, k)
+    ws = workspace(nb, dy.device) if nb > 0 else None      # allocated on the launch stream: stream-ordered reuse
+    call("gemm_tn_ws", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k, ptr(ws), nb)
+
+
 class LinearBNAct(torch.autograd.Function):
     """y = act(BN(x W^T + b)) with batch statistics taken in the GEMM epilogue.
 
@@ -540,18 +584,17 @@ class LinearBNAct(torch.autograd.Function):
             wt.copy_(w[:, :k].t())
             if ctx.gemm_nt != "gemm_nt":
                 dy = _aligned_rows(dy)
-            _gemm_nt(ctx.gemm_nt, dy, wt, None, dx, m, k, n, None)
+            _gemm_nt(_GEMM_BWD[ctx.gemm_nt], dy, wt, None, dx, m, k, n, None)
         dw = None
         if ctx.needs_input_grad[1]:
             into = _main_grad(ctx.main_grad_of, n, k)
             if into is None and ctx.main_grad_of is not None:
                 _main_grad_cancel(ctx.main_grad_of)
             dw = into if into is not None else _rows(n, k, dev, zero=True)
-            if ctx.gemm_nt == "gemm_nt_bf16":
+            if ctx.gemm_nt in ("gemm_nt_bf16", "gemm_nt_f16"):
                 dy = _aligned_rows(dy)
             with _WgradScope(into, dy, x):
-                call("gemm_tn_bf16" if ctx.gemm_nt == "gemm_nt_bf16" else "gemm_tn", ptr(dy), _ld(dy), ptr(x), _ld(x),
-                     ptr(dw), _ld(dw), m, n, k)
+                _wgrad(ctx.gemm_nt, dy, x, dw, m, n, k)
             if into is not None:
                 dw = _main_grad_done(ctx.main_grad_of)
         db = None
@@ -853,7 +896,7 @@ class SegMax(torch.autograd.Function):
     """scatter_max over destinations (ref point_conv.py:81-82)."""
 
     @staticmethod
-    def forward(ctx, msg, offsets, num_dst):
+    def forward(ctx, msg, offsets, num_dst, src=None):
         msg = _mat(msg)
         c = msg.size(1)
         out = _rows(num_dst, c, msg.device)
@@ -861,6 +904,8 @@ class SegMax(torch.autograd.Function):
         call("seg_max_fwd", ptr(msg), _ld(msg), ptr(offsets), num_dst, c, ptr(out), _ld(out), ptr(arg))
         ctx.save_for_backward(arg, offsets)
         ctx.e = msg.size(0)
+        if MAX_TRACE is not None:
+            _trace_max(arg, offsets[:-1], src if src is not None else torch.arange(ctx.e, device=msg.device))
         return out
 
     @staticmethod
@@ -870,7 +915,7 @@ class SegMax(torch.autograd.Function):
         m, c = g.shape
         dmsg = _rows(ctx.e, c, g.device)
         call("seg_max_bwd", ptr(g), _ld(g), ptr(arg), ptr(offsets), m, c, ptr(dmsg), _ld(dmsg))
-        return dmsg, None, None
+        return dmsg, None, None, None
 
 
 # --------------------------------------------------------------------------------------
@@ -914,6 +959,12 @@ class SGMax(torch.autograd.Function):
         call("sg_max_fwd", ptr(f), _ld(f), ptr(nbr), ptr(cloud_ptr), b, nmax, k, c, ptr(out), _ld(out), ptr(arg))
         ctx.save_for_backward(arg, cloud_ptr)
         ctx.shape = (b, nmax, k, c)
+        if MAX_TRACE is not None:       # slot 0 = the point itself, slot s = FRNN entry s-1 (cloud-local index)
+            lens = cloud_ptr[1:] - cloud_ptr[:-1]
+            cloud = torch.repeat_interleave(torch.arange(b, device=f.device), lens)
+            local = torch.arange(n, device=f.device) - cloud_ptr[cloud]
+            ids = torch.cat([torch.arange(n, device=f.device)[:, None], nbr[cloud, local] + cloud_ptr[cloud][:, None]], 1)
+            _trace_max(arg, torch.arange(n, device=f.device) * (k + 1), ids.reshape(-1))
         return out
 
     @staticmethod
@@ -1334,17 +1385,16 @@ class LinearBNActTail(torch.autograd.Function):
             dx = _rows(m, k, dev)
             wtt = _rows(k, n, dev, zero=(n % 4 != 0))
             wtt.copy_(wt[:, :k].t())
-            _gemm_nt(ctx.gemm_nt, dy, wtt, None, dx, m, k, n, None)
+            _gemm_nt(_GEMM_BWD[ctx.gemm_nt], dy, wtt, None, dx, m, k, n, None)
         into = _main_grad(ctx.main_grad_of, n, k)
         if into is None and ctx.main_grad_of is not None:
             _main_grad_cancel(ctx.main_grad_of)
         dw = into if into is not None else _rows(n, k, dev, zero=True)
-        gemm_tn = "gemm_tn_bf16" if ctx.gemm_nt == "gemm_nt_bf16" else "gemm_tn"
         dyt = _rows(t, n, dev)
         torch.mul(dy[tail:], w[:, None], out=dyt)
         xt = x[tail:]
         with _WgradScope(into, dy, x, dyt):
-            call(gemm_tn, ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), tail, n, k)
+            _wgrad(ctx.gemm_nt, dy, x, dw, tail, n, k)
             call("gemm_tn", ptr(dyt), _ld(dyt), ptr(xt), _ld(x), ptr(dw), _ld(dw), t, n, k)   # few rows: fp32
         if into is not None:
             dw = _main_grad_done(ctx.main_grad_of)
@@ -1363,7 +1413,7 @@ class CGMax(torch.autograd.Function):
     """``SGMax`` on compact rows (ref dgcnn.py:181,187-189,206)."""
 
     @staticmethod
-    def forward(ctx, f, grp_ptr, rep_row, n):
+    def forward(ctx, f, grp_ptr, rep_row, n, row_src=None):
         f = _mat(f)
         c = f.size(1)
         out = _rows(n, c, f.device)
@@ -1371,6 +1421,8 @@ class CGMax(torch.autograd.Function):
         call("cg_max_fwd", ptr(f), _ld(f), ptr(grp_ptr), ptr(rep_row), n, c, ptr(out), _ld(out), ptr(arg))
         ctx.save_for_backward(arg, grp_ptr, rep_row)
         ctx.shape = (n, f.size(0), c)
+        if MAX_TRACE is not None and row_src is not None:
+            _trace_max(arg, grp_ptr[:-1], row_src)
         return out
 
     @staticmethod
@@ -1380,7 +1432,7 @@ class CGMax(torch.autograd.Function):
         n, rows, c = ctx.shape
         df = _rows(rows, c, g.device)
         call("cg_max_bwd", ptr(g), _ld(g), ptr(arg), ptr(grp_ptr), ptr(rep_row), n, rows, c, ptr(df), _ld(df))
-        return df, None, None, None
+        return df, None, None, None, None
 
 
 class ShiftAddBNAct(torch.autograd.Function):

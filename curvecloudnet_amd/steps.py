@@ -307,7 +307,7 @@ class PointNetConv2(nn.Module):
             if nn0 is not None:
                 msg = nn0(msg)
         if self.aggr_type == "max":
-            out = ops.SegMax.apply(msg, edges.offsets, edges.num_dst)
+            out = ops.SegMax.apply(msg, edges.offsets, edges.num_dst, edges.col)
         else:
             out = ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst)
         if self.global_nn is not None:
@@ -495,7 +495,7 @@ class SGCNNLayer(nn.Module):
             edges = g.edges
             msg = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row))
             if self.aggr_type == "max":
-                return ops.SegMax.apply(msg, edges.offsets, edges.num_dst)
+                return ops.SegMax.apply(msg, edges.offsets, edges.num_dst, edges.col)
             return ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst)
         topo, nbr, comp = g.topo, g.nbr, g.comp
         algebraic, _ = self._mode()
@@ -510,7 +510,7 @@ class SGCNNLayer(nn.Module):
             feat = ops.cg_edge_layer(ps, comp, self.nn.norms[0].module if hidden0 else None, self.training,
                                      self.nn.act if hidden0 else None)
             feat = self.nn(feat, start=1, tail=(comp.e, comp.row_w, comp.count))
-            return ops.CGMax.apply(feat, comp.grp_ptr, comp.rep_row, topo.n)
+            return ops.CGMax.apply(feat, comp.grp_ptr, comp.rep_row, topo.n, comp.row_src)
         if algebraic:
             # first layer in algebraic form: two per-point products + a gather-add instead of a GEMM over
             # 21x the rows (ops.SGEdgeLayer); exact up to fp32 re-association
@@ -549,7 +549,7 @@ class _DynamicEdgeConv(nn.Module):
             topo = _topology(batch, point2curveidx, kwargs, curves=False)
             edges = geo.publish(self._search(x.detach(), topo))
         msg = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row))
-        return ops.SegMax.apply(msg, edges.offsets, edges.num_dst), pos, batch, point2curveidx
+        return ops.SegMax.apply(msg, edges.offsets, edges.num_dst, edges.col), pos, batch, point2curveidx
 
 
 class DGCNNLayer(_DynamicEdgeConv):

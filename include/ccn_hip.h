@@ -166,6 +166,22 @@ int ccn_gemm_nn(const float* dY, int64_t lddy, const float* W, int64_t ldw, floa
                 int64_t N, int64_t K, void* stream);                              /* dX = dY W      */
 int ccn_gemm_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
                 int64_t N, int64_t K, void* stream);
+/* Weight gradient on the LDS-DMA pipeline (csrc/ccn_gemm_tn.hip): same product as ccn_gemm_tn (autograd of F.linear /
+ * F.conv1d at src/models/modules/fast_conv1d.py:183 and of the PyG MLP layers, base.py:90-125), with caller-owned scratch
+ * for the per-workgroup partial tiles (ccn_gemm_tn_workspace_bytes, 16-byte aligned; may be NULL: the partial tiles are
+ * then added to dW with fp32 atomics).  With scratch the result is deterministic: every work item stores its partial
+ * tile once and a second launch adds the tiles of each output block to dW in chunk order.  Operands that do not
+ * qualify (unaligned, leading dimension not a multiple of 4, N or K <= 32, M < 1024) take ccn_gemm_tn. */
+size_t ccn_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int ccn_gemm_tn_use_dma(int on);    /* A/B hook: 0 = always the register-staged split-K kernel of ccn_gemm_tn */
+int ccn_gemm_tn_ws(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                   int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+/* fp16 MFMA form of ccn_gemm_nt (BASELINE configs[4], "fp16 features"): A and W are read as fp32 and rounded to fp16
+ * (round to nearest even) inside the kernel, products accumulate in fp32 (v_mfma_f32_32x32x16_f16); bias / Y / colstats
+ * stay fp32.  Same requirements as ccn_gemm_nt_bf16.  The fp16 MLP mode uses it for the FORWARD products; gradients
+ * (whose magnitudes fall below fp16's normal range without loss scaling) take the bf16 kernels. */
+int ccn_gemm_nt_f16(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                    int64_t M, int64_t N, int64_t K, double* colstats, void* stream);
 /* bf16 MFMA form of ccn_gemm_tn (bf16 MLP mode): dW += bf16(dY)^T bf16(X), fp32 accumulation; 16-byte aligned operands. */
 int ccn_gemm_tn_bf16(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
                      int64_t N, int64_t K, void* stream); /* dW += dY^T X (dW pre-zeroed by caller) */

@@ -1,0 +1,72 @@
+"""fp32 MFMA GEMM entry points against an fp64 product AT THE SHAPES THAT CARRY THE BENCHMARK
+(profiles/*_kitti_gemm_shapes.txt): forward / data-gradient products (ccn_gemm_nt), weight gradients (ccn_gemm_tn),
+including the K = 512 / 1024 / 2048 depths and the widths made by the +3 xyz concat (259, 262, 1027, 2051).
+
+Bound: |y - y64| <= 1e-6 * sum_k |a_k||w_k| per output element.  v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain:
+the guide measures 0.75-1.5e-7 at K <= 1024 and 3.5e-7 at K = 4096 for it; the weight gradient adds the rounding of its
+split-row partial sums."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+NT_SHAPES = [  # (M, N, K)
+    (58660, 1024, 1024), (197729, 512, 512), (3168, 1024, 2048), (10550, 1024, 2051), (1342781, 256, 256),
+    (208234, 256, 259), (498380, 160, 262), (3168, 2048, 1027), (2341754, 64, 64), (1342781, 192, 256),
+]
+TN_SHAPES = [  # (M rows contracted, N, K): dW[N x K] += dY[M x N]^T X[M x K]
+    (1342781, 256, 256), (58660, 1024, 1024), (197729, 512, 512), (1342781, 256, 192), (208234, 256, 259),
+    (498380, 160, 262), (2341754, 64, 64), (10550, 1024, 1024), (3168, 1024, 2051), (1342781, 192, 128),
+]
+
+
+def _operands(rows, cols, gen, scale=1.0):
+    from curvecloudnet_amd.ops import _rows
+    t = _rows(rows, cols, DEV, zero=True)
+    # values spanning three decades with both signs: cancellation inside the dot products, as real activations have
+    t.copy_((torch.randn(rows, cols, generator=gen, device=DEV) *
+             torch.pow(10.0, torch.rand(rows, cols, generator=gen, device=DEV) * 3 - 2)) * scale)
+    return t
+
+
+@pytest.mark.parametrize("M,N,K", NT_SHAPES)
+def test_gemm_nt_against_fp64_at_bench_shapes(M, N, K):
+    from curvecloudnet_amd._lib import call, ptr
+    from curvecloudnet_amd.ops import _ld, _rows
+    gen = torch.Generator(device=DEV).manual_seed(M + 7 * N + K)
+    x, w = _operands(M, K, gen), _operands(N, K, gen, K ** -0.5)
+    y = _rows(M, N, DEV)
+    y.fill_(float("nan"))
+    call("gemm_nt", ptr(x), _ld(x), ptr(w), _ld(w), None, ptr(y), _ld(y), M, N, K, None)
+    worst = 0.0
+    step = max(1, (1 << 27) // (N * 8))             # fp64 reference in row blocks (bounded memory)
+    wd = w[:, :K].double()
+    for r0 in range(0, M, step):
+        xd = x[r0:r0 + step, :K].double()
+        ref = xd @ wd.t()
+        scale = xd.abs() @ wd.abs().t()
+        worst = max(worst, float(((y[r0:r0 + step, :N].double() - ref).abs() / scale.clamp_min(1e-300)).max()))
+    print("gemm_nt %dx%dx%d: max |err| / sum|a||w| = %.3g" % (M, N, K, worst))
+    assert worst < 1e-6, worst
+
+
+@pytest.mark.parametrize("M,N,K", TN_SHAPES)
+def test_gemm_tn_against_fp64_at_bench_shapes(M, N, K):
+    from curvecloudnet_amd import ops
+    gen = torch.Generator(device=DEV).manual_seed(M + 3 * N + K)
+    dy, x = _operands(M, N, gen), _operands(M, K, gen)
+    dw = ops.gemm_tn(dy, x)                                # (N, K), zero-initialised accumulation target inside
+    ref = torch.zeros((N, K), dtype=torch.float64, device=DEV)
+    scale = torch.zeros((N, K), dtype=torch.float64, device=DEV)
+    step = max(1, (1 << 27) // (max(N, K) * 8))
+    for r0 in range(0, M, step):
+        a, b = dy[r0:r0 + step, :N].double(), x[r0:r0 + step, :K].double()
+        ref += a.t() @ b
+        scale += a.abs().t() @ b.abs()
+    worst = float(((dw[:, :K].double() - ref).abs() / scale.clamp_min(1e-300)).max())
+    print("gemm_tn %dx%dx%d: max |err| / sum|a||b| = %.3g" % (M, N, K, worst))
+    assert worst < 1e-6, worst
+    # accumulation semantics: a second call adds the same product again
+    dw2 = ops.gemm_tn(dy, x, into=dw.clone())
+    assert float(((dw2[:, :K].double() - 2 * ref).abs() / scale.clamp_min(1e-300)).max()) < 2e-6

@@ -53,3 +53,57 @@ def maxdiff(a, b):
     if a.numel() == 0:
         return 0.0
     return float((a - b).abs().max())
+
+
+def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backward=True):
+    """Product forward (+ backward) with its max-routing tables recorded, then the CPU oracle with those tables FORCED
+    (oracle.torch_ref.MAX_TRACE): both sides then differentiate along identical arg-max routes, so gradients can be held
+    to a tight tolerance, and the tables the oracle would have chosen by itself give the number of flipped entries.
+
+    Returns dict(out_d, out_r, loss_d, loss_r, flips, entries, grad_err=[(err, name)], grad_scale)."""
+    from oracle import torch_ref as R
+    from curvecloudnet_amd import ops
+    from curvecloudnet_amd.model import segmentation_loss
+    kw = fwd_kwargs or {}
+    kw_d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    ops.MAX_TRACE = []
+    try:
+        torch.manual_seed(seed)
+        out_d = mine(batch_to(data, dev), **kw_d)
+    finally:
+        tables, ops.MAX_TRACE = ops.MAX_TRACE, None
+    loss_d = segmentation_loss(out_d, labels.to(dev))
+    if backward:
+        loss_d.backward()
+    R.MAX_TRACE = {"record": [], "force": [t.clone() for t in tables]}
+    try:
+        torch.manual_seed(seed)
+        out_r = ref(data, **kw)
+        natural = R.MAX_TRACE["record"]
+        max_gap = R.MAX_TRACE.get("max_gap", 0.0)
+        assert not R.MAX_TRACE["force"], "the oracle ran fewer max aggregations than the product"
+    finally:
+        R.MAX_TRACE = None
+    assert len(natural) == len(tables)
+    loss_r = R.segmentation_loss(out_r, labels)
+    if backward:
+        loss_r.backward()
+    flips = sum(int((a != b).sum()) for a, b in zip(natural, tables))
+    entries = sum(a.numel() for a in natural)
+    res = dict(out_d=out_d, out_r=out_r, loss_d=loss_d, loss_r=loss_r, flips=flips, entries=entries, grad_err=[],
+               grad_scale=0.0, max_gap=max_gap)
+    if backward:
+        pairs = [(n, pr.grad, pd.grad) for (n, pr), (_, pd) in zip(ref.named_parameters(), mine.named_parameters())]
+        for n, gr, gd in pairs:
+            assert gd is not None, n
+        gmax = max(float(gr.abs().max()) for _, gr, _ in pairs)
+        res["grad_scale"] = gmax
+        for n, gr, gd in pairs:
+            # per tensor, relative to its own largest entry -- but not below 1e-3 of the model's largest gradient entry:
+            # a bias in front of a BatchNorm has a mathematically zero gradient, what is left of it is summation noise
+            denom = max(float(gr.abs().max()), 1e-3 * gmax)
+            res["grad_err"].append((float((gd.detach().cpu() - gr).abs().max()) / denom, n))
+    return res
+
+
+GRAD_TOL = 3e-4          # routed gradients, per tensor (see routed_parity)
