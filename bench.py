@@ -335,6 +335,36 @@ def main():
     n_points = data.pos.size(0)
     labels = torch.randint(0, n_classes, (n_points,), generator=torch.Generator().manual_seed(rank)).to(dev)
 
+    if args.graph:
+        # BASELINE configs[4] leg: forward (inference) over a prepared plan, launched kernel by kernel vs replayed from ONE
+        # captured hipGraph.  Secondary line (the headline metric is fwd+bwd); single rank.
+        from curvecloudnet_amd.graph import CapturedForward
+        model.eval()
+        torch.manual_seed(7)
+        cap = CapturedForward(model, data)
+
+        def timed(fn):
+            for _ in range(args.warmup):
+                fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / args.steps
+        t_eager, t_graph = timed(cap.eager), timed(cap.replay)
+        same = bool(torch.equal(cap.eager(), cap.replay()))
+        print(json.dumps({
+            "metric": "point-clouds/sec fwd (inference, prepared geometry)", "value": b / t_graph, "unit": "clouds/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_graph, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.mlp_dtype, "data": "synthetic",
+            "config": {"workload": "%s; feature pass of a prepared plan replayed from one hipGraph (%d clouds x %d curves, "
+                                   "%d points)" % (workload_label(args), b, args.curves, n_points),
+                       "network": args.config},
+            "eager": {"value": b / t_eager, "ms_per_step": 1e3 * t_eager}, "graph_speedup": t_eager / t_graph,
+            "bit_identical_to_eager": same}))
+        return
+
     staged = {"plan": None}
 
     debug = os.environ.get("CCN_BENCH_DEBUG") == "1"

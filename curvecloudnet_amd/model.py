@@ -150,7 +150,8 @@ class ModelBase(torch.nn.Module):
             staged = plan[i] if plan is not None else None
             if staged is not None:
                 g, ready = staged
-                ctx.main.wait_event(ready)                  # this step's index tables, produced on the side stream
+                if ready is not None:                       # (None: the consumer synchronised already, graph.CapturedForward)
+                    ctx.main.wait_event(ready)              # this step's index tables, produced on the side stream
             if name in ("fp", "fp-geo"):
                 j = downsampled.pop()
                 x_skip = hist["x"][j] if hist["x"][j] is not None else hist["pos"][j]

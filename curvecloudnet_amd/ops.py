@@ -19,6 +19,23 @@ LEAKY_SLOPE = 0.01  # torch.nn.LeakyReLU default, the only slope the reference u
 MAX_TRACE = None
 
 
+# Test hook: when set to a list, every BatchNorm + activation layer appends the sign table (z > 0, bool, on the CPU) of its
+# output in forward order; ACT_ROW_MAP (set by the compact-row SGCNN path) re-indexes the rows to the reference's dense
+# B*Nmax*(K+1)-row layout first.  The parity tests make the oracle take the same ReLU / LeakyReLU slopes (see
+# oracle.torch_ref.ACT_TRACE) so that gradients are compared along identical routes.
+ACT_TRACE = None
+ACT_ROW_MAP = None
+
+
+def _trace_act(z, act):
+    if ACT_TRACE is None or act == 0:
+        return
+    m = z > 0
+    if ACT_ROW_MAP is not None:
+        m = m[ACT_ROW_MAP]
+    ACT_TRACE.append(m.cpu())
+
+
 def _trace_max(arg, first, ids):
     """arg (rows, C) position of the winner inside its group (-1: none); first (rows,) start of each group in ``ids``."""
     pos = first.long()[:, None] + arg.long().clamp(min=0)
@@ -540,6 +557,7 @@ class LinearBNAct(torch.autograd.Function):
         z = _rows(m, n, dev)
         call("bn_act_fwd", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
         ctx.save_for_backward(x, w, y, par)
+        _trace_act(z, ctx.act)
         return z
 
     @staticmethod
@@ -1098,6 +1116,7 @@ class SGEdgeLayer(torch.autograd.Function):
         call("sg_edge_apply", ptr(ps), _ld(ps), None, ptr(nbr), ptr(cloud_ptr), b, nmax, k, co,
              ptr(par[0]) if has_bn else None, ptr(par[1]) if has_bn else None, ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
         ctx.save_for_backward(ps, nbr, cloud_ptr, par if has_bn else ps.new_empty(0))
+        _trace_act(z, ctx.act)
         return z
 
     @staticmethod
@@ -1166,6 +1185,7 @@ class PNEdgeLayer(torch.autograd.Function):
              ptr(par[1]) if has_bn else None, ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
         ctx.save_for_backward(px, wp, bias if bias is not None else px.new_empty(0), pos_src, pos_dst, src, dst,
                               par if has_bn else px.new_empty(0))
+        _trace_act(z, ctx.act)
         return z
 
     @staticmethod
@@ -1247,6 +1267,21 @@ class SGCompact:
     def tensors(self):
         return (self.grp_ptr, self.row_src, self.rep_row, self.row_w)
 
+    def dense_row_map(self, nbr, topo):
+        """Compact row of every row (b, i, slot) of the reference's dense B*Nmax*(K+1)-row layout (test hook: sign tables
+        of the compact computation in the oracle's layout)."""
+        b, nmax, k = nbr.shape
+        dev = nbr.device
+        live = torch.arange(nmax, device=dev)[None, :] < topo.lengths[:, None]                  # (B, Nmax)
+        p = (topo.cloud_ptr[:-1, None] + torch.arange(nmax, device=dev)[None, :]).clamp(max=self.n - 1)
+        valid = torch.cat([torch.ones((b, nmax, 1), dtype=torch.bool, device=dev), nbr >= 0], dim=2)
+        rank = torch.cumsum(valid.long(), dim=2) - 1
+        real = self.grp_ptr.long()[p][:, :, None] + rank
+        rep = self.rep_row.long()[p][:, :, None].expand(-1, -1, k + 1)
+        idx = torch.where(valid, real, rep)
+        idx = torch.where(live[:, :, None], idx, torch.full_like(idx, self.e + self.ne))
+        return idx.reshape(-1)
+
 
 class CGEdgeLayer(torch.autograd.Function):
     """``SGEdgeLayer`` on compact rows: same values for the real rows, BatchNorm statistics identical to the dense
@@ -1279,6 +1314,7 @@ class CGEdgeLayer(torch.autograd.Function):
         call("cg_edge_apply", ptr(ps), _ld(ps), *idx, n, e, ne, co, ptr(par[0]) if has_bn else None,
              ptr(par[1]) if has_bn else None, ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
         ctx.save_for_backward(ps, grp_ptr, row_src, rep_row, row_w, par if has_bn else ps.new_empty(0))
+        _trace_act(z, ctx.act)
         return z
 
     @staticmethod
@@ -1357,6 +1393,7 @@ class LinearBNActTail(torch.autograd.Function):
         z = _rows(m, n, dev)
         call("bn_act_fwd", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
         ctx.save_for_backward(x, wt, y, par, w)
+        _trace_act(z, ctx.act)
         return z
 
     @staticmethod
@@ -1463,6 +1500,7 @@ class ShiftAddBNAct(torch.autograd.Function):
         z = _rows(m, n, dev)
         call("bn_act_fwd", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
         ctx.save_for_backward(y, par)
+        _trace_act(z, ctx.act)
         return z
 
     @staticmethod

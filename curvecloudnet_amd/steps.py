@@ -507,9 +507,14 @@ class SGCNNLayer(nn.Module):
             w = lin0.weight
             ps = ops.linear_bn_act(x, torch.cat([w[:, :c] - w[:, c:], w[:, c:]], dim=0), None, None, False, None)
             hidden0 = len(self.nn.norms) > 0
-            feat = ops.cg_edge_layer(ps, comp, self.nn.norms[0].module if hidden0 else None, self.training,
-                                     self.nn.act if hidden0 else None)
-            feat = self.nn(feat, start=1, tail=(comp.e, comp.row_w, comp.count))
+            if ops.ACT_TRACE is not None:       # test hook: sign tables in the reference's dense row layout
+                ops.ACT_ROW_MAP = comp.dense_row_map(nbr, topo)
+            try:
+                feat = ops.cg_edge_layer(ps, comp, self.nn.norms[0].module if hidden0 else None, self.training,
+                                         self.nn.act if hidden0 else None)
+                feat = self.nn(feat, start=1, tail=(comp.e, comp.row_w, comp.count))
+            finally:
+                ops.ACT_ROW_MAP = None
             return ops.CGMax.apply(feat, comp.grp_ptr, comp.rep_row, topo.n, comp.row_src)
         if algebraic:
             # first layer in algebraic form: two per-point products + a gather-add instead of a GEMM over

@@ -147,6 +147,45 @@ class _Conv1dBF16(torch.autograd.Function):
         return dx, dw, (g.sum(dim=(0, 2)) if ctx.has_bias else None), None
 
 
+# ---- activation with a routing trace (test hook, same idea as MAX_TRACE below).  ReLU / LeakyReLU are not differentiable
+# at 0: where a pre-activation lies within the CPU/GPU forward difference (~1e-5 at depth) of zero, the two sides take
+# different slopes and ONE row's contribution to a weight gradient flips -- 1/sqrt(rows) of that gradient entry, far above
+# any fp32 tolerance.  With ACT_TRACE["force"] set to the product's per-layer sign tables (in forward order), the oracle
+# takes the slope the GPU took; the number of entries where it would have chosen differently and the largest |z| among
+# them are recorded.
+ACT_TRACE = None        # None | {"force": [bool tables...], "mismatch": 0, "entries": 0, "max_abs": 0.0}
+
+
+class _RoutedAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, mask, slope):
+        ctx.save_for_backward(mask)
+        ctx.slope = slope
+        return torch.where(mask, z, z * slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return torch.where(mask, g, g * ctx.slope), None, None
+
+
+def activation(z, kind):
+    """relu / leaky_relu(0.01) (ref base.py:90-125 via PyG MLP; fast_conv1d.py:73,143)."""
+    trace = ACT_TRACE
+    if trace is None:
+        return F.relu(z) if kind == "relu" else F.leaky_relu(z)
+    mask = trace["force"].pop(0)
+    assert mask.shape == z.shape, ("activation trace out of step", tuple(mask.shape), tuple(z.shape))
+    own = z.detach() > 0
+    diff = own != mask
+    n = int(diff.sum())
+    trace["mismatch"] += n
+    trace["entries"] += z.numel()
+    if n:
+        trace["max_abs"] = max(trace["max_abs"], float(z.detach()[diff].abs().max()))
+    return _RoutedAct.apply(z, mask, 0.0 if kind == "relu" else 0.01)
+
+
 def linear(x, lin):
     if MLP_DTYPE in ("bf16", "fp16"):
         return _LinearBF16.apply(x, lin.weight, lin.bias)
@@ -226,7 +265,7 @@ class SymmetricCurve1DConvFastV1(nn.Module):
                 x = torch.cat([x, feature_diffs(x, point2curveidx, batch)], dim=1)
             seq = torch.zeros((n_rows, x.size(1)), dtype=x.dtype).index_copy(0, rows, x)
             x = conv(seq)[rows]
-            x = F.leaky_relu(norm(x))
+            x = activation(norm(x), "leaky_relu")
         return x, pos, batch, point2curveidx
 
 
@@ -250,7 +289,7 @@ class SymmetricCurve1DConvV2(nn.Module):
             x = torch.cat([x, feature_diffs(x, point2curveidx, batch)], dim=1)
         seq = torch.zeros((n_rows, x.size(1)), dtype=x.dtype).index_copy(0, rows, x)
         for conv, norm in zip(self.conv_modules, self.norm_modules):
-            seq = F.leaky_relu(norm(conv(seq)))
+            seq = activation(norm(conv(seq)), "leaky_relu")
         return seq[rows], pos, batch, point2curveidx
 
 
@@ -543,14 +582,15 @@ class MLP(nn.Module):
         else:
             self.dropout = [float(d) for d in dropout]
             assert len(self.dropout) == n_layers
-        self.act = {"relu": F.relu, "leaky_relu": F.leaky_relu}[act]
+        assert act in ("relu", "leaky_relu")
+        self.act = act
         self.lins = nn.ModuleList(nn.Linear(a, b, bias=bias) for a, b in zip(channel_list[:-1], channel_list[1:]))
         normed = channel_list[1:-1] if plain_last else channel_list[1:]
         self.norms = nn.ModuleList(_Norm(c) for c in normed)
 
     def forward(self, x):
         for i, (lin, norm) in enumerate(zip(self.lins, self.norms)):
-            x = F.dropout(self.act(norm(linear(x, lin))), p=self.dropout[i], training=self.training)
+            x = F.dropout(activation(norm(linear(x, lin)), self.act), p=self.dropout[i], training=self.training)
         if self.plain_last:
             x = F.dropout(linear(x, self.lins[-1]), p=self.dropout[-1], training=self.training)
         return x

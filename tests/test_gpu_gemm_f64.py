@@ -2,14 +2,19 @@
 (profiles/*_kitti_gemm_shapes.txt): forward / data-gradient products (ccn_gemm_nt), weight gradients (ccn_gemm_tn),
 including the K = 512 / 1024 / 2048 depths and the widths made by the +3 xyz concat (259, 262, 1027, 2051).
 
-Bound: |y - y64| <= 1e-6 * sum_k |a_k||w_k| per output element.  v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain:
-the guide measures 0.75-1.5e-7 at K <= 1024 and 3.5e-7 at K = 4096 for it; the weight gradient adds the rounding of its
-split-row partial sums."""
+Bound: max over ALL output elements of |y - y64| / sum_k |a_k||w_k| <= 2.5e-6, AND no worse than 1.5x what rocBLAS'
+fp32 product (torch.matmul) leaves on the same operands.  v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain (one
+rounding per product, u = 6e-8): typical error ~1e-7 (the guide: 0.75-1.5e-7 at K <= 1024), but these operands span
+three decades with both signs and the maximum is taken over 1e7..3e8 outputs, where a chain of K roundings reaches
+~20 u (measured 1.2-1.5e-6 at every depth, K = 64 .. 2051, on both kernels and on rocBLAS alike).  The weight gradient
+adds the rounding of its split-row partial sums."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+
+ERR_BOUND = 2.5e-6
 
 NT_SHAPES = [  # (M, N, K)
     (58660, 1024, 1024), (197729, 512, 512), (3168, 1024, 2048), (10550, 1024, 2051), (1342781, 256, 256),
@@ -39,16 +44,18 @@ def test_gemm_nt_against_fp64_at_bench_shapes(M, N, K):
     y = _rows(M, N, DEV)
     y.fill_(float("nan"))
     call("gemm_nt", ptr(x), _ld(x), ptr(w), _ld(w), None, ptr(y), _ld(y), M, N, K, None)
-    worst = 0.0
+    worst = yard = 0.0
     step = max(1, (1 << 27) // (N * 8))             # fp64 reference in row blocks (bounded memory)
     wd = w[:, :K].double()
+    wc = w[:, :K].contiguous()
     for r0 in range(0, M, step):
         xd = x[r0:r0 + step, :K].double()
         ref = xd @ wd.t()
-        scale = xd.abs() @ wd.abs().t()
-        worst = max(worst, float(((y[r0:r0 + step, :N].double() - ref).abs() / scale.clamp_min(1e-300)).max()))
-    print("gemm_nt %dx%dx%d: max |err| / sum|a||w| = %.3g" % (M, N, K, worst))
-    assert worst < 1e-6, worst
+        scale = (xd.abs() @ wd.abs().t()).clamp_min(1e-300)
+        worst = max(worst, float(((y[r0:r0 + step, :N].double() - ref).abs() / scale).max()))
+        yard = max(yard, float((((x[r0:r0 + step, :K].contiguous() @ wc.t()).double() - ref).abs() / scale).max()))
+    print("gemm_nt %dx%dx%d: max |err| / sum|a||w| = %.3g (rocBLAS fp32 on the same operands: %.3g)" % (M, N, K, worst, yard))
+    assert worst < ERR_BOUND and worst <= 1.5 * yard + 2e-7, (worst, yard)
 
 
 @pytest.mark.parametrize("M,N,K", TN_SHAPES)
@@ -66,7 +73,7 @@ def test_gemm_tn_against_fp64_at_bench_shapes(M, N, K):
         scale += a.abs().t() @ b.abs()
     worst = float(((dw[:, :K].double() - ref).abs() / scale.clamp_min(1e-300)).max())
     print("gemm_tn %dx%dx%d: max |err| / sum|a||b| = %.3g" % (M, N, K, worst))
-    assert worst < 1e-6, worst
+    assert worst < ERR_BOUND, worst
     # accumulation semantics: a second call adds the same product again
     dw2 = ops.gemm_tn(dy, x, into=dw.clone())
-    assert float(((dw2[:, :K].double() - 2 * ref).abs() / scale.clamp_min(1e-300)).max()) < 2e-6
+    assert float(((dw2[:, :K].double() - 2 * ref).abs() / scale.clamp_min(1e-300)).max()) < 2 * ERR_BOUND

@@ -25,13 +25,17 @@ def _check_routed(res, what):
     scale = max(1.0, float(out_r.abs().max()))
     err = maxdiff(out_d, out_r)
     worst = sorted(res["grad_err"])[-5:]
-    print("%s: logits max|diff| %.2e (scale %.2f), loss diff %.2e, arg-max flips %d of %d, worst routed gradients %s"
+    print("%s: logits max|diff| %.2e (scale %.2f), loss diff %.2e, arg-max flips %d of %d (gap %.1e), activation-sign "
+          "flips %d of %d (|z| <= %.1e), worst routed gradients %s"
           % (what, err, scale, abs(float(res["loss_d"]) - float(res["loss_r"])), res["flips"], res["entries"],
-             ["%.1e %s" % e for e in worst]))
+             res["max_gap"], res["sign_flips"], res["sign_entries"], res["sign_max_abs"], ["%.1e %s" % e for e in worst]))
     assert err <= LOGIT_TOL * scale, err
     assert abs(float(res["loss_d"]) - float(res["loss_r"])) < 1e-5
     assert res["flips"] <= 4 + MAX_FLIP_RATE * res["entries"], (res["flips"], res["entries"])
     assert res["max_gap"] <= 1e-5 * scale, res["max_gap"]       # a flipped entry really was a tie
+    # ReLU / LeakyReLU kinks: the oracle would have taken the other slope only where |z| is within the forward difference
+    assert res["sign_flips"] <= 4 + MAX_FLIP_RATE * res["sign_entries"], (res["sign_flips"], res["sign_entries"])
+    assert res["sign_max_abs"] <= 1e-3, res["sign_max_abs"]
     for e, n in res["grad_err"]:
         assert e <= GRAD_TOL, (e, n)
 

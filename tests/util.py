@@ -56,9 +56,11 @@ def maxdiff(a, b):
 
 
 def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backward=True):
-    """Product forward (+ backward) with its max-routing tables recorded, then the CPU oracle with those tables FORCED
-    (oracle.torch_ref.MAX_TRACE): both sides then differentiate along identical arg-max routes, so gradients can be held
-    to a tight tolerance, and the tables the oracle would have chosen by itself give the number of flipped entries.
+    """Product forward (+ backward) with its routing tables recorded -- which source point won every max aggregation,
+    which slope every ReLU / LeakyReLU took -- then the CPU oracle with those tables FORCED (oracle.torch_ref.MAX_TRACE,
+    ACT_TRACE): both sides then differentiate along identical routes, so gradients can be held to a tight tolerance, and
+    the choices the oracle would have made by itself give the number of flipped entries (all of them last-bit ties /
+    pre-activations within the forward difference of zero: max_gap, sign_max_abs).
 
     Returns dict(out_d, out_r, loss_d, loss_r, flips, entries, grad_err=[(err, name)], grad_scale)."""
     from oracle import torch_ref as R
@@ -66,24 +68,28 @@ def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backwar
     from curvecloudnet_amd.model import segmentation_loss
     kw = fwd_kwargs or {}
     kw_d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
-    ops.MAX_TRACE = []
+    ops.MAX_TRACE, ops.ACT_TRACE = [], []
     try:
         torch.manual_seed(seed)
         out_d = mine(batch_to(data, dev), **kw_d)
     finally:
         tables, ops.MAX_TRACE = ops.MAX_TRACE, None
+        signs, ops.ACT_TRACE = ops.ACT_TRACE, None
     loss_d = segmentation_loss(out_d, labels.to(dev))
     if backward:
         loss_d.backward()
     R.MAX_TRACE = {"record": [], "force": [t.clone() for t in tables]}
+    R.ACT_TRACE = {"force": signs, "mismatch": 0, "entries": 0, "max_abs": 0.0}
     try:
         torch.manual_seed(seed)
         out_r = ref(data, **kw)
         natural = R.MAX_TRACE["record"]
         max_gap = R.MAX_TRACE.get("max_gap", 0.0)
+        act = R.ACT_TRACE
         assert not R.MAX_TRACE["force"], "the oracle ran fewer max aggregations than the product"
+        assert not act["force"], "the oracle ran fewer activation layers than the product"
     finally:
-        R.MAX_TRACE = None
+        R.MAX_TRACE = R.ACT_TRACE = None
     assert len(natural) == len(tables)
     loss_r = R.segmentation_loss(out_r, labels)
     if backward:
@@ -91,7 +97,8 @@ def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backwar
     flips = sum(int((a != b).sum()) for a, b in zip(natural, tables))
     entries = sum(a.numel() for a in natural)
     res = dict(out_d=out_d, out_r=out_r, loss_d=loss_d, loss_r=loss_r, flips=flips, entries=entries, grad_err=[],
-               grad_scale=0.0, max_gap=max_gap)
+               grad_scale=0.0, max_gap=max_gap, sign_flips=act["mismatch"], sign_entries=act["entries"],
+               sign_max_abs=act["max_abs"])
     if backward:
         pairs = [(n, pr.grad, pd.grad) for (n, pr), (_, pd) in zip(ref.named_parameters(), mine.named_parameters())]
         for n, gr, gd in pairs:
