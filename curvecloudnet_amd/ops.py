@@ -225,6 +225,14 @@ class DiffConcat(torch.autograd.Function):
         out = _rows(n, 2 * c, x.device)
         call("diff_concat_fwd", ptr(x), _ld(x), ptr(cid), n, c, ptr(out), _ld(out))
         ctx.save_for_backward(x, cid)
+        if ACT_TRACE is not None:
+            # test hook: the sign of (x[i+1] - x[i]) + (x[i] - x[i-1]) with out-of-curve edges dropped, evaluated with the
+            # kernel's own operations in the kernel's order (bit-identical: plain fp32 subtract / add), for the oracle's
+            # routed |.| (oracle.torch_ref.routed_abs)
+            link = (cid[1:] == cid[:-1])[:, None]
+            step = torch.where(link, x[1:] - x[:-1], torch.zeros((), dtype=x.dtype, device=x.device))
+            zero = torch.zeros((1, c), dtype=x.dtype, device=x.device)
+            ACT_TRACE.append(torch.sign(torch.cat([step, zero]) + torch.cat([zero, step])).to(torch.int8).cpu())
         return out
 
     @staticmethod
@@ -495,9 +503,28 @@ def gemm_tn(dy, x, into=None):
         raise ValueError("gemm_tn: dY has %d rows, X has %d" % (m, x.size(0)))
     dw = into if into is not None else _rows(n, k, dy.device, zero=True)
     nb = lib().ccn_gemm_tn_workspace_bytes(m, n, k)
-    ws = workspace(nb, dy.device) if nb > 0 else None
+    ws = _tn_scratch(nb, dy.device)
     call("gemm_tn_ws", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k, ptr(ws), nb)
     return dw
+
+
+_TN_SCRATCH = {}
+
+
+def _tn_scratch(nbytes, device):
+    """Partial-tile scratch of the weight-gradient kernel: ONE grow-only buffer per (device, stream).  Launches on a
+    stream run in order, so every product can reuse it; allocating ~32 MB per call from the caching allocator -- on the
+    weight-gradient side stream -- left blocks parked across streams and cost several hipMallocs per step."""
+    if nbytes <= 0:
+        return None
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    buf = _TN_SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            return workspace(nbytes, device)                 # inside a graph capture: the capture's private pool
+        buf = _TN_SCRATCH[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+    return buf
 
 
 def _wgrad(gemm_nt, dy, x, dw, m, n, k):
@@ -506,7 +533,7 @@ def _wgrad(gemm_nt, dy, x, dw, m, n, k):
         call("gemm_tn_bf16", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k)
         return
     nb = lib().ccn_gemm_tn_workspace_bytes(m, n, k)
-    ws = workspace(nb, dy.device) if nb > 0 else None      # allocated on the launch stream: stream-ordered reuse
+    ws = _tn_scratch(nb, dy.device)
     call("gemm_tn_ws", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k, ptr(ws), nb)
 
 

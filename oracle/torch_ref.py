@@ -86,7 +86,7 @@ def feature_diffs(x, point2curveidx, batch):
     ahead = torch.cat([step, zrow], 0)               # edge i -> i+1
     behind = torch.cat([zrow, step], 0)              # edge i-1 -> i
     n_edges = torch.cat([linked.to(x.dtype), zflag]) + torch.cat([zflag, linked.to(x.dtype)])
-    return torch.abs((ahead + behind) / torch.clamp(n_edges, min=1)[:, None])
+    return routed_abs((ahead + behind) / torch.clamp(n_edges, min=1)[:, None])
 
 
 # --------------------------------------------------------------------------------------
@@ -167,6 +167,23 @@ class _RoutedAct(torch.autograd.Function):
     def backward(ctx, g):
         (mask,) = ctx.saved_tensors
         return torch.where(mask, g, g * ctx.slope), None, None
+
+
+def routed_abs(v):
+    """|v| (ref fast_conv1d.py:205).  Not differentiable at 0 either: with ACT_TRACE set, the sign the GPU computed (an
+    int8 table of -1 / 0 / +1, same forward order as the activation tables) is used, out = sign * v."""
+    trace = ACT_TRACE
+    if trace is None:
+        return torch.abs(v)
+    sign = trace["force"].pop(0)
+    assert sign.shape == v.shape and sign.dtype == torch.int8, ("abs trace out of step", tuple(sign.shape), tuple(v.shape))
+    diff = torch.sign(v.detach()).to(torch.int8) != sign
+    n = int(diff.sum())
+    trace["mismatch"] += n
+    trace["entries"] += v.numel()
+    if n:
+        trace["max_abs"] = max(trace["max_abs"], float(v.detach()[diff].abs().max()))
+    return v * sign.to(v.dtype)
 
 
 def activation(z, kind):

@@ -109,7 +109,10 @@ def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backwar
             # per tensor, relative to its own largest entry -- but not below 1e-3 of the model's largest gradient entry:
             # a bias in front of a BatchNorm has a mathematically zero gradient, what is left of it is summation noise
             denom = max(float(gr.abs().max()), 1e-3 * gmax)
-            res["grad_err"].append((float((gd.detach().cpu() - gr).abs().max()) / denom, n))
+            err = float((gd.detach().cpu() - gr).abs().max())
+            if err <= 2e-6 * gmax:          # both sides at the fp32 noise floor of the summation
+                err = 0.0
+            res["grad_err"].append((err / denom, n))
     return res
 
 
