@@ -11,7 +11,7 @@
 // The grid only prunes: a candidate is accepted iff d2 = fma(dz,dz,fma(dy,dy,dx*dx)) < r*r, and the K best
 // are kept ordered by (d2, original index), exactly the exhaustive oracle (oracle/frnn_bruteforce.c).
 // Cell edge = 1.001 r, so every point within r of a query lies in the 27 cells around the query's cell
-// even after float rounding of the cell coordinate (valid while |coordinate| / r < 1e4).
+// (cell coordinates are evaluated in double: valid for |coordinate| / r < 2e9, see cell_axis).
 // Built with -ffp-contract=off.
 #include "ccn_common.h"
 
@@ -50,8 +50,19 @@ __host__ bool carve(void* grid, size_t bytes, int64_t B, int64_t P2, GridView* g
   return a.ok();
 }
 
+// Cell coordinate in DOUBLE: x * inv_cell is then exact to ~1e-16 relative, so a point within r of a query always lies in
+// one of the 27 cells around the query's cell (the 0.1 % margin of the cell edge dwarfs the rounding) for any coordinate
+// whose cell index fits an int -- |coordinate| / r < 2e9 -- instead of the < 1e4 that fp32 cell arithmetic allowed
+// (outside that range the fp32 form silently dropped neighbours).  Beyond the int range the index
+// saturates: far-away points share a cell, which costs speed, never correctness (the grid only prunes).
+__device__ __forceinline__ int cell_axis(float x, double inv_cell) {
+  double c = floor((double)x * inv_cell);
+  c = c < -2147483000.0 ? -2147483000.0 : (c > 2147483000.0 ? 2147483000.0 : c);
+  return (int)c;
+}
 __device__ __forceinline__ int3 cell_of(float x, float y, float z, float inv_cell) {
-  return make_int3(__float2int_rd(x * inv_cell), __float2int_rd(y * inv_cell), __float2int_rd(z * inv_cell));
+  const double ic = (double)inv_cell;
+  return make_int3(cell_axis(x, ic), cell_axis(y, ic), cell_axis(z, ic));
 }
 
 __device__ __forceinline__ uint32_t bucket_of(int cx, int cy, int cz, uint32_t mask) {
@@ -176,6 +187,128 @@ __global__ __launch_bounds__(QUERY_TPB) void grid_query_kernel(
   if (count_out && i < P1) count_out[b * P1 + i] = have;
 }
 
+// ------------------------------------------------------------------ team form: TEAM lanes per query
+// The thread-per-query kernel above walks every query's candidates serially in one lane: with few queries and many
+// candidates per query (the coarse levels: 35 k queries at r = 0.3 see ~200 candidates each and keep ~30) the chip
+// holds two waves per CU and each lane spends its time shifting an insertion-sorted list in LDS.  Here a TEAM of 32 or
+// 64 lanes serves ONE query:
+//   * lanes 0..26 hash one neighbour cell each and fetch its bucket range (one load instruction for all 27 ranges)
+//   * the non-empty buckets are visited one after the other, their points read TEAM at a time (coalesced float4 records);
+//     accepted candidates (d2 < r*r) are appended to the team's list in LDS as 64-bit keys (d2 bits << 32 | index:
+//     unsigned order of the keys == (d2, index) order, d2 >= +0) at positions given by a ballot / prefix count
+//   * ranking instead of sorting: lane l counts the keys smaller than its own (every key is read from LDS as a
+//     broadcast), which IS its output position; ranks >= K are dropped.  A full list is pruned to its K best the same way.
+// Output identical to the thread form (same acceptance test, same (d2, index) order).
+constexpr int TEAM_TPB = 256;
+constexpr int TEAM_CAP = 128;      // accepted keys held per team before a prune (K <= 128 - 64)
+
+template <int TEAM>
+__global__ __launch_bounds__(TEAM_TPB) void grid_query_team_kernel(
+    const float* __restrict__ q_pts, const int64_t* __restrict__ lengths1, const float* __restrict__ radius, int64_t P1,
+    int K, int64_t T, const int32_t* __restrict__ cell_start, const float4* __restrict__ sorted_pts,
+    int64_t* __restrict__ idx_out, float* __restrict__ dist_out, int32_t* __restrict__ count_out) {
+  constexpr int TEAMS = TEAM_TPB / TEAM;
+  __shared__ unsigned long long keys[TEAMS][TEAM_CAP];
+  const int tl = threadIdx.x % TEAM;                 // lane inside the team
+  const int team = threadIdx.x / TEAM;
+  const int half = (threadIdx.x & 63) / TEAM;        // team inside the wave (TEAM = 32: 0 / 1)
+  const int64_t b = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * TEAMS + team;
+  if (i >= P1) return;                               // (whole teams leave together)
+  unsigned long long* mine = keys[team];
+  const bool live = i < lengths1[b];
+  int A = 0;                                         // accepted keys in the list (team-uniform)
+  int total = 0;                                     // accepted candidates seen (for count_out)
+  // rank the list's first n keys; keep the K smallest, in order, at the front.  Returns the new length.
+  auto prune = [&](int n) -> int {
+    unsigned long long kk[TEAM_CAP / TEAM];           // this lane's share of the list (2 or 4 keys)
+    int rk[TEAM_CAP / TEAM];
+#pragma unroll
+    for (int u = 0; u < TEAM_CAP / TEAM; ++u) {
+      kk[u] = tl + u * TEAM < n ? mine[tl + u * TEAM] : ~0ull;
+      rk[u] = 0;
+    }
+    for (int j = 0; j < n; ++j) {
+      const unsigned long long kj = mine[j];          // same address for the whole team: LDS broadcast
+#pragma unroll
+      for (int u = 0; u < TEAM_CAP / TEAM; ++u) rk[u] += kj < kk[u];
+    }
+    __builtin_amdgcn_wave_barrier();                  // every lane has read the old list
+#pragma unroll
+    for (int u = 0; u < TEAM_CAP / TEAM; ++u)
+      if (tl + u * TEAM < n && rk[u] < K) mine[rk[u]] = kk[u];
+    __builtin_amdgcn_wave_barrier();
+    return n < K ? n : K;
+  };
+
+  if (live) {
+    const float* q = q_pts + (b * P1 + i) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    const float r = radius[b];
+    const float r2 = r * r;
+    const int3 cq = cell_of(qx, qy, qz, inv_cell_of(r));
+    const uint32_t mask = (uint32_t)(T - 1);
+    const int32_t* starts = cell_start + b * T;
+    // ---- the 27 bucket ranges: one cell per lane
+    uint32_t h = 0xffffffffu;
+    int32_t lo = 0, cnt = 0;
+    if (tl < 27) {
+      const int dx = tl % 3 - 1, dy = (tl / 3) % 3 - 1, dz = tl / 9 - 1;
+      h = bucket_of(cq.x + dx, cq.y + dy, cq.z + dz, mask);
+      lo = starts[h];
+      cnt = starts[h + 1] - lo;
+    }
+    // a bucket shared by two of the cells is visited once (the first lane keeps it)
+    for (int e = 0; e < 26; ++e) {
+      const uint32_t he = (uint32_t)__shfl((int)h, e, TEAM);
+      if (tl > e && tl < 27 && he == h) cnt = 0;
+    }
+    unsigned long long todo = __ballot(cnt > 0);
+    uint32_t work = TEAM == 64 ? 0u : (uint32_t)(todo >> (32 * half));    // 32-lane teams: this team's half of the ballot
+    unsigned long long work64 = todo;
+    while (TEAM == 64 ? work64 != 0ull : work != 0u) {
+      int c;
+      if (TEAM == 64) {
+        c = __builtin_ctzll(work64);
+        work64 &= work64 - 1;
+      } else {
+        c = __builtin_ctz(work);
+        work &= work - 1;
+      }
+      const int32_t lo_c = __shfl(lo, c, TEAM), cnt_c = __shfl(cnt, c, TEAM);
+      for (int32_t off = 0; off < cnt_c; off += TEAM) {
+        const int32_t t = off + tl;
+        const bool in = t < cnt_c;
+        const float4 p = sorted_pts[lo_c + (in ? t : 0)];
+        const float d2 = ccn_sqdist3(p.x - qx, p.y - qy, p.z - qz);
+        const bool ok = in && d2 < r2;
+        const unsigned long long bal = __ballot(ok);
+        const unsigned long long mybits = TEAM == 64 ? bal : ((bal >> (32 * half)) & 0xffffffffull);
+        const int before = __popcll(mybits & ((1ull << tl) - 1ull));
+        if (ok) mine[A + before] = ((unsigned long long)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(p.w);
+        const int add = __popcll(mybits);
+        A += add;
+        total += add;
+        __builtin_amdgcn_wave_barrier();
+        if (A > TEAM_CAP - TEAM) A = prune(A);          // room for one more round of TEAM candidates
+      }
+    }
+    A = prune(A);                                       // final order
+  }
+  // ---- output row: K entries, -1 padded
+  int64_t* out_i = idx_out + (b * P1 + i) * K;
+  float* out_d = dist_out ? dist_out + (b * P1 + i) * K : nullptr;
+  for (int sl = tl; sl < K; sl += TEAM) {
+    const bool ok = sl < A;
+    const unsigned long long key = ok ? mine[sl] : 0ull;
+    out_i[sl] = ok ? (int64_t)(uint32_t)(key & 0xffffffffull) : -1;
+    if (out_d) out_d[sl] = ok ? __uint_as_float((uint32_t)(key >> 32)) : -1.0f;
+  }
+  if (count_out && tl == 0) count_out[b * P1 + i] = total < K ? total : K;
+}
+
+static int g_query_mode = 0;   // A/B hook (ccn_frnn_query_mode): 0 auto, 1 thread per query, 2 / 3 teams of 32 / 64 lanes
+
 // ------------------------------------------------------------------ dense idx -> CSR edge list
 __global__ void dense_count_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ cloud_ptr1, int64_t P1,
                                    int64_t K, int32_t* __restrict__ counts) {
@@ -248,11 +381,30 @@ int ccn_frnn_query(const float* points1, const int64_t* lengths1, const float* r
   CCN_REQUIRE(K >= 1 && K <= 128, "frnn_query: K must be in [1, 128] (got %lld)", (long long)K);
   GridView g;
   CCN_REQUIRE(carve(const_cast<void*>(grid), grid_bytes(B, P2), B, P2, &g), "frnn_query: carve failed");
-  const size_t lds = (size_t)K * QUERY_TPB * 8;
-  dim3 gridDim_(ccn_blocks(P1, QUERY_TPB), (unsigned)B);
-  hipLaunchKernelGGL(grid_query_kernel, gridDim_, dim3(QUERY_TPB), lds, (hipStream_t)stream, points1, lengths1, r, P1,
-                     (int)K, g.T, g.cell_start, g.sorted_pts, idx, dist2, count);
+  // teams need K <= TEAM_CAP - 64 list slots free for a round of candidates
+  int mode = g_query_mode;
+  if (mode == 0) mode = K > TEAM_CAP - 64 ? 1 : (B * P1 <= 120000 ? 3 : 2);
+  if (K > TEAM_CAP - 64) mode = 1;
+  if (mode == 1) {
+    const size_t lds = (size_t)K * QUERY_TPB * 8;
+    dim3 gridDim_(ccn_blocks(P1, QUERY_TPB), (unsigned)B);
+    hipLaunchKernelGGL(grid_query_kernel, gridDim_, dim3(QUERY_TPB), lds, (hipStream_t)stream, points1, lengths1, r, P1,
+                       (int)K, g.T, g.cell_start, g.sorted_pts, idx, dist2, count);
+  } else if (mode == 2) {
+    dim3 gridDim_(ccn_blocks(P1, TEAM_TPB / 32), (unsigned)B);
+    hipLaunchKernelGGL(grid_query_team_kernel<32>, gridDim_, dim3(TEAM_TPB), 0, (hipStream_t)stream, points1, lengths1, r,
+                       P1, (int)K, g.T, g.cell_start, g.sorted_pts, idx, dist2, count);
+  } else {
+    dim3 gridDim_(ccn_blocks(P1, TEAM_TPB / 64), (unsigned)B);
+    hipLaunchKernelGGL(grid_query_team_kernel<64>, gridDim_, dim3(TEAM_TPB), 0, (hipStream_t)stream, points1, lengths1, r,
+                       P1, (int)K, g.T, g.cell_start, g.sorted_pts, idx, dist2, count);
+  }
   CCN_LAUNCH_OK("frnn_query");
+  return CCN_OK;
+}
+
+int ccn_frnn_query_mode(int mode) {
+  g_query_mode = (mode >= 0 && mode <= 3) ? mode : 0;
   return CCN_OK;
 }
 

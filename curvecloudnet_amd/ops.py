@@ -545,7 +545,9 @@ class LinearBNAct(torch.autograd.Function):
     fast_conv1d.py:71-73 / :140-143.  ``gamma is None`` = plain Linear (MLP's last layer)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum, grad_on=True):
+        # grad_on: torch.is_grad_enabled() at the call site (inside forward grad mode is always off, and
+        # ctx.needs_input_grad ignores no_grad): no backward will come for a pass made under no_grad
         x = _mat(x)
         require_gpu(weight)
         m, k = x.shape
@@ -558,7 +560,6 @@ class LinearBNAct(torch.autograd.Function):
         has_bn = gamma is not None
         ctx.has_bn, ctx.act, ctx.training, ctx.has_bias = has_bn, ACT[act], bool(training), bias is not None
         gemm_nt = ctx.gemm_nt = _nt_name()
-        grad_on = torch.is_grad_enabled()
         ctx.main_grad_of = weight if (grad_on and ctx.needs_input_grad[1] and _main_grad(weight, n, k) is not None) else None
         ctx.bn_refs = ((gamma, beta) if has_bn and grad_on and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]
                        and _main_grad_vec(gamma, n) is not None and _main_grad_vec(beta, n) is not None else None)
@@ -647,18 +648,19 @@ class LinearBNAct(torch.autograd.Function):
             acc = _stats_buffer(m, n, dev)
             db = torch.empty(n, dtype=torch.float32, device=dev)
             call("colsum", ptr(dy), _ld(dy), m, n, ptr(acc), ptr(db))
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
 
 
 def linear_bn_act(x, weight, bias, bn, training, act):
     """bn: a torch.nn.BatchNorm1d used as parameter/buffer container, or None."""
+    grad_on = torch.is_grad_enabled()
     if bn is None:
-        return LinearBNAct.apply(x, weight, bias, None, None, None, None, False, None, 0.0, 0.0)
+        return LinearBNAct.apply(x, weight, bias, None, None, None, None, False, None, 0.0, 0.0, grad_on)
     if training and bn.track_running_stats:
         bn.num_batches_tracked += 1
     use_batch_stats = training or not bn.track_running_stats
     return LinearBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats,
-                             act, bn.eps, bn.momentum if bn.momentum is not None else 0.1)
+                             act, bn.eps, bn.momentum if bn.momentum is not None else 0.1, grad_on)
 
 
 # --------------------------------------------------------------------------------------
@@ -1386,15 +1388,15 @@ class LinearBNActTail(torch.autograd.Function):
     reductions and the weight gradient count row r of the tail ``w[r - tail]`` times (total ``count`` rows)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, act, eps, momentum, tail, w, count):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, training, act, eps, momentum, tail, w, count,
+                grad_on=True):
         x = _mat(x)
         m, k = x.shape
         n = weight.size(0)
         dev = x.device
         wt = _aligned_weight(weight.detach())
         ctx.act, ctx.training, ctx.tail, ctx.count = ACT[act], bool(training), int(tail), float(count)
-        ctx.main_grad_of = weight if (torch.is_grad_enabled() and ctx.needs_input_grad[1]
-                                      and _main_grad(weight, n, k) is not None) else None
+        ctx.main_grad_of = weight if (grad_on and ctx.needs_input_grad[1] and _main_grad(weight, n, k) is not None) else None
         _main_grad_note(ctx.main_grad_of)
         gemm_nt = ctx.gemm_nt = _nt_name()
         if gemm_nt != "gemm_nt":
@@ -1462,7 +1464,7 @@ class LinearBNActTail(torch.autograd.Function):
             call("gemm_tn", ptr(dyt), _ld(dyt), ptr(xt), _ld(x), ptr(dw), _ld(dw), t, n, k)   # few rows: fp32
         if into is not None:
             dw = _main_grad_done(ctx.main_grad_of)
-        return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None
+        return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None, None, None, None, None
 
 
 def linear_bn_act_tail(x, weight, bn, training, act, tail, w, count):
@@ -1470,7 +1472,8 @@ def linear_bn_act_tail(x, weight, bn, training, act, tail, w, count):
         bn.num_batches_tracked += 1
     use_batch_stats = training or not bn.track_running_stats
     return LinearBNActTail.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats, act,
-                                 bn.eps, bn.momentum if bn.momentum is not None else 0.1, tail, w, count)
+                                 bn.eps, bn.momentum if bn.momentum is not None else 0.1, tail, w, count,
+                                 torch.is_grad_enabled())
 
 
 class CGMax(torch.autograd.Function):

@@ -131,6 +131,7 @@ int ccn_frnn_grid_build(const float* points2, const int64_t* lengths2, const flo
                         void* grid, size_t grid_bytes, void* stream);
 int ccn_frnn_query(const float* points1, const int64_t* lengths1, const float* r, int64_t B, int64_t P1, int64_t K,
                    const void* grid, int64_t P2, int64_t* idx, float* dist2, int32_t* count, void* stream);
+int ccn_frnn_query_mode(int mode); /* A/B hook: 0 = automatic, 1 = one thread per query, 2 / 3 = a team of 32 / 64 lanes per query */
 
 /* ---- A12: point_ops.py:98-111 / :287-290 dense (B,P1,K) idx -> flat (row, col) edge list ----------
  * counts: int32 per packed query (cloud_ptr1[b] + i).  fill writes row = packed query, col = packed point. */
