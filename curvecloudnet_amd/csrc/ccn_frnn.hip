@@ -5,9 +5,9 @@
 //   cell_start  int32 [B*T + 1]   exclusive prefix of bucket populations, T = pow2 >= 2*P2 buckets per cloud
 //   cell_fill   int32 [B*T]       bucket populations (build) / scatter cursors
 //   sorted_pts  float4[B*P2]      (x, y, z, original index) grouped by bucket -> coalesced candidate reads
-// A query reads the (at most 27, de-duplicated) buckets of the cells around it; points of other cells that hash into
-// the same buckets are rejected by the distance test, and a bucket shared by two of the 27 cells is read once, so no
-// per-point cell table is needed and no candidate is seen twice.
+// A query reads the 27 buckets of the cells around it (pairwise different by construction of the hash, see bucket_of);
+// points of other cells that hash into the same buckets are rejected by the distance test, so no per-point cell table
+// is needed and no candidate is seen twice.
 // The grid only prunes: a candidate is accepted iff d2 = fma(dz,dz,fma(dy,dy,dx*dx)) < r*r, and the K best
 // are kept ordered by (d2, original index), exactly the exhaustive oracle (oracle/frnn_bruteforce.c).
 // Cell edge = 1.001 r, so every point within r of a query lies in the 27 cells around the query's cell
@@ -65,8 +65,14 @@ __device__ __forceinline__ int3 cell_of(float x, float y, float z, float inv_cel
   return make_int3(cell_axis(x, ic), cell_axis(y, ic), cell_axis(z, ic));
 }
 
+// Bucket of a cell: the low 6 bits are (cx mod 4, cy mod 4, cz mod 4), the rest a hash of the 4 x 4 x 4 block the cell lies
+// in.  Three consecutive integers are distinct mod 4, so the 27 cells around any cell ALWAYS fall into 27 different
+// buckets (T >= 256 keeps the low 6 bits): no bucket is visited twice by one query, and the cells of a block sit next to
+// each other in the table (their range loads share cache lines).
 __device__ __forceinline__ uint32_t bucket_of(int cx, int cy, int cz, uint32_t mask) {
-  return (((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u) ^ ((uint32_t)cz * 83492791u)) & mask;
+  const uint32_t low = (uint32_t)(cx & 3) | ((uint32_t)(cy & 3) << 2) | ((uint32_t)(cz & 3) << 4);
+  const uint32_t blk = ((uint32_t)(cx >> 2) * 73856093u) ^ ((uint32_t)(cy >> 2) * 19349663u) ^ ((uint32_t)(cz >> 2) * 83492791u);
+  return ((blk << 6) | low) & mask;
 }
 
 __device__ __forceinline__ float inv_cell_of(float r) { return __frcp_rn(r * 1.001f); }
@@ -116,9 +122,8 @@ __global__ __launch_bounds__(QUERY_TPB) void grid_query_kernel(
     const uint32_t mask = (uint32_t)(T - 1);
     const int32_t* starts = cell_start + b * T;
     // Phase 1: the 27 bucket ranges, all loads in flight together.  Every point within r of the query lies in one of
-    // the 27 cells, hence in one of these buckets; a bucket shared by two of the cells (hash collision) is visited
-    // once, and points of colliding far-away cells fail the distance test -- so the exact-cell table need not be
-    // read and the accepted set is exactly {d2 < r*r}.
+    // the 27 cells, hence in one of these (distinct) buckets; points of colliding far-away cells fail the distance
+    // test -- so the exact-cell table need not be read and the accepted set is exactly {d2 < r*r}.
     int32_t lo[27], hi[27];
     uint32_t hs[27];
 #pragma unroll
@@ -127,13 +132,6 @@ __global__ __launch_bounds__(QUERY_TPB) void grid_query_kernel(
       hs[c] = bucket_of(cq.x + dx, cq.y + dy, cq.z + dz, mask);
       lo[c] = starts[hs[c]];
       hi[c] = starts[hs[c] + 1];
-    }
-#pragma unroll
-    for (int c = 1; c < 27; ++c) {
-      bool dup = false;
-#pragma unroll
-      for (int e = 0; e < c; ++e) dup |= hs[e] == hs[c];
-      if (dup) hi[c] = lo[c];
     }
     // Phase 2: candidates, two point records in flight
 #pragma unroll 1
@@ -258,11 +256,7 @@ __global__ __launch_bounds__(TEAM_TPB) void grid_query_team_kernel(
       lo = starts[h];
       cnt = starts[h + 1] - lo;
     }
-    // a bucket shared by two of the cells is visited once (the first lane keeps it)
-    for (int e = 0; e < 26; ++e) {
-      const uint32_t he = (uint32_t)__shfl((int)h, e, TEAM);
-      if (tl > e && tl < 27 && he == h) cnt = 0;
-    }
+    // (the 27 buckets are pairwise different by construction of bucket_of: nothing is visited twice)
     unsigned long long todo = __ballot(cnt > 0);
     uint32_t work = TEAM == 64 ? 0u : (uint32_t)(todo >> (32 * half));    // 32-lane teams: this team's half of the ballot
     unsigned long long work64 = todo;
@@ -383,7 +377,9 @@ int ccn_frnn_query(const float* points1, const int64_t* lengths1, const float* r
   CCN_REQUIRE(carve(const_cast<void*>(grid), grid_bytes(B, P2), B, P2, &g), "frnn_query: carve failed");
   // teams need K <= TEAM_CAP - 64 list slots free for a round of candidates
   int mode = g_query_mode;
-  if (mode == 0) mode = K > TEAM_CAP - 64 ? 1 : (B * P1 <= 120000 ? 3 : 2);
+  // measured (tools/bench_frnn.py, profiles/r02_frnn_microbench.txt): 32-lane teams win at every level of the KITTI
+  // model -- 2.5x on the full 8 x 50 k cloud, 4-10x on the coarse levels -- over both the thread form and 64-lane teams
+  if (mode == 0) mode = 2;
   if (K > TEAM_CAP - 64) mode = 1;
   if (mode == 1) {
     const size_t lds = (size_t)K * QUERY_TPB * 8;

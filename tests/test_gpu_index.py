@@ -201,7 +201,7 @@ def test_frnn_far_from_the_origin(frnn_mode):
     from oracle import torch_ref as R
     gen = torch.Generator().manual_seed(77)
     for centre, r in ((5000.0, 0.05), (-20000.0, 0.005), (3.0e4, 0.0078125)):
-        p = (torch.rand(2, 1500, 3, generator=gen) * (40 * r) + centre).float()
+        p = (torch.rand(2, 1500, 3, generator=gen) * (8 * r) + centre).float()     # ~12 neighbours inside r
         n = torch.tensor([1500, 1100])
         want, want_d = R.frnn_bruteforce(p, p, n, n, 16, r, return_dists=True)
         got, got_d = ops.fast_knn(p.to(DEV), p.to(DEV), n.to(DEV), n.to(DEV), 16, r, return_dists=True)
