@@ -1067,7 +1067,8 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
                                                                    const float* __restrict__ bias, float* __restrict__ C,
                                                                    int64_t ldc, int64_t M, int64_t N, int64_t K,
                                                                    int64_t tiles, int64_t gn, int xcd_order,
-                                                                   double* __restrict__ colstats) {
+                                                                   double* __restrict__ colstats, int64_t a_extent) {
+  // a_extent: floats readable from the start of an A row (= lda, or K when rows overlap: ccn_conv_rows_nt)
   constexpr int AF = PR_BM * BK, BF = PR_BN * BK, STAGE = AF + BF;
   constexpr int NC = 4;  // LDS-DMA copies (8 rows x 128 B) per wave, slice and operand
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
@@ -1140,7 +1141,8 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
         const int64_t lim = isA ? M : N;
         row = row < lim ? row : lim - 1;
         const int64_t k = k0 + kq * 4;
-        const int64_t kc = k <= ld - 4 ? k : ld - 4;      // (k > ld - 4 implies k >= K: everything is zeroed below)
+        const int64_t ext = isA ? a_extent : ldb;
+        const int64_t kc = k <= ext - 4 ? k : ext - 4;    // (k > extent - 4 implies k >= K: everything is zeroed below)
         float4 v = *reinterpret_cast<const float4*>(p + row * ld + kc);
         v.x = k + 0 < K ? v.x : 0.f;
         v.y = k + 1 < K ? v.y : 0.f;
@@ -1280,12 +1282,12 @@ static bool g_use_pair = true;  // A-B hook (ccn_gemm_use_dma(4) = the 8-wave pe
 constexpr int64_t PAIR_MIN_TILES = 128;
 
 int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
-                     int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s) {
+                     int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s, int64_t a_extent) {
   const int64_t gm = (M + PR_BM - 1) / PR_BM, gn = (N + PR_BN - 1) / PR_BN;
   const int64_t tiles = gm * gn;
   const int64_t grid = tiles < 512 ? tiles : 512;  // two workgroups per CU
   hipLaunchKernelGGL(gemm_glds_pair_kernel, dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy, M, N, K,
-                     tiles, gn, g_xcd_map ? 1 : 0, colstats);
+                     tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent);
   return CCN_OK;
 }
 
@@ -1310,7 +1312,7 @@ static int64_t g_dma_min_k = 64;      // DMA kernels from this K on (A-B hook: c
 
 template <int BM, int BN, int WM, int ALAY, int BLAY, int EPI>
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
-                int64_t M, int64_t N, int64_t K, int64_t ksplit, double* colstats, hipStream_t s) {
+                int64_t M, int64_t N, int64_t K, int64_t ksplit, double* colstats, hipStream_t s, bool generic = false) {
   const int64_t gm = (M + BM - 1) / BM, gn = (N + BN - 1) / BN;
   int64_t kchunk = (K + ksplit - 1) / ksplit;
   kchunk = (kchunk + BK - 1) / BK * BK;
@@ -1322,7 +1324,8 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const 
     return CCN_ERR_ARG;
   }
   // fast path needs 16-byte aligned rows and at least one 16-byte group per row to clamp into
-  const bool fast = a_vec && b_vec && lda >= 4 && ldb >= 4 && !g_force_generic;
+  // (generic: an operand whose rows overlap -- ccn_conv_rows_* -- has no leading dimension to clamp tail loads against)
+  const bool fast = a_vec && b_vec && lda >= 4 && ldb >= 4 && !g_force_generic && !generic;
   // split-K (weight-gradient) products with several tiles per chunk: XCD-ordered one-dimensional grid (see the kernel)
   const bool xcd_order = EPI == EPI_ATOMIC && g_xcd_map && gz >= 8 && gm * gn > 1 &&
                          gm * gn * ((gz + 7) / 8 * 8) <= 2147483647LL;
@@ -1785,12 +1788,29 @@ int ccn_gemm_nt_f16(const float* A, int64_t lda, const float* W, int64_t ldw, co
   return CCN_OK;
 }
 
+static int gemm_nt_impl(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                        int64_t M, int64_t N, int64_t K, double* colstats, void* stream, bool overlap);
+
 int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                 int64_t M, int64_t N, int64_t K, double* colstats, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
   CCN_REQUIRE(A && W && Y, "gemm_nt: null pointer");
   CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, "gemm_nt: bad sizes M=%lld N=%lld K=%lld",
               (long long)M, (long long)N, (long long)K);
+  return gemm_nt_impl(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, stream, false);
+}
+
+int ccn_conv_rows_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                     int64_t M, int64_t N, int64_t K, double* colstats, void* stream) {
+  CCN_REQUIRE(A && W && Y, "conv_rows_nt: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lda > 0 && K % lda == 0 && ldw >= K && ldy >= N,
+              "conv_rows_nt: bad sizes M=%lld N=%lld K=%lld lda=%lld (K must be taps * lda)", (long long)M, (long long)N,
+              (long long)K, (long long)lda);
+  return gemm_nt_impl(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, stream, K > lda);
+}
+
+static int gemm_nt_impl(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                        int64_t M, int64_t N, int64_t K, double* colstats, void* stream, bool overlap) {
+  hipStream_t s = (hipStream_t)stream;
   if (M == 0) return CCN_OK;
   int rc;
   // K < 64, or fewer than two rounds of 256-row tiles over the 256 CUs: the register-staged kernels (128-row tiles,
@@ -1803,7 +1823,7 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
   // (K % 32 != 0 -- the widths made by the +3 xyz concat: 259, 262, 515, 1027, 2051 -- is handled inside the kernel)
   if (base_ok && N > 64 && g_use_persistent && g_use_pair &&
       ((M + PR_BM - 1) / PR_BM) * ((N + PR_BN - 1) / PR_BN) >= PAIR_MIN_TILES) {
-    rc = launch_glds_pair(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s);
+    rc = launch_glds_pair(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s, overlap ? K : lda);
     if (rc) return rc;
     CCN_LAUNCH_OK("gemm_nt");
     return CCN_OK;
@@ -1819,7 +1839,7 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
     CCN_LAUNCH_OK("gemm_nt");
     return CCN_OK;
   }
-  if (dma_ok) {
+  if (dma_ok && !overlap) {
     if (N <= 32)
       rc = launch_glds<32>(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s);
     else if (N <= 64)
@@ -1830,12 +1850,14 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
     CCN_LAUNCH_OK("gemm_nt");
     return CCN_OK;
   }
+  // overlapping rows with a K tail: the fast loaders clamp tail loads against the leading dimension -> generic kernel
+  const bool gen = overlap && K % BK != 0;
   if (N <= 32)
-    rc = launch_gemm<128, 32, 4, KC, KC, EPI_STORE>(A, lda, W, ldw, bias, Y, ldy, M, N, K, 1, colstats, s);
+    rc = launch_gemm<128, 32, 4, KC, KC, EPI_STORE>(A, lda, W, ldw, bias, Y, ldy, M, N, K, 1, colstats, s, gen);
   else if (N <= 64)
-    rc = launch_gemm<128, 64, 4, KC, KC, EPI_STORE>(A, lda, W, ldw, bias, Y, ldy, M, N, K, 1, colstats, s);
+    rc = launch_gemm<128, 64, 4, KC, KC, EPI_STORE>(A, lda, W, ldw, bias, Y, ldy, M, N, K, 1, colstats, s, gen);
   else
-    rc = launch_gemm<128, 128, 4, KC, KC, EPI_STORE>(A, lda, W, ldw, bias, Y, ldy, M, N, K, 1, colstats, s);
+    rc = launch_gemm<128, 128, 4, KC, KC, EPI_STORE>(A, lda, W, ldw, bias, Y, ldy, M, N, K, 1, colstats, s, gen);
   if (rc) return rc;
   CCN_LAUNCH_OK("gemm_nt");
   return CCN_OK;
@@ -1860,13 +1882,23 @@ int ccn_gemm_nn(const float* dY, int64_t lddy, const float* W, int64_t ldw, floa
   return CCN_OK;
 }
 
+int ccn_gemm_tn_generic(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                        int64_t N, int64_t K, int overlap, void* stream);
+
 int ccn_gemm_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
                 int64_t N, int64_t K, void* stream) {
-  // dW[N x K] += dY[M x N]^T * X[M x K]: contraction over the M rows, split across workgroups
-  hipStream_t s = (hipStream_t)stream;
   CCN_REQUIRE(dY && X && dW, "gemm_tn: null pointer");
   CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "gemm_tn: bad sizes");
+  return ccn_gemm_tn_generic(dY, lddy, X, ldx, dW, lddw, M, N, K, 0, stream);
+}
+
+int ccn_gemm_tn_generic(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                        int64_t N, int64_t K, int overlap, void* stream) {
+  // dW[N x K] += dY[M x N]^T * X[M x K]: contraction over the M rows, split across workgroups.
+  // overlap: the rows of X overlap (ldx < K, ccn_conv_rows_tn) -> the kernels with per-element bounds
+  hipStream_t s = (hipStream_t)stream;
   if (M == 0) return CCN_OK;
+  const bool gen = overlap != 0;
   const int64_t tiles = ((N + 63) / 64) * ((K + 127) / 128);
   int64_t ksplit = (2048 + tiles - 1) / tiles;  // aim at ~2048 workgroups
   const int64_t max_split = (M + 4 * BK - 1) / (4 * BK);
@@ -1874,15 +1906,15 @@ int ccn_gemm_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, floa
   if (ksplit < 1) ksplit = 1;
   int rc;
   if (N <= 32) {
-    rc = launch_gemm<32, 128, 1, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s);
+    rc = launch_gemm<32, 128, 1, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s, gen);
   } else {
     if (K <= 64)
-      rc = launch_gemm<64, 64, 2, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s);
+      rc = launch_gemm<64, 64, 2, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s, gen);
     else if (N > 64 && M >= 50000)  // 128 x 128 tiles once the row split alone fills the chip: 112 -> 121 TFLOP/s at
                                     // M = 1.3 M, K = N = 256 (but 112 -> 105 at M = 10 k, where the 64-row tile stays)
-      rc = launch_gemm<128, 128, 4, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s);
+      rc = launch_gemm<128, 128, 4, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s, gen);
     else
-      rc = launch_gemm<64, 128, 2, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s);
+      rc = launch_gemm<64, 128, 2, MC, MC, EPI_ATOMIC>(dY, lddy, X, ldx, nullptr, dW, lddw, N, K, M, ksplit, nullptr, s, gen);
   }
   if (rc) return rc;
   CCN_LAUNCH_OK("gemm_tn");

@@ -45,7 +45,8 @@ __global__ __launch_bounds__(TN_TPB, 2) void gemm_tn_glds_kernel(const float* __
                                                                  float* __restrict__ C, int64_t ldc, int64_t M, int64_t N,
                                                                  int64_t K, int tiles_k, int tiles, int split,
                                                                  int64_t slices_per_chunk, int64_t n_ids, int xcd_order,
-                                                                 float* __restrict__ slabs) {
+                                                                 float* __restrict__ slabs, int64_t b_extent) {
+  // b_extent: floats readable from the start of a B row (= ldb, or K when the rows overlap: ccn_conv_rows_tn)
   constexpr int QN = TN / 64, QK = TK / 64, WC = 4 / (QN * QK);   // quadrants, waves sharing a quadrant
   constexpr int STEPS = TN_SLICE / 2 / WC;                          // 2-row MFMA steps per wave and slice
   constexpr int AF = TN_SLICE * TN, BF = TN_SLICE * TK, STAGE = AF + BF;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(TN_TPB, 2) void gemm_tn_glds_kernel(const float* __
         const int g = wave * NIB + q;
         b_row[q] = g * RPI_B + lane / (TK / 4);
         int64_t c = k0 + 4 * (lane % (TK / 4));
-        b_col[q] = c <= ldb - 4 ? c : ldb - 4;
+        b_col[q] = c <= b_extent - 4 ? c : b_extent - 4;
       }
       auto issue = [&](int64_t s, int stage) {
         float* st = lds + stage * STAGE;
@@ -285,17 +286,17 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 template <int TN, int TK>
 int launch_tn(const TnPlan& p, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw,
-              int64_t M, int64_t N, int64_t K, float* slabs, hipStream_t s) {
+              int64_t M, int64_t N, int64_t K, float* slabs, hipStream_t s, int64_t b_extent) {
   const int64_t grid = p.n_ids < 512 ? p.n_ids : 512;
   if (p.split == 1)
     hipLaunchKernelGGL((gemm_tn_glds_kernel<TN, TK, 2>), dim3((unsigned)grid), dim3(TN_TPB), 0, s, dY, lddy, X, ldx, dW, lddw,
-                       M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, (float*)nullptr);
+                       M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, (float*)nullptr, b_extent);
   else if (slabs == nullptr)
     hipLaunchKernelGGL((gemm_tn_glds_kernel<TN, TK, 1>), dim3((unsigned)grid), dim3(TN_TPB), 0, s, dY, lddy, X, ldx, dW, lddw,
-                       M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, (float*)nullptr);
+                       M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, (float*)nullptr, b_extent);
   else {
     hipLaunchKernelGGL((gemm_tn_glds_kernel<TN, TK, 0>), dim3((unsigned)grid), dim3(TN_TPB), 0, s, dY, lddy, X, ldx, dW, lddw,
-                       M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, slabs);
+                       M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, slabs, b_extent);
     const int64_t work = N * ((K + 3) / 4);
     hipLaunchKernelGGL((tn_reduce_kernel<TN, TK>), dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, slabs, p.split,
                        p.tiles_k, N, K, dW, lddw);
@@ -314,25 +315,27 @@ int ccn_gemm_tn_use_dma(int on) {
   return CCN_OK;
 }
 
-// The LDS-DMA kernel takes 16-byte aligned operands whose leading dimensions are multiples of 4, from N > 32 and K > 32
+// The LDS-DMA kernel takes 16-byte aligned operands whose leading dimensions are multiples of 4, from N >= 32 and K >= 32
 // on (narrower outputs leave most of a 64-wide tile empty: the register-staged kernels keep those) and M >= 1024.
 static bool tn_dma_ok(const float* dY, int64_t lddy, const float* X, int64_t ldx, int64_t M, int64_t N, int64_t K) {
-  return g_tn_dma && aligned16(dY) && aligned16(X) && lddy % 4 == 0 && ldx % 4 == 0 && lddy >= 4 && ldx >= 4 && N > 32 &&
-         K > 32 && M >= 1024;
+  return g_tn_dma && aligned16(dY) && aligned16(X) && lddy % 4 == 0 && ldx % 4 == 0 && lddy >= 4 && ldx >= 4 && N >= 32 &&
+         K >= 32 && M >= 1024;
 }
 
 size_t ccn_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
-  if (M <= 0 || N <= 32 || K <= 32 || M < 1024 || !g_tn_dma) return 0;
+  if (M <= 0 || N < 32 || K < 32 || M < 1024 || !g_tn_dma) return 0;
   return (size_t)tn_plan(M, N, K).slab_floats * sizeof(float);
 }
 
-int ccn_gemm_tn_ws(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
-                   int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+int ccn_gemm_tn_generic(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                        int64_t N, int64_t K, int overlap, void* stream);
+
+static int tn_ws_impl(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                      int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream, bool overlap) {
   hipStream_t s = (hipStream_t)stream;
-  CCN_REQUIRE(dY && X && dW, "gemm_tn_ws: null pointer");
-  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "gemm_tn_ws: bad sizes");
   if (M == 0) return CCN_OK;
-  if (!tn_dma_ok(dY, lddy, X, ldx, M, N, K)) return ccn_gemm_tn(dY, lddy, X, ldx, dW, lddw, M, N, K, stream);
+  if (!tn_dma_ok(dY, lddy, X, ldx, M, N, K))
+    return ccn_gemm_tn_generic(dY, lddy, X, ldx, dW, lddw, M, N, K, overlap ? 1 : 0, stream);
   const TnPlan p = tn_plan(M, N, K);
   float* slabs = nullptr;
   if (p.slab_floats > 0 && workspace != nullptr) {
@@ -341,18 +344,34 @@ int ccn_gemm_tn_ws(const float* dY, int64_t lddy, const float* X, int64_t ldx, f
                 (size_t)p.slab_floats * sizeof(float));
     slabs = (float*)workspace;
   }
+  const int64_t ext = overlap ? K : ldx;
   int rc;
   if (p.tn == 128 && p.tk == 128)
-    rc = launch_tn<128, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s);
+    rc = launch_tn<128, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
   else if (p.tn == 128)
-    rc = launch_tn<128, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s);
+    rc = launch_tn<128, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
   else if (p.tk == 128)
-    rc = launch_tn<64, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s);
+    rc = launch_tn<64, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
   else
-    rc = launch_tn<64, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s);
+    rc = launch_tn<64, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
   if (rc) return rc;
   CCN_LAUNCH_OK("gemm_tn_ws");
   return CCN_OK;
+}
+
+int ccn_gemm_tn_ws(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
+                   int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  CCN_REQUIRE(dY && X && dW, "gemm_tn_ws: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "gemm_tn_ws: bad sizes");
+  return tn_ws_impl(dY, lddy, X, ldx, dW, lddw, M, N, K, workspace, workspace_bytes, stream, false);
+}
+
+int ccn_conv_rows_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
+                     int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  CCN_REQUIRE(dY && X && dW, "conv_rows_tn: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx > 0 && K % ldx == 0 && lddw >= K,
+              "conv_rows_tn: bad sizes (K must be taps * ldx)");
+  return tn_ws_impl(dY, lddy, X, ldx, dW, lddw, M, N, K, workspace, workspace_bytes, stream, K > ldx);
 }
 
 }  // extern "C"

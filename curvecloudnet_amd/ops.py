@@ -3,6 +3,7 @@
 PyTorch supplies device memory, streams and autograd bookkeeping only; every arithmetic step on
 the hot path is a ``ccn_*`` kernel launch.  Reference call sites are cited per operator.
 """
+import ctypes
 import os
 
 import torch
@@ -65,6 +66,35 @@ def _rows(rows, cols, device, zero=False):
     alloc = torch.zeros if zero else torch.empty
     buf = alloc((rows, ld), dtype=torch.float32, device=device)
     return buf if ld == cols else buf[:, :cols]
+
+
+def _rows_halo(rows, cols, h, device):
+    """(rows, cols) matrix for the implicit-GEMM curve convolution (ccn_conv_rows_*): ``h`` zeroed halo rows in front of and
+    behind it in the same allocation, the leading dimension padded with ZERO columns to a multiple of 4 (to a multiple of 32
+    from 64 channels on, so that taps * ld is a whole number of 32-deep GEMM slices).  The buffer is remembered on the view
+    (``_ccn_halo``): a consumer that does not find it makes its own halo copy."""
+    ld = (cols + 31) // 32 * 32 if cols >= 64 else (cols + 3) // 4 * 4
+    buf = torch.empty((rows + 2 * h, ld), dtype=torch.float32, device=device)
+    if h:
+        buf[:h].zero_()
+        buf[rows + h:].zero_()
+    if ld != cols:
+        buf[:, cols:].zero_()
+    view = buf[h:h + rows, :cols]
+    view._ccn_halo = (buf, h)
+    return view
+
+
+def _halo_of(x, h):
+    """(buffer, halo rows) when ``x`` is a _rows_halo view with at least h halo rows, else None."""
+    info = getattr(x, "_ccn_halo", None)
+    if info is None:
+        return None
+    buf, hh = info
+    if (hh < h or x.dim() != 2 or x.stride(0) != buf.stride(0) or x.stride(1) != 1 or buf.size(0) != x.size(0) + 2 * hh
+            or x.data_ptr() != buf.data_ptr() + hh * buf.stride(0) * 4):
+        return None
+    return buf, hh
 
 
 def cat_cols(parts):
@@ -195,9 +225,13 @@ class ScatterRows(torch.autograd.Function):
     """out = zeros(rows, C); out[index] = src  (index entries unique)."""
 
     @staticmethod
-    def forward(ctx, src, index, rows):
+    def forward(ctx, src, index, rows, halo=0):
         src, index = _mat(src), _i64(index)
-        out = _rows(rows, src.size(1), src.device, zero=True)
+        if halo:
+            out = _rows_halo(rows, src.size(1), halo, src.device)
+            out.zero_()
+        else:
+            out = _rows(rows, src.size(1), src.device, zero=True)
         call("scatter_rows", ptr(src), _ld(src), ptr(index), index.numel(), src.size(1), ptr(out), _ld(out), 0)
         ctx.save_for_backward(index)
         return out
@@ -208,7 +242,7 @@ class ScatterRows(torch.autograd.Function):
         g = _mat(g)
         d = _rows(index.numel(), g.size(1), g.device)
         call("gather_rows", ptr(g), _ld(g), ptr(index), index.numel(), g.size(1), ptr(d), _ld(d))
-        return d, None, None
+        return d, None, None, None
 
 
 # --------------------------------------------------------------------------------------
@@ -219,10 +253,10 @@ class DiffConcat(torch.autograd.Function):
     """cat([x, compute_feature_diffs(x)], dim=1)  (ref fast_conv1d.py:190-205 with :66 / :133)."""
 
     @staticmethod
-    def forward(ctx, x, cid):
+    def forward(ctx, x, cid, halo=0):
         x = _mat(x)
         n, c = x.shape
-        out = _rows(n, 2 * c, x.device)
+        out = _rows_halo(n, 2 * c, halo, x.device) if halo else _rows(n, 2 * c, x.device)
         call("diff_concat_fwd", ptr(x), _ld(x), ptr(cid), n, c, ptr(out), _ld(out))
         ctx.save_for_backward(x, cid)
         if ACT_TRACE is not None:
@@ -242,7 +276,7 @@ class DiffConcat(torch.autograd.Function):
         n, c = x.shape
         dx = _rows(n, c, x.device)
         call("diff_concat_bwd", ptr(x), _ld(x), ptr(cid), n, c, ptr(g), _ld(g), ptr(dx), _ld(dx))
-        return dx, None
+        return dx, None, None
 
 
 def compute_feature_diffs(x, topo):
@@ -1554,6 +1588,120 @@ class ShiftAddBNAct(torch.autograd.Function):
             db = torch.empty(n, dtype=torch.float32, device=dev)
             call("colsum", ptr(dy), _ld(dy), m, n, ptr(acc), ptr(db))
         return dp, db, dgb[0], dgb[1], None, None, None, None, None, None, None
+
+
+class ConvRowsBNAct(torch.autograd.Function):
+    """One conv + BatchNorm + activation layer of the curve convolutions as an IMPLICIT GEMM over the row sequence
+    (ccn_conv_rows_nt / _tn, include/ccn_hip.h): no shifted-row matrix is materialised -- row i of it is the contiguous
+    span of ``taps`` consecutive sequence rows, which the GEMM loaders read in place from a buffer with taps // 2 zero
+    halo rows at both ends (ref fast_conv1d.py:71-73 on the zero-separated sequence of :48-61; :136-143 for V1).
+
+    ``excl`` (int64 row numbers, V1): the zero separator rows between curves.  They take part in the convolution as zeros
+    but NOT in the BatchNorm (the reference normalises the N real rows only, quirk Q1): their share is subtracted from the
+    batch statistics, their output and their gradients are zeroed."""
+
+    @staticmethod
+    def forward(ctx, x, gw, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum, taps, excl):
+        x = _mat(x)
+        rows, cin = x.shape
+        cout = gw.size(0)
+        h = taps // 2
+        dev = x.device
+        if gw.size(1) != taps * cin:
+            raise ValueError("conv: input has %d channels, weight expects %d" % (cin, gw.size(1) // taps))
+        if _halo_of(x, h) is None:              # producer did not leave a halo: one copy (still no taps-wide matrix)
+            xh = _rows_halo(rows, cin, h, dev)
+            xh.copy_(x)
+            x = xh
+        buf, hh = _halo_of(x, h)
+        ld = buf.stride(0)
+        a_ptr = ctypes.c_void_p(x.data_ptr() - h * ld * 4)
+        k = taps * ld
+        wp = torch.zeros((cout, taps, ld), dtype=torch.float32, device=dev)
+        wp[:, :, :cin] = gw.detach().view(cout, taps, cin)
+        ctx.act, ctx.training, ctx.taps, ctx.has_bias, ctx.cin = ACT[act], bool(training), taps, bias is not None, cin
+        n_excl = 0 if excl is None else excl.numel()
+        ctx.count = float(rows - n_excl)
+        y = _rows(rows, cout, dev)
+        par = torch.empty((4, cout), dtype=torch.float32, device=dev)
+        if training:
+            if rows - n_excl < 2:
+                raise ValueError("Expected more than 1 value per channel when training")
+            nparts = lib().ccn_stats_rows(rows)
+            stats = torch.zeros((nparts + 2) * 2 * cout, dtype=torch.float64, device=dev)
+            call("conv_rows_nt", a_ptr, ld, ptr(wp), k, ptr(bias), ptr(y), _ld(y), rows, cout, k, ptr(stats))
+            if n_excl:
+                ye = y.index_select(0, excl)
+                acc = torch.empty((lib().ccn_stats_rows(n_excl) + 1) * 2 * cout, dtype=torch.float64, device=dev)
+                call("colstats_weighted", ptr(ye), _ld(ye), None, n_excl, cout, ptr(acc))
+                stats[nparts * 2 * cout:(nparts + 1) * 2 * cout] = -acc[:2 * cout]     # one more (negative) partial row
+            call("bn_finalize_n", ptr(stats), nparts + 1, int(ctx.count), cout, ptr(gamma), ptr(beta), float(eps),
+                 float(momentum), ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        else:
+            call("conv_rows_nt", a_ptr, ld, ptr(wp), k, ptr(bias), ptr(y), _ld(y), rows, cout, k, None)
+            call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), cout,
+                 ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        z = _rows_halo(rows, cout, h, dev)       # the next layer convolves it in place
+        call("bn_act_fwd", ptr(y), _ld(y), rows, cout, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
+        if n_excl:
+            z.index_fill_(0, excl, 0.0)
+        ctx.save_for_backward(x, wp, y, par, excl if n_excl else x.new_empty(0, dtype=torch.int64))
+        _trace_act(z, ctx.act)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wp, y, par, excl = ctx.saved_tensors
+        g = _mat(g)
+        dev = g.device
+        rows, cout = y.shape
+        taps, cin = ctx.taps, ctx.cin
+        h = taps // 2
+        ld = x.stride(0)
+        k = taps * ld
+        pp = (ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        if excl.numel():
+            g = g.index_fill(0, excl, 0.0)       # separator rows are constants
+        sums = _stats_buffer(rows, cout, dev)
+        call("bn_act_bwd_reduce", ptr(g), _ld(g), ptr(y), _ld(y), rows, cout, *pp, ctx.act, LEAKY_SLOPE, ptr(sums))
+        dy = _rows_halo(rows, cout, h, dev)
+        dgb = torch.empty((2, cout), dtype=torch.float32, device=dev)
+        call("bn_act_bwd_apply_count", ptr(g), _ld(g), ptr(y), _ld(y), rows, cout, *pp, ctx.act, LEAKY_SLOPE, ptr(sums),
+             ctx.count, 1 if ctx.training else 0, ptr(dy), _ld(dy), ptr(dgb[0]), ptr(dgb[1]))
+        if excl.numel():
+            dy.index_fill_(0, excl, 0.0)
+        ldo = dy.stride(0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dX[j] = sum_t dY[j + h - t] W_t: the same implicit GEMM over dY with the taps reversed
+            wf = torch.zeros((cin, taps, ldo), dtype=torch.float32, device=dev)
+            wf[:, :, :cout] = wp[:, :, :cin].flip(1).permute(2, 1, 0)
+            dx = _rows(rows, cin, dev)
+            call("conv_rows_nt", ctypes.c_void_p(dy.data_ptr() - h * ldo * 4), ldo, ptr(wf), taps * ldo, None, ptr(dx),
+                 _ld(dx), rows, cin, taps * ldo, None)
+        dgw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((cout, k), dtype=torch.float32, device=dev)
+            nb = lib().ccn_gemm_tn_workspace_bytes(rows, cout, k)
+            ws = _tn_scratch(nb, dev)
+            call("conv_rows_tn", ptr(dy), ldo, ctypes.c_void_p(x.data_ptr() - h * ld * 4), ld, ptr(dw), k, rows, cout, k,
+                 ptr(ws), nb)
+            dgw = dw.view(cout, taps, ld)[:, :, :cin].reshape(cout, taps * cin)
+        db = None
+        if ctx.has_bias:
+            acc = _stats_buffer(rows, cout, dev)
+            db = torch.empty(cout, dtype=torch.float32, device=dev)
+            call("colsum", ptr(dy), _ld(dy), rows, cout, ptr(acc), ptr(db))
+        return dx, dgw, db, dgb[0], dgb[1], None, None, None, None, None, None, None, None
+
+
+def conv_rows_implicit(x, gemm_weight, bias, bn, training, act, taps, excl=None):
+    """conv + BatchNorm + activation over a row sequence without the shifted-row matrix (ConvRowsBNAct)."""
+    if training and bn.track_running_stats:
+        bn.num_batches_tracked += 1
+    use_batch_stats = training or not bn.track_running_stats
+    return ConvRowsBNAct.apply(x, gemm_weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats,
+                               act, bn.eps, bn.momentum if bn.momentum is not None else 0.1, taps, excl)
 
 
 def conv_rows_bn_act(x, gemm_weight, bias, bn, training, act, taps):

@@ -177,6 +177,23 @@ size_t ccn_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int ccn_gemm_tn_use_dma(int on);    /* A/B hook: 0 = always the register-staged split-K kernel of ccn_gemm_tn */
 int ccn_gemm_tn_ws(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
                    int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+/* ---- A4-A6: the symmetric curve convolution as an IMPLICIT GEMM over the row sequence (no shifted-row matrix) ----
+ * Replaces F.conv1d(input(1,C,L), weight, bias, 1, 'same') at src/models/modules/fast_conv1d.py:183 (called from
+ * SymmetricCurve1DConvV2 :71 and SymmetricCurve1DConvFastV1 :140) on the reference's own zero-separated sequence
+ * (:48-61 / :115-126).  With the sequence stored row-major as (L + 2h) x ld floats -- h = taps / 2 zero halo rows at both
+ * ends, channels padded to ld % 4 == 0 with zeros -- row i of the would-be shifted-row matrix IS the contiguous span
+ * starting at sequence row i - h: `A` points at the FIRST HALO ROW, `lda` = ld, K = taps * ld, and consecutive rows of
+ * the operand simply overlap.  W is the (C_out, taps * ld) [tap][channel] matrix (zero in the padding columns).
+ *   ccn_conv_rows_nt : Y[M x N] = A_overlap W^T + b (+ BatchNorm partial statistics, as ccn_gemm_nt)  -- forward, and the
+ *                      data gradient (A = dY with halo, W = the tap-flipped transpose)
+ *   ccn_conv_rows_tn : dW[N x K] += dY[M x N]^T X_overlap[M x K]                                    -- weight gradient
+ * Same kernels, scratch and determinism as ccn_gemm_nt / ccn_gemm_tn_ws; K == lda degenerates to those. */
+int ccn_conv_rows_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                     int64_t M, int64_t N, int64_t K, double* colstats, void* stream);
+int ccn_conv_rows_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                     int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+int ccn_gemm_tn_generic(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                        int64_t N, int64_t K, int overlap, void* stream); /* the split-K register-staged kernels of ccn_gemm_tn; overlap != 0: X rows overlap (per-element bounds) */
 /* fp16 MFMA form of ccn_gemm_nt (BASELINE configs[4], "fp16 features"): A and W are read as fp32 and rounded to fp16
  * (round to nearest even) inside the kernel, products accumulate in fp32 (v_mfma_f32_32x32x16_f16); bias / Y / colstats
  * stay fp32.  Same requirements as ccn_gemm_nt_bf16.  The fp16 MLP mode uses it for the FORWARD products; gradients
