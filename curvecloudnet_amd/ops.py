@@ -266,7 +266,8 @@ class DiffConcat(torch.autograd.Function):
             link = (cid[1:] == cid[:-1])[:, None]
             step = torch.where(link, x[1:] - x[:-1], torch.zeros((), dtype=x.dtype, device=x.device))
             zero = torch.zeros((1, c), dtype=x.dtype, device=x.device)
-            ACT_TRACE.append(torch.sign(torch.cat([step, zero]) + torch.cat([zero, step])).to(torch.int8).cpu())
+            sign = torch.sign(torch.cat([step, zero]) + torch.cat([zero, step])).to(torch.int8)
+            ACT_TRACE.append((sign if ACT_ROW_MAP is None else sign[ACT_ROW_MAP]).cpu())
         return out
 
     @staticmethod

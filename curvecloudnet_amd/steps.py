@@ -183,6 +183,14 @@ def _conv_bn_act(x, seg, taps, conv, norm, training):
 
 
 CONV_SHIFT_ADD = os.environ.get("CCN_CONV_SHIFT_ADD", "1") != "0"
+# implicit-GEMM convolution over the zero-separated row sequence (ops.ConvRowsBNAct); 0 = the shifted-row matrix + GEMM
+CONV_IMPLICIT = os.environ.get("CCN_CONV_IMPLICIT", "1") != "0"
+
+
+def _conv_implicit():
+    """The implicit-GEMM kernels are the fp32 MFMA ones: the 16-bit MLP modes (whose conv products round their operands
+    to bf16 / fp16, as the oracle's emulation does) keep the shifted-row matrix + 16-bit GEMM."""
+    return CONV_IMPLICIT and ops.mlp_dtype() in ("fp32", "bf16x3")
 
 
 class SymmetricCurve1DConvFastV1(nn.Module):
@@ -198,10 +206,40 @@ class SymmetricCurve1DConvFastV1(nn.Module):
         self.conv_modules, self.norm_modules = _conv_stack(feat_dims, kernel_size, bias, with_diff, True)
 
     def geometry(self, pos, batch, point2curveidx, kwargs):
-        return SimpleNamespace(topo=_topology(batch, point2curveidx, kwargs), out=(pos, batch, point2curveidx))
+        topo = _topology(batch, point2curveidx, kwargs)
+        g = SimpleNamespace(topo=topo, out=(pos, batch, point2curveidx))
+        pad = self.kernel_size // 2
+        if _conv_implicit() and pad > 0:
+            # the reference's own layout (fast_conv1d.py:115-126): k//2 zero rows between consecutive curves, none at the
+            # ends; row of point i = i + pad * (its curve number)
+            cid = topo.cid.long()
+            g.rows = torch.arange(topo.n, device=pos.device) + pad * cid
+            g.n_rows = topo.n + (topo.num_curves - 1) * pad
+            is_sep = torch.ones(g.n_rows, dtype=torch.bool, device=pos.device)
+            is_sep[g.rows] = False
+            g.sep = torch.nonzero(is_sep).flatten()
+            g.cid_seq = torch.full((g.n_rows,), -1, dtype=torch.int32, device=pos.device)
+            g.cid_seq[g.rows] = topo.cid
+        return g
 
     def features(self, x, pos, g):
         x = _with_xyz(x, pos, self.with_xyz)
+        if hasattr(g, "sep"):
+            # implicit-GEMM form: every layer runs on the zero-separated sequence (one scatter in, one gather out); the
+            # separators are excluded from the BatchNorm and re-zeroed after every layer (ops.ConvRowsBNAct, quirk Q1)
+            h = self.kernel_size // 2
+            seq = ops.ScatterRows.apply(x, g.rows, g.n_rows, h)
+            if ops.ACT_TRACE is not None:       # test hook: sign tables on the N real rows, as the reference has them
+                ops.ACT_ROW_MAP = g.rows
+            try:
+                for conv, norm in zip(self.conv_modules, self.norm_modules):
+                    if self.with_diff:
+                        seq = ops.DiffConcat.apply(seq, g.cid_seq, h)
+                    seq = ops.conv_rows_implicit(seq, conv.gemm_weight(), conv.bias, norm, self.training, "leaky_relu",
+                                                 self.kernel_size, g.sep)
+            finally:
+                ops.ACT_ROW_MAP = None
+            return ops.gather_rows(seq, g.rows)
         for conv, norm in zip(self.conv_modules, self.norm_modules):
             if self.with_diff:
                 x = ops.DiffConcat.apply(x, g.topo.cid)
@@ -237,6 +275,17 @@ class SymmetricCurve1DConvV2(nn.Module):
         x = _with_xyz(x, pos, self.with_xyz)
         if self.with_diff:
             x = ops.DiffConcat.apply(x, g.topo.cid)
+        if _conv_implicit() and self.kernel_size > 1:
+            seq = ops.ScatterRows.apply(x, g.rows, g.n_rows, self.kernel_size // 2)
+            for conv, norm in zip(self.conv_modules, self.norm_modules):
+                if seq.size(1) >= 2 * conv.out_channels and seq.size(1) > 64 and CONV_SHIFT_ADD:
+                    # many more input than output channels (262 -> 32): product first, shift-add second
+                    seq = ops.conv_rows_bn_act(seq, conv.gemm_weight(), conv.bias, norm, self.training, "leaky_relu",
+                                               self.kernel_size)
+                else:
+                    seq = ops.conv_rows_implicit(seq, conv.gemm_weight(), conv.bias, norm, self.training, "leaky_relu",
+                                                 self.kernel_size)
+            return ops.gather_rows(seq, g.rows)
         seq = ops.ScatterRows.apply(x, g.rows, g.n_rows)
         for conv, norm in zip(self.conv_modules, self.norm_modules):
             seq = _conv_bn_act(seq, None, self.kernel_size, conv, norm, self.training)

@@ -670,6 +670,52 @@ def test_conv_shift_add_matches_shifted_row_gemm():
         _close(a, b, 1e-5, "running statistics")
 
 
+@pytest.mark.parametrize("ver,dims,k,clouds,curves", [
+    (1, [128, 128, 128], 5, [1, 2, 3, 4], 400),      # wide V1 layers (K = 5 * 288): paired LDS-DMA kernel, DMA weight gradient
+    (1, [64, 64, 48], 7, [1, 2], 150),               # k = 7 (Kortx), register-staged kernels
+    (2, [4, 32, 32, 32], 5, [0, 1, 2, 3, 4, 5], 1100),   # narrow V2 layers over > 131 k rows: persistent kernel, K = 40 tail
+    (2, [37, 16, 8, 12], 5, [1, 2], 70),             # shift-add first layer followed by implicit layers
+])
+def test_implicit_gemm_conv_matches_shifted_row_gemm(ver, dims, k, clouds, curves):
+    """The implicit-GEMM form of the curve convolutions (ccn_conv_rows_nt / _tn: overlapping rows of the zero-separated
+    sequence read in place) against the shifted-row matrix + GEMM form: outputs, gradients of the input, of every weight
+    and BatchNorm parameter, running statistics.  (Both are checked against the reference goldens in
+    test_curve_conv_golden; this one reaches the LDS-DMA kernels.)"""
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch(clouds, n_curves=curves)
+    torch.manual_seed(0)
+    cls = steps.SymmetricCurve1DConvFastV1 if ver == 1 else steps.SymmetricCurve1DConvV2
+    mod = cls(dims, k, with_xyz=True, with_diff=True).to(DEV).train()
+    n = d.pos.size(0)
+    x = torch.randn(n, dims[0] - 3, generator=torch.Generator().manual_seed(4)).to(DEV)
+    cot = torch.randn(n, dims[-1], generator=torch.Generator().manual_seed(5)).to(DEV)
+    res, stats = [], []
+    for flag in (True, False):
+        steps.CONV_IMPLICIT = flag
+        try:
+            for bn in mod.norm_modules:
+                bn.reset_running_stats()
+            xi = x.clone().requires_grad_(True)
+            out = mod(xi, d.pos.to(DEV), d.batch.to(DEV), d.curve_idxs.to(DEV))[0]
+            res.append([out.detach()] + list(torch.autograd.grad((out * cot).sum(), [xi] + list(mod.parameters()))))
+            stats.append([b.detach().clone().float() for b in mod.buffers()])
+        finally:
+            steps.CONV_IMPLICIT = True
+    _close(res[0][0], res[1][0], 1e-4, "outputs, implicit vs shifted-row GEMM")
+    # Gradients: the two forms sum in different orders, so a pre-activation within ~1e-6 of a LeakyReLU / |.| kink takes
+    # the other slope in one of them and moves ONE row's contribution to a gradient entry (~1/sqrt(rows) of it).  Bounds:
+    # 2e-3 in the l2 sense and 1e-2 on any single entry; a wrong tap order or halo gives O(1).
+    gnorm = max(float(b.norm()) for b in res[1][1:])
+    for a, b in zip(res[0][1:], res[1][1:]):
+        # (a conv bias in front of a BatchNorm has a zero gradient: what both sides hold there is summation noise)
+        rel = float((a - b).norm() / max(float(b.norm()), 1e-3 * gnorm))
+        assert rel < 2e-3, rel
+        _close(a, b, 1e-2, "gradients, implicit vs shifted-row GEMM")
+    for a, b in zip(*stats):
+        _close(a, b, 1e-5, "running statistics")
+
+
 def test_sgcnn_compact_rows_edge_cases():
     """Compact-row SGCNN at the corners: a radius that gives every slot a neighbour (no representative rows), a radius
     that gives none (every point: self + one representative), and a batch with a one-point cloud (padding rows)."""
