@@ -252,6 +252,7 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")                 # see main(): one hardware queue per stream in use
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
     return subprocess.call(cmd, env=env)
 
@@ -303,6 +304,11 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(self_launch(args))
 
+    # Streams in play per rank: backward (default), geometry, weight-gradient, RCCL's own.  The ROCm runtime maps streams
+    # onto GPU_MAX_HW_QUEUES hardware queues (default 4): with a fifth stream two of them share a queue and serialise --
+    # measured with a one-rank RCCL group: the geometry stream of the NEXT batch waited behind the whole backward pass
+    # (prepare() 18 -> 105 ms of host time, 66.4 -> 61.3 clouds/s).  Must be set before the runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     global torch, _lib                      # (module-level helpers use them; the self-launching parent never imports torch)
     import torch
     from curvecloudnet_amd import _lib, ops
@@ -403,6 +409,10 @@ def main():
                 torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # setup, outside warm-up and timing: the first steps grow the caching allocator's pools (hipMalloc is synchronous and
+    # slow); two priming steps keep device allocations out of the timed region whatever --warmup is
+    for _ in range(2):
+        step()
     for _ in range(args.warmup):
         step()
     barrier()

@@ -391,8 +391,11 @@ def _wgrad_stream(device):
         return None
     if (os.environ.get("CCN_WGRAD_STREAM") != "force" and torch.distributed.is_available()
             and torch.distributed.is_initialized()
-            and (torch.distributed.get_world_size() > 1 or os.environ.get("CCN_SINGLE_RANK_GROUP"))):
-        # Multi-rank runs keep the products on the backward stream.  In the 2-rank rehearsal (gloo, BOTH ranks on one GPU)
+            and (torch.distributed.get_world_size() > 1 or os.environ.get("CCN_SINGLE_RANK_GROUP"))
+            and torch.distributed.get_backend() != "nccl"):
+        # Multi-rank runs over gloo (the rehearsal backend: several ranks share ONE GPU) keep the products on the backward
+        # stream; over RCCL (one process per GPU) the side stream stays on and the bucket all-reduce is launched from it
+        # (parallel.GradientAllReduce._reduce).  In the 2-rank rehearsal (gloo, BOTH ranks on one GPU)
         # the extra stream made a step 3-30x slower, the more hardware queues were in play the worse (no geometry stream:
         # 3x; GPU_MAX_HW_QUEUES=8: no progress) -- queue oversubscription of that one GPU by two processes plus gloo's copy
         # streams.  A single process that owns its GPU and runs the same hooks over a one-rank RCCL group
@@ -405,6 +408,12 @@ def _wgrad_stream(device):
     if key not in _WGRAD_STREAMS:
         _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
     return _WGRAD_STREAMS[key]
+
+
+def wgrad_stream_of(device):
+    """The weight-gradient side stream of ``device`` if products have been queued on it since the last join, else None."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    return _WGRAD_STREAMS.get(key) if key in _WGRAD_PENDING else None
 
 
 def join_wgrad():

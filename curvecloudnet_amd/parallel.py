@@ -25,6 +25,11 @@ def init_process_group_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_initialized():
+        # backward, geometry, weight-gradient and RCCL streams: more than the runtime's default 4 hardware queues, and two
+        # streams on one queue serialise (measured: the next batch's geometry waited behind the whole backward pass).  Only
+        # effective before the HIP runtime initialises -- export it in the launcher otherwise.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if world == 1 and os.environ.get("CCN_SINGLE_RANK_GROUP") and not dist.is_initialized():
         # diagnostic (CCN_SINGLE_RANK_GROUP=nccl|gloo): a one-rank process group, so that the data-parallel code path
         # (hooks, joins, one all_reduce call per bucket) can be timed by a single process that has the GPU to itself
@@ -166,9 +171,22 @@ class GradientAllReduce:
         if self._launched[b]:
             raise RuntimeError("gradient bucket %d would be all-reduced twice in one step" % b)
         self._launched[b] = True
-        _join_wgrad()               # weight gradients of the HIP layers may still be running on their side stream
         self.reduce_calls += 1
-        self._handles.append(dist.all_reduce(self.buckets[b][0], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        flat = self.buckets[b][0]
+        from .ops import wgrad_stream_of
+        ws = wgrad_stream_of(flat.device) if flat.is_cuda else None
+        if ws is None:
+            _join_wgrad()           # (no side stream in use, or CPU tensors: plain ordering on the current stream)
+            self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        # The bucket's weight gradients are still being added on the weight-gradient stream.  Joining that stream into
+        # the backward stream here would serialise the rest of backward behind them (and with it the overlap the side
+        # stream exists for): instead the COLLECTIVE is ordered behind both -- it is launched from the side stream
+        # (RCCL orders itself behind the stream it is called on), after that stream has waited for what backward has
+        # queued so far (the BatchNorm / bias gradients of the bucket).
+        ws.wait_stream(torch.cuda.current_stream(flat.device))
+        with torch.cuda.stream(ws):
+            self._handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         """Call after ``loss.backward()``: waits for the collectives and averages over ranks."""
