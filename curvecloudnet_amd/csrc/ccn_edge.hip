@@ -1022,6 +1022,184 @@ __global__ __launch_bounds__(TPB) void seg_max_bwd_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------ the remaining aggregation branches
+// (no shipped config selects them; built so that every branch of the reference's two aggregate() functions computes)
+//
+// CSR groups, point_conv.py:82-88:
+//   mode 0 'mean'         out = sum_e msg / max(count, 1)                  (torch_scatter scatter_mean)
+//   mode 1 'weighted-sum' out = sum_e msg * sigmoid(att)                   (scatter_add of inputs * F.sigmoid(attend_nn))
+__device__ __forceinline__ float sigmoidf_(float a) { return 1.0f / (1.0f + __expf(-a)); }
+
+__global__ __launch_bounds__(TPB) void seg_wsum_fwd_kernel(const float* __restrict__ msg, int64_t ldm,
+                                                           const float* __restrict__ att, int64_t lda,
+                                                           const int32_t* __restrict__ offsets, int64_t M, int C, int mode,
+                                                           float* __restrict__ out, int64_t ldo) {
+  CCN_LANES;
+  const int64_t i = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (i >= M) return;
+  const int32_t lo = offsets[i], hi = offsets[i + 1];
+  const float inv = 1.0f / (float)(hi - lo > 1 ? hi - lo : 1);
+  for (int c = cx; c < C; c += 64) {
+    float acc = 0.f;
+    for (int32_t e = lo; e < hi; ++e) {
+      const float v = msg[(int64_t)e * ldm + c];
+      acc += mode == 0 ? v : v * sigmoidf_(att[(int64_t)e * lda + c]);
+    }
+    out[i * ldo + c] = mode == 0 ? acc * inv : acc;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void seg_wsum_bwd_kernel(const float* __restrict__ msg, int64_t ldm,
+                                                           const float* __restrict__ att, int64_t lda,
+                                                           const int32_t* __restrict__ offsets, int64_t M, int C, int mode,
+                                                           const float* __restrict__ dout, int64_t lddo,
+                                                           float* __restrict__ dmsg, int64_t lddm, float* __restrict__ datt,
+                                                           int64_t ldda) {
+  CCN_LANES;
+  const int64_t i = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (i >= M) return;
+  const int32_t lo = offsets[i], hi = offsets[i + 1];
+  const float inv = 1.0f / (float)(hi - lo > 1 ? hi - lo : 1);
+  for (int c = cx; c < C; c += 64) {
+    const float g = dout[i * lddo + c];
+    for (int32_t e = lo; e < hi; ++e) {
+      if (mode == 0) {
+        dmsg[(int64_t)e * lddm + c] = g * inv;
+      } else {
+        const float sg = sigmoidf_(att[(int64_t)e * lda + c]);
+        dmsg[(int64_t)e * lddm + c] = g * sg;
+        datt[(int64_t)e * ldda + c] = g * msg[(int64_t)e * ldm + c] * sg * (1.0f - sg);
+      }
+    }
+  }
+}
+
+// Dense SGCNN rows (b, i, slot), dgcnn.py:182-203; slot 0 (self) is always valid, slot s > 0 iff its FRNN entry >= 0:
+//   mode 0 'mean'         sum of the valid f / number of valid slots
+//   mode 1 'weighted-sum' w = sigmoid(a) on the valid slots, 0 elsewhere; out = sum f w / clamp(sum w, min 1e-3)
+//   mode 2 'attend'       a = -5e2 on the invalid slots, softmax over ALL K+1 slots, out = sum f softmax
+__global__ __launch_bounds__(TPB) void sg_reduce_fwd_kernel(const float* __restrict__ f, int64_t ldf,
+                                                            const float* __restrict__ att, int64_t lda,
+                                                            const int64_t* __restrict__ idx,
+                                                            const int64_t* __restrict__ cloud_ptr, int64_t B, int64_t Nmax,
+                                                            int K, int C, int mode, float* __restrict__ out, int64_t ldo) {
+  CCN_LANES;
+  const int64_t bi = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (bi >= B * Nmax) return;
+  const int64_t b = bi / Nmax, i = bi - b * Nmax;
+  const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
+  if (i >= len) return;
+  const SgNbrs nb = sg_nbrs(idx, bi, K, cx, true);
+  const float* frow = f + bi * (K + 1) * ldf;
+  const float* arow = att ? att + bi * (K + 1) * lda : nullptr;
+  for (int c = cx; c < C; c += 64) {
+    if (mode == 0) {
+      float acc = 0.f;
+      int cnt = 0;
+      for (int s = 0; s <= K; ++s) {
+        const bool ok = s == 0 || sg_nbr(nb, s) != -1;
+        if (ok) {
+          acc += frow[s * ldf + c];
+          ++cnt;
+        }
+      }
+      out[(base + i) * ldo + c] = acc / (float)cnt;
+    } else if (mode == 1) {
+      float acc = 0.f, tot = 0.f;
+      for (int s = 0; s <= K; ++s) {
+        const bool ok = s == 0 || sg_nbr(nb, s) != -1;
+        if (ok) {
+          const float w = sigmoidf_(arow[s * lda + c]);
+          acc += frow[s * ldf + c] * w;
+          tot += w;
+        }
+      }
+      out[(base + i) * ldo + c] = acc / (tot > 1e-3f ? tot : 1e-3f);
+    } else {
+      SoftAcc sm = {-__builtin_inff(), 0.f, 0.f};
+      for (int s = 0; s <= K; ++s) {
+        const bool ok = s == 0 || sg_nbr(nb, s) != -1;
+        soft_push(sm, ok ? arow[s * lda + c] : -5e2f, frow[s * ldf + c]);
+      }
+      out[(base + i) * ldo + c] = sm.acc / sm.tot;
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void sg_reduce_bwd_kernel(const float* __restrict__ f, int64_t ldf,
+                                                            const float* __restrict__ att, int64_t lda,
+                                                            const int64_t* __restrict__ idx,
+                                                            const int64_t* __restrict__ cloud_ptr, int64_t B, int64_t Nmax,
+                                                            int K, int C, int mode, const float* __restrict__ dout,
+                                                            int64_t lddo, float* __restrict__ df, int64_t lddf,
+                                                            float* __restrict__ datt, int64_t ldda) {
+  CCN_LANES;
+  const int64_t bi = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (bi >= B * Nmax) return;
+  const int64_t b = bi / Nmax, i = bi - b * Nmax;
+  const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
+  const bool live = i < len;
+  const SgNbrs nb = sg_nbrs(idx, bi, K, cx, live);
+  const float* frow = f + bi * (K + 1) * ldf;
+  const float* arow = att ? att + bi * (K + 1) * lda : nullptr;
+  float* dfrow = df + bi * (K + 1) * lddf;
+  float* darow = datt ? datt + bi * (K + 1) * ldda : nullptr;
+  for (int c = cx; c < C; c += 64) {
+    if (!live) {  // padding rows of the dense layout receive no gradient
+      for (int s = 0; s <= K; ++s) {
+        dfrow[s * lddf + c] = 0.f;
+        if (darow) darow[s * ldda + c] = 0.f;
+      }
+      continue;
+    }
+    const float g = dout[(base + i) * lddo + c];
+    if (mode == 0) {
+      int cnt = 0;
+      for (int s = 0; s <= K; ++s) cnt += (s == 0 || sg_nbr(nb, s) != -1) ? 1 : 0;
+      const float w = g / (float)cnt;
+      for (int s = 0; s <= K; ++s) dfrow[s * lddf + c] = (s == 0 || sg_nbr(nb, s) != -1) ? w : 0.f;
+    } else if (mode == 1) {
+      float acc = 0.f, tot = 0.f;
+      for (int s = 0; s <= K; ++s)
+        if (s == 0 || sg_nbr(nb, s) != -1) {
+          const float w = sigmoidf_(arow[s * lda + c]);
+          acc += frow[s * ldf + c] * w;
+          tot += w;
+        }
+      const bool clamped = !(tot > 1e-3f);
+      const float den = clamped ? 1e-3f : tot;
+      const float o = acc / den;
+      for (int s = 0; s <= K; ++s) {
+        const bool ok = s == 0 || sg_nbr(nb, s) != -1;
+        float dfv = 0.f, dav = 0.f;
+        if (ok) {
+          const float w = sigmoidf_(arow[s * lda + c]);
+          dfv = g * w / den;
+          // d out / d w_s = (f_s - out) / den (the clamp passes no gradient to the total)
+          const float dw = g * (frow[s * ldf + c] - (clamped ? 0.f : o)) / den;
+          dav = dw * w * (1.0f - w);
+        }
+        dfrow[s * lddf + c] = dfv;
+        darow[s * ldda + c] = dav;
+      }
+    } else {
+      SoftAcc sm = {-__builtin_inff(), 0.f, 0.f};
+      for (int s = 0; s <= K; ++s) {
+        const bool ok = s == 0 || sg_nbr(nb, s) != -1;
+        soft_push(sm, ok ? arow[s * lda + c] : -5e2f, frow[s * ldf + c]);
+      }
+      const float inv = 1.0f / sm.tot;
+      const float o = sm.acc * inv;
+      for (int s = 0; s <= K; ++s) {
+        const bool ok = s == 0 || sg_nbr(nb, s) != -1;
+        const float w = __expf((ok ? arow[s * lda + c] : -5e2f) - sm.top) * inv;
+        dfrow[s * lddf + c] = g * w;                      // (the reference's invalid rows receive w = exp(-500 - max) = 0)
+        darow[s * ldda + c] = ok ? g * w * (frow[s * ldf + c] - o) : 0.f;   // masked entries were overwritten: no gradient
+      }
+    }
+  }
+}
+
 inline unsigned row_blocks(int64_t rows) { return (unsigned)((rows + ROWS_PER_WG - 1) / ROWS_PER_WG); }
 
 }  // namespace
@@ -1141,6 +1319,52 @@ int ccn_sg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const in
   hipLaunchKernelGGL(sg_max_bwd_kernel, dim3(row_blocks(B * Nmax)), dim3(TPB), 0, (hipStream_t)stream, dout, lddo, arg,
                      cloud_ptr, B, Nmax, (int)K, (int)C, df, lddf);
   CCN_LAUNCH_OK("sg_max_bwd");
+  return CCN_OK;
+}
+
+int ccn_seg_wsum_fwd(const float* msg, int64_t ldm, const float* att, int64_t lda, const int32_t* offsets, int64_t M,
+                     int64_t C, int mode, float* out, int64_t ldo, void* stream) {
+  CCN_REQUIRE(msg && offsets && out && M >= 0 && CCN_SMALL_INT(C) && ldm >= C && ldo >= C && (mode == 0 || (mode == 1 && att)),
+              "seg_wsum_fwd: bad arguments");
+  if (M == 0) return CCN_OK;
+  hipLaunchKernelGGL(seg_wsum_fwd_kernel, dim3(row_blocks(M)), dim3(TPB), 0, (hipStream_t)stream, msg, ldm, att, lda, offsets,
+                     M, (int)C, mode, out, ldo);
+  CCN_LAUNCH_OK("seg_wsum_fwd");
+  return CCN_OK;
+}
+
+int ccn_seg_wsum_bwd(const float* msg, int64_t ldm, const float* att, int64_t lda, const int32_t* offsets, int64_t M,
+                     int64_t C, int mode, const float* dout, int64_t lddo, float* dmsg, int64_t lddm, float* datt,
+                     int64_t ldda, void* stream) {
+  CCN_REQUIRE(msg && offsets && dout && dmsg && M >= 0 && CCN_SMALL_INT(C) && (mode == 0 || (mode == 1 && att && datt)),
+              "seg_wsum_bwd: bad arguments");
+  if (M == 0) return CCN_OK;
+  hipLaunchKernelGGL(seg_wsum_bwd_kernel, dim3(row_blocks(M)), dim3(TPB), 0, (hipStream_t)stream, msg, ldm, att, lda, offsets,
+                     M, (int)C, mode, dout, lddo, dmsg, lddm, datt, ldda);
+  CCN_LAUNCH_OK("seg_wsum_bwd");
+  return CCN_OK;
+}
+
+int ccn_sg_reduce_fwd(const float* f, int64_t ldf, const float* att, int64_t lda, const int64_t* idx, const int64_t* cloud_ptr,
+                      int64_t B, int64_t Nmax, int64_t K, int64_t C, int mode, float* out, int64_t ldo, void* stream) {
+  CCN_REQUIRE(f && idx && cloud_ptr && out && B > 0 && Nmax > 0 && CCN_SMALL_INT(K) && CCN_SMALL_INT(C) && ldo >= C && ldf >= C &&
+                  mode >= 0 && mode <= 2 && (mode == 0 || att),
+              "sg_reduce_fwd: bad arguments");
+  hipLaunchKernelGGL(sg_reduce_fwd_kernel, dim3(row_blocks(B * Nmax)), dim3(TPB), 0, (hipStream_t)stream, f, ldf, att, lda, idx,
+                     cloud_ptr, B, Nmax, (int)K, (int)C, mode, out, ldo);
+  CCN_LAUNCH_OK("sg_reduce_fwd");
+  return CCN_OK;
+}
+
+int ccn_sg_reduce_bwd(const float* f, int64_t ldf, const float* att, int64_t lda, const int64_t* idx, const int64_t* cloud_ptr,
+                      int64_t B, int64_t Nmax, int64_t K, int64_t C, int mode, const float* dout, int64_t lddo, float* df,
+                      int64_t lddf, float* datt, int64_t ldda, void* stream) {
+  CCN_REQUIRE(f && idx && cloud_ptr && dout && df && B > 0 && Nmax > 0 && CCN_SMALL_INT(K) && CCN_SMALL_INT(C) && mode >= 0 &&
+                  mode <= 2 && (mode == 0 || (att && datt)),
+              "sg_reduce_bwd: bad arguments");
+  hipLaunchKernelGGL(sg_reduce_bwd_kernel, dim3(row_blocks(B * Nmax)), dim3(TPB), 0, (hipStream_t)stream, f, ldf, att, lda, idx,
+                     cloud_ptr, B, Nmax, (int)K, (int)C, mode, dout, lddo, df, lddf, datt, ldda);
+  CCN_LAUNCH_OK("sg_reduce_bwd");
   return CCN_OK;
 }
 

@@ -983,6 +983,34 @@ class SegSoftmaxAgg(torch.autograd.Function):
         return dmsg, datt, None, None
 
 
+class SegWSum(torch.autograd.Function):
+    """scatter_mean(msg) (mode 0) / scatter_add(msg * sigmoid(att)) (mode 1) over CSR groups (ref point_conv.py:82-88)."""
+
+    @staticmethod
+    def forward(ctx, msg, att, offsets, num_dst, mode):
+        msg = _mat(msg)
+        att = _mat(att) if att is not None else None
+        c = msg.size(1)
+        out = _rows(num_dst, c, msg.device)
+        call("seg_wsum_fwd", ptr(msg), _ld(msg), ptr(att), _ld(att) if att is not None else 0, ptr(offsets), num_dst, c, mode,
+             ptr(out), _ld(out))
+        ctx.save_for_backward(msg, att if att is not None else msg.new_empty(0), offsets)
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        msg, att, offsets = ctx.saved_tensors
+        g = _mat(g)
+        m, c = g.shape
+        has_att = ctx.mode == 1
+        dmsg = _rows(msg.size(0), c, g.device)
+        datt = _rows(msg.size(0), c, g.device) if has_att else None
+        call("seg_wsum_bwd", ptr(msg), _ld(msg), ptr(att) if has_att else None, _ld(att) if has_att else 0, ptr(offsets), m, c,
+             ctx.mode, ptr(g), _ld(g), ptr(dmsg), _ld(dmsg), ptr(datt), _ld(datt) if has_att else 0)
+        return dmsg, datt, None, None, None
+
+
 class SegMax(torch.autograd.Function):
     """scatter_max over destinations (ref point_conv.py:81-82)."""
 
@@ -1066,6 +1094,40 @@ class SGMax(torch.autograd.Function):
         df = _rows(b * nmax * (k + 1), c, g.device)
         call("sg_max_bwd", ptr(g), _ld(g), ptr(arg), ptr(cloud_ptr), b, nmax, k, c, ptr(df), _ld(df))
         return df, None, None, None
+
+
+SG_REDUCE_MODE = {"mean": 0, "weighted-sum": 1, "attend": 2}
+
+
+class SGReduce(torch.autograd.Function):
+    """The mean / weighted-sum / attend reductions of the dense SGCNN path over the K+1 slots (ref dgcnn.py:182-203),
+    packed output rows (:206)."""
+
+    @staticmethod
+    def forward(ctx, f, att, nbr, cloud_ptr, n, mode):
+        f = _mat(f)
+        att = _mat(att) if att is not None else None
+        b, nmax, k = nbr.shape
+        c = f.size(1)
+        out = _rows(n, c, f.device)
+        call("sg_reduce_fwd", ptr(f), _ld(f), ptr(att), _ld(att) if att is not None else 0, ptr(nbr), ptr(cloud_ptr), b, nmax,
+             k, c, mode, ptr(out), _ld(out))
+        ctx.save_for_backward(f, att if att is not None else f.new_empty(0), nbr, cloud_ptr)
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        f, att, nbr, cloud_ptr = ctx.saved_tensors
+        g = _mat(g)
+        b, nmax, k = nbr.shape
+        c = f.size(1)
+        has_att = ctx.mode != 0
+        df = _rows(f.size(0), c, g.device)
+        datt = _rows(f.size(0), c, g.device) if has_att else None
+        call("sg_reduce_bwd", ptr(f), _ld(f), ptr(att) if has_att else None, _ld(att) if has_att else 0, ptr(nbr),
+             ptr(cloud_ptr), b, nmax, k, c, ctx.mode, ptr(g), _ld(g), ptr(df), _ld(df), ptr(datt), _ld(datt) if has_att else 0)
+        return df, datt, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------

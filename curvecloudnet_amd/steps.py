@@ -330,8 +330,6 @@ class PointNetConv2(nn.Module):
         assert aggr_type in ["max", "attend", "mean", "weighted-sum"]
         if add_self_loops:
             raise NotImplementedError("the reference always passes add_self_loops=False")
-        if aggr_type in ("mean", "weighted-sum"):
-            raise NotImplementedError("aggr_type %r is not used by any reference config" % aggr_type)
         self.local_nn, self.global_nn, self.attend_nn = local_nn, global_nn, attend_nn
         self.aggr_type, self.normalize_radius = aggr_type, normalize_radius
         self.force_edge_gemm = False        # tests: run the literal message + GEMM formulation
@@ -357,6 +355,10 @@ class PointNetConv2(nn.Module):
                 msg = nn0(msg)
         if self.aggr_type == "max":
             out = ops.SegMax.apply(msg, edges.offsets, edges.num_dst, edges.col)
+        elif self.aggr_type == "mean":
+            out = ops.SegWSum.apply(msg, None, edges.offsets, edges.num_dst, 0)
+        elif self.aggr_type == "weighted-sum":
+            out = ops.SegWSum.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst, 1)
         else:
             out = ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst)
         if self.global_nn is not None:
@@ -421,10 +423,11 @@ class CurveSAModule(nn.Module):
                                   attend_nn=attend_nn, normalize_radius=self.normalize_radius)
 
     def geometry(self, pos, batch, point2curveidx, kwargs):
-        if not self.use_curve_fps:
-            raise NotImplementedError("the shipped configs always set use_curve_fps (ref pointnet2.py:165-168)")
         topo = _topology(batch, point2curveidx, kwargs)
-        idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
+        if not self.use_curve_fps:
+            idx = ops.fps(pos, topo, self.ratio)              # ref pointnet2.py:165-166 fps_pytorch3d
+        else:
+            idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
         edges = ops.radius_1d_group_subset(pos, idx, topo, self.r)
         return SimpleNamespace(edges=edges, out=(pos[idx], batch[idx], point2curveidx[idx], None, idx))
 
@@ -505,7 +508,9 @@ class SGCNNLayer(nn.Module):
 
     def _mode(self):
         lin0 = self.nn.lins[0]
-        algebraic = lin0.bias is None and self.nn.dropout == 0.0 and not self.force_edge_gemm
+        # (the algebraic / compact forms are built for the masked max; the other reductions take the literal dense rows)
+        algebraic = (lin0.bias is None and self.nn.dropout == 0.0 and not self.force_edge_gemm
+                     and (self.aggr_type == "max" or self.use_sparse_feat_agg))
         compact = (algebraic and self.compact_rows and self.k <= 63
                    and all(l.bias is None for l in self.nn.lins[:len(self.nn.norms)]))
         return algebraic, compact
@@ -515,12 +520,10 @@ class SGCNNLayer(nn.Module):
         out = (pos, batch, point2curveidx)
         if self.use_sparse_feat_agg:
             # ref dgcnn.py:209-246 forward_slow: edge list from FRNN / exact kNN
-            if self.aggr_type not in ("max", "attend"):
-                raise NotImplementedError("aggr_type=%r" % self.aggr_type)
             edges = ops.frnn_edges(pos, topo, pos, topo, self.k, self.r, accel_knn=self.use_fast_knn)
             return SimpleNamespace(edges=edges, out=out)
-        if not self.use_fast_knn or self.aggr_type != "max":
-            raise NotImplementedError("dense SGCNN path: only the FRNN + max configuration the shipped configs use")
+        # (ref dgcnn.py:163 calls knn_ball_group_pytorch3d without accel_knn: the dense path searches with FRNN whatever
+        # use_fast_knn says)
         radius = 0.25 if self.r is None else self.r
         compact = self._mode()[1]
         # the decoder revisits every level with the same K and radius as the encoder (and two consecutive steps share
@@ -545,6 +548,7 @@ class SGCNNLayer(nn.Module):
             msg = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row))
             if self.aggr_type == "max":
                 return ops.SegMax.apply(msg, edges.offsets, edges.num_dst, edges.col)
+            # ref dgcnn.py:239-244: every other aggr_type takes the softmax-attention branch
             return ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst)
         topo, nbr, comp = g.topo, g.nbr, g.comp
         algebraic, _ = self._mode()
@@ -577,6 +581,11 @@ class SGCNNLayer(nn.Module):
             feat = self.nn(feat, start=1)
         else:
             feat = self.nn(ops.SGGather.apply(x, nbr, topo.cloud_ptr))
+        if self.aggr_type != "max":
+            # ref dgcnn.py:182-203: mean / sigmoid-weighted / softmax-attention over the K+1 slots; attend_nn (and its
+            # batch statistics) runs over ALL B*Nmax*(K+1) rows, as the reference's does
+            att = self.attend_nn(feat) if self.aggr_type != "mean" else None
+            return ops.SGReduce.apply(feat, att, nbr, topo.cloud_ptr, topo.n, ops.SG_REDUCE_MODE[self.aggr_type])
         return ops.SGMax.apply(feat, nbr, topo.cloud_ptr, topo.n)
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):

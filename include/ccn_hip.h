@@ -260,6 +260,22 @@ int ccn_sg_max_fwd(const float* f, int64_t ldf, const int64_t* idx, const int64_
                    int64_t K, int64_t C, float* out, int64_t ldo, int32_t* arg, void* stream);
 int ccn_sg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const int64_t* cloud_ptr, int64_t B,
                    int64_t Nmax, int64_t K, int64_t C, float* df, int64_t lddf, void* stream);
+/* The remaining aggregation branches of the reference (no shipped config selects them):
+ * ccn_seg_wsum_*: PointNetConv2.aggregate over CSR groups (src/models/modules/point_conv.py:82-88) -- mode 0 'mean'
+ * (scatter_mean: sum / max(count, 1)), mode 1 'weighted-sum' (scatter_add of msg * sigmoid(att)).
+ * ccn_sg_reduce_*: StaticEdgeConv.forward_fast over the dense (b, i, slot) rows (src/models/modules/dgcnn.py:182-203) --
+ * mode 0 'mean' (valid slots), 1 'weighted-sum' (sigmoid weights, masked, normalised by clamp(total, 1e-3)),
+ * 2 'attend' (softmax over the K+1 slots with -5e2 at the invalid ones).  att / datt may be NULL for mode 0. */
+int ccn_seg_wsum_fwd(const float* msg, int64_t ldm, const float* att, int64_t lda, const int32_t* offsets, int64_t M,
+                     int64_t C, int mode, float* out, int64_t ldo, void* stream);
+int ccn_seg_wsum_bwd(const float* msg, int64_t ldm, const float* att, int64_t lda, const int32_t* offsets, int64_t M,
+                     int64_t C, int mode, const float* dout, int64_t lddo, float* dmsg, int64_t lddm, float* datt,
+                     int64_t ldda, void* stream);
+int ccn_sg_reduce_fwd(const float* f, int64_t ldf, const float* att, int64_t lda, const int64_t* idx, const int64_t* cloud_ptr,
+                      int64_t B, int64_t Nmax, int64_t K, int64_t C, int mode, float* out, int64_t ldo, void* stream);
+int ccn_sg_reduce_bwd(const float* f, int64_t ldf, const float* att, int64_t lda, const int64_t* idx, const int64_t* cloud_ptr,
+                      int64_t B, int64_t Nmax, int64_t K, int64_t C, int mode, const float* dout, int64_t lddo, float* df,
+                      int64_t lddf, float* datt, int64_t ldda, void* stream);
 
 /* ---- A13: src/models/modules/point_conv.py:60-93 PointNetConv2 message + aggregate ----------------
  * msg[e] = [x_src[src[e]], (pos_src[src[e]] - pos_dst[dst[e]]) / radius]   (radius <= 0: no division). */

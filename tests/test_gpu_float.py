@@ -359,6 +359,63 @@ def test_sa_module_vs_oracle(aggr):
     assert out_r[0].size(0) < x.size(0)
 
 
+@pytest.mark.parametrize("aggr", ["mean", "weighted-sum", "attend"])
+def test_dense_sgcnn_other_reductions_vs_oracle(aggr):
+    """The mean / weighted-sum / attend reductions of the dense SGCNN path (ref dgcnn.py:182-203; no shipped config selects
+    them): attend_nn and its batch statistics run over all B*Nmax*(K+1) rows on both sides."""
+    from oracle import torch_ref as R
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([1, 2, 3], n_curves=50)
+    c = 11
+
+    def mk(mod, mlp):
+        att = mlp([24, 24, 24], act="leaky_relu", bias=False) if aggr != "mean" else None
+        return mod(mlp([2 * (c + 3), 32, 24], bias=False), 8, r=0.03, with_xyz=True, attend_nn=att, aggr_type=aggr)
+    ref, mine = _pair(lambda: mk(R.SGCNNLayer, R.MLP), lambda: mk(steps.SGCNNLayer, MLP))
+    x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4))
+    _run_pair(ref, mine, [x, d.pos, d.batch, d.curve_idxs], seed=0)
+
+
+@pytest.mark.parametrize("aggr", ["mean", "weighted-sum"])
+def test_sa_module_other_aggregations_vs_oracle(aggr):
+    """PointNetConv2's scatter_mean / sigmoid weighted-sum aggregations (ref point_conv.py:82-88)."""
+    from oracle import torch_ref as R
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([5, 6], n_curves=80)
+    c = 10
+    kw = dict(curve_fps_arclen=0.012, downsample_type="curve-fps", aggr_type=aggr, normalize_radius=True)
+
+    def mk(mod, mlp):
+        att = mlp([24, 12, 24], act="leaky_relu", bias=False) if aggr == "weighted-sum" else None
+        return mod(None, 0.05, mlp([c + 3, 32, 24], bias=False), 16, attend_nn=att, **kw)
+    ref, mine = _pair(lambda: mk(R.SAModule, R.MLP), lambda: mk(steps.SAModule, MLP))
+    x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4))
+    _run_pair(ref, mine, [x, d.pos, d.batch, d.curve_idxs], seed=11)
+
+
+def test_curve_sa_without_curve_fps_vs_oracle():
+    """CurveSAModule with use_curve_fps=False: farthest point sampling at `ratio` (ref pointnet2.py:165-166), then the same
+    curve grouping.  Both sides draw the per-cloud start points from torch's CPU generator in the same order."""
+    from oracle import torch_ref as R
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([9, 10], n_curves=40)
+    c = 7
+
+    def mk(mod, mlp):
+        return mod(0.4, 0.02, mlp([c + 6, 24, 40], act="leaky_relu", bias=False), use_curve_fps=False, with_xyz=True,
+                   aggr_type="max", normalize_radius=True)
+    ref, mine = _pair(lambda: mk(R.CurveSAModule, R.MLP), lambda: mk(steps.CurveSAModule, MLP))
+    x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4))
+    out_r, out_d = _run_pair(ref, mine, [x, d.pos, d.batch, d.curve_idxs], seed=21)
+    assert torch.equal(out_d[5].cpu(), out_r[5])
+
+
 def test_curve_sa_and_fp_modules_vs_oracle():
     from oracle import torch_ref as R
     from curvecloudnet_amd import steps
