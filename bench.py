@@ -500,11 +500,11 @@ def main():
             busy += cur_e - cur_s
             fam_flops = sum(gemm_label(r[0], r[1], r[4])[1] for r in records)
             fam = fam_flops / (busy * 1e-3) / 1e12
-            if world == 1 and os.environ.get("CCN_WGRAD_STREAM", "1") != "0" and args.mlp_dtype == "fp32":
+            if world == 1 and os.environ.get("CCN_WGRAD_STREAM", "1") != "0":
                 result["roofline"]["note"] = ("launch durations include the time this kernel shares the chip with the "
-                                              "weight-gradient stream (ops._WgradScope); with CCN_WGRAD_STREAM=0 the same "
-                                              "kernel measures 105.8 TFLOP/s (frac 0.672) and the step is 2.3 % slower "
-                                              "(profiles/r01o_kitti_bench_nows.json)")
+                                              "weight-gradient stream (ops._WgradScope); the same kernel without that stream "
+                                              "(CCN_WGRAD_STREAM=0, step ~5 % slower) and stand-alone: "
+                                              "profiles/r02*_kitti_bench_nows.json, DESIGN.md section 5")
             result["roofline"]["all_gemm_launches"] = {
                 "achieved": fam, "frac": fam / peak, "busy_ms_per_step": busy / args.steps,
                 "note": "flops of every GEMM launch / union of their execution intervals (two streams overlap)"}

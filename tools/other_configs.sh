@@ -7,10 +7,15 @@ while read -r flags; do
   timeout -k 10 300 python bench.py --no-cpu-baseline --no-kernel-timing --steps 8 --warmup 3 $flags $* 2>/dev/null | tail -1 >> $out || echo "FAILED" >> $out
   echo "done: $flags $*"
 done <<'CFG'
---config nuscenes --curves 1430 --clouds-per-gpu 16
---config kitti --curves 4900 --clouds-per-gpu 4
---config a2d2 --mixed-lengths --clouds-per-gpu 8
---config shapenet-seg --curves 84 --clouds-per-gpu 64
+--baseline-config 0 --clouds-per-gpu 64
+--baseline-config 2
+--baseline-config 2 --mlp-dtype fp32
+--baseline-config 3
+--baseline-config 4
+--baseline-config 4 --mlp-dtype fp32
+--baseline-config 4 --graph
 --config kortx
 --config hotpath
+--mlp-dtype bf16
+--mlp-dtype bf16x3
 CFG
