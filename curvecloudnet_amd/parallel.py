@@ -173,6 +173,8 @@ class GradientAllReduce:
         self._launched[b] = True
         self.reduce_calls += 1
         flat = self.buckets[b][0]
+        if os.environ.get("CCN_DP_DRYRUN"):       # diagnostic: hooks and bookkeeping without the collective itself
+            return
         from .ops import wgrad_stream_of
         ws = wgrad_stream_of(flat.device) if flat.is_cuda else None
         if ws is None:
