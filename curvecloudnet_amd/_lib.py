@@ -63,6 +63,8 @@ def lib():
             raise RuntimeError("libccn_hip.so ABI version mismatch")
         if os.environ.get("CCN_GEMM_DMA"):       # A/B hook of the GEMM dispatch (include/ccn_hip.h: ccn_gemm_use_dma)
             handle.ccn_gemm_use_dma(int(os.environ["CCN_GEMM_DMA"]))
+        if os.environ.get("CCN_GEMM_PAIR_OPT"):  # A/B hook (ccn_gemm_pair_opt)
+            handle.ccn_gemm_pair_opt(int(os.environ["CCN_GEMM_PAIR_OPT"]))
         if os.environ.get("CCN_FPS_CLAIM"):      # A/B hook (ccn_fps_set_lds_claim)
             handle.ccn_fps_set_lds_claim(int(os.environ["CCN_FPS_CLAIM"]))
         _lib = handle

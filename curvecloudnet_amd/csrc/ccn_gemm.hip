@@ -1067,8 +1067,9 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
                                                                    const float* __restrict__ bias, float* __restrict__ C,
                                                                    int64_t ldc, int64_t M, int64_t N, int64_t K,
                                                                    int64_t tiles, int64_t gn, int xcd_order,
-                                                                   double* __restrict__ colstats, int64_t a_extent) {
+                                                                   double* __restrict__ colstats, int64_t a_extent, int opt) {
   // a_extent: floats readable from the start of an A row (= lda, or K when rows overlap: ccn_conv_rows_nt)
+  // opt (A/B hook ccn_gemm_pair_opt): bit 0 = counted wait behind an interior tile's stores, bit 1 = s_setprio around MFMAs
   constexpr int AF = PR_BM * BK, BF = PR_BN * BK, STAGE = AF + BF;
   constexpr int NC = 4;  // LDS-DMA copies (8 rows x 128 B) per wave, slice and operand
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
@@ -1175,6 +1176,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   };
 
   int64_t g = 0;
+  bool stores_behind = false;   // the previous tile was interior: exactly 64 stores per lane were issued after the last copy
   for (int64_t j = 0, tile; (tile = tile_of(j)) < tiles; ++j) {
     const int64_t m0 = (tile / gn) * PR_BM, n0 = (tile % gn) * PR_BN;
     f32x16 acc[2][2];
@@ -1189,7 +1191,12 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     }
 
     for (int u = 0; u < TT; ++u, ++g) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice g has landed (and the previous tile's stores retired)
+      if (u == 0 && stores_behind && (opt & 1))
+        // the copy of this slice was issued BEFORE the previous tile's 64 stores (vmcnt retires in issue order): wait for it
+        // and the first store only, not for the whole store burst to drain
+        asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice g has landed (and the previous tile's stores retired)
       __builtin_amdgcn_s_barrier();
       issue_next();
       if (u == 0 && stat_tile >= 0) stats_readout();
@@ -1212,6 +1219,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (opt & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ab = 0; ab < 2; ++ab)
 #pragma unroll
@@ -1221,11 +1229,13 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
             acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][ab].z, fb[q & 1][t].z, acc[ab][t], 0, 0, 0);
             acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][ab].w, fb[q & 1][t].w, acc[ab][t], 0, 0, 0);
           }
+        if (opt & 2) __builtin_amdgcn_s_setprio(0);
       }
     }
 
     // ---- tile epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
     const bool interior = m0 + PR_BM <= M && n0 + PR_BN <= N;
+    stores_behind = interior && has_tail == 0;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int ncol = wn * 64 + t * 32 + i;
@@ -1276,6 +1286,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   }
 }
 
+static int g_pair_opt = 0;      // A-B hook (ccn_gemm_pair_opt)
 static bool g_use_pair = true;  // A-B hook (ccn_gemm_use_dma(4) = the 8-wave persistent kernel for N > 64 as well)
 // from this many 128 x 128 tiles on (measured at 128 / 256 / 512 / 1024: 3168 x 2048 -> 1024 (200 tiles) 87 vs 80 TFLOP/s on
 // the register-staged kernel, 10550 x 1024 -> 1024 (664 tiles) 99 vs 84, 35151 x 512 -> 512 107 vs 88 on the 8-wave kernel)
@@ -1287,7 +1298,7 @@ int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, c
   const int64_t tiles = gm * gn;
   const int64_t grid = tiles < 512 ? tiles : 512;  // two workgroups per CU
   hipLaunchKernelGGL(gemm_glds_pair_kernel, dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy, M, N, K,
-                     tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent);
+                     tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt);
   return CCN_OK;
 }
 
@@ -1732,6 +1743,11 @@ int ccn_gemm_use_dma(int on) {
   g_use_persistent = on == 1 || on == 3 || on == 4;
   g_xcd_map = on != 3;
   g_use_pair = on != 4;
+  return CCN_OK;
+}
+
+int ccn_gemm_pair_opt(int bits) {
+  g_pair_opt = bits;
   return CCN_OK;
 }
 
