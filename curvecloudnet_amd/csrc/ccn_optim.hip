@@ -37,7 +37,132 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// ---- mean negative log-likelihood of log_softmax(logits) (harness row H: F.log_softmax + F.nll_loss, ref
+// src/run/kitti_seg.py:184-192 and the other runners): one pass over the logits forward (row max, log-sum-exp, per-row
+// loss; workgroup partial sums in double), one backward (softmax - onehot, scaled).  torch's two nll_loss kernels alone
+// took 0.8 ms per step on 400 k x 20 logits.
+constexpr int NLL_TPB = 256;
+
+__global__ __launch_bounds__(NLL_TPB) void nll_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          const int64_t* __restrict__ target, int64_t rows, int C,
+                                                          int64_t ignore, float* __restrict__ lse_out,
+                                                          float* __restrict__ per_point, double* __restrict__ partial) {
+  __shared__ double red[2][NLL_TPB / 64];
+  const int64_t i = (int64_t)blockIdx.x * NLL_TPB + threadIdx.x;
+  double loss = 0.0, cnt = 0.0;
+  if (i < rows) {
+    const float* row = x + i * ldx;
+    float m = row[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, row[c]);
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) sum += expf(row[c] - m);
+    const float lse = m + logf(sum);
+    lse_out[i] = lse;
+    const int64_t t = target[i];
+    float li = 0.f;
+    if (t != ignore && t >= 0 && t < C) {
+      li = lse - row[t];
+      loss = (double)li;
+      cnt = 1.0;
+    }
+    if (per_point) per_point[i] = li;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    loss += __shfl_xor(loss, d, 64);
+    cnt += __shfl_xor(cnt, d, 64);
+  }
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][w] = loss;
+    red[1][w] = cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < NLL_TPB / 64; ++k) {
+      a += red[0][k];
+      b += red[1][k];
+    }
+    partial[(int64_t)blockIdx.x * 2] = a;
+    partial[(int64_t)blockIdx.x * 2 + 1] = b;
+  }
+}
+
+// totals[0] = sum of the per-row losses, totals[1] = number of counted rows; loss = totals[0] / totals[1]
+__global__ __launch_bounds__(256) void nll_final_kernel(const double* __restrict__ partial, int64_t nblocks,
+                                                        double* __restrict__ totals, float* __restrict__ loss) {
+  __shared__ double red[2][256];
+  double a = 0.0, b = 0.0;
+  for (int64_t k = threadIdx.x; k < nblocks; k += 256) {   // fixed assignment and order: deterministic
+    a += partial[2 * k];
+    b += partial[2 * k + 1];
+  }
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (threadIdx.x < d) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + d];
+      red[1][threadIdx.x] += red[1][threadIdx.x + d];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    totals[0] = red[0][0];
+    totals[1] = red[1][0];
+    *loss = (float)(red[0][0] / red[1][0]);        // 0 / 0 = nan for an all-ignored batch, as torch
+  }
+}
+
+__global__ __launch_bounds__(NLL_TPB) void nll_bwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          const int64_t* __restrict__ target,
+                                                          const float* __restrict__ lse, int64_t rows, int C,
+                                                          int64_t ignore, const float* __restrict__ gout,
+                                                          const double* __restrict__ totals, float* __restrict__ dx,
+                                                          int64_t lddx) {
+  const int64_t e = (int64_t)blockIdx.x * NLL_TPB + threadIdx.x;   // one logit per thread: coalesced
+  if (e >= rows * C) return;
+  const int64_t i = e / C;
+  const int c = (int)(e - i * C);
+  const int64_t t = target[i];
+  float g = 0.f;
+  if (t != ignore && t >= 0 && t < C) {
+    const float scale = gout[0] / (float)totals[1];
+    g = (expf(x[i * ldx + c] - lse[i]) - (c == t ? 1.f : 0.f)) * scale;
+  }
+  dx[i * lddx + c] = g;
+}
+
 }  // namespace
+
+extern "C" int64_t ccn_nll_loss_blocks(int64_t rows) { return (rows + NLL_TPB - 1) / NLL_TPB; }
+
+extern "C" int ccn_nll_loss_fwd(const float* logits, int64_t ld, const int64_t* target, int64_t rows, int64_t C,
+                                int64_t ignore_index, float* lse, float* per_point, double* scratch, float* loss,
+                                void* stream) {
+  // scratch: double[2 * ccn_nll_loss_blocks(rows) + 2]; its LAST two doubles receive (sum of losses, counted rows)
+  CCN_REQUIRE(logits && target && lse && scratch && loss && rows > 0 && C > 0 && C < (1 << 20) && ld >= C,
+              "nll_loss_fwd: bad arguments");
+  const int64_t nb = ccn_nll_loss_blocks(rows);
+  hipLaunchKernelGGL(nll_fwd_kernel, dim3((unsigned)nb), dim3(NLL_TPB), 0, (hipStream_t)stream, logits, ld, target, rows,
+                     (int)C, ignore_index, lse, per_point, scratch);
+  hipLaunchKernelGGL(nll_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, nb, scratch + 2 * nb, loss);
+  CCN_LAUNCH_OK("nll_loss_fwd");
+  return CCN_OK;
+}
+
+extern "C" int ccn_nll_loss_bwd(const float* logits, int64_t ld, const int64_t* target, const float* lse, int64_t rows,
+                                int64_t C, int64_t ignore_index, const float* grad_loss, const double* totals,
+                                float* dlogits, int64_t ldd, void* stream) {
+  CCN_REQUIRE(logits && target && lse && grad_loss && totals && dlogits && rows > 0 && C > 0 && ld >= C && ldd >= C,
+              "nll_loss_bwd: bad arguments");
+  const int64_t n = rows * C;
+  hipLaunchKernelGGL(nll_bwd_kernel, dim3((unsigned)((n + NLL_TPB - 1) / NLL_TPB)), dim3(NLL_TPB), 0, (hipStream_t)stream,
+                     logits, ld, target, lse, rows, (int)C, ignore_index, grad_loss, totals, dlogits, ldd);
+  CCN_LAUNCH_OK("nll_loss_bwd");
+  return CCN_OK;
+}
 
 extern "C" int ccn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int64_t step, void* stream) {

@@ -240,6 +240,8 @@ def build_model(model_cfg, in_dim, n_out):
     return ModelBase(in_dim, n_out, **cfg)
 
 
-def segmentation_loss(logits, target):
-    """Harness counterpart of ref src/run/kitti_seg.py:184-192 (mean NLL over points)."""
-    return F.nll_loss(F.log_softmax(logits, dim=-1), target)
+def segmentation_loss(logits, target, ignore_index=-100):
+    """Harness counterpart of ref src/run/kitti_seg.py:184-192 (mean NLL over points): F.nll_loss(F.log_softmax(logits),
+    target) as one fused forward and one backward pass (ops.NLLLoss)."""
+    from . import ops
+    return ops.NLLLoss.apply(logits, target, ignore_index)

@@ -707,6 +707,39 @@ def linear_bn_act(x, weight, bias, bn, training, act):
                              act, bn.eps, bn.momentum if bn.momentum is not None else 0.1, grad_on)
 
 
+class NLLLoss(torch.autograd.Function):
+    """mean over the rows with target != ignore_index of -log_softmax(logits)[target] (harness row H; ref
+    src/run/kitti_seg.py:184-192): ccn_nll_loss_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index=-100):
+        logits, target = _mat(logits), _i64(target)
+        rows, c = logits.shape
+        if target.numel() != rows:
+            raise ValueError("Expected input batch_size (%d) to match target batch_size (%d)." % (rows, target.numel()))
+        dev = logits.device
+        nb = lib().ccn_nll_loss_blocks(rows)
+        lse = torch.empty(rows, dtype=torch.float32, device=dev)
+        scratch = torch.empty(2 * nb + 2, dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        call("nll_loss_fwd", ptr(logits), _ld(logits), ptr(target), rows, c, int(ignore_index), ptr(lse), None, ptr(scratch),
+             ptr(loss))
+        ctx.save_for_backward(logits, target, lse, scratch)
+        ctx.ignore = int(ignore_index)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, lse, scratch = ctx.saved_tensors
+        rows, c = logits.shape
+        nb = lib().ccn_nll_loss_blocks(rows)
+        d = _rows(rows, c, logits.device)
+        g = g.to(torch.float32).contiguous()
+        call("nll_loss_bwd", ptr(logits), _ld(logits), ptr(target), ptr(lse), rows, c, ctx.ignore, ptr(g),
+             ptr(scratch[2 * nb:]), ptr(d), _ld(d))
+        return d, None, None
+
+
 # --------------------------------------------------------------------------------------
 # A7: CurveFPS
 # --------------------------------------------------------------------------------------

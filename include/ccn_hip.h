@@ -430,6 +430,17 @@ int ccn_curve_split(const float* pos, const int64_t* beam, int64_t n, float thre
 /* Harness row H (src/main.py:56 torch.optim.Adam; src/run/kitti_seg.py:19-63 train loop): one Adam update over a
  * flat, 16-byte aligned run of n parameters (param, grad, exp_avg, exp_avg_sq contiguous fp32), same arithmetic as
  * torch.optim.Adam(amsgrad=False, maximize=False): step >= 1 is the 1-based update count. */
+/* Mean negative log-likelihood of log_softmax(logits) over the rows whose target != ignore_index (harness counterpart:
+ * F.log_softmax + F.nll_loss at src/run/kitti_seg.py:184-192, shapenet_seg.py, nuscenes_seg.py, audi_seg.py).
+ * fwd: lse (rows) float, per_point (rows, nullable) float, scratch double[2 * ccn_nll_loss_blocks(rows) + 2] whose last two
+ * doubles receive (sum of losses, counted rows), loss = their quotient (device scalar).  bwd: dlogits = (softmax - onehot) *
+ * grad_loss / counted rows.  Deterministic (fixed-order double sums). */
+int64_t ccn_nll_loss_blocks(int64_t rows);
+int ccn_nll_loss_fwd(const float* logits, int64_t ld, const int64_t* target, int64_t rows, int64_t C, int64_t ignore_index,
+                     float* lse, float* per_point, double* scratch, float* loss, void* stream);
+int ccn_nll_loss_bwd(const float* logits, int64_t ld, const int64_t* target, const float* lse, int64_t rows, int64_t C,
+                     int64_t ignore_index, const float* grad_loss, const double* totals, float* dlogits, int64_t ldd,
+                     void* stream);
 int ccn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int64_t step, void* stream);
 

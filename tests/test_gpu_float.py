@@ -803,3 +803,23 @@ def test_conv_shift_add_short_sequences():
                       lambda: steps.SymmetricCurve1DConvV2([40, 8, 6], 7, with_xyz=True, with_diff=True))
     x = torch.randn(d.pos.size(0), 37, generator=torch.Generator().manual_seed(4))
     _run_pair(ref, mine, [x, d.pos, d.batch, d.curve_idxs], seed=0)
+
+
+@pytest.mark.parametrize("rows,C,ignore", [(1, 5, -100), (1000, 20, -100), (400070, 20, -100), (70001, 17, 0), (513, 55, 3)])
+def test_nll_loss_matches_torch(rows, C, ignore):
+    """segmentation_loss = F.nll_loss(F.log_softmax(logits), target) (ref kitti_seg.py:184-192): value, gradient, ignore_index."""
+    from curvecloudnet_amd.model import segmentation_loss
+    gen = torch.Generator().manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=gen) * 3
+    t = torch.randint(0, C, (rows,), generator=gen)
+    xr = x.clone().requires_grad_(True)
+    lr = F.nll_loss(F.log_softmax(xr, dim=-1), t, ignore_index=ignore)
+    (gr,) = torch.autograd.grad(lr * 1.7, xr)
+    xd = x.to(DEV).requires_grad_(True)
+    ld = segmentation_loss(xd, t.to(DEV), ignore_index=ignore)
+    (gd,) = torch.autograd.grad(ld * 1.7, xd)
+    assert abs(float(ld) - float(lr)) <= 2e-6 * max(1.0, abs(float(lr)))
+    _close(gd, gr, 1e-6, "dlogits")
+    if ignore >= 0:
+        assert float(gd[t.to(DEV) == ignore].abs().max()) == 0.0
+
