@@ -1062,6 +1062,9 @@ static bool g_xcd_map = true;  // A-B hook (ccn_gemm_use_dma(3) = persistent ker
 constexpr int PR_TPB = 256;
 constexpr int PR_BM = 128, PR_BN = 128;
 
+// ACC: Y += A W^T -- the accumulators start from the Y tile itself (64 loads per lane straight into the accumulator
+// registers at the top of a tile, covered by the first slice's wait) instead of from the bias (ccn_gemm_nt_acc).
+template <bool ACC>
 __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* __restrict__ A, int64_t lda,
                                                                    const float* __restrict__ B, int64_t ldb,
                                                                    const float* __restrict__ bias, float* __restrict__ C,
@@ -1180,6 +1183,22 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   for (int64_t j = 0, tile; (tile = tile_of(j)) < tiles; ++j) {
     const int64_t m0 = (tile / gn) * PR_BM, n0 = (tile % gn) * PR_BN;
     f32x16 acc[2][2];
+    if (ACC) {
+      const bool inside = m0 + PR_BM <= M && n0 + PR_BN <= N;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int64_t n = n0 + wn * 64 + t * 32 + i;
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab) {
+          const float* const crow = C + (m0 + wm * 64 + ab * 32 + 4 * h) * ldc + n;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * 64 + ab * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            acc[ab][t][r] = (inside || (m < M && n < N)) ? crow[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] : 0.f;
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int64_t n = n0 + wn * 64 + t * 32 + i;
@@ -1188,6 +1207,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       for (int ab = 0; ab < 2; ++ab)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ab][t][r] = bv;
+    }
     }
 
     for (int u = 0; u < TT; ++u, ++g) {
@@ -1293,12 +1313,16 @@ static bool g_use_pair = true;  // A-B hook (ccn_gemm_use_dma(4) = the 8-wave pe
 constexpr int64_t PAIR_MIN_TILES = 128;
 
 int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
-                     int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s, int64_t a_extent) {
+                     int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s, int64_t a_extent, bool accumulate = false) {
   const int64_t gm = (M + PR_BM - 1) / PR_BM, gn = (N + PR_BN - 1) / PR_BN;
   const int64_t tiles = gm * gn;
   const int64_t grid = tiles < 512 ? tiles : 512;  // two workgroups per CU
-  hipLaunchKernelGGL(gemm_glds_pair_kernel, dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy, M, N, K,
-                     tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt);
+  if (accumulate)
+    hipLaunchKernelGGL(gemm_glds_pair_kernel<true>, dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy, M,
+                       N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt);
+  else
+    hipLaunchKernelGGL(gemm_glds_pair_kernel<false>, dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
+                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt);
   return CCN_OK;
 }
 
@@ -1813,6 +1837,24 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
   CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, "gemm_nt: bad sizes M=%lld N=%lld K=%lld",
               (long long)M, (long long)N, (long long)K);
   return gemm_nt_impl(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, stream, false);
+}
+
+int ccn_gemm_nt_acc_ok(int64_t lda, int64_t ldw, int64_t M, int64_t N, int64_t K) {
+  return lda % 4 == 0 && ldw % 4 == 0 && lda >= 4 && ldw >= 4 && !g_force_generic && g_use_glds && g_use_persistent &&
+         g_use_pair && M >= 1024 && K >= g_dma_min_k && N > 64 &&
+         ((M + PR_BM - 1) / PR_BM) * ((N + PR_BN - 1) / PR_BN) >= PAIR_MIN_TILES;
+}
+
+int ccn_gemm_nt_acc(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M, int64_t N,
+                    int64_t K, void* stream) {
+  CCN_REQUIRE(A && W && Y, "gemm_nt_acc: null pointer");
+  CCN_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, "gemm_nt_acc: bad sizes");
+  CCN_REQUIRE(ccn_gemm_nt_acc_ok(lda, ldw, M, N, K) && aligned16(A) && aligned16(W),
+              "gemm_nt_acc: shape / alignment outside the paired LDS-DMA kernel (ask ccn_gemm_nt_acc_ok first)");
+  int rc = launch_glds_pair(A, lda, W, ldw, nullptr, Y, ldy, M, N, K, nullptr, (hipStream_t)stream, lda, true);
+  if (rc) return rc;
+  CCN_LAUNCH_OK("gemm_nt_acc");
+  return CCN_OK;
 }
 
 int ccn_conv_rows_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,

@@ -581,6 +581,32 @@ def _wgrad(gemm_nt, dy, x, dw, m, n, k):
     call("gemm_tn_ws", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(dw), _ld(dw), m, n, k, ptr(ws), nb)
 
 
+# Gradient sinks: an activation with two consumers whose backward passes both produce a full-size gradient (PointNetConv2's
+# message tensor: attend_nn and the softmax aggregation, point_conv.py:89-92).  The consumer that runs first in backward
+# registers the gradient tensor it returns (keyed by the activation's address); the Linear layer that consumes the same
+# activation then ADDS its data gradient into that tensor (ccn_gemm_nt_acc) and hands autograd nothing, instead of autograd
+# summing two E x C tensors in a pass of its own.  Cleared at the end of every backward pass.  CCN_GRAD_SINK=0 disables.
+_GRAD_SINK = {}
+GRAD_SINK = os.environ.get("CCN_GRAD_SINK", "1") != "0"
+
+
+def _grad_sink_offer(activation, grad):
+    if not GRAD_SINK or not activation.is_cuda:
+        return
+    torch.autograd.Variable._execution_engine.queue_callback(_GRAD_SINK.clear)     # (idempotent; survives a failed pass)
+    _GRAD_SINK[activation.data_ptr()] = (grad, tuple(activation.shape))
+
+
+def _grad_sink_take(x, m, k):
+    hit = _GRAD_SINK.pop(x.data_ptr(), None) if _GRAD_SINK else None
+    if hit is None:
+        return None
+    grad, shape = hit
+    if shape != (m, k) or tuple(grad.shape) != (m, k) or grad.stride(1) != 1:
+        return None
+    return grad
+
+
 class LinearBNAct(torch.autograd.Function):
     """y = act(BN(x W^T + b)) with batch statistics taken in the GEMM epilogue.
 
@@ -667,14 +693,20 @@ class LinearBNAct(torch.autograd.Function):
         k = x.size(1)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _rows(m, k, dev)
             # dX = dY W as an "NT" product with W^T (k x n): both operands then stream along their contiguous
             # index, which is the fastest tile layout (the weight transpose is a few KB..MB)
             wt = _rows(k, n, dev, zero=(n % 4 != 0))
             wt.copy_(w[:, :k].t())
             if ctx.gemm_nt != "gemm_nt":
                 dy = _aligned_rows(dy)
-            _gemm_nt(_GEMM_BWD[ctx.gemm_nt], dy, wt, None, dx, m, k, n, None)
+            sink = _grad_sink_take(x, m, k) if ctx.gemm_nt == "gemm_nt" else None
+            if (sink is not None and dy.data_ptr() % 16 == 0 and wt.data_ptr() % 16 == 0
+                    and lib().ccn_gemm_nt_acc_ok(_ld(dy), _ld(wt), m, k, n)):
+                # the other consumer of x has written its gradient already: add this one to it (autograd gets None)
+                call("gemm_nt_acc", ptr(dy), _ld(dy), ptr(wt), _ld(wt), ptr(sink), _ld(sink), m, k, n)
+            else:
+                dx = _rows(m, k, dev)
+                _gemm_nt(_GEMM_BWD[ctx.gemm_nt], dy, wt, None, dx, m, k, n, None)
         dw = None
         if ctx.needs_input_grad[1]:
             into = _main_grad(ctx.main_grad_of, n, k)
@@ -1002,6 +1034,7 @@ class SegSoftmaxAgg(torch.autograd.Function):
         c = msg.size(1)
         out = _rows(num_dst, c, msg.device)
         call("seg_softmax_agg_fwd", ptr(msg), _ld(msg), ptr(att), _ld(att), ptr(offsets), num_dst, c, ptr(out), _ld(out))
+        _GRAD_SINK.clear()                   # (nothing of an earlier backward pass may survive into this one)
         ctx.save_for_backward(msg, att, offsets)
         return out
 
@@ -1013,6 +1046,7 @@ class SegSoftmaxAgg(torch.autograd.Function):
         dmsg, datt = _rows(msg.size(0), c, g.device), _rows(att.size(0), c, g.device)
         call("seg_softmax_agg_bwd", ptr(msg), _ld(msg), ptr(att), _ld(att), ptr(offsets), m, c, ptr(g), _ld(g),
              ptr(dmsg), _ld(dmsg), ptr(datt), _ld(datt))
+        _grad_sink_offer(msg, dmsg)          # attend_nn's first layer adds its data gradient into dmsg (see _GRAD_SINK)
         return dmsg, datt, None, None
 
 

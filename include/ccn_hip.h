@@ -178,6 +178,13 @@ size_t ccn_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int ccn_gemm_tn_use_dma(int on);    /* A/B hook: 0 = always the register-staged split-K kernel of ccn_gemm_tn */
 int ccn_gemm_tn_ws(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
                    int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+/* Y += A W^T (the accumulators start from Y): lets a data-gradient product ADD into a gradient that another consumer of the
+ * same activation has already written -- PointNetConv2's message tensor feeds both attend_nn and the softmax aggregation
+ * (src/models/modules/point_conv.py:89-92), autograd would otherwise sum two E x C tensors in a separate pass.  Paired
+ * LDS-DMA kernel only: ccn_gemm_nt_acc_ok says whether a shape takes it. */
+int ccn_gemm_nt_acc_ok(int64_t lda, int64_t ldw, int64_t M, int64_t N, int64_t K);
+int ccn_gemm_nt_acc(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M, int64_t N,
+                    int64_t K, void* stream);
 /* ---- A4-A6: the symmetric curve convolution as an IMPLICIT GEMM over the row sequence (no shifted-row matrix) ----
  * Replaces F.conv1d(input(1,C,L), weight, bias, 1, 'same') at src/models/modules/fast_conv1d.py:183 (called from
  * SymmetricCurve1DConvV2 :71 and SymmetricCurve1DConvFastV1 :140) on the reference's own zero-separated sequence
