@@ -1051,6 +1051,8 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
 
 static bool g_xcd_map = true;  // A-B hook (ccn_gemm_use_dma(3) = persistent kernel with round-robin tiles)
 
+static int g_pair_opt = 0;      // A-B hook (ccn_gemm_pair_opt)
+
 // ------------------------------------------------------------------ two independent workgroups per CU (N > 64)
 // The 8-wave persistent kernel above keeps ONE workgroup on a CU, so nothing runs while its waves store a finished tile
 // (3.65 us of a 36 us tile at K = 256, 19 % at K = 128).  Here a CU holds TWO 4-wave workgroups on 128 x 128 tiles (each
@@ -1162,6 +1164,14 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       it_tile = tile_of(++it_j);
     }
   };
+  // experiments (A/B hook; profiles/r02_pair_kernel_experiments.txt: none of them pays): bit 3 = the second workgroup of a CU
+  // starts (opt >> 8) x 3.6 us late, bit 4 = ... and runs at low instruction priority; bit 2 (host side) = one workgroup per CU
+  if ((opt & 8) && blockIdx.x >= 256)
+    for (int r = 0; r < (opt >> 8); ++r) __builtin_amdgcn_s_sleep(127);
+  if (opt & 16) {
+    if (blockIdx.x >= 256) __builtin_amdgcn_s_setprio(0);
+    else __builtin_amdgcn_s_setprio(3);
+  }
   issue_next();
 
   int64_t stat_tile = -1;
@@ -1306,7 +1316,6 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   }
 }
 
-static int g_pair_opt = 0;      // A-B hook (ccn_gemm_pair_opt)
 static bool g_use_pair = true;  // A-B hook (ccn_gemm_use_dma(4) = the 8-wave persistent kernel for N > 64 as well)
 // from this many 128 x 128 tiles on (measured at 128 / 256 / 512 / 1024: 3168 x 2048 -> 1024 (200 tiles) 87 vs 80 TFLOP/s on
 // the register-staged kernel, 10550 x 1024 -> 1024 (664 tiles) 99 vs 84, 35151 x 512 -> 512 107 vs 88 on the 8-wave kernel)
@@ -1316,7 +1325,8 @@ int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, c
                      int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s, int64_t a_extent, bool accumulate = false) {
   const int64_t gm = (M + PR_BM - 1) / PR_BM, gn = (N + PR_BN - 1) / PR_BN;
   const int64_t tiles = gm * gn;
-  const int64_t grid = tiles < 512 ? tiles : 512;  // two workgroups per CU
+  const int64_t slots = (g_pair_opt & 4) ? 256 : 512;
+  const int64_t grid = tiles < slots ? tiles : slots;  // two workgroups per CU
   if (accumulate)
     hipLaunchKernelGGL(gemm_glds_pair_kernel<true>, dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy, M,
                        N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt);

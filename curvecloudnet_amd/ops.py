@@ -843,33 +843,59 @@ def knn_1d_group_superset(pos, idx, topo, k):
     return rows[keep], nbr[keep]
 
 
+INTERP_GATHER = os.environ.get("CCN_INTERP_GATHER", "1") != "0"
+
+
+def interp_inverse(nbr, w, m):
+    """The (n, k) neighbour table of an interpolation turned around: for every one of the ``m`` coarse rows the list of
+    fine rows that read it (sorted), their weights, and every fine row's weight sum.  Built with the geometry (no
+    gradient flows through it) so that CurveInterp's backward is an ordered gather instead of k atomic row adds per
+    fine row.  None when no gradient is being recorded."""
+    if not (INTERP_GATHER and torch.is_grad_enabled()) or m == 0:
+        return None
+    n, k = nbr.shape
+    dev = nbr.device
+    inv_ptr = torch.empty(m + 1, dtype=torch.int32, device=dev)
+    inv_src = torch.empty(max(n * k, 1), dtype=torch.int32, device=dev)
+    inv_w = torch.empty(max(n * k, 1), dtype=torch.float32, device=dev)
+    den = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+    ws = workspace(lib().ccn_interp_inverse_workspace_bytes(m), dev)
+    call("interp_inverse", ptr(nbr), ptr(w), n, k, m, ptr(inv_ptr), ptr(inv_src), ptr(inv_w), ptr(den), ptr(ws),
+         ws.numel())
+    return inv_ptr, inv_src, inv_w, den
+
+
 class CurveInterp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, nbr, w):
+    def forward(ctx, x, nbr, w, inv=None):
         x = _mat(x)
         n, k = nbr.shape
         c = x.size(1)
         y = _rows(n, c, x.device)
         call("interp_fwd", ptr(x), _ld(x), ptr(nbr), ptr(w), n, k, c, ptr(y), _ld(y))
-        ctx.save_for_backward(nbr, w)
+        ctx.save_for_backward(nbr, w, *(inv or ()))
         ctx.m = x.size(0)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        nbr, w = ctx.saved_tensors
+        nbr, w, *inv = ctx.saved_tensors
         g = _mat(g)
         n, k = nbr.shape
         c = g.size(1)
-        dx = _rows(ctx.m, c, g.device, zero=True)
-        call("interp_bwd", ptr(g), _ld(g), ptr(nbr), ptr(w), n, k, c, ptr(dx), _ld(dx))
-        return dx, None, None
+        if inv:
+            dx = _rows(ctx.m, c, g.device)
+            call("interp_bwd_gather", ptr(g), _ld(g), *(ptr(t) for t in inv), ctx.m, c, ptr(dx), _ld(dx))
+        else:
+            dx = _rows(ctx.m, c, g.device, zero=True)
+            call("interp_bwd", ptr(g), _ld(g), ptr(nbr), ptr(w), n, k, c, ptr(dx), _ld(dx))
+        return dx, None, None, None
 
 
 def knn_interpolate_1D(x, idx, pos_y, topo_y, k):
     """ref point_ops.py:344-355."""
     nbr, w = knn_1d_group_superset_dense(pos_y, idx, topo_y, k)
-    return CurveInterp.apply(x, nbr, w)
+    return CurveInterp.apply(x, nbr, w, interp_inverse(nbr, w, x.size(0)) if x.requires_grad else None)
 
 
 # --------------------------------------------------------------------------------------
@@ -1240,7 +1266,7 @@ def knn_points_packed(pos_q, topo_q, pos_s, topo_s, k):
 def knn_interpolate(x, pos_x, pos_y, topo_x, topo_y, k=3):
     """ref point_ops.py:293-341 knn_interpolate_pytorch3d (inverse squared distance, exact kNN)."""
     nbr, w = knn_points_packed(pos_y, topo_y, pos_x, topo_x, k)
-    return CurveInterp.apply(x, nbr, w)
+    return CurveInterp.apply(x, nbr, w, interp_inverse(nbr, w, x.size(0)) if x.requires_grad else None)
 
 
 def voxel_fps(pos, batch, voxel_size, rnd=None):

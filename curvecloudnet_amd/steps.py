@@ -461,10 +461,11 @@ class FPModule(nn.Module):
         topo_x = _topology(batch, point2curveidx, kwargs, curves=False)
         topo_y = _topology(batch_skip, point2curveidx_skip, kwargs, curves=False)
         nbr, w = ops.knn_points_packed(pos_skip, topo_y, pos, topo_x, self.k)
-        return SimpleNamespace(nbr=nbr, w=w, out=(pos_skip, batch_skip, point2curveidx_skip))
+        return SimpleNamespace(nbr=nbr, w=w, inv=ops.interp_inverse(nbr, w, pos.size(0)),
+                               out=(pos_skip, batch_skip, point2curveidx_skip))
 
     def features(self, x, x_skip, g):
-        x = ops.CurveInterp.apply(x, g.nbr, g.w)
+        x = ops.CurveInterp.apply(x, g.nbr, g.w, g.inv)
         return self.nn(_fp_concat(x, x_skip, g.out[0], self.with_xyz))
 
     def forward(self, x, pos, batch, x_skip, pos_skip, batch_skip, point2curveidx=None, point2curveidx_skip=None,
@@ -480,7 +481,8 @@ class CurveFPModule(FPModule):
     def geometry(self, idx, pos_skip, batch_skip, point2curveidx_skip, kwargs):
         topo = _topology(batch_skip, point2curveidx_skip, kwargs)
         nbr, w = ops.knn_1d_group_superset_dense(pos_skip, idx, topo, self.k)
-        return SimpleNamespace(nbr=nbr, w=w, out=(pos_skip, batch_skip, point2curveidx_skip))
+        return SimpleNamespace(nbr=nbr, w=w, inv=ops.interp_inverse(nbr, w, idx.numel()),
+                               out=(pos_skip, batch_skip, point2curveidx_skip))
 
     def forward(self, x, idx, x_skip, pos_skip, batch_skip, point2curveidx_skip=None, **kwargs):
         with _geometry(kwargs) as geo:

@@ -112,6 +112,16 @@ int ccn_interp_fwd(const float* x, int64_t ldx, const int64_t* nbr, const float*
                    int64_t C, float* y, int64_t ldy, void* stream);
 int ccn_interp_bwd(const float* dy, int64_t lddy, const int64_t* nbr, const float* weight, int64_t n, int64_t k,
                    int64_t C, float* dx, int64_t lddx, void* stream);
+/* Backward of the interpolations without atomics (knn_interpolate_1D_pytorch3d / knn_interpolate_pytorch3d,
+ * src/models/utils/point_ops.py:344-355, 293-341: the autograd of their scatter_add over (y_idx, x_idx)): ccn_interp_inverse
+ * turns the (n, k) neighbour table into per-coarse-row lists (inv_ptr int32[M+1], inv_src int32[n*k], inv_w float[n*k], sorted by
+ * fine row; den float[n] = the weight sum of every fine row), ccn_interp_bwd_gather sums dX[m] = sum_e dY[src_e] / den[src_e] *
+ * w_e in list order: deterministic.  Workspace: ccn_interp_inverse_workspace_bytes(M). */
+size_t ccn_interp_inverse_workspace_bytes(int64_t M);
+int ccn_interp_inverse(const int64_t* nbr, const float* weight, int64_t n, int64_t k, int64_t M, int32_t* inv_ptr,
+                       int32_t* inv_src, float* inv_w, float* den, void* ws, size_t ws_bytes, void* stream);
+int ccn_interp_bwd_gather(const float* dy, int64_t lddy, const int32_t* inv_ptr, const int32_t* inv_src, const float* inv_w,
+                          const float* den, int64_t M, int64_t C, float* dx, int64_t lddx, void* stream);
 
 /* Symmetric curve convolution on the zero-separated V2 sequence (fast_conv1d.py:60-73) for layers with many more input
  * than output channels, as "product first, shift-add second": P = X W_all^T (W_all: taps*C_out x C_in, one GEMM) and

@@ -249,6 +249,36 @@ def test_curve_interpolate_golden(case):
     _close(gx, t(g[case + ".interp_grad_x"]), 5e-5, "interp grad")
 
 
+def test_interp_backward_gather_matches_scatter():
+    """The inverse-list gather and the atomic scatter are the same sum in a different order; the gather is deterministic."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(5)
+    n, m, k, c = 50_000, 9_000, 3, 96
+    nbr = torch.randint(0, m - 50, (n, k), generator=gen)              # the last 50 coarse rows are read by nobody
+    nbr[torch.rand(n, generator=gen) < 0.1, 2] = -1                  # short lists, as at curve ends
+    nbr[:7] = -1                                                    # rows with no neighbour at all
+    w = torch.rand(n, k, generator=gen) + 0.05
+    x = torch.randn(m, c, generator=gen)
+    cot = torch.randn(n, c, generator=gen)
+    nbr, w, cot = nbr.to(DEV), w.to(DEV), cot.to(DEV)
+    grads = []
+    for gather in (True, False, True):
+        xd = x.to(DEV).requires_grad_(True)
+        inv = ops.interp_inverse(nbr, w, m) if gather else None
+        assert (inv is not None) == gather
+        y = ops.CurveInterp.apply(xd, nbr, w, inv)
+        grads.append(torch.autograd.grad((y * cot).sum(), xd)[0])
+    assert torch.equal(grads[0], grads[2]), "gather backward is not deterministic"
+    _close(grads[0], grads[1], 2e-5, "gather vs scatter")
+    valid = (nbr >= 0).cpu()
+    wv = torch.where(valid, w.cpu(), torch.zeros(()))
+    coef = (wv / wv.sum(1, keepdim=True).clamp_min(1e-30)).double()
+    ref = torch.zeros(m, c, dtype=torch.float64)
+    for s_ in range(k):
+        ref.index_add_(0, nbr[:, s_].clamp_min(0).cpu(), coef[:, s_:s_ + 1] * cot.cpu().double())
+    _close(grads[0], ref.float(), 2e-5, "gather vs fp64 index_add")
+
+
 # ---------------------------------------------------------------- A13-A15: step modules vs the oracle modules
 def _pair(make_ref, make_mine):
     torch.manual_seed(1)

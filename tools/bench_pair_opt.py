@@ -23,14 +23,15 @@ def timeit(fn, n=8):
     return b.elapsed_time(e) / n
 
 
-print("%-26s %s   (TFLOP/s, with BN statistics / without)" % ("M x N x K", "  ".join("opt=%d      " % o for o in range(4))))
+OPTS = [int(a, 0) for a in sys.argv[1:]] or list(range(4))
+print("%-26s %s   (TFLOP/s, with BN statistics / without)" % ("M x N x K", "  ".join("opt=%-7d" % o for o in OPTS)))
 for m, n, k in SHAPES:
     x = _rows(m, k, dev); x.normal_(); w = _rows(n, k, dev, zero=True); w.normal_(); w.mul_(0.05)
     y = _rows(m, n, dev)
     stats = torch.empty((lib().ccn_stats_rows(m) + 1) * 2 * n, dtype=torch.float64, device=dev)
     ref = None
     row = []
-    for opt in range(4):
+    for opt in OPTS:
         lib().ccn_gemm_pair_opt(opt)
         t1 = min(timeit(lambda: call("gemm_nt", ptr(x), _ld(x), ptr(w), _ld(w), None, ptr(y), _ld(y), m, n, k, ptr(stats)))
                  for _ in range(2))
