@@ -416,6 +416,10 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if os.environ.get("CCN_BENCH_ATEN_TABLE") == "1":           # diagnostics: who issues torch-side device ops in a step
+        from tools.aten_callers import table
+        table(step)
+        return
     if not args.no_kernel_timing:
         # inside the timed region only the GEMM launches (the dominant kernel family) are bracketed by HIP events: an
         # event pair costs ~3 us of GPU time, which over all ~2300 launches of a step would be 4 % of the step

@@ -461,6 +461,84 @@ int ccn_nll_loss_bwd(const float* logits, int64_t ld, const int64_t* target, con
 int ccn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int64_t step, void* stream);
 
+/* ================================================================================================================
+ * The entry points SURVEY.md section 8(b) lists as the minimum C-ABI of the hot path (ccn_contract.hip).  Each is a FIXED
+ * composition of the kernels declared above, for a host that does not want to sequence them itself; the Python mirror
+ * calls the pieces directly because it interleaves them with autograd bookkeeping and a second stream.  Section 8(b)
+ * name -> export:
+ *   ccn_segment_ptr                       as above (A1/A2)              ccn_curve_fps              as above (A7)
+ *   ccn_frnn_grid_build / ccn_frnn_query  as above (A11)                ccn_curve_group_superset   as above (A9)
+ *   ccn_curve_group_subset                two phases, the host allocates E edges in between: _count then _fill (A8)
+ *   ccn_bn_act_fwd                        as above
+ *   ccn_curve_conv_{fwd,bwd_data,bwd_weight}, ccn_bn_act_bwd, ccn_linear_bn_act_{fwd,bwd}, ccn_gather_edge_{fwd,bwd},
+ *   ccn_edge_reduce_{max,attend}_{fwd,bwd}                              below
+ * ================================================================================================================ */
+#define CCN_DTYPE_F32 0   /* v_mfma_f32_32x32x2_f32 products */
+#define CCN_DTYPE_BF16 1  /* operands rounded to bf16 inside the kernel, fp32 accumulate (BASELINE configs[2]) */
+#define CCN_DTYPE_F16 2   /* forward products in fp16, gradients in bf16 (BASELINE configs[4]) */
+
+/* F.conv1d(input (1, C_in, L), weight, bias, stride 1, 'same') at src/models/modules/fast_conv1d.py:183 and its autograd, on the
+ * reference's zero-separated row sequence (fast_conv1d.py:48-61 V2, :115-126 V1) stored as (L + 2h) x ld floats, h = taps / 2
+ * zero halo rows on both ends, ld % 4 == 0, padding columns zero.  `seq` / `dYseq` point at the FIRST HALO ROW.
+ *   fwd        : Y (L x C_out) = conv(seq) + b, W in (C_out, taps, ld) [tap][channel] order (ldw >= taps * ld); colstats (nullable)
+ *                receives the BatchNorm partial sums of Y exactly as ccn_gemm_nt does
+ *   bwd_data   : dX (L x C_in) from dYseq ((L + 2h) x lddy, halo rows zero) and the SAME forward weight W (row stride taps * ld_in);
+ *                workspace holds the tap-reversed transpose
+ *   bwd_weight : dW (C_out x taps*ld) += dY^T shifted(seq); dY points at its row 0 (no halo needed) */
+int ccn_curve_conv_fwd(const float* seq, int64_t ld, int64_t rows, int64_t taps, const float* W, int64_t ldw, const float* bias,
+                       int64_t Cout, float* Y, int64_t ldy, double* colstats, void* stream);
+size_t ccn_curve_conv_bwd_data_workspace_bytes(int64_t Cin, int64_t taps, int64_t lddy);
+int ccn_curve_conv_bwd_data(const float* dYseq, int64_t lddy, int64_t rows, int64_t taps, const float* W, int64_t ld_in,
+                            int64_t Cout, int64_t Cin, float* dX, int64_t lddx, void* workspace, size_t workspace_bytes,
+                            void* stream);
+size_t ccn_curve_conv_bwd_weight_workspace_bytes(int64_t rows, int64_t Cout, int64_t taps, int64_t ld);
+int ccn_curve_conv_bwd_weight(const float* dY, int64_t lddy, const float* seq, int64_t ld, int64_t rows, int64_t taps,
+                              int64_t Cout, float* dW, int64_t lddw, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of z = act(BatchNorm(y)) (fast_conv1d.py:72-73, 141-143; the norm + act of torch_geometric.nn.MLP, base.py:90-125):
+ * params = the 4 x C table (scale, shift, mean, rstd) the forward produced; training != 0: batch statistics (the two column
+ * sums are taken first, then dY, dgamma, dbeta in one pass); dY may alias dZ. */
+size_t ccn_bn_act_bwd_workspace_bytes(int64_t rows, int64_t C);
+int ccn_bn_act_bwd(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C, const float* params,
+                   int act, float slope, int training, float* dY, int64_t lddy, float* dgamma, float* dbeta, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* One hidden layer of torch_geometric.nn.MLP as the reference builds it (src/models/base.py:32,64,90-125, mlp.py:13):
+ * Z = act(BatchNorm1d(X W^T + b)); gamma == NULL: the plain last Linear (Y only).  fwd keeps Y (pre-normalisation product)
+ * and params (4 x N: scale, shift, mean, rstd) for bwd and updates the running statistics when training.  bwd: dY (M x N)
+ * receives the gradient of the product; dX / dW / dbias may be NULL; dW is ACCUMULATED INTO (a gradient bucket), dbias,
+ * dgamma, dbeta are overwritten.  One workspace size serves both. */
+size_t ccn_linear_bn_act_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int ccn_linear_bn_act_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, int64_t M, int64_t N, int64_t K, float eps,
+                          float momentum, int training, int act, float slope, int dtype, float* Y, int64_t ldy, float* Z,
+                          int64_t ldz, float* params, void* workspace, size_t workspace_bytes, void* stream);
+int ccn_linear_bn_act_bwd(const float* dZ, int64_t lddz, const float* X, int64_t ldx, const float* W, int64_t ldw, const float* Y,
+                          int64_t ldy, const float* params, int64_t M, int64_t N, int64_t K, int training, int act, float slope,
+                          int dtype, float* dY, int64_t lddy, float* dX, int64_t lddx, float* dW, int64_t lddw, float* dbias,
+                          float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* frnn.frnn_gather(x, idxs, lengths) and its gradient (src/models/modules/dgcnn.py:172), literally: feat[(b, i, s), :] =
+ * x[cloud_ptr[b] + idx[b, i, s], :] over the PACKED x (N x C), zero where idx < 0 (which includes the rows past a cloud's
+ * length); bwd adds into dx, which must be zero on entry.  (The SGCNN steps do not go through it: ccn_sg_* / ccn_cg_* fold the
+ * gather into the first layer.) */
+int ccn_gather_edge_fwd(const float* x, int64_t ldx, const int64_t* idx, const int64_t* cloud_ptr, int64_t B, int64_t Nmax,
+                        int64_t K, int64_t C, float* feat, int64_t ldf, void* stream);
+int ccn_gather_edge_bwd(const float* dfeat, int64_t lddf, const int64_t* idx, const int64_t* cloud_ptr, int64_t B, int64_t Nmax,
+                        int64_t K, int64_t C, float* dx, int64_t lddx, void* stream);
+/* Aggregation of the messages of an edge list sorted by destination (offsets int32[M + 1]): max (scatter_max,
+ * src/models/modules/point_conv.py:80-81) = ccn_seg_max_*, attend (softmax over the destination's edges times the message,
+ * summed: point_conv.py:89-92) = ccn_seg_softmax_agg_*. */
+int ccn_edge_reduce_max_fwd(const float* msg, int64_t ldm, const int32_t* offsets, int64_t M, int64_t C, float* out, int64_t ldo,
+                            int32_t* arg, void* stream);
+int ccn_edge_reduce_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const int32_t* offsets, int64_t M, int64_t C,
+                            float* dmsg, int64_t lddm, void* stream);
+int ccn_edge_reduce_attend_fwd(const float* msg, int64_t ldm, const float* att, int64_t lda, const int32_t* offsets, int64_t M,
+                               int64_t C, float* out, int64_t ldo, void* stream);
+int ccn_edge_reduce_attend_bwd(const float* msg, int64_t ldm, const float* att, int64_t lda, const int32_t* offsets, int64_t M,
+                               int64_t C, const float* dout, int64_t lddo, float* dmsg, int64_t lddm, float* datt, int64_t ldda,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,24 @@ for s_, e_, name in iv[1:]:
         gaps_main.append((cur_e, s_, name))
     cur_e = max(cur_e, e_)
 tot_gap = sum(b - a for a, b, _ in gaps_main)
+# who sits on either side of the feature queue's gaps
+pair = defaultdict(lambda: [0, 0])
+cur_e, cur_name = iv[0][1], iv[0][2]
+for s_, e_, name in iv[1:]:
+    if s_ > cur_e:
+        k = (cur_name[:48], name[:48])
+        pair[k][0] += s_ - cur_e
+        pair[k][1] += 1
+    if e_ >= cur_e:
+        cur_e, cur_name = e_, name
+print("feature-queue gaps by (kernel before -> kernel after):")
+for (a_, b_), (tot_, cnt_) in sorted(pair.items(), key=lambda kv: -kv[1][0])[:30]:
+    print("  %8.2f ms %5d x  %s -> %s" % (tot_ / 1e6, cnt_, a_, b_))
+sizes = [0, 0, 0, 0]
+for a_, b_, _ in gaps_main:
+    g_ = b_ - a_
+    sizes[0 if g_ < 5e3 else 1 if g_ < 5e4 else 2 if g_ < 5e5 else 3] += g_
+print("feature-queue idle by gap size: <5us %.1f ms, 5-50us %.1f ms, 50-500us %.1f ms, >500us %.1f ms" % tuple(b_ / 1e6 for b_ in sizes))
 print("feature queue %s: idle %.1f ms of %.1f ms window (%d gaps)" % (main_q, tot_gap / 1e6, span / 1e6, len(gaps_main)))
 others = sorted((s_, e_, name) for q in by_q if q != main_q for s_, e_, name in by_q[q])
 blame = defaultdict(float)
@@ -75,3 +93,37 @@ for a, b, nxt in gaps_main:
 print("kernels on the other queues running during feature-queue gaps > 20 us:")
 for name, t_ in sorted(blame.items(), key=lambda kv: -kv[1])[:15]:
     print("  %8.2f ms  %s" % (t_ / 1e6, name))
+
+# ---- timeline of the last large feature-queue gap: everything that runs on any queue from 2 ms before it to its end
+big = [g for g in gaps_main if g[1] - g[0] > 2e6]
+if big:
+    a, b, nxt = big[-1]
+    print("timeline around the last feature-queue gap > 2 ms (%.2f ms, before %s); times in ms relative to the gap start:"
+          % ((b - a) / 1e6, nxt[:40]))
+    for s_, e_, name, q in rows:
+        if e_ >= a - 2e6 and s_ <= b + 2e5:
+            print("  q%-2s %9.3f .. %9.3f  %s" % (q, (s_ - a) / 1e6, (e_ - a) / 1e6, name[:90]))
+
+# ---- coarse timeline of the last full step (between the last two optimizer launches): per queue, runs of kernels whose
+# gaps are below 150 us, with the first and last kernel of each run
+adams = [s_ for s_, e_, name, q in rows if "adam_kernel" in name]
+marks = [adams[0]] if adams else []
+for t_ in adams[1:]:
+    if t_ - marks[-1] > 20e6:
+        marks.append(t_)
+if len(marks) >= 2:
+    lo_, hi_ = marks[-2], marks[-1]
+    print("coarse timeline of the last step (%.1f ms between optimizer launches), ms from the first:" % ((hi_ - lo_) / 1e6))
+    for q in sorted(by_q):
+        runs = []
+        for s_, e_, name in sorted(by_q[q]):
+            if e_ < lo_ or s_ > hi_:
+                continue
+            if runs and s_ - runs[-1][1] < 150e3:
+                runs[-1][1] = max(runs[-1][1], e_)
+                runs[-1][3] = name
+                runs[-1][4] += 1
+            else:
+                runs.append([s_, e_, name, name, 1])
+        for s_, e_, first, last, cnt in runs:
+            print("  q%-2s %8.2f .. %8.2f  %5d kernels  %s ... %s" % (q, (s_ - lo_) / 1e6, (e_ - lo_) / 1e6, cnt, first[:40], last[:40]))
