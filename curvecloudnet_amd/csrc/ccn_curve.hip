@@ -267,6 +267,27 @@ __global__ void scatter_rows_kernel(const float* __restrict__ src, int64_t lds_,
     *p = v;
 }
 
+// scatter of the rows of a matrix into a LONGER zero-separated sequence whose target rows are strictly ascending (the curve
+// convolutions' layout): one pass writes EVERY row of the destination -- row index[i] <- src row i (columns >= C zero), the
+// rows between index[i-1] and index[i] (before index[0], after index[m-1]) zero -- instead of a memset of the whole
+// sequence followed by the scatter.  One source row per wave.
+__global__ __launch_bounds__(256) void scatter_rows_fill_kernel(const float* __restrict__ src, int64_t lds_,
+                                                                const int64_t* __restrict__ index, int64_t m, int64_t C,
+                                                                float* __restrict__ dst, int64_t ldd, int64_t total,
+                                                                int64_t row_offset) {
+  const int cx = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= m) return;
+  const int64_t at = index[i] + row_offset;
+  const int64_t lo = i == 0 ? 0 : index[i - 1] + row_offset + 1;
+  const int64_t hi = i == m - 1 ? total : at + 1;
+  for (int64_t c = cx; c < ldd; c += 64) {
+    for (int64_t r = lo; r < at; ++r) dst[r * ldd + c] = 0.f;
+    dst[at * ldd + c] = c < C ? src[i * lds_ + c] : 0.f;
+    for (int64_t r = at + 1; r < hi; ++r) dst[r * ldd + c] = 0.f;
+  }
+}
+
 // ------------------------------------------------------------------ shared curve helpers
 // NB: sqrtf() is correctly rounded on gfx950 (hipcc default); the __fsqrt_rn intrinsic is NOT (measured: 15% of
 // inputs differ from IEEE by one ulp), which flips arclength buckets.
@@ -822,6 +843,16 @@ int ccn_scatter_rows(const float* src, int64_t lds_, const int64_t* index, int64
   hipLaunchKernelGGL(scatter_rows_kernel, dim3(ccn_blocks(m * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, src, lds_,
                      index, m, C, dst, ldd, accumulate);
   CCN_LAUNCH_OK("scatter_rows");
+  return CCN_OK;
+}
+
+int ccn_scatter_rows_fill(const float* src, int64_t lds_, const int64_t* index, int64_t m, int64_t C, float* dst, int64_t ldd,
+                          int64_t total_rows, int64_t row_offset, void* stream) {
+  CCN_REQUIRE(src && index && dst && lds_ >= C && ldd >= C && m > 0 && total_rows >= m + row_offset && row_offset >= 0,
+              "scatter_rows_fill: bad arguments");
+  hipLaunchKernelGGL(scatter_rows_fill_kernel, dim3(ccn_blocks(m, 4)), dim3(256), 0, (hipStream_t)stream, src, lds_, index, m, C,
+                     dst, ldd, total_rows, row_offset);
+  CCN_LAUNCH_OK("scatter_rows_fill");
   return CCN_OK;
 }
 

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(TPB) void cg_edge_apply_kernel(
   }
 }
 
-// dPS must be zero on entry.  dS[p] is owned by point p (plain store), dP[src] is accumulated atomically.
+// dS[p] is owned by point p (plain store), dP[src] is accumulated atomically (the entry point zeroes that half).
 __global__ __launch_bounds__(TPB) void cg_edge_bwd_kernel(
     const float* __restrict__ ps, int64_t ldps, const int32_t* __restrict__ grp_ptr, const int32_t* __restrict__ row_src,
     const int32_t* __restrict__ rep_row, const float* __restrict__ row_w, int64_t N, int64_t E, int Co,
@@ -758,7 +758,8 @@ __global__ __launch_bounds__(TPB) void pn_edge_apply_kernel(
 }
 
 // dPX must be zero on entry (atomic accumulation per source point).  Each wave walks `per_wave` consecutive edges
-// and keeps the sums dWp[c][0..2] = sum dy*rel, dbias[c] = sum dy in registers; wpart: [gridDim.x*4][4][Co] doubles.
+// and keeps the sums dWp[c][0..2] = sum dy*rel, dbias[c] = sum dy in registers; wpart: [gridDim.x*4][4][Co] doubles,
+// every row written (no initialisation needed).
 __global__ __launch_bounds__(TPB) void pn_edge_bwd_kernel(
     const float* __restrict__ px, int64_t ldpx, const float* __restrict__ wp, int64_t ldwp,
     const float* __restrict__ bias, const float* __restrict__ pos_src, const float* __restrict__ pos_dst,
@@ -770,7 +771,10 @@ __global__ __launch_bounds__(TPB) void pn_edge_bwd_kernel(
   CCN_LANES;
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + ry;
   const int64_t first = wave_id * per_wave;
-  if (first >= E) return;  // wpart is zero-initialised by the caller
+  if (first >= E) {  // a wave without edges still owns a row of partial sums
+    for (int c = cx; c < 4 * Co; c += 64) wpart[wave_id * 4 * Co + c] = 0.0;
+    return;
+  }
   const int64_t last = first + per_wave < E ? first + per_wave : E;
   const float inv_n = 1.0f / (float)E;
   for (int c0 = 0; c0 < Co; c0 += 64) {
@@ -1448,6 +1452,9 @@ int ccn_cg_edge_bwd(const float* ps, int64_t ldps, const int32_t* grp_ptr, const
   CCN_REQUIRE(ps && grp_ptr && row_src && rep_row && row_w && dZ && dps && N > 0 && CCN_SMALL_INT(Co) && ldps >= 2 * Co &&
                   lddz >= Co && lddps >= 2 * Co && count > 0,
               "cg_edge_bwd: bad arguments");
+  // dP (the left half of every row) is accumulated atomically: zeroed here; dS (right half) is stored by its owner
+  CCN_HIP(hipMemset2DAsync(dps, (size_t)lddps * sizeof(float), 0, (size_t)Co * sizeof(float), (size_t)N, (hipStream_t)stream),
+          "cg_edge_bwd");
   hipLaunchKernelGGL(cg_edge_bwd_kernel, dim3(row_blocks(N)), dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr,
                      row_src, rep_row, row_w, N, E, (int)Co, dZ, lddz, scale, shift, mean, rstd, act, slope, sums, count,
                      training, dps, lddps);

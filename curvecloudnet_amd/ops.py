@@ -68,18 +68,19 @@ def _rows(rows, cols, device, zero=False):
     return buf if ld == cols else buf[:, :cols]
 
 
-def _rows_halo(rows, cols, h, device):
+def _rows_halo(rows, cols, h, device, init=True):
     """(rows, cols) matrix for the implicit-GEMM curve convolution (ccn_conv_rows_*): ``h`` zeroed halo rows in front of and
     behind it in the same allocation, the leading dimension padded with ZERO columns to a multiple of 4 (to a multiple of 32
     from 64 channels on, so that taps * ld is a whole number of 32-deep GEMM slices).  The buffer is remembered on the view
     (``_ccn_halo``): a consumer that does not find it makes its own halo copy."""
     ld = (cols + 31) // 32 * 32 if cols >= 64 else (cols + 3) // 4 * 4
     buf = torch.empty((rows + 2 * h, ld), dtype=torch.float32, device=device)
-    if h:
-        buf[:h].zero_()
-        buf[rows + h:].zero_()
-    if ld != cols:
-        buf[:, cols:].zero_()
+    if init:
+        if h:
+            buf[:h].zero_()
+            buf[rows + h:].zero_()
+        if ld != cols:
+            buf[:, cols:].zero_()
     view = buf[h:h + rows, :cols]
     view._ccn_halo = (buf, h)
     return view
@@ -199,40 +200,52 @@ def curveidx_local2global(point2curveidx, batch):
 
 class GatherRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, index, unique):
+    def forward(ctx, src, index, unique, ascending=False):
         src, index = _mat(src), _i64(index)
         out = _rows(index.numel(), src.size(1), src.device)
         call("gather_rows", ptr(src), _ld(src), ptr(index), index.numel(), src.size(1), ptr(out), _ld(out))
         ctx.save_for_backward(index)
-        ctx.rows, ctx.unique = src.size(0), unique
+        ctx.rows, ctx.unique, ctx.ascending = src.size(0), unique, ascending
         return out
 
     @staticmethod
     def backward(ctx, g):
         (index,) = ctx.saved_tensors
         g = _mat(g)
+        if ctx.ascending and index.numel():
+            dsrc = _rows(ctx.rows, g.size(1), g.device)          # every row written: no memset of the sequence
+            call("scatter_rows_fill", ptr(g), _ld(g), ptr(index), index.numel(), g.size(1), ptr(dsrc), _ld(dsrc), ctx.rows, 0)
+            return dsrc, None, None, None
         dsrc = _rows(ctx.rows, g.size(1), g.device, zero=True)
         call("scatter_rows", ptr(g), _ld(g), ptr(index), index.numel(), g.size(1), ptr(dsrc), _ld(dsrc),
              0 if ctx.unique else 1)
-        return dsrc, None, None
+        return dsrc, None, None, None
 
 
-def gather_rows(src, index, unique=True):
-    return GatherRows.apply(src, index, unique)
+def gather_rows(src, index, unique=True, ascending=False):
+    """``ascending``: the index is strictly increasing (the curve sequences): the backward pass writes its zero rows itself."""
+    return GatherRows.apply(src, index, unique, ascending)
 
 
 class ScatterRows(torch.autograd.Function):
-    """out = zeros(rows, C); out[index] = src  (index entries unique)."""
+    """out = zeros(rows, C); out[index] = src  (index entries unique; ``ascending``: strictly increasing, one pass writes
+    the zero rows, the halo and the padding columns too)."""
 
     @staticmethod
-    def forward(ctx, src, index, rows, halo=0):
+    def forward(ctx, src, index, rows, halo=0, ascending=False):
         src, index = _mat(src), _i64(index)
-        if halo:
-            out = _rows_halo(rows, src.size(1), halo, src.device)
-            out.zero_()
+        if ascending and index.numel():
+            out = _rows_halo(rows, src.size(1), halo, src.device, init=False) if halo else _rows(rows, src.size(1), src.device)
+            buf = out._ccn_halo[0] if halo else out
+            call("scatter_rows_fill", ptr(src), _ld(src), ptr(index), index.numel(), src.size(1), ptr(buf), buf.stride(0),
+                 buf.size(0), halo)
         else:
-            out = _rows(rows, src.size(1), src.device, zero=True)
-        call("scatter_rows", ptr(src), _ld(src), ptr(index), index.numel(), src.size(1), ptr(out), _ld(out), 0)
+            if halo:
+                out = _rows_halo(rows, src.size(1), halo, src.device)
+                out.zero_()
+            else:
+                out = _rows(rows, src.size(1), src.device, zero=True)
+            call("scatter_rows", ptr(src), _ld(src), ptr(index), index.numel(), src.size(1), ptr(out), _ld(out), 0)
         ctx.save_for_backward(index)
         return out
 
@@ -242,7 +255,7 @@ class ScatterRows(torch.autograd.Function):
         g = _mat(g)
         d = _rows(index.numel(), g.size(1), g.device)
         call("gather_rows", ptr(g), _ld(g), ptr(index), index.numel(), g.size(1), ptr(d), _ld(d))
-        return d, None, None, None
+        return d, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------
@@ -1436,7 +1449,7 @@ class PNEdgeLayer(torch.autograd.Function):
             dbeta, dgamma = sums[:co].float(), sums[co:].float()
         dpx = _rows(px.size(0), co, dev, zero=True)
         nw = lib().ccn_pn_edge_bwd_rows(e)
-        wpart = torch.zeros((nw + 1) * 4 * co, dtype=torch.float64, device=dev)
+        wpart = torch.empty((nw + 1) * 4 * co, dtype=torch.float64, device=dev)       # every partial row is written
         call("pn_edge_bwd", ptr(px), _ld(px), ptr(wp), _ld(wp), bias_p, *geo, ptr(g), _ld(g), *pp, ctx.act, LEAKY_SLOPE,
              ptr(sums) if sums is not None else None, 1 if (ctx.training and ctx.has_bn) else 0, ptr(dpx), _ld(dpx),
              ptr(wpart))
@@ -1564,7 +1577,9 @@ class CGEdgeLayer(torch.autograd.Function):
             sums = partial[nparts * 2 * co:]
             call("reduce_partials", ptr(partial), nparts, 2 * co, ptr(sums))
             dbeta, dgamma = sums[:co].float(), sums[co:].float()
-        dps = _rows(ps.size(0), 2 * co, dev, zero=True)
+        dps = _rows(ps.size(0), 2 * co, dev)        # (the entry point zeroes the half it accumulates into)
+        if ps.size(0) > n:
+            dps[n:].zero_()
         call("cg_edge_bwd", ptr(ps), _ld(ps), *idx, ptr(row_w), n, e, co, ptr(g), _ld(g), *pp, ctx.act, LEAKY_SLOPE,
              ptr(sums) if sums is not None else None, float(count), 1 if (ctx.training and ctx.has_bn) else 0, ptr(dps),
              _ld(dps))

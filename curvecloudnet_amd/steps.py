@@ -228,7 +228,7 @@ class SymmetricCurve1DConvFastV1(nn.Module):
             # implicit-GEMM form: every layer runs on the zero-separated sequence (one scatter in, one gather out); the
             # separators are excluded from the BatchNorm and re-zeroed after every layer (ops.ConvRowsBNAct, quirk Q1)
             h = self.kernel_size // 2
-            seq = ops.ScatterRows.apply(x, g.rows, g.n_rows, h)
+            seq = ops.ScatterRows.apply(x, g.rows, g.n_rows, h, True)
             if ops.ACT_TRACE is not None:       # test hook: sign tables on the N real rows, as the reference has them
                 ops.ACT_ROW_MAP = g.rows
             try:
@@ -239,7 +239,7 @@ class SymmetricCurve1DConvFastV1(nn.Module):
                                                  self.kernel_size, g.sep)
             finally:
                 ops.ACT_ROW_MAP = None
-            return ops.gather_rows(seq, g.rows)
+            return ops.gather_rows(seq, g.rows, ascending=True)
         for conv, norm in zip(self.conv_modules, self.norm_modules):
             if self.with_diff:
                 x = ops.DiffConcat.apply(x, g.topo.cid)
@@ -276,7 +276,7 @@ class SymmetricCurve1DConvV2(nn.Module):
         if self.with_diff:
             x = ops.DiffConcat.apply(x, g.topo.cid)
         if _conv_implicit() and self.kernel_size > 1:
-            seq = ops.ScatterRows.apply(x, g.rows, g.n_rows, self.kernel_size // 2)
+            seq = ops.ScatterRows.apply(x, g.rows, g.n_rows, self.kernel_size // 2, True)
             for conv, norm in zip(self.conv_modules, self.norm_modules):
                 if seq.size(1) >= 2 * conv.out_channels and seq.size(1) > 64 and CONV_SHIFT_ADD:
                     # many more input than output channels (262 -> 32): product first, shift-add second
@@ -285,11 +285,11 @@ class SymmetricCurve1DConvV2(nn.Module):
                 else:
                     seq = ops.conv_rows_implicit(seq, conv.gemm_weight(), conv.bias, norm, self.training, "leaky_relu",
                                                  self.kernel_size)
-            return ops.gather_rows(seq, g.rows)
-        seq = ops.ScatterRows.apply(x, g.rows, g.n_rows)
+            return ops.gather_rows(seq, g.rows, ascending=True)
+        seq = ops.ScatterRows.apply(x, g.rows, g.n_rows, 0, True)
         for conv, norm in zip(self.conv_modules, self.norm_modules):
             seq = _conv_bn_act(seq, None, self.kernel_size, conv, norm, self.training)
-        return ops.gather_rows(seq, g.rows)
+        return ops.gather_rows(seq, g.rows, ascending=True)
 
     def forward(self, x, pos, batch, point2curveidx, **kwargs):
         with _geometry(kwargs) as geo:

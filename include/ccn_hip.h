@@ -84,6 +84,12 @@ int ccn_gather_rows(const float* src, int64_t lds, const int64_t* index, int64_t
                     int64_t ldd, void* stream);
 int ccn_scatter_rows(const float* src, int64_t lds, const int64_t* index, int64_t m, int64_t C, float* dst,
                      int64_t ldd, int accumulate, void* stream);
+/* ccn_scatter_rows into an all-zero destination in ONE pass, for a strictly ascending index (the zero-separated sequences of
+ * fast_conv1d.py:48-61 / :115-126 and the adjoint of their gather, :67-74 / :136-143): writes every one of the total_rows x ldd
+ * floats of dst -- row index[i] + row_offset <- src row i with the columns C..ldd-1 zero, every other row zero (row_offset:
+ * leading halo rows of the destination buffer). */
+int ccn_scatter_rows_fill(const float* src, int64_t lds, const int64_t* index, int64_t m, int64_t C, float* dst, int64_t ldd,
+                          int64_t total_rows, int64_t row_offset, void* stream);
 
 /* ---- A7: src/models/modules/fps_ops.py:16-39 CurveFPS -------------------------------------------
  * u is the reference's torch.rand(1) draw.  idx_out: capacity n (sorted point indices), count_out: device int64. */

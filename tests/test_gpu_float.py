@@ -249,6 +249,37 @@ def test_curve_interpolate_golden(case):
     _close(gx, t(g[case + ".interp_grad_x"]), 5e-5, "interp grad")
 
 
+@pytest.mark.parametrize("halo,c", [(0, 32), (2, 131), (3, 64), (2, 5)])
+def test_scatter_gather_rows_one_pass_fill(halo, c):
+    """The ascending-index form writes the zero rows, the halo and the padding columns in the same pass as the rows: the
+    whole buffer must equal the memset + scatter form, forward and backward."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(c)
+    n = 7000
+    gaps = torch.randint(0, 4, (n,), generator=gen)
+    gaps[0] = 3                                                       # zero rows before the first row
+    index = (torch.arange(n) + gaps.cumsum(0)).to(DEV)
+    rows = int(index[-1]) + 4                                         # ... and after the last
+    x = torch.randn(n, c, generator=gen).to(DEV)
+    outs = []
+    for asc in (False, True):
+        xa = x.clone().requires_grad_(True)
+        seq = ops.ScatterRows.apply(xa, index, rows, halo, asc)
+        buf = seq._ccn_halo[0] if halo else seq
+        if not halo and buf.stride(0) != c:                           # padding columns of the plain buffer: not part of the contract
+            buf = buf[:, :c]
+        back = ops.gather_rows(seq * 2.0, index, ascending=asc)
+        cot = torch.randn(n, c, generator=torch.Generator().manual_seed(1)).to(DEV)
+        (gx,) = torch.autograd.grad((back * cot).sum(), xa)
+        outs.append((buf.clone(), back.detach(), gx))
+    for a, b_, what in zip(outs[0], outs[1], ("sequence buffer", "gather", "gradient")):
+        assert torch.equal(a, b_), what
+    ref = torch.zeros(rows, c, device=DEV)
+    ref[index] = x
+    view = outs[1][0][halo:halo + rows, :c] if halo else outs[1][0][:, :c]
+    assert torch.equal(view, ref)
+
+
 def test_interp_backward_gather_matches_scatter():
     """The inverse-list gather and the atomic scatter are the same sum in a different order; the gather is deterministic."""
     ops = _ops()
