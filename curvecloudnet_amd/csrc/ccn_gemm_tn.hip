@@ -287,10 +287,24 @@ struct TnPlan {
   bool xcd;
 };
 
-inline int pick_tile(int64_t d) {   // 128 unless the last 128-wide tile would be at most half used
+// Tile choice (A/B hook ccn_gemm_tn_use_dma(2 + mode)).  mode 2 (default): an output dimension d > 128 whose last 128-wide
+// tile would be at most half used is SPLIT into d - d % 128 columns on 128-wide tiles and a remainder launch on 64-wide tiles
+// (192 = 128 + 64, 259 = 256 + 3): the 128 x 128 tile runs at ~116 TFLOP/s, anything with a 64-wide side at 60-98, and a
+// remainder launch only costs another pass over the operands (measured, M = 1.34 M: 256 x 192 67 -> 99 TFLOP/s, 192 x 128
+// 69 -> 90; 208 k x 256 x 259: 58 -> 94).  mode 0: 64-wide tiles over the whole dimension in that case (the r2a rule);
+// mode 1: 128-wide tiles whenever d > 64.
+static int g_tn_pick = 2;
+
+inline int pick_tile(int64_t d) {
   if (d <= 64) return 64;
+  if (g_tn_pick == 1) return 128;
   const int64_t rem = d % 128;
   return (rem == 0 || rem > 64) ? 128 : 64;
+}
+
+// [0, main) on the plan's tiles, [main, d) as a second launch (0: none)
+inline int64_t tn_main_part(int64_t d) {
+  return (g_tn_pick == 2 && d > 128 && d % 128 != 0 && d % 128 <= 64) ? d / 128 * 128 : d;
 }
 
 inline TnPlan tn_plan(int64_t M, int64_t N, int64_t K) {
@@ -342,8 +356,9 @@ static bool g_tn_dma = true;   // A/B hook (ccn_gemm_tn_use_dma)
 
 extern "C" {
 
-int ccn_gemm_tn_use_dma(int on) {
-  g_tn_dma = on != 0;
+int ccn_gemm_tn_use_dma(int on) {   // 0 / 1: the register-staged / LDS-DMA kernels; 2 + mode: tile choice A/B (pick_tile)
+  if (on >= 2) g_tn_pick = on - 2;
+  else g_tn_dma = on != 0;
   return CCN_OK;
 }
 
@@ -356,18 +371,24 @@ static bool tn_dma_ok(const float* dY, int64_t lddy, const float* X, int64_t ldx
 
 size_t ccn_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N < 32 || K < 32 || M < 1024 || !g_tn_dma) return 0;
-  return (size_t)tn_plan(M, N, K).slab_floats * sizeof(float);
+  const int64_t nm = tn_main_part(N), km = tn_main_part(K);
+  int64_t most = 0;
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const int64_t n = a ? N - nm : nm, k = b ? K - km : km;
+      if (n <= 0 || k <= 0) continue;
+      const int64_t f = tn_plan(M, n, k).slab_floats;
+      most = f > most ? f : most;
+    }
+  return (size_t)most * sizeof(float);
 }
 
 int ccn_gemm_tn_generic(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
                         int64_t N, int64_t K, int overlap, void* stream);
 
-static int tn_ws_impl(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
-                      int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream, bool overlap) {
-  hipStream_t s = (hipStream_t)stream;
-  if (M == 0) return CCN_OK;
-  if (!tn_dma_ok(dY, lddy, X, ldx, M, N, K))
-    return ccn_gemm_tn_generic(dY, lddy, X, ldx, dW, lddw, M, N, K, overlap ? 1 : 0, stream);
+// one launch (+ its slab reduction) of the LDS-DMA kernel over an N x K block of the output
+static int tn_launch_block(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                           int64_t N, int64_t K, void* workspace, size_t workspace_bytes, hipStream_t s, int64_t ext) {
   const TnPlan p = tn_plan(M, N, K);
   float* slabs = nullptr;
   if (p.slab_floats > 0 && workspace != nullptr) {
@@ -376,17 +397,30 @@ static int tn_ws_impl(const float* dY, int64_t lddy, const float* X, int64_t ldx
                 (size_t)p.slab_floats * sizeof(float));
     slabs = (float*)workspace;
   }
+  if (p.tn == 128 && p.tk == 128) return launch_tn<128, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
+  if (p.tn == 128) return launch_tn<128, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
+  if (p.tk == 128) return launch_tn<64, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
+  return launch_tn<64, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
+}
+
+static int tn_ws_impl(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                      int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream, bool overlap) {
+  hipStream_t s = (hipStream_t)stream;
+  if (M == 0) return CCN_OK;
+  if (!tn_dma_ok(dY, lddy, X, ldx, M, N, K))
+    return ccn_gemm_tn_generic(dY, lddy, X, ldx, dW, lddw, M, N, K, overlap ? 1 : 0, stream);
   const int64_t ext = overlap ? K : ldx;
-  int rc;
-  if (p.tn == 128 && p.tk == 128)
-    rc = launch_tn<128, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
-  else if (p.tn == 128)
-    rc = launch_tn<128, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
-  else if (p.tk == 128)
-    rc = launch_tn<64, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
-  else
-    rc = launch_tn<64, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
-  if (rc) return rc;
+  // up to 2 x 2 blocks, launched back to back on the stream (they share the slab scratch in stream order): multiples of
+  // 128 columns keep every block's operand pointers 16-byte aligned
+  const int64_t nm = tn_main_part(N), km = tn_main_part(K);
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const int64_t n0 = a ? nm : 0, n = a ? N - nm : nm, k0 = b ? km : 0, k = b ? K - km : km;
+      if (n <= 0 || k <= 0) continue;
+      const int rc = tn_launch_block(dY + n0, lddy, X + k0, ldx, dW + n0 * lddw + k0, lddw, M, n, k, workspace,
+                                     workspace_bytes, s, ext - k0);
+      if (rc) return rc;
+    }
   CCN_LAUNCH_OK("gemm_tn_ws");
   return CCN_OK;
 }
