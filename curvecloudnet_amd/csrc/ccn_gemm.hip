@@ -1891,6 +1891,17 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* W, int64_t ldw
   // (K % 32 != 0 -- the widths made by the +3 xyz concat: 259, 262, 515, 1027, 2051 -- is handled inside the kernel)
   if (base_ok && N > 64 && g_use_persistent && g_use_pair &&
       ((M + PR_BM - 1) / PR_BM) * ((N + PR_BN - 1) / PR_BN) >= PAIR_MIN_TILES) {
+    // The last 128-wide column tile at most half used (N = 192, 259, 262: a quarter to a third of the launch's MFMA work
+    // would be on padding): the first N - N % 128 columns here, the remainder as a second product on the 64-wide kernels
+    // (another pass over A, ~0.3 ms at 1.3 M x 256).  Not with BatchNorm statistics (their partial rows are laid out by N).
+    const int64_t n_main = N / PR_BN * PR_BN;
+    if ((g_pair_opt & 64) == 0 && colstats == nullptr && N > PR_BN && N % PR_BN != 0 && N % PR_BN <= 64 &&
+        ((M + PR_BM - 1) / PR_BM) * (n_main / PR_BN) >= PAIR_MIN_TILES) {
+      rc = launch_glds_pair(A, lda, W, ldw, bias, Y, ldy, M, n_main, K, nullptr, s, overlap ? K : lda);
+      if (rc) return rc;
+      return gemm_nt_impl(A, lda, W + n_main * ldw, ldw, bias ? bias + n_main : nullptr, Y + n_main, ldy, M, N - n_main, K,
+                          nullptr, stream, overlap);
+    }
     rc = launch_glds_pair(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s, overlap ? K : lda);
     if (rc) return rc;
     CCN_LAUNCH_OK("gemm_nt");
