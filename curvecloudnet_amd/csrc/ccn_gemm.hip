@@ -1620,41 +1620,54 @@ __global__ __launch_bounds__(256) void col_slice_kernel(double* __restrict__ par
   if (ry == 0 && w < width && p0 < nparts) partial[p0 * width + w] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
 }
 
+// sum of the slice heads of one column: 4 waves x strided heads, 8 loads in flight per lane (the heads were written by other
+// XCDs: every load is an L2 miss), combined in a fixed order
+__device__ __forceinline__ double col_heads_sum(const double* __restrict__ partial, int64_t nslices, int64_t per_slice,
+                                                int64_t width, int64_t w, bool live, double (*red)[64]) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (live)
+    for (int64_t p0 = ry; p0 < nslices; p0 += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t p = p0 + 4 * u;
+        acc[u] += p < nslices ? partial[p * per_slice * width + w] : 0.0;
+      }
+    }
+  red[ry][cx] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+  __syncthreads();
+  const double total = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+  __syncthreads();
+  return total;
+}
+
 __global__ __launch_bounds__(256) void col_final_kernel(const double* __restrict__ partial, int64_t nslices,
                                                         int64_t per_slice, int64_t width, double* __restrict__ sums) {
   __shared__ double red[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int64_t w = (int64_t)blockIdx.x * 64 + cx;
-  double s = 0.0;
-  if (w < width)
-    for (int64_t p = ry; p < nslices; p += 4) s += partial[p * per_slice * width + w];
-  red[ry][cx] = s;
-  __syncthreads();
-  if (ry == 0 && w < width) sums[w] = red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx];
+  const int64_t w = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const double total = col_heads_sum(partial, nslices, per_slice, width, w, w < width, red);
+  if ((threadIdx.x >> 6) == 0 && w < width) sums[w] = total;
 }
 
-void launch_col_reduce(double* partial, int64_t nparts, int64_t width, double* sums, hipStream_t s) {
-  int64_t nslices = (nparts + 7) / 8;
-  if (nslices > 256) nslices = 256;
-  if (nslices < 1) nslices = 1;
-  const int64_t per_slice = (nparts + nslices - 1) / nslices;
-  nslices = (nparts + per_slice - 1) / per_slice;
-  const unsigned gx = (unsigned)ccn_blocks(width, 64);
-  if (per_slice > 1)
-    hipLaunchKernelGGL(col_slice_kernel, dim3(gx, (unsigned)nslices), dim3(256), 0, s, partial, nparts, width, per_slice);
-  hipLaunchKernelGGL(col_final_kernel, dim3(gx), dim3(256), 0, s, partial, nslices, per_slice, width, sums);
-}
-
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t rows, int64_t C,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
-                                   float* __restrict__ save_rstd) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// the same for a table of [sum | sum of squares] (width = 2 C) with the BatchNorm finalisation of ccn_bn_finalize fused in:
+// one workgroup per 64 channels reduces both halves and writes scale / shift / mean / rstd and the running statistics
+__global__ __launch_bounds__(256) void col_final_bn_kernel(const double* __restrict__ partial, int64_t nslices,
+                                                           int64_t per_slice, int64_t rows, int64_t C,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float eps, float momentum, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float* __restrict__ scale,
+                                                           float* __restrict__ shift, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_rstd, double* __restrict__ sums) {
+  __shared__ double red[4][64];
+  const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const double s1 = col_heads_sum(partial, nslices, per_slice, 2 * C, c, c < C, red);
+  const double s2 = col_heads_sum(partial, nslices, per_slice, 2 * C, C + c, c < C, red);
+  if ((threadIdx.x >> 6) != 0 || c >= C) return;
+  sums[c] = s1;
+  sums[C + c] = s2;
   const double n = (double)rows;
-  const double mean = sums[c] / n;
-  double var = sums[C + c] / n - mean * mean;
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -1668,6 +1681,38 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t rows
     const double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
+}
+
+struct ColSlices {
+  int64_t nslices, per_slice;
+};
+
+// level 1 of the reduction (in place, into the first row of every slice); at most 64 slices, so that level 2 is short
+ColSlices launch_col_slices(double* partial, int64_t nparts, int64_t width, hipStream_t s) {
+  int64_t nslices = (nparts + 7) / 8;
+  if (nslices > 64) nslices = 64;
+  if (nslices < 1) nslices = 1;
+  const int64_t per_slice = (nparts + nslices - 1) / nslices;
+  nslices = (nparts + per_slice - 1) / per_slice;
+  if (per_slice > 1)
+    hipLaunchKernelGGL(col_slice_kernel, dim3((unsigned)ccn_blocks(width, 64), (unsigned)nslices), dim3(256), 0, s, partial,
+                       nparts, width, per_slice);
+  return ColSlices{nslices, per_slice};
+}
+
+void launch_col_reduce(double* partial, int64_t nparts, int64_t width, double* sums, hipStream_t s) {
+  const ColSlices cs = launch_col_slices(partial, nparts, width, s);
+  hipLaunchKernelGGL(col_final_kernel, dim3((unsigned)ccn_blocks(width, 64)), dim3(256), 0, s, partial, cs.nslices,
+                     cs.per_slice, width, sums);
+}
+
+void launch_bn_finalize(double* partial, int64_t nparts, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
+                        float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* save_mean,
+                        float* save_rstd, hipStream_t s) {
+  const ColSlices cs = launch_col_slices(partial, nparts, 2 * C, s);
+  hipLaunchKernelGGL(col_final_bn_kernel, dim3((unsigned)ccn_blocks(C, 64)), dim3(256), 0, s, partial, cs.nslices, cs.per_slice,
+                     rows, C, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_rstd,
+                     partial + nparts * 2 * C);
 }
 
 __global__ void bn_eval_params_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -2027,10 +2072,8 @@ int ccn_bn_finalize(const double* colstats, int64_t rows, int64_t C, const float
   hipStream_t s = (hipStream_t)stream;
   CCN_REQUIRE(colstats && scale && shift && save_mean && save_rstd && rows > 0 && C > 0, "bn_finalize: bad arguments");
   const int64_t nparts = ccn_stats_rows(rows);
-  double* sums = const_cast<double*>(colstats) + nparts * 2 * C;
-  launch_col_reduce(const_cast<double*>(colstats), nparts, 2 * C, sums, s);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ccn_blocks(C, 128)), dim3(128), 0, s, sums, rows, C, gamma, beta, eps,
-                     momentum, running_mean, running_var, scale, shift, save_mean, save_rstd);
+  launch_bn_finalize(const_cast<double*>(colstats), nparts, rows, C, gamma, beta, eps, momentum, running_mean, running_var,
+                     scale, shift, save_mean, save_rstd, s);      // (the totals land behind the partial rows, as before)
   CCN_LAUNCH_OK("bn_finalize");
   return CCN_OK;
 }
@@ -2041,10 +2084,8 @@ int ccn_bn_finalize_n(const double* partial, int64_t nparts, int64_t rows, int64
   hipStream_t s = (hipStream_t)stream;
   CCN_REQUIRE(partial && scale && shift && save_mean && save_rstd && rows > 0 && C > 0 && nparts > 0,
               "bn_finalize_n: bad arguments");
-  double* sums = const_cast<double*>(partial) + nparts * 2 * C;
-  launch_col_reduce(const_cast<double*>(partial), nparts, 2 * C, sums, s);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ccn_blocks(C, 128)), dim3(128), 0, s, sums, rows, C, gamma, beta, eps,
-                     momentum, running_mean, running_var, scale, shift, save_mean, save_rstd);
+  launch_bn_finalize(const_cast<double*>(partial), nparts, rows, C, gamma, beta, eps, momentum, running_mean, running_var,
+                     scale, shift, save_mean, save_rstd, s);
   CCN_LAUNCH_OK("bn_finalize_n");
   return CCN_OK;
 }
