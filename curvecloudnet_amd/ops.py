@@ -1377,7 +1377,8 @@ class SGEdgeLayer(torch.autograd.Function):
                  *pp, ctx.act, LEAKY_SLOPE, ptr(partial))
             sums = partial[nparts * 2 * co:]
             call("reduce_partials", ptr(partial), nparts, 2 * co, ptr(sums))
-            dbeta, dgamma = sums[:co].float(), sums[co:].float()
+            dgb = sums[:2 * co].float()                   # one conversion, two views
+            dbeta, dgamma = dgb[:co], dgb[co:]
         dps = _rows(ps.size(0), 2 * co, dev, zero=True)
         call("sg_edge_bwd", ptr(ps), _ld(ps), None, ptr(nbr), ptr(cloud_ptr), b, nmax, k, co, ptr(g), _ld(g), *pp,
              ctx.act, LEAKY_SLOPE, ptr(sums) if sums is not None else None, 1 if ctx.training else 0, ptr(dps), _ld(dps))
@@ -1446,7 +1447,8 @@ class PNEdgeLayer(torch.autograd.Function):
                  LEAKY_SLOPE, ptr(partial))
             sums = partial[nparts * 2 * co:]
             call("reduce_partials", ptr(partial), nparts, 2 * co, ptr(sums))
-            dbeta, dgamma = sums[:co].float(), sums[co:].float()
+            dgb = sums[:2 * co].float()                   # one conversion, two views
+            dbeta, dgamma = dgb[:co], dgb[co:]
         dpx = _rows(px.size(0), co, dev, zero=True)
         nw = lib().ccn_pn_edge_bwd_rows(e)
         wpart = torch.empty((nw + 1) * 4 * co, dtype=torch.float64, device=dev)       # every partial row is written
@@ -1576,7 +1578,8 @@ class CGEdgeLayer(torch.autograd.Function):
                  LEAKY_SLOPE, ptr(partial))
             sums = partial[nparts * 2 * co:]
             call("reduce_partials", ptr(partial), nparts, 2 * co, ptr(sums))
-            dbeta, dgamma = sums[:co].float(), sums[co:].float()
+            dgb = sums[:2 * co].float()                   # one conversion, two views
+            dbeta, dgamma = dgb[:co], dgb[co:]
         dps = _rows(ps.size(0), 2 * co, dev)        # (the entry point zeroes the half it accumulates into)
         if ps.size(0) > n:
             dps[n:].zero_()
