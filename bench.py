@@ -35,8 +35,8 @@ def gemm_label(name, ints, nulls=()):
     ld_a, ld_b, _, m, n, k = ints[:6]
     flops = 2.0 * m * n * k
     if name == "gemm_tn_ws":
-        def tile(d):
-            return 64 if (d <= 64 or 0 < d % 128 <= 64) else 128
+        def tile(d):        # (a small remainder over 128 goes to a second, 64-wide launch: the label is the main one's)
+            return 64 if d <= 64 else 128
         if ld_a % 4 == 0 and ld_b % 4 == 0 and n > 32 and k > 32 and m >= 1024:
             split = min(max(1, (512 + ((n + tile(n) - 1) // tile(n)) * ((k + tile(k) - 1) // tile(k)) - 1)
                             // (((n + tile(n) - 1) // tile(n)) * ((k + tile(k) - 1) // tile(k)))), max(1, (m + 31) // 32 // 4))
@@ -83,8 +83,9 @@ def pmc_traffic(kernel):
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc*.json")), reverse=True):
         table = json.load(open(path))
-        for name, t in table.items():
-            if kernel + "(" in name:
+        hits = [(name, t) for name, t in table.items() if kernel + "(" in name or kernel + "<" in name]
+        for name, t in sorted(hits, key=lambda kv: -kv[1]["launches"])[:1]:      # (template variants: the most launched)
+            if True:
                 out = {"bytes_per_launch": t["fetch_bytes_per_launch_corrected"] + t["write_bytes_per_launch"],
                        "source": os.path.relpath(path, ROOT), "launches_profiled": t["launches"]}
                 for k in ("mfma_pipe_utilisation", "effective_clock_ghz"):
@@ -421,9 +422,27 @@ def main():
         table(step)
         return
     if not args.no_kernel_timing:
-        # inside the timed region only the GEMM launches (the dominant kernel family) are bracketed by HIP events: an
-        # event pair costs ~3 us of GPU time, which over all ~2300 launches of a step would be 4 % of the step
-        _lib.PROFILE, _lib.PROFILE_ONLY = [], "gemm_"
+        # inside the timed region only the launches of the DOMINANT kernel are bracketed by HIP events (on the stream they
+        # run on): an event pair costs ~3 us of GPU time -- over all ~2300 launches of a step 4 % of the step, over every
+        # GEMM launch of both streams, or over all ~130 launches of the dominant kernel, still ~1 % (70.8 vs 71.5 clouds/s)
+        dominant = {"fp32": "gemm_glds_pair_kernel", "bf16": "gemm_bf16_kernel<128, 128", "fp16": "gemm_bf16_kernel<128, 128",
+                    "bf16x3": "gemm_x3_pair_kernel"}[args.mlp_dtype]
+
+        seen = [0]
+
+        def only_dominant(name, cargs):
+            # ... and of those every eighth one (133 launch sites per step, 133 mod 8 = 5: the phase moves on each step and
+            # eight steps visit every site once): flops and time are summed over the SAME sampled launches.  A timing
+            # event is a system-scope release on this runtime (~10 us of GPU time each): every launch of the kernel
+            # bracketed costs 1 % of the step, every third 0.8 %, every eighth 0.1 %
+            label = gemm_label(name, tuple(a for a in cargs if isinstance(a, int)),
+                               tuple(i for i, a in enumerate(cargs) if a is None))[0]
+            if label is None or not label.startswith(dominant):
+                return False
+            seen[0] += 1
+            return seen[0] % 8 == 0
+
+        _lib.PROFILE, _lib.PROFILE_ONLY, _lib.PROFILE_FILTER = [], "gemm_", only_dominant
     ref_event = torch.cuda.Event(enable_timing=True)
     ref_event.record()
     mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
@@ -433,7 +452,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     device_mallocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - mallocs0
-    records, _lib.PROFILE, _lib.PROFILE_ONLY = _lib.PROFILE, None, None
+    records, _lib.PROFILE, _lib.PROFILE_ONLY, _lib.PROFILE_FILTER = _lib.PROFILE, None, None, None
     full_records = None
     if records is not None and world == 1:
         # every launch, two extra steps OUTSIDE the timed region: the complete per-kernel table
@@ -470,11 +489,11 @@ def main():
                    "loss": float(loss.detach())},
     }
     if records:
-        rows, _ = summarise_profile(records, args.steps, write_shapes=True)
+        rows, _ = summarise_profile(records, args.steps, write_shapes=not full_records)
         name, top = rows[0]
         table_rows, total_ms, table_steps = rows, sum(t["ms"] for _, t in rows), args.steps
         if full_records:
-            table_rows, total_ms = summarise_profile(full_records, 2, write_shapes=False)
+            table_rows, total_ms = summarise_profile(full_records, 2, write_shapes=True)
             table_steps = 2
         full_share = dict(table_rows).get(name, {"ms": 0.0})["ms"] / total_ms if total_ms else None
         if top["flops"] > 0:
@@ -488,11 +507,14 @@ def main():
                                   "traffic": tr["bytes_per_launch"] if tr else None, "traffic_source": tr,
                                   "flops_per_launch": top["flops"] / top["launches"],
                                   "kernel": name, "avg_launch_ms": top["ms"] / top["launches"],
-                                  "launches": top["launches"], "share_of_kernel_time": full_share}
+                                  "launches": top["launches"], "share_of_kernel_time": full_share,
+                                  "launches_note": "every eighth launch of this kernel inside the timed region is bracketed by "
+                                                   "HIP events (sampling keeps the events' own cost out of `value`)"}
             # The GEMM launches run on two streams (weight-gradient products overlap the rest of the backward pass), so a
             # launch's own duration includes the time it shares the chip.  All GEMM launches together: flops over the
             # UNION of their execution intervals = the MFMA throughput the step actually gets out of the chip.
-            spans = sorted((ref_event.elapsed_time(r[2]), ref_event.elapsed_time(r[3])) for r in records
+            fam_records, fam_steps = (full_records, 2) if full_records else (records, args.steps)
+            spans = sorted((ref_event.elapsed_time(r[2]), ref_event.elapsed_time(r[3])) for r in fam_records
                            if r[0].startswith("gemm_"))
             busy, cur_s, cur_e = 0.0, spans[0][0], spans[0][1]
             for s_, e_ in spans[1:]:
@@ -502,7 +524,7 @@ def main():
                 else:
                     cur_e = max(cur_e, e_)
             busy += cur_e - cur_s
-            fam_flops = sum(gemm_label(r[0], r[1], r[4])[1] for r in records)
+            fam_flops = sum(gemm_label(r[0], r[1], r[4])[1] for r in fam_records)
             fam = fam_flops / (busy * 1e-3) / 1e12
             if world == 1 and os.environ.get("CCN_WGRAD_STREAM", "1") != "0":
                 result["roofline"]["note"] = ("launch durations include the time this kernel shares the chip with the "
@@ -510,8 +532,9 @@ def main():
                                               "(CCN_WGRAD_STREAM=0, step ~5 % slower) and stand-alone: "
                                               "profiles/r02*_kitti_bench_nows.json, DESIGN.md section 5")
             result["roofline"]["all_gemm_launches"] = {
-                "achieved": fam, "frac": fam / peak, "busy_ms_per_step": busy / args.steps,
-                "note": "flops of every GEMM launch / union of their execution intervals (two streams overlap)"}
+                "achieved": fam, "frac": fam / peak, "busy_ms_per_step": busy / fam_steps,
+                "note": "flops of every GEMM launch / union of their execution intervals (two streams overlap)"
+                        + ("; from the 2 fully instrumented steps after the timed region" if full_records else "")}
         else:
             result["roofline"] = {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
                                   "traffic": None, "kernel": name, "avg_launch_ms": top["ms"] / top["launches"],
@@ -520,7 +543,7 @@ def main():
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "bench_kernels.txt"), "w") as f:
             f.write("per-kernel time (HIP events on the launch stream), %d steps%s\n"
-                    % (table_steps, " after the timed region (inside it only the GEMM launches are timed)" if full_records else ""))
+                    % (table_steps, " after the timed region (inside it only the dominant kernel's launches are timed)" if full_records else ""))
             for k, t in table_rows:
                 tf = " %7.1f TFLOP/s" % (t["flops"] / (t["ms"] * 1e-3) / 1e12) if t["flops"] else ""
                 f.write("%9.2f ms %5.1f%% %6d launches  %s%s\n" % (t["ms"], 100 * t["ms"] / total_ms, t["launches"], k, tf))

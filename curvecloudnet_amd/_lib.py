@@ -86,12 +86,14 @@ def check(rc, what):
 
 PROFILE = None          # bench.py sets this to a list to time launches with HIP events on the launch stream
 PROFILE_ONLY = None     # optional name prefix: only these entry points are timed (events cost ~1.5 us each on the GPU)
+PROFILE_FILTER = None   # optional predicate(name, args): only the launches it accepts are timed
 
 
 def call(name, *args):
     """Invoke ``ccn_<name>`` on the current torch stream (appended as the last argument)."""
     fn = getattr(lib(), "ccn_" + name)
-    if PROFILE is None or (PROFILE_ONLY is not None and not name.startswith(PROFILE_ONLY)):
+    if (PROFILE is None or (PROFILE_ONLY is not None and not name.startswith(PROFILE_ONLY))
+            or (PROFILE_FILTER is not None and not PROFILE_FILTER(name, args))):
         check(fn(*args, stream()), name)
         return
     # torch.cuda.Event records on torch's current stream, which is exactly the stream passed to the kernel
