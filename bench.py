@@ -373,6 +373,17 @@ def main():
         return
 
     staged = {"plan": None}
+    if os.environ.get("CCN_BENCH_EXTRA_LAUNCH"):        # experiment: what one more tiny kernel per library call costs
+        _one = torch.zeros(4, device=dev)
+        _idx = torch.zeros(1, dtype=torch.int64, device=dev)
+        _out = torch.zeros(4, device=dev)
+        _fn = _lib.lib().ccn_gather_rows
+        _reps = int(os.environ["CCN_BENCH_EXTRA_LAUNCH"])
+
+        def _extra():
+            for _ in range(_reps):
+                _fn(_lib.ptr(_one), 4, _lib.ptr(_idx), 1, 1, _lib.ptr(_out), 4, _lib.stream())
+        _lib.EXTRA_LAUNCH = _extra
 
     debug = os.environ.get("CCN_BENCH_DEBUG") == "1"
 

@@ -89,9 +89,14 @@ PROFILE_ONLY = None     # optional name prefix: only these entry points are time
 PROFILE_FILTER = None   # optional predicate(name, args): only the launches it accepts are timed
 
 
+EXTRA_LAUNCH = None     # experiment (tools/launch_cost.py): a callable launching one trivial kernel after every call
+
+
 def call(name, *args):
     """Invoke ``ccn_<name>`` on the current torch stream (appended as the last argument)."""
     fn = getattr(lib(), "ccn_" + name)
+    if EXTRA_LAUNCH is not None:
+        EXTRA_LAUNCH()
     if (PROFILE is None or (PROFILE_ONLY is not None and not name.startswith(PROFILE_ONLY))
             or (PROFILE_FILTER is not None and not PROFILE_FILTER(name, args))):
         check(fn(*args, stream()), name)

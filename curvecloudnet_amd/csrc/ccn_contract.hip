@@ -91,6 +91,15 @@ int gemm_nt_dtype(int dtype, const float* A, int64_t lda, const float* W, int64_
 
 
 
+// ------------------------------------------------------------------ weight transpose for the data-gradient product
+int ccn_transpose_pad(const float* W, int64_t ldw, int64_t N, int64_t K, float* Wt, int64_t ldt, void* stream) {
+  CCN_REQUIRE(W && Wt && N > 0 && K > 0 && ldw >= K && ldt >= N, "transpose_pad: bad arguments");
+  hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((ldt + 31) / 32), (unsigned)((K + 31) / 32)), dim3(256), 0,
+                     (hipStream_t)stream, W, ldw, N, K, Wt, ldt);
+  CCN_LAUNCH_OK("transpose_pad");
+  return CCN_OK;
+}
+
 // ------------------------------------------------------------------ curve convolution
 int ccn_curve_conv_fwd(const float* seq, int64_t ld, int64_t rows, int64_t taps, const float* W, int64_t ldw, const float* bias,
                        int64_t Cout, float* Y, int64_t ldy, double* colstats, void* stream) {
@@ -202,9 +211,8 @@ int ccn_linear_bn_act_bwd(const float* dZ, int64_t lddz, const float* X, int64_t
   }
   if (dX != nullptr) {
     // dX = g W as an NT product with W^T (K x N): both operands stream along their contiguous index
-    hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((N + 31) / 32), (unsigned)((K + 31) / 32)), dim3(256), 0,
-                       (hipStream_t)stream, W, ldw, N, K, Wt, ldt);
-    CCN_LAUNCH_OK("linear_bn_act_bwd");
+    rc = ccn_transpose_pad(W, ldw, N, K, Wt, ldt, stream);
+    if (rc) return rc;
     rc = gemm_nt_dtype(dtype == CCN_DTYPE_F16 ? CCN_DTYPE_BF16 : dtype, g, ldg, Wt, ldt, nullptr, dX, lddx, M, K, N, nullptr, stream);
     if (rc) return rc;
   }

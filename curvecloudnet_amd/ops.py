@@ -339,6 +339,14 @@ def _aligned_weight(weight):
     return wp
 
 
+def _transposed(w, n, k):
+    """(k, n) transpose of the (n, >= k) weight ``w`` in an aligned-row buffer, padding columns zero (LDS-tiled kernel: the
+    strided torch copy it replaces read the weight uncoalesced, 9 us on average over the 79 layers of the KITTI network)."""
+    wt = _rows(k, n, w.device)
+    call("transpose_pad", ptr(w), _ld(w), n, k, ptr(wt), _ld(wt))
+    return wt
+
+
 _MLP_DTYPE = os.environ.get("CCN_MLP_DTYPE", "fp32")
 
 
@@ -708,8 +716,7 @@ class LinearBNAct(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # dX = dY W as an "NT" product with W^T (k x n): both operands then stream along their contiguous
             # index, which is the fastest tile layout (the weight transpose is a few KB..MB)
-            wt = _rows(k, n, dev, zero=(n % 4 != 0))
-            wt.copy_(w[:, :k].t())
+            wt = _transposed(w, n, k)
             if ctx.gemm_nt != "gemm_nt":
                 dy = _aligned_rows(dy)
             sink = _grad_sink_take(x, m, k) if ctx.gemm_nt == "gemm_nt" else None
@@ -1666,8 +1673,7 @@ class LinearBNActTail(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _rows(m, k, dev)
-            wtt = _rows(k, n, dev, zero=(n % 4 != 0))
-            wtt.copy_(wt[:, :k].t())
+            wtt = _transposed(wt, n, k)
             _gemm_nt(_GEMM_BWD[ctx.gemm_nt], dy, wtt, None, dx, m, k, n, None)
         into = _main_grad(ctx.main_grad_of, n, k)
         if into is None and ctx.main_grad_of is not None:

@@ -483,6 +483,10 @@ int ccn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 #define CCN_DTYPE_BF16 1  /* operands rounded to bf16 inside the kernel, fp32 accumulate (BASELINE configs[2]) */
 #define CCN_DTYPE_F16 2   /* forward products in fp16, gradients in bf16 (BASELINE configs[4]) */
 
+/* Wt (K x ldt) = W (N x K, row stride ldw) transposed, columns N..ldt-1 zero: the operand of the data-gradient product
+ * dX = dY W written as an NT product (autograd of F.linear in torch_geometric.nn.MLP, src/models/base.py:90-125). */
+int ccn_transpose_pad(const float* W, int64_t ldw, int64_t N, int64_t K, float* Wt, int64_t ldt, void* stream);
+
 /* F.conv1d(input (1, C_in, L), weight, bias, stride 1, 'same') at src/models/modules/fast_conv1d.py:183 and its autograd, on the
  * reference's zero-separated row sequence (fast_conv1d.py:48-61 V2, :115-126 V1) stored as (L + 2h) x ld floats, h = taps / 2
  * zero halo rows on both ends, ld % 4 == 0, padding columns zero.  `seq` / `dYseq` point at the FIRST HALO ROW.
