@@ -261,8 +261,10 @@ def self_launch(args):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=16)       # (a multiple of 8: every launch site of the dominant kernel is timed equally often)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--event-stride", type=int, default=8,
+                    help="inside the timed region every n-th launch of the dominant kernel is bracketed by HIP events")
     ap.add_argument("--baseline-config", type=int, choices=sorted(BASELINE_PRESETS), default=None,
                     help="set --config / --clouds-per-gpu / --curves / --mixed-lengths / --mlp-dtype to BASELINE.json "
                          "configs[i] (explicit flags given alongside still win)")
@@ -387,7 +389,10 @@ def main():
 
     debug = os.environ.get("CCN_BENCH_DEBUG") == "1"
 
+    site = [0, 0]          # [launch sites of the dominant kernel seen in this step, steps started]
+
     def step():
+        site[0], site[1] = 0, site[1] + 1
         marks = [time.perf_counter()]
         sync.zero_grad()
         plan = staged["plan"]
@@ -439,19 +444,21 @@ def main():
         dominant = {"fp32": "gemm_glds_pair_kernel", "bf16": "gemm_bf16_kernel<128, 128", "fp16": "gemm_bf16_kernel<128, 128",
                     "bf16x3": "gemm_x3_pair_kernel"}[args.mlp_dtype]
 
-        seen = [0]
-
         def only_dominant(name, cargs):
-            # ... and of those every eighth one (133 launch sites per step, 133 mod 8 = 5: the phase moves on each step and
-            # eight steps visit every site once): flops and time are summed over the SAME sampled launches.  A timing
+            # ... and of those every eighth one, the phase moving on by one launch site each step (eight steps visit
+            # every site exactly once, the default 16 steps twice): flops and time are summed over the SAME sampled
+            # launches.  A timing
             # event is a system-scope release on this runtime (~10 us of GPU time each): every launch of the kernel
             # bracketed costs 1 % of the step, every third 0.8 %, every eighth 0.1 %
             label = gemm_label(name, tuple(a for a in cargs if isinstance(a, int)),
                                tuple(i for i, a in enumerate(cargs) if a is None))[0]
             if label is None or not label.startswith(dominant):
                 return False
-            seen[0] += 1
-            return seen[0] % 8 == 0
+            ints = [a for a in cargs if isinstance(a, int)]
+            if (name == "gemm_nt" and len(ints) >= 6 and ints[4] > 128 and 0 < ints[4] % 128 <= 64 and cargs[-1] is None):
+                return False      # this call also launches a 64-wide remainder product (ccn_gemm.hip): not one kernel
+            site[0] += 1
+            return (site[0] + site[1]) % args.event_stride == 0
 
         _lib.PROFILE, _lib.PROFILE_ONLY, _lib.PROFILE_FILTER = [], "gemm_", only_dominant
     ref_event = torch.cuda.Event(enable_timing=True)
