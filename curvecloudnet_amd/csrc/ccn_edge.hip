@@ -1452,9 +1452,10 @@ int ccn_cg_edge_bwd(const float* ps, int64_t ldps, const int32_t* grp_ptr, const
   CCN_REQUIRE(ps && grp_ptr && row_src && rep_row && row_w && dZ && dps && N > 0 && CCN_SMALL_INT(Co) && ldps >= 2 * Co &&
                   lddz >= Co && lddps >= 2 * Co && count > 0,
               "cg_edge_bwd: bad arguments");
-  // dP (the left half of every row) is accumulated atomically: zeroed here; dS (right half) is stored by its owner
-  CCN_HIP(hipMemset2DAsync(dps, (size_t)lddps * sizeof(float), 0, (size_t)Co * sizeof(float), (size_t)N, (hipStream_t)stream),
-          "cg_edge_bwd");
+  // dP (the left half of every row) is accumulated atomically and must start from zero; dS (right half) is stored by its
+  // owner.  One linear memset of the whole table: the 2-D fill of the left half alone (hipMemset2DAsync) measured 73 us
+  // against ~45 us for twice the bytes in one run.
+  CCN_HIP(hipMemsetAsync(dps, 0, (size_t)N * (size_t)lddps * sizeof(float), (hipStream_t)stream), "cg_edge_bwd");
   hipLaunchKernelGGL(cg_edge_bwd_kernel, dim3(row_blocks(N)), dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr,
                      row_src, rep_row, row_w, N, E, (int)Co, dZ, lddz, scale, shift, mean, rstd, act, slope, sums, count,
                      training, dps, lddps);

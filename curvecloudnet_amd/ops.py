@@ -1587,7 +1587,7 @@ class CGEdgeLayer(torch.autograd.Function):
             call("reduce_partials", ptr(partial), nparts, 2 * co, ptr(sums))
             dgb = sums[:2 * co].float()                   # one conversion, two views
             dbeta, dgamma = dgb[:co], dgb[co:]
-        dps = _rows(ps.size(0), 2 * co, dev)        # (the entry point zeroes the half it accumulates into)
+        dps = _rows(ps.size(0), 2 * co, dev)        # (the entry point zeroes the table it accumulates into)
         if ps.size(0) > n:
             dps[n:].zero_()
         call("cg_edge_bwd", ptr(ps), _ld(ps), *idx, ptr(row_w), n, e, co, ptr(g), _ld(g), *pp, ctx.act, LEAKY_SLOPE,
