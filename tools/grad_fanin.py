@@ -11,10 +11,11 @@ ap.add_argument("--config", default="kitti")
 a = ap.parse_args()
 args = argparse.Namespace(config=a.config, curves=2048, mixed_lengths=False, clouds_per_gpu=8, width=1.0)
 dev = torch.device("cuda", 0)
-make_cfg, in_dim, n_classes, _ = bench.NETWORKS[args.config]
+make_cfg, in_dim, n_classes, _ = bench.networks()[args.config]
 cfg = make_cfg(width=1.0)
 model = ModelBase(in_dim, n_classes, **{k: v for k, v in cfg.items() if k != "type"}).to(dev).train()
-data = bench.to_device(bench.make_input(list(range(8)), in_dim, args), dev)
+from curvecloudnet_amd.synth import to_device  # noqa: E402
+data = to_device(bench.make_input(list(range(8)), in_dim, args), dev)
 labels = torch.randint(0, n_classes, (data.pos.size(0),), device=dev)
 torch.manual_seed(7)
 loss = segmentation_loss(model(data), labels)
@@ -40,4 +41,4 @@ for (node, idx), c in sorted(uses.items(), key=lambda kv: -kv[1]):
             meta = str([tuple(m.shape) for m in node._input_metadata][:2])
         except Exception:
             pass
-        print("%d consumers of output %d of %-34s <- %s %s" % (c, idx, node.name(), sorted(set(parents[(node, idx)])), meta))
+        print("%d consumers of output %d of %-34s <- %s %s" % (c, idx, node.name(), sorted(parents[(node, idx)]), meta))
