@@ -433,6 +433,13 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if os.environ.get("CCN_BENCH_LAZY_LOG") == "1":             # diagnostics: which layers hand over deferred activations
+        from curvecloudnet_amd import ops as _ops
+        _ops.LAZY_ACT_LOG = []
+        step()
+        for row in _ops.LAZY_ACT_LOG:
+            print("deferred input: rows %8d  N %5d  K %5d  %s" % (row[0], row[1], row[2], "fused" if row[3] else "written out"))
+        return
     if os.environ.get("CCN_BENCH_ATEN_TABLE") == "1":           # diagnostics: who issues torch-side device ops in a step
         from tools.aten_callers import table
         table(step)

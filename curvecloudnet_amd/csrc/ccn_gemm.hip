@@ -1053,6 +1053,21 @@ static bool g_xcd_map = true;  // A-B hook (ccn_gemm_use_dma(3) = persistent ker
 
 static int g_pair_opt = 0;      // A-B hook (ccn_gemm_pair_opt)
 
+__device__ __forceinline__ float act_fwd(float z, int act, float slope) {
+  if (act == CCN_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (act == CCN_ACT_LEAKY) return z > 0.f ? z : z * slope;
+  return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act, float slope) {
+  if (act == CCN_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == CCN_ACT_LEAKY) return z > 0.f ? 1.f : slope;
+  return 1.f;
+}
+// BatchNorm + activation of one value, the expression of bn_act_fwd (ONE definition: the fused form below must give the same bits)
+__device__ __forceinline__ float bn_act_value(float y, float sc, float sh, int act, float slope) {
+  return act_fwd(y * sc + sh, act, slope);
+}
+
 // ------------------------------------------------------------------ two independent workgroups per CU (N > 64)
 // The 8-wave persistent kernel above keeps ONE workgroup on a CU, so nothing runs while its waves store a finished tile
 // (3.65 us of a 36 us tile at K = 256, 19 % at K = 128).  Here a CU holds TWO 4-wave workgroups on 128 x 128 tiles (each
@@ -1066,19 +1081,38 @@ constexpr int PR_BM = 128, PR_BN = 128;
 
 // ACC: Y += A W^T -- the accumulators start from the Y tile itself (64 loads per lane straight into the accumulator
 // registers at the top of a tile, covered by the first slice's wait) instead of from the bias (ccn_gemm_nt_acc).
-template <bool ACC>
+// XF: the A operand is the PRE-normalisation output of the previous layer and z = act(a * scale[k] + shift[k]) -- its
+// BatchNorm + activation (ccn_bn_act_fwd) -- is applied to the fragments on their way from LDS to the MFMAs, so that the
+// activation tensor is never written or read (ccn_gemm_nt_xf).  The per-channel table (K <= 1024, K % 32 == 0) sits in LDS;
+// the transform of K group q + 1 runs on the VALU while the matrix pipe works on group q.
+constexpr int XF_MAX_K = 1024;
+
+template <bool ACC, bool XF>
 __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* __restrict__ A, int64_t lda,
                                                                    const float* __restrict__ B, int64_t ldb,
                                                                    const float* __restrict__ bias, float* __restrict__ C,
                                                                    int64_t ldc, int64_t M, int64_t N, int64_t K,
                                                                    int64_t tiles, int64_t gn, int xcd_order,
-                                                                   double* __restrict__ colstats, int64_t a_extent, int opt) {
+                                                                   double* __restrict__ colstats, int64_t a_extent, int opt,
+                                                                   const float* __restrict__ xf_scale,
+                                                                   const float* __restrict__ xf_shift, int xf_act,
+                                                                   float xf_slope) {
   // a_extent: floats readable from the start of an A row (= lda, or K when rows overlap: ccn_conv_rows_nt)
   // opt (A/B hook ccn_gemm_pair_opt): bit 0 = counted wait behind an interior tile's stores, bit 1 = s_setprio around MFMAs
   constexpr int AF = PR_BM * BK, BF = PR_BN * BK, STAGE = AF + BF;
   constexpr int NC = 4;  // LDS-DMA copies (8 rows x 128 B) per wave, slice and operand
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
   __shared__ float stat_part[2 * PR_BN * 2];  // [wm][column][sum, sum of squares] of the finished tile
+  __shared__ __attribute__((aligned(16))) float xf_tab[XF ? 2 * XF_MAX_K : 4];   // [scale | shift] of the A channels
+  if (XF) {
+    for (int k = threadIdx.x; k < K; k += PR_TPB) {
+      xf_tab[k] = xf_scale[k];
+      xf_tab[XF_MAX_K + k] = xf_shift[k];
+    }
+    __syncthreads();
+  }
+  const uint32_t xf_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)xf_tab;
+  const float xf_neg = xf_act == CCN_ACT_RELU ? 0.f : (xf_act == CCN_ACT_LEAKY ? xf_slope : 1.f);   // multiplier of v <= 0
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave & 1, wn = wave >> 1;
@@ -1245,6 +1279,82 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
         asm volatile("ds_read_b128 %0, %1" : "=v"(db[0]) : "v"(stage_b + b_off + ch) : "memory");
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(db[1]) : "v"(stage_b + b_off + ch), "n"(32 * BK * 4) : "memory");
       };
+      auto mfma_group = [&](int par) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (opt & 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][ab].x, fb[par][t].x, acc[ab][t], 0, 0, 0);
+            acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][ab].y, fb[par][t].y, acc[ab][t], 0, 0, 0);
+            acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][ab].z, fb[par][t].z, acc[ab][t], 0, 0, 0);
+            acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][ab].w, fb[par][t].w, acc[ab][t], 0, 0, 0);
+          }
+        if (opt & 2) __builtin_amdgcn_s_setprio(0);
+      };
+      if (XF) {
+        f32x4 xs[2], xh[2];   // scale / shift of the four channels of a K group, [parity]
+        auto xf_read = [&](int q, f32x4& sc, f32x4& sh) {
+          const uint32_t at = xf_base + (uint32_t)((u * BK + 4 * (2 * q + h)) * 4);
+          asm volatile("ds_read_b128 %0, %1" : "=v"(sc) : "v"(at) : "memory");
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sh) : "v"(at), "n"(XF_MAX_K * 4) : "memory");
+        };
+        // One K component (x / y / z / w of the fragment quads) at a time: four MFMAs on four different accumulators, then
+        // a handful of VALU instructions of the NEXT group's transform.  A wave issues in order and the matrix pipe takes
+        // one MFMA per 64 cycles, so VALU work placed between MFMAs is free, VALU work behind all sixteen is not (first
+        // form: transform after the group's MFMAs, 10-25 % slower than the plain product).
+        auto xform_comp = [&](int par, int comp) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ab = 0; ab < 2; ++ab)
+          {
+            // branch-free form of bn_act_value (the run-time switch on the activation compiled to scalar branches around
+            // every element: 304 s_cbranch in the kernel): same bits, except that ReLU gives -0.0 instead of +0.0 for a
+            // negative input -- equal under comparison and in every sum it enters
+            const float v = fa[par][ab][comp] * xs[par][comp] + xh[par][comp];
+            fa[par][ab][comp] = v > 0.f ? v : v * xf_neg;
+          }
+        };
+        auto mfma_comp = [&](int par, int comp) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+              acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][ab][comp], fb[par][t][comp], acc[ab][t], 0, 0, 0);
+        };
+        // (the waits in front of a transform name its registers as operands: a plain VALU use of an inline-asm ds_read's
+        // result is otherwise free to be scheduled in front of the wait)
+        read_group(0, fa[0], fb[0]);
+        xf_read(0, xs[0], xh[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(xs[0]), "+v"(xh[0]) : : "memory");
+#pragma unroll
+        for (int comp = 0; comp < 4; ++comp) xform_comp(0, comp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int par = q & 1, nxt = (q + 1) & 1;
+          if (q < 3) {
+            read_group(q + 1, fa[nxt], fb[nxt]);
+            xf_read(q + 1, xs[nxt], xh[nxt]);
+          }
+          mfma_comp(par, 0);
+          if (q < 3) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[nxt][0]), "+v"(fa[nxt][1]), "+v"(xs[nxt]), "+v"(xh[nxt]) : : "memory");   // (issued before four MFMAs: long landed)
+            xform_comp(nxt, 0);
+            xform_comp(nxt, 1);
+          }
+          mfma_comp(par, 1);
+          if (q < 3) {
+            xform_comp(nxt, 2);
+            xform_comp(nxt, 3);
+          }
+          mfma_comp(par, 2);
+          mfma_comp(par, 3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        continue;
+      }
       read_group(0, fa[0], fb[0]);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1254,18 +1364,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (opt & 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ab = 0; ab < 2; ++ab)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][ab].x, fb[q & 1][t].x, acc[ab][t], 0, 0, 0);
-            acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][ab].y, fb[q & 1][t].y, acc[ab][t], 0, 0, 0);
-            acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][ab].z, fb[q & 1][t].z, acc[ab][t], 0, 0, 0);
-            acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q & 1][ab].w, fb[q & 1][t].w, acc[ab][t], 0, 0, 0);
-          }
-        if (opt & 2) __builtin_amdgcn_s_setprio(0);
+        mfma_group(q & 1);
       }
     }
 
@@ -1328,7 +1427,8 @@ static bool g_use_pair = true;  // A-B hook (ccn_gemm_use_dma(4) = the 8-wave pe
 constexpr int64_t PAIR_MIN_TILES = 128;
 
 int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
-                     int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s, int64_t a_extent, bool accumulate = false) {
+                     int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s, int64_t a_extent, bool accumulate = false,
+                     const float* xf_scale = nullptr, const float* xf_shift = nullptr, int xf_act = 0, float xf_slope = 0.f) {
   const int64_t gm = (M + PR_BM - 1) / PR_BM, gn = (N + PR_BN - 1) / PR_BN;
   const int64_t tiles = gm * gn;
   if (tiles >= ((int64_t)1 << 31)) {
@@ -1337,12 +1437,15 @@ int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, c
   }
   const int64_t slots = (g_pair_opt & 4) ? 256 : 512;
   const int64_t grid = tiles < slots ? tiles : slots;  // two workgroups per CU
-  if (accumulate)
-    hipLaunchKernelGGL(gemm_glds_pair_kernel<true>, dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy, M,
-                       N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt);
+  if (xf_scale != nullptr)
+    hipLaunchKernelGGL((gemm_glds_pair_kernel<false, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
+                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, xf_scale, xf_shift, xf_act, xf_slope);
+  else if (accumulate)
+    hipLaunchKernelGGL((gemm_glds_pair_kernel<true, false>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
+                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, nullptr, nullptr, 0, 0.f);
   else
-    hipLaunchKernelGGL(gemm_glds_pair_kernel<false>, dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
-                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt);
+    hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
+                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, nullptr, nullptr, 0, 0.f);
   return CCN_OK;
 }
 
@@ -1400,16 +1503,6 @@ int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const 
 // ------------------------------------------------------------------ column reductions (BatchNorm)
 constexpr int RED_ROWS = 128;  // rows per workgroup == GEMM BM, so both produce ceil(rows/128) partial rows
 
-__device__ __forceinline__ float act_fwd(float z, int act, float slope) {
-  if (act == CCN_ACT_RELU) return z > 0.f ? z : 0.f;
-  if (act == CCN_ACT_LEAKY) return z > 0.f ? z : z * slope;
-  return z;
-}
-__device__ __forceinline__ float act_grad(float z, int act, float slope) {
-  if (act == CCN_ACT_RELU) return z > 0.f ? 1.f : 0.f;
-  if (act == CCN_ACT_LEAKY) return z > 0.f ? 1.f : slope;
-  return 1.f;
-}
 
 // MODE 0: (sum x, 0)   MODE 1: (sum g, sum g*xhat) with g = dZ * act'(y*scale+shift)
 template <int MODE>
@@ -1747,7 +1840,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   const int64_t r0 = (int64_t)blockIdx.x * 32;
   for (int c = cx; c < C; c += 64) {
     const float sc = scale[c], sh = shift[c];
-    for (int64_t r = r0 + ry; r < r0 + 32 && r < rows; r += 4) Z[r * ldz + c] = act_fwd(Y[r * ldy + c] * sc + sh, act, slope);
+    for (int64_t r = r0 + ry; r < r0 + 32 && r < rows; r += 4) Z[r * ldz + c] = bn_act_value(Y[r * ldy + c], sc, sh, act, slope);
   }
 }
 
@@ -1759,10 +1852,10 @@ __global__ void bn_act_fwd_vec_kernel(const float4* __restrict__ Y, int64_t ldy4
   const int64_t r = t / C4, c = t - r * C4;
   const float4 y = Y[r * ldy4 + c], sc = scale[c], sh = shift[c];
   float4 z;
-  z.x = act_fwd(y.x * sc.x + sh.x, act, slope);
-  z.y = act_fwd(y.y * sc.y + sh.y, act, slope);
-  z.z = act_fwd(y.z * sc.z + sh.z, act, slope);
-  z.w = act_fwd(y.w * sc.w + sh.w, act, slope);
+  z.x = bn_act_value(y.x, sc.x, sh.x, act, slope);
+  z.y = bn_act_value(y.y, sc.y, sh.y, act, slope);
+  z.z = bn_act_value(y.z, sc.z, sh.z, act, slope);
+  z.w = bn_act_value(y.w, sc.w, sh.w, act, slope);
   Z[r * ldz4 + c] = z;
 }
 
@@ -1919,6 +2012,24 @@ int ccn_gemm_nt_acc(const float* A, int64_t lda, const float* W, int64_t ldw, fl
   int rc = launch_glds_pair(A, lda, W, ldw, nullptr, Y, ldy, M, N, K, nullptr, (hipStream_t)stream, lda, true);
   if (rc) return rc;
   CCN_LAUNCH_OK("gemm_nt_acc");
+  return CCN_OK;
+}
+
+int ccn_gemm_nt_xf_ok(int64_t lda, int64_t ldw, int64_t M, int64_t N, int64_t K) {
+  return ccn_gemm_nt_acc_ok(lda, ldw, M, N, K) && K % BK == 0 && K <= XF_MAX_K;
+}
+
+int ccn_gemm_nt_xf(const float* A, int64_t lda, const float* a_scale, const float* a_shift, int a_act, float a_slope,
+                   const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                   double* colstats, void* stream) {
+  CCN_REQUIRE(A && a_scale && a_shift && W && Y, "gemm_nt_xf: null pointer");
+  CCN_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, "gemm_nt_xf: bad sizes");
+  CCN_REQUIRE(ccn_gemm_nt_xf_ok(lda, ldw, M, N, K) && aligned16(A) && aligned16(W),
+              "gemm_nt_xf: shape / alignment outside the paired LDS-DMA kernel (ask ccn_gemm_nt_xf_ok first)");
+  int rc = launch_glds_pair(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, (hipStream_t)stream, lda, false, a_scale, a_shift,
+                            a_act, a_slope);
+  if (rc) return rc;
+  CCN_LAUNCH_OK("gemm_nt_xf");
   return CCN_OK;
 }
 

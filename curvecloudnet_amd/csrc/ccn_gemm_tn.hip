@@ -39,13 +39,19 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
 }
 
 // EPI 0: slab store, 1: atomic add into dW, 2: plain add into dW (single owner)
-template <int TN, int TK, int EPI>
+// XF: the X operand is the PRE-normalisation product of the previous layer; x = act(b * scale[k] + shift[k]) (that layer's
+// BatchNorm + activation, the expression of ccn_bn_act_fwd) is applied to the fragments between LDS and the MFMAs.  A lane's
+// two X columns are fixed for a work item, so scale / shift are four registers; the transform of step t + 1 sits between the
+// MFMAs of step t (ccn_gemm_tn_ws_xf; counterpart of ccn_gemm_nt_xf).
+template <int TN, int TK, int EPI, bool XF>
 __global__ __launch_bounds__(TN_TPB, 2) void gemm_tn_glds_kernel(const float* __restrict__ A, int64_t lda,
                                                                  const float* __restrict__ B, int64_t ldb,
                                                                  float* __restrict__ C, int64_t ldc, int64_t M, int64_t N,
                                                                  int64_t K, int tiles_k, int tiles, int split,
                                                                  int64_t slices_per_chunk, int64_t n_ids, int xcd_order,
-                                                                 float* __restrict__ slabs, int64_t b_extent) {
+                                                                 float* __restrict__ slabs, int64_t b_extent,
+                                                                 const float* __restrict__ xf_scale,
+                                                                 const float* __restrict__ xf_shift, float xf_neg) {
   // b_extent: floats readable from the start of a B row (= ldb, or K when the rows overlap: ccn_conv_rows_tn)
   constexpr int QN = TN / 64, QK = TK / 64, WC = 4 / (QN * QK);   // quadrants, waves sharing a quadrant
   constexpr int STEPS = TN_SLICE / 2 / WC;                          // 2-row MFMA steps per wave and slice
@@ -91,6 +97,21 @@ __global__ __launch_bounds__(TN_TPB, 2) void gemm_tn_glds_kernel(const float* __
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ta][tb][r] = 0.f;
 
+    float xsc[2] = {1.f, 1.f}, xsh[2] = {0.f, 0.f};
+    if (XF) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        int64_t k = k0 + wk * 64 + 2 * i + c;
+        k = k < K ? k : K - 1;
+        xsc[c] = xf_scale[k];
+        xsh[c] = xf_shift[k];
+      }
+    }
+    auto xform = [&](f32x2& b) {      // (branch-free; bits of act(b * scale + shift), ReLU's zero may be -0.0)
+      const float v0 = b.x * xsc[0] + xsh[0], v1 = b.y * xsc[1] + xsh[1];
+      b.x = v0 > 0.f ? v0 : v0 * xf_neg;
+      b.y = v1 > 0.f ? v1 : v1 * xf_neg;
+    };
     if (s_beg < s_end) {
       // ---- per-lane DMA source columns (clamped into the row: lda, ldb are multiples of 4 and >= 4)
       int64_t a_col[NIA], b_col[NIB];
@@ -140,6 +161,34 @@ __global__ __launch_bounds__(TN_TPB, 2) void gemm_tn_glds_kernel(const float* __
         // step t+1 is read before the MFMAs of step t and waited for with a counted lgkmcnt
         asm volatile("ds_read_b64 %0, %1" : "=v"(fa[0]) : "v"(sb + a_off) : "memory");
         asm volatile("ds_read_b64 %0, %1" : "=v"(fb[0]) : "v"(sb + b_off) : "memory");
+        if (XF) {
+          // (the waits name the fragment registers as operands: a plain VALU use of an inline-asm ds_read's result is otherwise
+          // free to be scheduled in front of the wait)
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0]) : : "memory");
+          xform(fb[0]);
+#pragma unroll
+          for (int t = 0; t < STEPS; ++t) {
+            if (t + 1 < STEPS) {
+              asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[(t + 1) & 1]) : "v"(sb + a_off), "n"((t + 1) * 2 * TN * 4) : "memory");
+              asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb[(t + 1) & 1]) : "v"(sb + b_off), "n"((t + 1) * 2 * TK * 4) : "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x2 a = fa[t & 1];
+            const f32x2 b = fb[t & 1];
+            if (rows_left < TN_SLICE && wc * 2 * STEPS + 2 * t + h >= rows_left) a = f32x2{0.f, 0.f};   // rows beyond M
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < STEPS) {       // the next step's transform between this step's MFMAs (in-order issue: free there)
+              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[(t + 1) & 1]) : : "memory");
+              xform(fb[(t + 1) & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+          }
+          continue;
+        }
 #pragma unroll
         for (int t = 0; t < STEPS; ++t) {
           if (t + 1 < STEPS) {
@@ -330,23 +379,37 @@ inline TnPlan tn_plan(int64_t M, int64_t N, int64_t K) {
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+struct TnXf {
+  const float* scale;
+  const float* shift;
+  float neg;      // multiplier of non-positive values: 0 (ReLU), slope (LeakyReLU), 1 (none)
+};
+
 template <int TN, int TK>
 int launch_tn(const TnPlan& p, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw,
-              int64_t M, int64_t N, int64_t K, float* slabs, hipStream_t s, int64_t b_extent) {
+              int64_t M, int64_t N, int64_t K, float* slabs, hipStream_t s, int64_t b_extent, const TnXf* xf) {
   const int64_t grid = p.n_ids < 512 ? p.n_ids : 512;
-  if (p.split == 1)
-    hipLaunchKernelGGL((gemm_tn_glds_kernel<TN, TK, 2>), dim3((unsigned)grid), dim3(TN_TPB), 0, s, dY, lddy, X, ldx, dW, lddw,
-                       M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, (float*)nullptr, b_extent);
-  else if (slabs == nullptr)
-    hipLaunchKernelGGL((gemm_tn_glds_kernel<TN, TK, 1>), dim3((unsigned)grid), dim3(TN_TPB), 0, s, dY, lddy, X, ldx, dW, lddw,
-                       M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, (float*)nullptr, b_extent);
-  else {
-    hipLaunchKernelGGL((gemm_tn_glds_kernel<TN, TK, 0>), dim3((unsigned)grid), dim3(TN_TPB), 0, s, dY, lddy, X, ldx, dW, lddw,
-                       M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, slabs, b_extent);
+  const float* xs = xf ? xf->scale : nullptr;
+  const float* xh = xf ? xf->shift : nullptr;
+  const float xn = xf ? xf->neg : 1.f;
+#define CCN_TN_LAUNCH(EPI_, XF_, SLABS_)                                                                                       \
+  hipLaunchKernelGGL((gemm_tn_glds_kernel<TN, TK, EPI_, XF_>), dim3((unsigned)grid), dim3(TN_TPB), 0, s, dY, lddy, X, ldx, dW,   \
+                     lddw, M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, SLABS_, b_extent, \
+                     xs, xh, xn)
+  if (p.split == 1) {
+    if (xf) CCN_TN_LAUNCH(2, true, (float*)nullptr);
+    else CCN_TN_LAUNCH(2, false, (float*)nullptr);
+  } else if (slabs == nullptr) {
+    if (xf) CCN_TN_LAUNCH(1, true, (float*)nullptr);
+    else CCN_TN_LAUNCH(1, false, (float*)nullptr);
+  } else {
+    if (xf) CCN_TN_LAUNCH(0, true, slabs);
+    else CCN_TN_LAUNCH(0, false, slabs);
     const int64_t work = (int64_t)p.tiles * (TN * TK / 4);
     hipLaunchKernelGGL((tn_reduce_kernel<TN, TK>), dim3((unsigned)((work + 63) / 64)), dim3(64 * RED_WAVES), 0, s, slabs,
                        p.split, p.tiles_k, p.tiles, N, K, dW, lddw);
   }
+#undef CCN_TN_LAUNCH
   return CCN_OK;
 }
 
@@ -388,7 +451,8 @@ int ccn_gemm_tn_generic(const float* dY, int64_t lddy, const float* X, int64_t l
 
 // one launch (+ its slab reduction) of the LDS-DMA kernel over an N x K block of the output
 static int tn_launch_block(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
-                           int64_t N, int64_t K, void* workspace, size_t workspace_bytes, hipStream_t s, int64_t ext) {
+                           int64_t N, int64_t K, void* workspace, size_t workspace_bytes, hipStream_t s, int64_t ext,
+                           const TnXf* xf) {
   const TnPlan p = tn_plan(M, N, K);
   float* slabs = nullptr;
   if (p.slab_floats > 0 && workspace != nullptr) {
@@ -397,18 +461,21 @@ static int tn_launch_block(const float* dY, int64_t lddy, const float* X, int64_
                 (size_t)p.slab_floats * sizeof(float));
     slabs = (float*)workspace;
   }
-  if (p.tn == 128 && p.tk == 128) return launch_tn<128, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
-  if (p.tn == 128) return launch_tn<128, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
-  if (p.tk == 128) return launch_tn<64, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
-  return launch_tn<64, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext);
+  if (p.tn == 128 && p.tk == 128) return launch_tn<128, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext, xf);
+  if (p.tn == 128) return launch_tn<128, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext, xf);
+  if (p.tk == 128) return launch_tn<64, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext, xf);
+  return launch_tn<64, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext, xf);
 }
 
 static int tn_ws_impl(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
-                      int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream, bool overlap) {
+                      int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream, bool overlap,
+                      const TnXf* xf = nullptr) {
   hipStream_t s = (hipStream_t)stream;
   if (M == 0) return CCN_OK;
-  if (!tn_dma_ok(dY, lddy, X, ldx, M, N, K))
+  if (!tn_dma_ok(dY, lddy, X, ldx, M, N, K)) {
+    CCN_REQUIRE(xf == nullptr, "gemm_tn_ws_xf: shape / alignment outside the LDS-DMA kernel (ask ccn_gemm_tn_xf_ok first)");
     return ccn_gemm_tn_generic(dY, lddy, X, ldx, dW, lddw, M, N, K, overlap ? 1 : 0, stream);
+  }
   const int64_t ext = overlap ? K : ldx;
   // up to 2 x 2 blocks, launched back to back on the stream (they share the slab scratch in stream order): multiples of
   // 128 columns keep every block's operand pointers 16-byte aligned
@@ -417,8 +484,10 @@ static int tn_ws_impl(const float* dY, int64_t lddy, const float* X, int64_t ldx
     for (int b = 0; b < 2; ++b) {
       const int64_t n0 = a ? nm : 0, n = a ? N - nm : nm, k0 = b ? km : 0, k = b ? K - km : km;
       if (n <= 0 || k <= 0) continue;
+      TnXf part;
+      if (xf) part = TnXf{xf->scale + k0, xf->shift + k0, xf->neg};
       const int rc = tn_launch_block(dY + n0, lddy, X + k0, ldx, dW + n0 * lddw + k0, lddw, M, n, k, workspace,
-                                     workspace_bytes, s, ext - k0);
+                                     workspace_bytes, s, ext - k0, xf ? &part : nullptr);
       if (rc) return rc;
     }
   CCN_LAUNCH_OK("gemm_tn_ws");
@@ -430,6 +499,19 @@ int ccn_gemm_tn_ws(const float* dY, int64_t lddy, const float* X, int64_t ldx, f
   CCN_REQUIRE(dY && X && dW, "gemm_tn_ws: null pointer");
   CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "gemm_tn_ws: bad sizes");
   return tn_ws_impl(dY, lddy, X, ldx, dW, lddw, M, N, K, workspace, workspace_bytes, stream, false);
+}
+
+int ccn_gemm_tn_xf_ok(const float* dY, int64_t lddy, const float* X, int64_t ldx, int64_t M, int64_t N, int64_t K) {
+  return tn_dma_ok(dY, lddy, X, ldx, M, N, K) ? 1 : 0;
+}
+
+int ccn_gemm_tn_ws_xf(const float* dY, int64_t lddy, const float* X, int64_t ldx, const float* x_scale, const float* x_shift,
+                      int x_act, float x_slope, float* dW, int64_t lddw, int64_t M, int64_t N, int64_t K, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  CCN_REQUIRE(dY && X && dW && x_scale && x_shift, "gemm_tn_ws_xf: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "gemm_tn_ws_xf: bad sizes");
+  const TnXf xf{x_scale, x_shift, x_act == CCN_ACT_RELU ? 0.f : (x_act == CCN_ACT_LEAKY ? x_slope : 1.f)};
+  return tn_ws_impl(dY, lddy, X, ldx, dW, lddw, M, N, K, workspace, workspace_bytes, stream, false, &xf);
 }
 
 int ccn_conv_rows_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,

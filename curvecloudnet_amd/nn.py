@@ -70,7 +70,9 @@ class MLP(nn.Module):
                     raise NotImplementedError("weighted rows: bias / dropout layers")
                 x = ops.linear_bn_act_tail(x, lin.weight, norm.module, self.training, self.act, *tail)
                 continue
-            x = ops.linear_bn_act(x, lin.weight, lin.bias, norm.module, self.training, self.act)
+            # (the next layer of this MLP is the only consumer: the activation may stay unwritten, ops.LAZY_ACT)
+            defer = self.dropouts[idx] == 0.0 and (idx + 1 < n_hidden or self.plain_last)
+            x = ops.linear_bn_act(x, lin.weight, lin.bias, norm.module, self.training, self.act, defer=defer)
             if self.dropouts[idx] > 0.0:
                 x = F.dropout(x, p=self.dropouts[idx], training=self.training)
         if self.plain_last and start <= n_hidden:

@@ -636,9 +636,13 @@ class LinearBNAct(torch.autograd.Function):
     fast_conv1d.py:71-73 / :140-143.  ``gamma is None`` = plain Linear (MLP's last layer)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum, grad_on=True):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum, grad_on=True,
+                defer=False, xf_par=None, xf_act=0):
         # grad_on: torch.is_grad_enabled() at the call site (inside forward grad mode is always off, and
         # ctx.needs_input_grad ignores no_grad): no backward will come for a pass made under no_grad
+        # defer: return the PRE-normalisation product (and the scale / shift table) instead of the activation: the caller
+        #   promises that the only consumer is another LinearBNAct, which applies BatchNorm + activation itself
+        # xf_par / xf_act: ``x`` is such a deferred product of the previous layer (its 4 x K table and activation code)
         x = _mat(x)
         require_gpu(weight)
         m, k = x.shape
@@ -647,44 +651,69 @@ class LinearBNAct(torch.autograd.Function):
             raise ValueError("linear: input has %d channels, weight expects %d" % (k, weight.size(1)))
         dev = x.device
         w = _aligned_weight(weight.detach())
+        gemm_nt = ctx.gemm_nt = _nt_name()
+        lazy = (xf_par is not None and gemm_nt == "gemm_nt" and k <= LAZY_ACT_MAX_K and x.data_ptr() % 16 == 0
+                and w.data_ptr() % 16 == 0 and bool(lib().ccn_gemm_nt_xf_ok(_ld(x), _ld(w), m, n, k)))
+        if xf_par is not None:
+            LAZY_ACT_COUNT["fused" if lazy else "written"] += 1
+            if LAZY_ACT_LOG is not None:
+                LAZY_ACT_LOG.append((m, n, k, lazy))
+        if xf_par is not None and not lazy:
+            # this product does not take the fused kernel: the previous layer's activation is written after all
+            z_in = _rows(m, k, dev)
+            call("bn_act_fwd", ptr(x), _ld(x), m, k, ptr(xf_par[0]), ptr(xf_par[1]), int(xf_act), LEAKY_SLOPE, ptr(z_in), _ld(z_in))
+            x, xf_par = z_in, None
+        ctx.xf_act = int(xf_act) if lazy else None
         y = _rows(m, n, dev)
         has_bn = gamma is not None
         ctx.has_bn, ctx.act, ctx.training, ctx.has_bias = has_bn, ACT[act], bool(training), bias is not None
-        gemm_nt = ctx.gemm_nt = _nt_name()
+        none = x.new_empty(0)
         ctx.main_grad_of = weight if (grad_on and ctx.needs_input_grad[1] and _main_grad(weight, n, k) is not None) else None
         ctx.bn_refs = ((gamma, beta) if has_bn and grad_on and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]
                        and _main_grad_vec(gamma, n) is not None and _main_grad_vec(beta, n) is not None else None)
         _main_grad_note(ctx.main_grad_of, *(ctx.bn_refs or ()))
         if gemm_nt != "gemm_nt":
             x = _aligned_rows(x)
+
+        def product(stats):
+            if lazy:      # act(BatchNorm(x)) of the previous layer applied between LDS and the matrix cores
+                call("gemm_nt_xf", ptr(x), _ld(x), ptr(xf_par[0]), ptr(xf_par[1]), ctx.xf_act, LEAKY_SLOPE, ptr(w), _ld(w),
+                     ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats))
+            else:
+                _gemm_nt(gemm_nt, x, w, bias, y, m, n, k, stats)
+
         if not has_bn:
-            _gemm_nt(gemm_nt, x, w, bias, y, m, n, k, None)
-            ctx.save_for_backward(x, w)
-            return y
+            product(None)
+            ctx.save_for_backward(x, w, xf_par if lazy else none)
+            ctx.mark_non_differentiable(none)
+            return y, none
         par = torch.empty((4, n), dtype=torch.float32, device=dev)      # scale, shift, mean, rstd
         if training:
             if m < 2:
                 raise ValueError("Expected more than 1 value per channel when training")
             stats = _stats_buffer(m, n, dev)
-            _gemm_nt(gemm_nt, x, w, bias, y, m, n, k, stats)
+            product(stats)
             call("bn_finalize", ptr(stats), m, n, ptr(gamma), ptr(beta), float(eps), float(momentum),
                  ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
         else:
-            _gemm_nt(gemm_nt, x, w, bias, y, m, n, k, None)
+            product(None)
             call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), n,
                  ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        ctx.save_for_backward(x, w, y, par, xf_par if lazy else none)
+        ctx.mark_non_differentiable(par)
+        if defer:
+            return y, par
         z = _rows(m, n, dev)
         call("bn_act_fwd", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
-        ctx.save_for_backward(x, w, y, par)
         _trace_act(z, ctx.act)
-        return z
+        return z, par
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _gpar=None):
         g = _mat(g)
         dev = g.device
         if ctx.has_bn:
-            x, w, y, par = ctx.saved_tensors
+            x, w, y, par, xf_par = ctx.saved_tensors
             m, n = y.shape
             sums = _stats_buffer(m, n, dev)
             call("bn_act_bwd_reduce", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
@@ -708,7 +737,7 @@ class LinearBNAct(torch.autograd.Function):
                      ptr(dgb[0]), ptr(dgb[1]))
                 dgamma, dbeta = dgb[0], dgb[1]
         else:
-            x, w = ctx.saved_tensors
+            x, w, xf_par = ctx.saved_tensors
             dy, dgamma, dbeta = g, None, None
             m, n = dy.shape
         k = x.size(1)
@@ -735,8 +764,19 @@ class LinearBNAct(torch.autograd.Function):
             dw = into if into is not None else _rows(n, k, dev, zero=True)
             if ctx.gemm_nt in ("gemm_nt_bf16", "gemm_nt_f16"):
                 dy = _aligned_rows(dy)
-            with _WgradScope(into, dy, x):
-                _wgrad(ctx.gemm_nt, dy, x, dw, m, n, k)
+            if ctx.xf_act is not None and not lib().ccn_gemm_tn_xf_ok(ptr(dy), _ld(dy), ptr(x), _ld(x), m, n, k):
+                # (an unaligned incoming gradient: the input activation is written for this product after all)
+                z_in = _rows(m, k, dev)
+                call("bn_act_fwd", ptr(x), _ld(x), m, k, ptr(xf_par[0]), ptr(xf_par[1]), ctx.xf_act, LEAKY_SLOPE, ptr(z_in), _ld(z_in))
+                x, ctx.xf_act = z_in, None
+            with _WgradScope(into, dy, x, xf_par):
+                if ctx.xf_act is not None:
+                    nb = lib().ccn_gemm_tn_workspace_bytes(m, n, k)
+                    ws = _tn_scratch(nb, dev)
+                    call("gemm_tn_ws_xf", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(xf_par[0]), ptr(xf_par[1]), ctx.xf_act,
+                         LEAKY_SLOPE, ptr(dw), _ld(dw), m, n, k, ptr(ws), nb)
+                else:
+                    _wgrad(ctx.gemm_nt, dy, x, dw, m, n, k)
             if into is not None:
                 dw = _main_grad_done(ctx.main_grad_of)
         db = None
@@ -744,19 +784,40 @@ class LinearBNAct(torch.autograd.Function):
             acc = _stats_buffer(m, n, dev)
             db = torch.empty(n, dtype=torch.float32, device=dev)
             call("colsum", ptr(dy), _ld(dy), m, n, ptr(acc), ptr(db))
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
-def linear_bn_act(x, weight, bias, bn, training, act):
-    """bn: a torch.nn.BatchNorm1d used as parameter/buffer container, or None."""
+# A hidden MLP layer whose only consumer is the next Linear of the same MLP hands over its PRE-normalisation product; the
+# consumer applies BatchNorm + activation to the A fragments inside its GEMM (ccn_gemm_nt_xf, and ccn_gemm_tn_ws_xf for its
+# weight gradient), so the activation tensor is never written or read: same bits, one pass over rows x K saved per layer
+# (tools/bench_xf.py: 1.34 M x 128 -> 192: 1.20 -> 0.98 ms).  Above K = 256 the pass saved is worth less than the transform
+# costs the two products, and the layer is written out as before.  CCN_LAZY_ACT=0 disables.
+LAZY_ACT = os.environ.get("CCN_LAZY_ACT", "1") != "0"
+LAZY_ACT_MAX_K = 256
+LAZY_ACT_COUNT = {"fused": 0, "written": 0}      # deferred inputs consumed by the fused kernel / written out after all (tests)
+LAZY_ACT_LOG = None                               # diagnostics: a list collects (rows, N, K, fused) per deferred input
+
+
+def linear_bn_act(x, weight, bias, bn, training, act, defer=False):
+    """bn: a torch.nn.BatchNorm1d used as parameter/buffer container, or None.  ``defer``: the caller feeds the result to
+    another linear_bn_act and nothing else (nn.MLP); the result may then be a deferred activation (see LAZY_ACT)."""
     grad_on = torch.is_grad_enabled()
+    pend = getattr(x, "_ccn_deferred", None)
+    xf_par, xf_act = pend if pend is not None else (None, 0)
     if bn is None:
-        return LinearBNAct.apply(x, weight, bias, None, None, None, None, False, None, 0.0, 0.0, grad_on)
+        return LinearBNAct.apply(x, weight, bias, None, None, None, None, False, None, 0.0, 0.0, grad_on, False, xf_par,
+                                 xf_act)[0]
     if training and bn.track_running_stats:
         bn.num_batches_tracked += 1
     use_batch_stats = training or not bn.track_running_stats
-    return LinearBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats,
-                             act, bn.eps, bn.momentum if bn.momentum is not None else 0.1, grad_on)
+    # (sign tables for the parity tests are taken from the activation itself: no deferral while they are recorded)
+    defer = bool(defer and LAZY_ACT and ACT_TRACE is None and _MLP_DTYPE == "fp32" and ACT[act] != 0
+                 and weight.size(0) <= LAZY_ACT_MAX_K)
+    out, par = LinearBNAct.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats,
+                                 act, bn.eps, bn.momentum if bn.momentum is not None else 0.1, grad_on, defer, xf_par, xf_act)
+    if defer:
+        out._ccn_deferred = (par, ACT[act])
+    return out
 
 
 class NLLLoss(torch.autograd.Function):

@@ -201,6 +201,20 @@ int ccn_gemm_tn_ws(const float* dY, int64_t lddy, const float* X, int64_t ldx, f
 int ccn_gemm_nt_acc_ok(int64_t lda, int64_t ldw, int64_t M, int64_t N, int64_t K);
 int ccn_gemm_nt_acc(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M, int64_t N,
                     int64_t K, void* stream);
+/* Y = act(A * scale + shift) W^T + b: ccn_gemm_nt whose A operand is the PRE-normalisation product of the previous layer,
+ * with that layer's BatchNorm + activation (ccn_bn_act_fwd: z = act(a * scale[k] + shift[k]), same bits) applied between LDS and
+ * the matrix cores -- the activation tensor of a hidden MLP layer (torch_geometric.nn.MLP: lin -> norm -> act -> lin,
+ * src/models/base.py:90-125) is then never written.  Paired LDS-DMA kernel only, K % 32 == 0, K <= 1024: ask _ok. */
+int ccn_gemm_nt_xf_ok(int64_t lda, int64_t ldw, int64_t M, int64_t N, int64_t K);
+int ccn_gemm_nt_xf(const float* A, int64_t lda, const float* a_scale, const float* a_shift, int a_act, float a_slope,
+                   const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                   double* colstats, void* stream);
+/* dW += dY^T act(X * scale + shift): ccn_gemm_tn_ws with the same transform on its X operand -- the weight gradient of a
+ * layer whose input was consumed through ccn_gemm_nt_xf (the activation was never stored).  LDS-DMA kernel only: ask _ok. */
+int ccn_gemm_tn_xf_ok(const float* dY, int64_t lddy, const float* X, int64_t ldx, int64_t M, int64_t N, int64_t K);
+int ccn_gemm_tn_ws_xf(const float* dY, int64_t lddy, const float* X, int64_t ldx, const float* x_scale, const float* x_shift,
+                      int x_act, float x_slope, float* dW, int64_t lddw, int64_t M, int64_t N, int64_t K, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* ---- A4-A6: the symmetric curve convolution as an IMPLICIT GEMM over the row sequence (no shifted-row matrix) ----
  * Replaces F.conv1d(input(1,C,L), weight, bias, 1, 'same') at src/models/modules/fast_conv1d.py:183 (called from
  * SymmetricCurve1DConvV2 :71 and SymmetricCurve1DConvFastV1 :140) on the reference's own zero-separated sequence

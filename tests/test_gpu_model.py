@@ -145,6 +145,56 @@ def test_full_size_cloud_properties():
     assert maxdiff(again, out) < 1e-5      # the same draw gives the same forward (BN stats are order-independent)
 
 
+def test_deferred_activations_give_the_same_bits():
+    """ops.LAZY_ACT: hidden MLP activations that only feed the next Linear are applied inside that Linear's GEMMs
+    (ccn_gemm_nt_xf / ccn_gemm_tn_ws_xf) instead of being written.  Logits, loss, running statistics and eval output
+    are the same bits (a ReLU zero may be -0.0, which compares equal) as with every activation written out; gradients
+    (which pass through atomic accumulations and are not run-to-run reproducible in either mode) differ by no more than
+    two passes in the SAME mode do."""
+    from curvecloudnet_amd import ops
+    from curvecloudnet_amd.configs import kitti_config
+    from curvecloudnet_amd.model import ModelBase, segmentation_loss
+    from curvecloudnet_amd.synth import make_batch
+    cfg = {k: v for k, v in kitti_config(width=1.0).items() if k != "type"}
+    data = batch_to(make_batch([0, 1]), DEV)
+    labels = _labels(data.pos.size(0), 20, 1).to(DEV)
+    torch.manual_seed(0)
+    model = ModelBase(4, 20, **cfg).to(DEV)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    runs = []
+    for lazy in (False, False, True):
+        ops.LAZY_ACT = lazy
+        ops.LAZY_ACT_COUNT.update(fused=0, written=0)
+        try:
+            model.load_state_dict(state)
+            model.train()
+            model.zero_grad(set_to_none=True)
+            torch.manual_seed(1)
+            out = model(data)
+            loss = segmentation_loss(out, labels)
+            loss.backward()
+            grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+            buffers = {n: b.clone() for n, b in model.named_buffers()}
+            model.eval()
+            torch.manual_seed(1)
+            with torch.no_grad():
+                ev = model(data)
+            runs.append((out.detach().clone(), loss.detach().clone(), grads, buffers, ev.clone(), dict(ops.LAZY_ACT_COUNT)))
+        finally:
+            ops.LAZY_ACT = True
+    (o0, l0, g0, b0, e0, c0), (oa, la, ga, ba, ea, ca), (o1, l1, g1, b1, e1, c1) = runs
+    assert c0 == {"fused": 0, "written": 0}
+    assert c1["fused"] >= 10, c1               # the fused kernels really ran (train + eval passes)
+    assert torch.equal(o0, o1) and torch.equal(l0, l1) and torch.equal(e0, e1)
+    for n in b0:
+        assert torch.equal(b0[n], b1[n]), "buffer %s differs" % n
+    for n in g0:
+        scale = float(g0[n].abs().max())
+        same_mode = float((g0[n] - ga[n]).abs().max())
+        across = float((g0[n] - g1[n]).abs().max())
+        assert across <= 3.0 * same_mode + 1e-5 * scale + 1e-12, (n, across, same_mode, scale)
+
+
 def test_full_kitti_config_matches_oracle():
     """The complete KITTI / nuScenes step list (33 steps: sa-geo, voxel and farthest-point SA levels, FP
     up-sampling, 10 SGCNN layers) at 1/8 width: logits and gradients against the CPU oracle."""
