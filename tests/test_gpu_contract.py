@@ -310,3 +310,40 @@ def test_gather_and_reduce_entries_alias_the_kernels():
     den = torch.zeros(m, c, device=DEV).index_add_(0, seg, ex) + 1e-16
     ref = torch.zeros(m, c, device=DEV).index_add_(0, seg, ex / den[seg] * msg)
     _close(o1.cpu(), ref.cpu(), 2e-5, "attend aggregation")
+
+
+@pytest.mark.parametrize("M,N,K", [(40000, 192, 128), (20000, 256, 256), (33000, 128, 64), (17000, 256, 192), (9000, 1024, 1024)])
+@pytest.mark.parametrize("act", [RELU, LEAKY])
+def test_transforming_gemms_match_written_activation(M, N, K, act):
+    """ccn_gemm_nt_xf / ccn_gemm_tn_ws_xf (the previous layer's BatchNorm + activation applied to the operand fragments
+    inside the kernel) give the bits of ccn_bn_act_fwd followed by ccn_gemm_nt / ccn_gemm_tn_ws, statistics included."""
+    ops, call, lib, ptr, workspace = _api()
+    gen = torch.Generator().manual_seed(M + N + K + act)
+    y0 = torch.randn(M, K, generator=gen).to(DEV)
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=gen).to(DEV)
+    par = torch.stack([torch.rand(K, generator=gen) + 0.5, torch.randn(K, generator=gen)]).to(DEV)
+    dy = torch.randn(M, N, generator=gen).to(DEV)
+    z = torch.empty(M, K, device=DEV)
+    call("bn_act_fwd", ptr(y0), K, M, K, ptr(par[0]), ptr(par[1]), act, 0.01, ptr(z), K)
+    zr = y0 * par[0] + par[1]
+    zr = torch.where(zr > 0, zr, zr * (0.01 if act == LEAKY else 0.0))
+    _close(z.cpu(), zr.cpu(), 1e-6, "bn_act_fwd")
+    nparts = lib().ccn_stats_rows(M)
+    s1 = torch.empty((nparts + 1) * 2 * N, dtype=torch.float64, device=DEV)
+    s2 = torch.empty_like(s1)
+    o1, o2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    call("gemm_nt", ptr(z), K, ptr(w), K, ptr(b), ptr(o1), N, M, N, K, ptr(s1))
+    if lib().ccn_gemm_nt_xf_ok(K, K, M, N, K):
+        call("gemm_nt_xf", ptr(y0), K, ptr(par[0]), ptr(par[1]), act, 0.01, ptr(w), K, ptr(b), ptr(o2), N, M, N, K, ptr(s2))
+        assert torch.equal(o1, o2), "product"
+        assert torch.equal(s1[:nparts * 2 * N], s2[:nparts * 2 * N]), "statistics"
+    else:
+        assert K > 1024 or N <= 64 or (M // 128) * (N // 128) < 128, "shape unexpectedly outside the fused kernel"
+    nb = lib().ccn_gemm_tn_workspace_bytes(M, N, K)
+    ws = workspace(nb, DEV)
+    d1, d2 = torch.zeros(N, K, device=DEV), torch.zeros(N, K, device=DEV)
+    call("gemm_tn_ws", ptr(dy), N, ptr(z), K, ptr(d1), K, M, N, K, ptr(ws), nb)
+    assert lib().ccn_gemm_tn_xf_ok(ptr(dy), N, ptr(y0), K, M, N, K)
+    call("gemm_tn_ws_xf", ptr(dy), N, ptr(y0), K, ptr(par[0]), ptr(par[1]), act, 0.01, ptr(d2), K, M, N, K, ptr(ws), nb)
+    assert torch.equal(d1, d2), "weight gradient"
