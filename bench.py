@@ -95,14 +95,27 @@ def pmc_traffic(kernel):
     return None
 
 
-def summarise_profile(records, steps, write_shapes=True):
+def empty_bracket_ms(n=64):
+    """What a pair of timing events measures around NOTHING on the current stream (median of n): the part of a bracketed
+    launch's duration that is the events' own latency (a timing event is a system-scope release on this runtime)."""
+    pairs = []
+    for _ in range(n):
+        b, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        b.record()
+        e.record()
+        pairs.append((b, e))
+    torch.cuda.synchronize()
+    return sorted(b.elapsed_time(e) for b, e in pairs)[n // 2]
+
+
+def summarise_profile(records, steps, write_shapes=True, bracket_ms=0.0):
     torch.cuda.synchronize()
     table = {}
     for name, ints, beg, end, nulls in records:
         label, flops = gemm_label(name, ints, nulls)
         key = label or name
         t = table.setdefault(key, {"ms": 0.0, "launches": 0, "flops": 0.0})
-        t["ms"] += beg.elapsed_time(end)
+        t["ms"] += max(beg.elapsed_time(end) - bracket_ms, 0.0)
         t["launches"] += 1
         t["flops"] += flops
     total = sum(t["ms"] for t in table.values())
@@ -514,7 +527,8 @@ def main():
                    "loss": float(loss.detach())},
     }
     if records:
-        rows, _ = summarise_profile(records, args.steps, write_shapes=not full_records)
+        bracket = empty_bracket_ms()
+        rows, _ = summarise_profile(records, args.steps, write_shapes=not full_records, bracket_ms=bracket)
         name, top = rows[0]
         table_rows, total_ms, table_steps = rows, sum(t["ms"] for _, t in rows), args.steps
         if full_records:
@@ -533,8 +547,10 @@ def main():
                                   "flops_per_launch": top["flops"] / top["launches"],
                                   "kernel": name, "avg_launch_ms": top["ms"] / top["launches"],
                                   "launches": top["launches"], "share_of_kernel_time": full_share,
+                                  "empty_bracket_us": round(1e3 * bracket, 2),
                                   "launches_note": "every eighth launch of this kernel inside the timed region is bracketed by "
-                                                   "HIP events (sampling keeps the events' own cost out of `value`)"}
+                                                   "HIP events (sampling keeps the events' own cost out of `value`); avg_launch_ms has the duration of an "
+                                                   "empty bracket (empty_bracket_us, measured after the run) subtracted"}
             # The GEMM launches run on two streams (weight-gradient products overlap the rest of the backward pass), so a
             # launch's own duration includes the time it shares the chip.  All GEMM launches together: flops over the
             # UNION of their execution intervals = the MFMA throughput the step actually gets out of the chip.
