@@ -178,14 +178,14 @@ __global__ __launch_bounds__(TN_TPB, 2) void gemm_tn_glds_kernel(const float* __
             if (rows_left < TN_SLICE && wc * 2 * STEPS + 2 * t + h >= rows_left) a = f32x2{0.f, 0.f};   // rows beyond M
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < STEPS) {       // the next step's transform between this step's MFMAs (in-order issue: free there)
-              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[(t + 1) & 1]) : : "memory");
-              xform(fb[(t + 1) & 1]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < STEPS) {       // the next step's transform behind this step's four MFMAs: the wave gets here when the
+              // fourth has ISSUED (in-order issue, one MFMA per 64 cycles), i.e. with 64 cycles of matrix work still ahead
+              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[(t + 1) & 1]), "+v"(fa[(t + 1) & 1]) : : "memory");
+              xform(fb[(t + 1) & 1]);
+            }
           }
           continue;
         }
