@@ -1089,7 +1089,17 @@ constexpr int XF_MAX_K = 1024;
 
 // TAG: 1 = the 128-wide part of a product that is split into this launch + a 64-wide remainder (gemm_nt_impl): the same
 // code under its own name, so that profiles list the single-launch products (what bench.py samples) separately.
-template <bool ACC, bool XF, int TAG = 0>
+// STAMP: diagnostic build (ccn_gemm_pair_debug): per workgroup, every wave adds up where its cycles go (s_memtime stamps)
+// and writes 16 words to the debug buffer.  Never launched unless a debug buffer is set.
+__device__ unsigned long long* g_pair_dbg_dev = nullptr;
+#define PR_STAMP(t)                                                                         \
+  do {                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");            \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  } while (0)
+
+template <bool ACC, bool XF, int TAG = 0, bool STAMP = false>
 __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* __restrict__ A, int64_t lda,
                                                                    const float* __restrict__ B, int64_t ldb,
                                                                    const float* __restrict__ bias, float* __restrict__ C,
@@ -1230,6 +1240,12 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     stat_tile = -1;
   };
 
+  unsigned long long st_t0 = 0, st_a = 0, st_b = 0, st_r0 = 0;
+  uint32_t sum_w = 0, sum_b = 0, sum_i = 0, sum_c = 0, sum_e = 0, n_sl = 0;
+  if (STAMP) {
+    PR_STAMP(st_t0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_r0) : : "memory");
+  }
   int64_t g = 0;
   bool stores_behind = false;   // the previous tile was interior: exactly 64 stores per lane were issued after the last copy
   for (int64_t j = 0, tile; (tile = tile_of(j)) < tiles; ++j) {
@@ -1267,11 +1283,16 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
         // the copy of this slice was issued BEFORE the previous tile's 64 stores (vmcnt retires in issue order): wait for it
         // and the first store only, not for the whole store burst to drain
         asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-      else
+      else {
+        if (STAMP) PR_STAMP(st_a);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice g has landed (and the previous tile's stores retired)
+        if (STAMP) { PR_STAMP(st_b); sum_w += (uint32_t)(st_b - st_a); }
+      }
       __builtin_amdgcn_s_barrier();
+      if (STAMP) { PR_STAMP(st_a); sum_b += (uint32_t)(st_a - st_b); }
       issue_next();
       if (u == 0 && stat_tile >= 0) stats_readout();
+      if (STAMP) { PR_STAMP(st_b); sum_i += (uint32_t)(st_b - st_a); }
       const uint32_t stage_b = lds_base + (uint32_t)((g & 1) * STAGE * 4);
       f32x4 fa[2][2], fb[2][2];   // [K group parity][block]
       auto read_group = [&](int q, f32x4 (&da)[2], f32x4 (&db)[2]) {
@@ -1368,7 +1389,9 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
         }
         mfma_group(q & 1);
       }
+      if (STAMP) { PR_STAMP(st_a); sum_c += (uint32_t)(st_a - st_b); ++n_sl; }
     }
+    if (STAMP) PR_STAMP(st_a);
 
     // ---- tile epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
     const bool interior = m0 + PR_BM <= M && n0 + PR_BN <= N;
@@ -1415,6 +1438,21 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       stat_tile = tile;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // table written before this wave reaches the next barrier
     }
+    if (STAMP) { PR_STAMP(st_b); sum_e += (uint32_t)(st_b - st_a); }
+  }
+  if (STAMP && g_pair_dbg_dev != nullptr) {
+    unsigned long long t1, r1;
+    PR_STAMP(t1);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1) : : "memory");
+    if (lane == 0) {
+      unsigned long long* d = g_pair_dbg_dev + ((int64_t)blockIdx.x * 4 + wave) * 16;
+      d[0] = t1 - st_t0; d[1] = r1 - st_r0; d[2] = sum_w; d[3] = sum_b; d[4] = sum_i; d[5] = sum_c; d[6] = sum_e; d[7] = n_sl;
+      d[8] = st_t0; d[9] = t1; d[10] = st_r0; d[11] = r1;
+      uint32_t xcc, hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      d[12] = xcc; d[13] = hwid;
+    }
   }
   if (stat_tile >= 0) {  // statistics of the last tile
     __builtin_amdgcn_s_barrier();
@@ -1423,6 +1461,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   }
 }
 
+static void* g_pair_dbg_host = nullptr;
 static bool g_use_pair = true;  // A-B hook (ccn_gemm_use_dma(4) = the 8-wave persistent kernel for N > 64 as well)
 // from this many 128 x 128 tiles on (measured at 128 / 256 / 512 / 1024: 3168 x 2048 -> 1024 (200 tiles) 87 vs 80 TFLOP/s on
 // the register-staged kernel, 10550 x 1024 -> 1024 (664 tiles) 99 vs 84, 35151 x 512 -> 512 107 vs 88 on the 8-wave kernel)
@@ -1440,7 +1479,10 @@ int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, c
   }
   const int64_t slots = (g_pair_opt & 4) ? 256 : 512;
   const int64_t grid = tiles < slots ? tiles : slots;  // two workgroups per CU
-  if (xf_scale != nullptr)
+  if (g_pair_dbg_host != nullptr && xf_scale == nullptr && !accumulate && !split_part)
+    hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 0, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y,
+                       ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, nullptr, nullptr, 0, 0.f);
+  else if (xf_scale != nullptr)
     hipLaunchKernelGGL((gemm_glds_pair_kernel<false, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
                        M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, xf_scale, xf_shift, xf_act, xf_slope);
   else if (accumulate)
@@ -1932,6 +1974,12 @@ int ccn_gemm_use_dma(int on) {
   g_xcd_map = on != 3;
   g_use_pair = on != 4;
   return CCN_OK;
+}
+
+int ccn_gemm_pair_debug(void* buf) {   // diagnostic: 512 x 4 x 16 uint64 words (see STAMP above); nullptr = off
+  g_pair_dbg_host = buf;
+  unsigned long long* p = (unsigned long long*)buf;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_pair_dbg_dev), &p, sizeof(p)) == hipSuccess ? CCN_OK : CCN_ERR_ARG;
 }
 
 int ccn_gemm_pair_opt(int bits) {

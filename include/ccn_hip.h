@@ -163,6 +163,7 @@ int ccn_dense_to_csr_fill(const int64_t* idx, const int64_t* cloud_ptr1, const i
  * into the BatchNorm batch statistics (torch.nn.BatchNorm1d inside PyG MLP; fast_conv1d.py:30,73). */
 int64_t ccn_stats_rows(int64_t rows); /* partial-statistics rows a reduction over `rows` rows produces (= ceil(rows/128)) */
 int ccn_gemm_use_dma(int on);       /* A/B hook: 0 = register-staged kernels only, 2 = LDS-DMA without the persistent tile loop, 3 = persistent with round-robin tiles, 4 = the 8-wave persistent kernel for every N (no paired 4-wave workgroups), 1 = default */
+int ccn_gemm_pair_debug(void* buf);  /* diagnostic: a device buffer of 512 x 4 x 16 uint64 words switches ccn_gemm_nt's paired kernel to a build that stamps (s_memtime) where every wave's cycles go; NULL = off (tools/pair_stamps.py) */
 int ccn_gemm_pair_opt(int bits);    /* A/B hook of the paired kernel: bit 0 = counted wait behind a tile's stores, bit 1 = s_setprio around the MFMA groups */
 int ccn_gemm_force_generic(int on); /* test hook: route every GEMM through the unaligned-operand kernel */
 int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,

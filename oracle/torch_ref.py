@@ -100,6 +100,17 @@ def feature_diffs(x, point2curveidx, batch):
 # --------------------------------------------------------------------------------------
 MLP_DTYPE = "fp32"
 
+# Feature arithmetic dtype of an adjudication run (tests only): None = the dtype the tensors arrive in (fp32, the reference's
+# arithmetic).  torch.float64 with a ``.double()`` model: every feature computation in fp64 while positions, and with them
+# every index decision (sampling, neighbour search, curve groups), stay the reference's fp32 -- "the value the network
+# defines on these inputs", against which the fp32 CPU oracle and the GPU are both measured.
+FEATURE_DTYPE = None
+
+
+def _feat(t):
+    """A position-derived tensor on its way into the feature path."""
+    return t if FEATURE_DTYPE is None else t.to(FEATURE_DTYPE)
+
 
 def set_mlp_dtype(name):
     """"bf16": operands of the forward / data-gradient / weight-gradient products rounded to bf16.  "fp16" (BASELINE
@@ -275,7 +286,7 @@ class SymmetricCurve1DConvFastV1(nn.Module):
     def forward(self, x, pos, batch, point2curveidx, **kwargs):
         g = curve_ids_global(point2curveidx, batch)
         if self.with_xyz:
-            x = pos if x is None else torch.cat([x, pos], dim=1)
+            x = _feat(pos) if x is None else torch.cat([x, _feat(pos)], dim=1)
         rows, n_rows = _separator_layout(g, x.size(0), self.kernel_size // 2 if self.kernel_size > 1 else 0, False)
         for conv, norm in zip(self.conv_modules, self.norm_modules):
             if self.with_diff:
@@ -299,7 +310,7 @@ class SymmetricCurve1DConvV2(nn.Module):
     def forward(self, x, pos, batch, point2curveidx, **kwargs):
         g = curve_ids_global(point2curveidx, batch)
         if self.with_xyz:
-            x = pos if x is None else torch.cat([x, pos], dim=1)
+            x = _feat(pos) if x is None else torch.cat([x, _feat(pos)], dim=1)
         pad = (self.kernel_size // 2) * (len(self.feat_dims) - 1) if self.kernel_size > 1 else 0
         rows, n_rows = _separator_layout(g, x.size(0), pad, True)
         if self.with_diff:
@@ -726,7 +737,7 @@ class PointNetConv2(nn.Module):
 
     def forward(self, x_src, pos_src, pos_dst, src, dst):
         n_dst = pos_dst.size(0)
-        rel = pos_src[src] - pos_dst[dst]
+        rel = _feat(pos_src)[src] - _feat(pos_dst)[dst]
         if self.normalize_radius is not None:
             rel = rel / self.normalize_radius
         msg = rel if x_src is None else torch.cat([x_src[src], rel], dim=1)
@@ -848,7 +859,7 @@ class CurveSAModule(nn.Module):
 
     def forward(self, x, pos, batch, point2curveidx, **kwargs):
         if self.with_xyz:
-            x = pos[:, :3] if x is None else torch.cat([x, pos[:, :3]], dim=1)
+            x = _feat(pos[:, :3]) if x is None else torch.cat([x, _feat(pos[:, :3])], dim=1)
         if "sample_idx" in kwargs and kwargs["sample_idx"] is not None:
             idx = kwargs["sample_idx"]
         elif self.use_curve_fps:
@@ -885,7 +896,7 @@ def _fp_concat(x, x_skip, pos_skip, with_xyz):
     if x_skip is not None:
         parts.append(x_skip)
     if with_xyz:
-        parts.append(pos_skip[:, :3])
+        parts.append(_feat(pos_skip[:, :3]))
     return torch.cat(parts, dim=1)
 
 
@@ -923,7 +934,7 @@ class SGCNNLayer(nn.Module):
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
         if self.with_xyz:
-            x = pos if x is None else torch.cat([x, pos], dim=1)
+            x = _feat(pos) if x is None else torch.cat([x, _feat(pos)], dim=1)
         if self.use_sparse_feat_agg:
             # ref dgcnn.py:209-246 forward_slow: message nn([x_i, x_j - x_i]) over the edge list, aggregate per query
             row, col = group_fixed_radius(pos, pos, batch, batch, self.k, self.r, accel_knn=self.use_fast_knn)
@@ -974,7 +985,7 @@ class DGCNNLayer(nn.Module):
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
         if self.with_xyz:
-            x = pos if x is None else torch.cat([x, pos], dim=1)
+            x = _feat(pos) if x is None else torch.cat([x, _feat(pos)], dim=1)
         row, col = group_fixed_radius(x.detach(), x.detach(), batch, batch, self.k, self.r, operation=self.operation)
         msg = self.nn(torch.cat([x[row], x[col] - x[row]], dim=-1))
         out = _segment_max(msg, row, col, x.size(0))
@@ -997,7 +1008,7 @@ class GlobalSAModule(nn.Module):
         self.nn, self.pooling = nn, kwargs.get("pooling", "max")
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
-        f = self.nn(torch.cat([x, pos], dim=1))
+        f = self.nn(torch.cat([x, _feat(pos)], dim=1))
         n_clouds = int(batch.max().item()) + 1
         if self.pooling == "max":
             f = _segment_max(f, batch, torch.arange(f.size(0)), n_clouds)
@@ -1019,7 +1030,7 @@ class SharedMLP(nn.Module):
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):
         if self.with_xyz:
-            x = pos if x is None else torch.cat([x, pos], dim=1)
+            x = _feat(pos) if x is None else torch.cat([x, _feat(pos)], dim=1)
         return self.mlp(x), pos, batch, point2curveidx
 
 
@@ -1127,6 +1138,7 @@ class ModelBase(nn.Module):
 
     def forward(self, data, **kwargs):
         x, pos, batch, p2c = data.x, data.pos, data.batch, data.curve_idxs
+        x = None if x is None else _feat(x)
         if hasattr(data, "labels"):
             kwargs["shapenet-categories"] = data.labels
         hist = {"x": [x], "pos": [pos], "batch": [batch], "p2c": [p2c], "idx": []}
@@ -1135,7 +1147,7 @@ class ModelBase(nn.Module):
         for i, (name, step) in enumerate(zip(self.step_names, self.steps)):
             if name in ("fp", "fp-geo"):
                 j = keep_down.pop()
-                skip_x = hist["x"][j] if hist["x"][j] is not None else hist["pos"][j]
+                skip_x = hist["x"][j] if hist["x"][j] is not None else _feat(hist["pos"][j])
                 if name == "fp":
                     out = step(x, pos, batch, skip_x, hist["pos"][j], hist["batch"][j], p2c, hist["p2c"][j], **kwargs)
                 else:
@@ -1143,7 +1155,7 @@ class ModelBase(nn.Module):
             elif name == "skip-connect":
                 take = keep_prop[-step.num_skips:]
                 del keep_prop[-step.num_skips:]
-                xs = [x] + [hist["x"][j] if hist["x"][j] is not None else hist["pos"][j] for j in take]
+                xs = [x] + [hist["x"][j] if hist["x"][j] is not None else _feat(hist["pos"][j]) for j in take]
                 out = step(xs, pos, batch, p2c, **kwargs)
             else:
                 out = step(x, pos, batch, p2c, **kwargs)
@@ -1155,7 +1167,7 @@ class ModelBase(nn.Module):
             if name in _DOWN:
                 keep_down.append(i)
         if "shapenet-categories" in kwargs and hasattr(self, "lin_categorical"):
-            cats = self.lin_categorical(F.one_hot(kwargs["shapenet-categories"], num_classes=16).float())
+            cats = self.lin_categorical(_feat(F.one_hot(kwargs["shapenet-categories"], num_classes=16).float()))
             x = torch.cat([x, cats[cloud_of_point]], dim=1)
         return self.mlp(x)
 

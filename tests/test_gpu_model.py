@@ -1,10 +1,12 @@
 """GPU parity of the assembled hot path (ModelBase over the section-8a steps) against the CPU oracle:
 logits, loss, gradients of every parameter, BatchNorm running statistics -- plus properties at the
 BASELINE size (2048 curves, ~50k points)."""
+import os
+
 import pytest
 import torch
 
-from tests.util import GRAD_TOL, batch_to, build_pair, hotpath_config, maxdiff, routed_parity
+from tests.util import GRAD_TOL, adjudicate, batch_to, build_pair, hotpath_config, maxdiff, routed_parity
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -18,27 +20,62 @@ LOGIT_TOL = 1e-4        # north_star: fp32 features within 1e-4 (times the logit
 MAX_FLIP_RATE = 1e-4    # arg-max entries that may differ between GPU and oracle (last-bit ties), plus 4
 
 
-def _check_routed(res, what, logit_floor=0.0):
-    """Shared assertions of a tests.util.routed_parity run (see there).  ``logit_floor``: measured fp32 re-association
-    noise of the network itself (only the deepest full-width test passes one)."""
+ADJ_RATIO = 1.5         # adjudicated by fp64: the GPU may be at most this much farther from the fp64 value than the fp32 CPU oracle
+
+
+def _log(line):
+    """Printed (pytest -s) and, when CCN_PARITY_LOG names a file, appended there (profiles/rNN_parity_margins.txt)."""
+    print(line)
+    path = os.environ.get("CCN_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(line + "\n")
+
+
+def _check_routed(res, what):
+    """Shared assertions of a tests.util.routed_parity run (see there).
+
+    Logits: within north_star's 1e-4 (times the logit scale where that exceeds 1) of the fp32 CPU oracle -- or, when the
+    run carries an fp64 evaluation of the oracle along the same routes (``fp64=True``), ADJUDICATED by it: two correct
+    fp32 evaluations of a deep network differ from each other by the sum of their rounding errors, so the GPU is held
+    to  |gpu - fp64| <= max(1e-4 scale, 1.5 |cpu_fp32 - fp64|)  and  |gpu - fp64| <= 1e-4 scale + |cpu_fp32 - fp64|:
+    as close to the value the network defines as the reference's own arithmetic is.  Gradients likewise: every tensor
+    within GRAD_TOL of the fp32 oracle, or no farther from the fp64 gradient than 1.5 x the fp32 oracle is (+ GRAD_TOL/3)."""
     out_d, out_r = res["out_d"], res["out_r"]
     assert out_d.shape == out_r.shape
     scale = max(1.0, float(out_r.abs().max()))
     err = maxdiff(out_d, out_r)
     worst = sorted(res["grad_err"])[-5:]
-    print("%s: logits max|diff| %.2e (scale %.2f), loss diff %.2e, arg-max flips %d of %d (gap %.1e), activation-sign "
-          "flips %d of %d (|z| <= %.1e), worst routed gradients %s"
-          % (what, err, scale, abs(float(res["loss_d"]) - float(res["loss_r"])), res["flips"], res["entries"],
-             res["max_gap"], res["sign_flips"], res["sign_entries"], res["sign_max_abs"], ["%.1e %s" % e for e in worst]))
-    assert err <= max(LOGIT_TOL * scale, logit_floor), (err, logit_floor)
+    _log("%s: logits max|diff| %.2e (scale %.2f), loss diff %.2e, arg-max flips %d of %d (gap %.1e), activation-sign "
+         "flips %d of %d (|z| <= %.1e), worst routed gradients %s"
+         % (what, err, scale, abs(float(res["loss_d"]) - float(res["loss_r"])), res["flips"], res["entries"],
+            res["max_gap"], res["sign_flips"], res["sign_entries"], res["sign_max_abs"], ["%.1e %s" % e for e in worst]))
+    band = LOGIT_TOL * scale
+    if "out_64" in res:
+        d_gpu, d_cpu = adjudicate(res)
+        _log("%s: fp64 adjudication: |gpu - fp64| %.2e, |cpu_fp32 - fp64| %.2e (ratio %.2f), 1e-4 x scale = %.2e"
+             % (what, d_gpu, d_cpu, d_gpu / max(d_cpu, 1e-30), band))
+        assert d_gpu <= max(band, ADJ_RATIO * d_cpu), (d_gpu, d_cpu, band)
+        assert d_gpu <= band + d_cpu, (d_gpu, d_cpu, band)
+        band = max(band, d_gpu + d_cpu)               # what the two fp32 evaluations may then differ by
+    assert err <= band, (err, band)
     assert abs(float(res["loss_d"]) - float(res["loss_r"])) < 1e-5
     assert res["flips"] <= 4 + MAX_FLIP_RATE * res["entries"], (res["flips"], res["entries"])
-    assert res["max_gap"] <= max(1e-5 * scale, logit_floor), res["max_gap"]       # a flipped entry really was a tie
+    assert res["max_gap"] <= band, res["max_gap"]       # a flipped entry really was a tie (within the forward difference)
     # ReLU / LeakyReLU kinks: the oracle would have taken the other slope only where |z| is within the forward difference
     assert res["sign_flips"] <= 4 + MAX_FLIP_RATE * res["sign_entries"], (res["sign_flips"], res["sign_entries"])
-    assert res["sign_max_abs"] <= max(1e-4 * scale, 2 * logit_floor), res["sign_max_abs"]
+    assert res["sign_max_abs"] <= band, res["sign_max_abs"]
+    adj = {n: (a, b) for a, b, n in res.get("grad_adj", [])}
+    if adj:
+        wa = sorted(adj.items(), key=lambda kv: kv[1][0])[-3:]
+        _log("%s: routed gradients vs fp64 (relative, gpu / cpu_fp32): %s"
+             % (what, ["%.1e / %.1e %s" % (a, b, n) for n, (a, b) in wa]))
     for e, n in res["grad_err"]:
-        assert e <= GRAD_TOL, (e, n)
+        if e <= GRAD_TOL:
+            continue
+        assert n in adj, (e, n)
+        g_gpu, g_cpu = adj[n]
+        assert g_gpu <= ADJ_RATIO * g_cpu + GRAD_TOL / 3, (n, e, g_gpu, g_cpu)
 
 
 @pytest.mark.parametrize("ids,n_curves", [([0], 96), ([1, 2], 64)])
@@ -81,36 +118,36 @@ def test_full_width_hotpath_cloud_matches_oracle():
 
 def test_full_width_kitti_cloud_forward_matches_oracle():
     """The reference's complete KITTI model section at full width (28.8 M parameters, the benchmark's network) on one
-    BASELINE-size cloud: logits against the CPU oracle (forward only: the oracle's backward at this size takes minutes)."""
+    BASELINE-size cloud (49 652 points): logits against the CPU oracle, adjudicated by the oracle evaluated in fp64 along
+    the same routes.  33 steps / ~70 GEMM layers deep, contractions up to K = 3072, BatchNorm over a few hundred rows at
+    the coarse levels: two fp32 evaluations of THIS network differ by more than 1e-4 from each other (the fp32 CPU oracle is
+    itself several 1e-4 from the fp64 value), so the bound is the GPU's distance to the fp64 value against the fp32
+    oracle's (see _check_routed)."""
     from curvecloudnet_amd.configs import kitti_config
     from curvecloudnet_amd.synth import make_batch
     ref, mine = build_pair(kitti_config(width=1.0), in_dim=4, n_out=20)
     mine = mine.to(DEV)
     data = make_batch([0])
+    assert data.pos.size(0) == 49652
     y = _labels(data.pos.size(0), 20, 3)
     ref.train(); mine.train()
     with torch.no_grad():
-        res = routed_parity(ref, mine, data, y, DEV, backward=False)
-        # 33 steps / ~70 GEMM layers deep, contractions up to K = 3072, BatchNorm over a few hundred rows at the coarse
-        # levels: fp32 re-association alone moves the logits of THIS network by more than 1e-4.  Measured here, on the
-        # GPU, as the distance between two legitimate fp32 evaluations of the same model and input that differ only in
-        # summation order (LDS-DMA GEMM kernels vs the register-staged ones); the distance to the oracle must stay
-        # within 3x that (or 1e-4 x scale, whichever is larger).
-        from curvecloudnet_amd import _lib
-        mine.load_state_dict(ref.state_dict())        # (undo the running-statistics update of the pass above)
-        outs = []
-        for dma in (1, 0):
-            _lib.lib().ccn_gemm_use_dma(dma)
-            try:
-                torch.manual_seed(5)
-                outs.append(mine(batch_to(data, DEV)))
-            finally:
-                _lib.lib().ccn_gemm_use_dma(1)
-            mine.load_state_dict(ref.state_dict())
-        floor = maxdiff(outs[0], outs[1])
-        print("fp32 re-association noise of the full-width KITTI network on this input: %.2e" % floor)
-        assert floor < 2e-3
-    _check_routed(res, "KITTI x1.0, 49652 points", logit_floor=3 * floor)
+        res = routed_parity(ref, mine, data, y, DEV, backward=False, fp64=True)
+    _check_routed(res, "KITTI x1.0, 49652 points, forward")
+
+
+def test_full_width_kitti_backward_matches_oracle():
+    """The full-width KITTI network WITH backward on a 512-curve cloud (~12 k points; the oracle's forward + backward
+    takes ~10 s there): logits, loss and every one of the 28.8 M-parameter model's gradient tensors along identical
+    routes, with the fp64 evaluation alongside."""
+    from curvecloudnet_amd.configs import kitti_config
+    from curvecloudnet_amd.synth import make_batch
+    ref, mine = build_pair(kitti_config(width=1.0), in_dim=4, n_out=20)
+    mine = mine.to(DEV)
+    data = make_batch([0], n_curves=512)
+    y = _labels(data.pos.size(0), 20, 3)
+    ref.train(); mine.train()
+    _check_routed(routed_parity(ref, mine, data, y, DEV, fp64=True), "KITTI x1.0, %d points, forward + backward" % data.pos.size(0))
 
 
 def test_full_size_cloud_properties():
@@ -234,10 +271,14 @@ def test_shapenet_seg_config_matches_oracle():
 @pytest.mark.parametrize("which", ["a2d2", "shapenet-cls", "kortx"])
 def test_remaining_reference_configs_match_oracle(which):
     """A2D2 (FRNN + attention in sparse SGCNN), ShapeNet classification (global pooling head) and Kortx (k=7
-    convolutions, K=30): logits against the CPU oracle at 1/8 width."""
+    convolutions, K=30; the network BASELINE configs[1] names) at 1/8 width: logits, loss and every gradient tensor
+    against the CPU oracle along identical routes, as for the KITTI section."""
     from curvecloudnet_amd import configs
     from curvecloudnet_amd.synth import make_batch
-    data = make_batch([0, 1], n_curves=90)
+    # (classification: the head's BatchNorm layers see ONE row per cloud.  Over two rows a BatchNorm output is +-gamma + beta
+    # whatever the input, so every gradient in front of it is exactly zero and both sides would be compared on rounding
+    # noise alone: eight clouds there.)
+    data = make_batch(list(range(8)), n_curves=24) if which == "shapenet-cls" else make_batch([0, 1], n_curves=90)
     if which == "a2d2":
         cfg, in_dim, n_out = configs.a2d2_config(0.125), 4, 12
     elif which == "kortx":
@@ -252,15 +293,11 @@ def test_remaining_reference_configs_match_oracle(which):
     mine = mine.to(DEV)
     ref.train(); mine.train()
     kw = {"shapenet-categories": torch.tensor([1, 2])} if which == "kortx" else {}
-    torch.manual_seed(5)
-    out_r = ref(data, **kw)
-    torch.manual_seed(5)
-    out_d = mine(batch_to(data, DEV), **{k: v.to(DEV) for k, v in kw.items()})
-    assert out_d.shape == out_r.shape
-    assert out_r.shape[0] == (2 if which == "shapenet-cls" else data.pos.size(0))
-    assert maxdiff(out_d, out_r) < 1e-3, maxdiff(out_d, out_r)
-    out_d.square().mean().backward()
-    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in mine.parameters())
+    n_rows = 8 if which == "shapenet-cls" else data.pos.size(0)
+    y = _labels(n_rows, n_out, 3)
+    res = routed_parity(ref, mine, data, y, DEV, fwd_kwargs=kw, fp64=True)
+    assert res["out_r"].shape == (n_rows, n_out)
+    _check_routed(res, "%s x0.125" % which)
 
 
 def test_geometry_stream_modes_agree(monkeypatch):
@@ -440,3 +477,82 @@ def test_kitti_4x120k_properties():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
     torch.manual_seed(1)
     assert maxdiff(model(data), out) < 1e-5
+
+
+# ---------------------------------------------------------------- BASELINE configs[2]: 16 x ~35k-point clouds, nuScenes section, bf16
+def test_nuscenes_16x35k_bf16_properties():
+    """configs[2] at its own size: 16 clouds of 1430 curves (~35k points each) through the full-width nuScenes section
+    with the 16-bit MLP path (``ops.set_mlp_dtype("bf16")``).  Size-independent properties: curve offsets exact, finite
+    logits and a finite gradient for every parameter, a repeatable forward, BatchNorm statistics finite and updated, the
+    16-bit kernels really ran (features differ from the fp32 path's), and the features of the FIRST steps -- before the
+    33-step network in training mode has amplified the perturbation (a random-initialised network of this depth turns the
+    fp32 rounding noise of 6e-8 into 2e-4 at the logits, see the fp64 adjudication above, and saturates on bf16's 4e-3) --
+    stay within the 16-bit band of the fp32 path's (operands rounded to 8 significant bits, fp32 accumulation); the loss of
+    the two paths agrees to a few per cent."""
+    from curvecloudnet_amd import configs, ops
+    from curvecloudnet_amd.model import build_model, segmentation_loss
+    from curvecloudnet_amd.synth import make_batch
+    cpu = make_batch(list(range(16)), n_curves=1430)
+    data = batch_to(cpu, DEV)
+    n = cpu.pos.size(0)
+    assert 16 * 33000 < n < 16 * 37000
+    topo = ops.CurveTopology(data.batch, data.curve_idxs)
+    assert topo.num_curves == 16 * 1430 and topo.num_clouds == 16
+    key = cpu.batch * (1 << 20) + cpu.curve_idxs
+    starts = torch.cat([torch.zeros(1, dtype=torch.long), torch.nonzero(key[1:] != key[:-1]).flatten() + 1,
+                        torch.tensor([key.numel()])])
+    assert torch.equal(topo.curve_ptr.cpu().long(), starts)
+    labels = _labels(n, 17, 1).to(DEV)
+    torch.manual_seed(0)
+    model = build_model(configs.nuscenes_config(1.0), in_dim=4, n_out=17).to(DEV).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    watch = (0, 1, 2, 3, 4)                       # conv1d-fast-v2, sa-geo, mlp, sgcnn, skip-connect: the full-resolution levels
+    feats, outs, losses = {}, {}, {}
+    hooks = [model.steps[i].register_forward_hook(
+        lambda mod, args, out, i=i: feats.setdefault(i, []).append(out[0].detach().clone())) for i in watch]
+    try:
+        for mode in ("fp32", "bf16"):
+            ops.set_mlp_dtype(mode)
+            try:
+                model.load_state_dict(state)
+                model.zero_grad(set_to_none=True)
+                torch.manual_seed(1)
+                out = model(data)
+                assert out.shape == (n, 17) and bool(torch.isfinite(out).all())
+                loss = segmentation_loss(out, labels)
+                losses[mode] = float(loss)
+                if mode == "bf16":
+                    loss.backward()
+                    for name, p in model.named_parameters():
+                        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+                    for name, b in model.named_buffers():
+                        assert bool(torch.isfinite(b.float()).all()), name
+                        if name.endswith("running_mean"):
+                            assert not torch.equal(b, state[name]), name
+                outs[mode] = out.detach().clone()
+                del out, loss
+            finally:
+                ops.set_mlp_dtype("fp32")
+    finally:
+        for h in hooks:
+            h.remove()
+    ops.set_mlp_dtype("bf16")
+    try:
+        model.load_state_dict(state)
+        torch.manual_seed(1)
+        with torch.no_grad():
+            assert maxdiff(model(data), outs["bf16"]) < 1e-5          # repeatable
+    finally:
+        ops.set_mlp_dtype("fp32")
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm())
+    per_step = {i: rel(feats[i][1], feats[i][0]) for i in watch}
+    r_out = rel(outs["bf16"], outs["fp32"])
+    _log("nuScenes x1.0, 16 x ~35k points (%d), bf16 MLP path vs fp32 path: relative l2 of the features after steps %s = %s, "
+         "of the logits %.2e; loss %.5f vs %.5f"
+         % (n, list(watch), ["%.1e" % per_step[i] for i in watch], r_out, losses["bf16"], losses["fp32"]))
+    assert all(v > 1e-5 for v in per_step.values()), per_step      # a different arithmetic really ran
+    assert per_step[0] < 2e-2 and per_step[1] < 3e-2 and per_step[2] < 5e-2, per_step
+    assert r_out < 1.0
+    assert abs(losses["bf16"] - losses["fp32"]) < 0.05 * losses["fp32"], losses

@@ -55,19 +55,33 @@ def maxdiff(a, b):
     return float((a - b).abs().max())
 
 
-def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backward=True):
+def _data_as(data, dtype):
+    out = SimpleNamespace(**vars(data))
+    if getattr(out, "x", None) is not None:
+        out.x = out.x.to(dtype)
+    return out
+
+
+def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backward=True, fp64=False):
     """Product forward (+ backward) with its routing tables recorded -- which source point won every max aggregation,
     which slope every ReLU / LeakyReLU took -- then the CPU oracle with those tables FORCED (oracle.torch_ref.MAX_TRACE,
     ACT_TRACE): both sides then differentiate along identical routes, so gradients can be held to a tight tolerance, and
     the choices the oracle would have made by itself give the number of flipped entries (all of them last-bit ties /
     pre-activations within the forward difference of zero: max_gap, sign_max_abs).
 
-    Returns dict(out_d, out_r, loss_d, loss_r, flips, entries, grad_err=[(err, name)], grad_scale)."""
+    ``fp64``: the oracle is evaluated a second time with every FEATURE computation in float64 (a ``.double()`` copy of
+    the model, oracle.torch_ref.FEATURE_DTYPE; positions and every index decision stay fp32, the routes are forced to
+    the same tables): ``out_64`` (and ``grad_64`` per parameter name when ``backward``) is then the value the network
+    defines on this input, and the fp32 CPU oracle and the GPU are two fp32 evaluations of it whose distances to it can
+    be compared (``adjudicate``).
+
+    Returns dict(out_d, out_r, loss_d, loss_r, flips, entries, grad_err=[(err, name)], grad_scale[, out_64, grad_64])."""
     from oracle import torch_ref as R
     from curvecloudnet_amd import ops
     from curvecloudnet_amd.model import segmentation_loss
     kw = fwd_kwargs or {}
     kw_d = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    ref64 = copy.deepcopy(ref).double() if fp64 else None     # (before the passes below update the running statistics)
     ops.MAX_TRACE, ops.ACT_TRACE = [], []
     try:
         torch.manual_seed(seed)
@@ -79,7 +93,7 @@ def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backwar
     if backward:
         loss_d.backward()
     R.MAX_TRACE = {"record": [], "force": [t.clone() for t in tables]}
-    R.ACT_TRACE = {"force": signs, "mismatch": 0, "entries": 0, "max_abs": 0.0}
+    R.ACT_TRACE = {"force": list(signs), "mismatch": 0, "entries": 0, "max_abs": 0.0}
     try:
         torch.manual_seed(seed)
         out_r = ref(data, **kw)
@@ -99,6 +113,23 @@ def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backwar
     res = dict(out_d=out_d, out_r=out_r, loss_d=loss_d, loss_r=loss_r, flips=flips, entries=entries, grad_err=[],
                grad_scale=0.0, max_gap=max_gap, sign_flips=act["mismatch"], sign_entries=act["entries"],
                sign_max_abs=act["max_abs"])
+    if fp64:
+        R.MAX_TRACE = {"record": [], "force": [t.clone() for t in tables]}
+        R.ACT_TRACE = {"force": list(signs), "mismatch": 0, "entries": 0, "max_abs": 0.0}
+        R.FEATURE_DTYPE = torch.float64
+        try:
+            torch.manual_seed(seed)
+            out_64 = ref64(_data_as(data, torch.float64), **kw)
+            assert out_64.dtype == torch.float64
+            assert not R.MAX_TRACE["force"] and not R.ACT_TRACE["force"]
+            if backward:
+                R.segmentation_loss(out_64, labels).backward()
+        finally:
+            R.MAX_TRACE = R.ACT_TRACE = None
+            R.FEATURE_DTYPE = None
+        res["out_64"] = out_64.detach()
+        if backward:
+            res["grad_64"] = {n: p.grad for n, p in ref64.named_parameters()}
     if backward:
         pairs = [(n, pr.grad, pd.grad) for (n, pr), (_, pd) in zip(ref.named_parameters(), mine.named_parameters())]
         for n, gr, gd in pairs:
@@ -113,7 +144,19 @@ def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backwar
             if err <= 2e-6 * gmax:          # both sides at the fp32 noise floor of the summation
                 err = 0.0
             res["grad_err"].append((err / denom, n))
+            if fp64:
+                g64 = res["grad_64"][n]
+                res.setdefault("grad_adj", []).append(
+                    (float((gd.detach().cpu().double() - g64).abs().max()) / denom,
+                     float((gr.double() - g64).abs().max()) / denom, n))
     return res
+
+
+def adjudicate(res):
+    """(d_gpu, d_cpu): max-norm distances of the GPU logits and of the fp32 CPU oracle's logits to the fp64 evaluation."""
+    o64 = res["out_64"]
+    return (float((res["out_d"].detach().cpu().double() - o64).abs().max()),
+            float((res["out_r"].detach().double() - o64).abs().max()))
 
 
 GRAD_TOL = 3e-4          # routed gradients, per tensor (see routed_parity)
