@@ -337,6 +337,8 @@ def main():
     local_rank = int(os.environ.get("CCN_FORCE_DEVICE", local_rank))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if os.environ.get("CCN_BENCH_FAIL_RANK") == str(rank):      # test hook: the launcher must exit non-zero with its rank
+        raise SystemExit("rank %d: failing on request (CCN_BENCH_FAIL_RANK)" % rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -478,8 +480,12 @@ def main():
             if (name == "gemm_nt" and len(ints) >= 6 and ints[4] > 128 and 0 < ints[4] % 128 <= 64 and cargs[-1] is None):
                 return False      # this call also launches a 64-wide remainder product (ccn_gemm.hip): not one kernel
             site[0] += 1
-            return (site[0] + site[1]) % args.event_stride == 0
+            if (site[0] + site[1]) % args.event_stride == 0:
+                sampled_sites.append(site[0])       # (records of this kernel are appended in the same order)
+                return True
+            return False
 
+        sampled_sites = []
         _lib.PROFILE, _lib.PROFILE_ONLY, _lib.PROFILE_FILTER = [], "gemm_", only_dominant
     ref_event = torch.cuda.Event(enable_timing=True)
     ref_event.record()
@@ -499,12 +505,38 @@ def main():
             step()
         barrier()
         full_records, _lib.PROFILE = _lib.PROFILE, None
+    # what a data-parallel run says about itself: the world size the process group reports, the points
+    # each rank processed per step (step time = the slowest rank's: load imbalance = max / mean), the bytes handed to
+    # all_reduce per step and the host time finish() waited for the collectives
+    dp_stats = dict(sync.stats)
+    points_per_rank = [n_points]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
+        gathered = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(world)]
+        mine = torch.tensor([n_points, dp_stats["finish_wait_s"], dp_stats["buckets_reduced_in_finish"]],
+                            dtype=torch.float64, device=dev)
+        torch.distributed.all_gather(gathered, mine)
+        points_per_rank = [int(g[0].item()) for g in gathered]
+        dp_stats["finish_wait_s_max_rank"] = max(float(g[1].item()) for g in gathered)
+        dp_stats["buckets_reduced_in_finish_max_rank"] = max(int(g[2].item()) for g in gathered)
     if rank != 0:
         return
+    all_steps = max(dp_stats["steps"], 1)        # (priming + warm-up + timed + instrumented steps all count)
+    multi_gpu = {
+        "world_size": world, "world_size_observed": (torch.distributed.get_world_size() if world > 1 or
+                                                     torch.distributed.is_initialized() else 1),
+        "backend": (torch.distributed.get_backend() if torch.distributed.is_initialized() else None),
+        "collective": "all_reduce(SUM) of the fp32 gradient buckets only" if world > 1 else None,
+        "points_per_rank": points_per_rank,
+        "load_imbalance_max_over_mean": max(points_per_rank) / (sum(points_per_rank) / len(points_per_rank)),
+        "gradient_buckets": len(sync.buckets), "gradient_bytes": sync.num_bytes,
+        "allreduce_bytes_per_step": dp_stats["bytes_reduced"] / all_steps,
+        "finish_wait_ms_per_step": 1e3 * dp_stats.get("finish_wait_s_max_rank", dp_stats["finish_wait_s"]) / all_steps,
+        "buckets_reduced_in_finish_per_step": dp_stats.get("buckets_reduced_in_finish_max_rank",
+                                                           dp_stats["buckets_reduced_in_finish"]) / all_steps,
+    }
 
     result = {
         "metric": "point-clouds/sec fwd+bwd @50k pts", "value": world * b * args.steps / elapsed, "unit": "clouds/s",
@@ -525,6 +557,7 @@ def main():
                    "device_mallocs_in_timed_region": device_mallocs,
                    "clouds_per_gpu": b, "points_per_cloud": n_points // b, "parallelism": "dp%d" % world,
                    "loss": float(loss.detach())},
+        "multi_gpu": multi_gpu,
     }
     if records:
         bracket = empty_bracket_ms()
@@ -536,7 +569,22 @@ def main():
             table_steps = 2
         full_share = dict(table_rows).get(name, {"ms": 0.0})["ms"] / total_ms if total_ms else None
         if top["flops"] > 0:
-            achieved = top["flops"] / (top["ms"] * 1e-3) / 1e12
+            # every launch site (one call site of the step = one shape) weighs the same whatever --steps / --event-stride
+            # sampled it how often: mean duration per site first, then flops and time summed over the sites seen
+            per_site = {}
+            if len(sampled_sites) == len(records):
+                for st, (rname, ints, beg, end, nulls) in zip(sampled_sites, records):
+                    e = per_site.setdefault(st, [0.0, 0, gemm_label(rname, ints, nulls)[1]])
+                    e[0] += max(beg.elapsed_time(end) - bracket, 0.0)
+                    e[1] += 1
+            if per_site:
+                site_ms = sum(ms / cnt for ms, cnt, _ in per_site.values())
+                site_flops = sum(fl for _, _, fl in per_site.values())
+                achieved = site_flops / (site_ms * 1e-3) / 1e12
+                top = dict(top, flops_per_launch=site_flops / len(per_site), avg_launch_ms=site_ms / len(per_site),
+                           sites=len(per_site))
+            else:
+                achieved = top["flops"] / (top["ms"] * 1e-3) / 1e12
             tr = pmc_traffic(name)
             # the split product spends six bf16 MFMAs per algorithmic multiply-add
             peak = (PEAK_BF16_MFMA_TFLOPS / 6.0 if "x3" in name else
@@ -544,13 +592,16 @@ def main():
             result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak,
                                   "unit": "TFLOP/s", "frac": achieved / peak,
                                   "traffic": tr["bytes_per_launch"] if tr else None, "traffic_source": tr,
-                                  "flops_per_launch": top["flops"] / top["launches"],
-                                  "kernel": name, "avg_launch_ms": top["ms"] / top["launches"],
-                                  "launches": top["launches"], "share_of_kernel_time": full_share,
+                                  "flops_per_launch": top.get("flops_per_launch", top["flops"] / top["launches"]),
+                                  "kernel": name, "avg_launch_ms": top.get("avg_launch_ms", top["ms"] / top["launches"]),
+                                  "launches": top["launches"], "launch_sites": top.get("sites"),
+                                  "share_of_kernel_time": full_share,
                                   "empty_bracket_us": round(1e3 * bracket, 2),
-                                  "launches_note": "every eighth launch of this kernel inside the timed region is bracketed by "
-                                                   "HIP events (sampling keeps the events' own cost out of `value`); avg_launch_ms has the duration of an "
-                                                   "empty bracket (empty_bracket_us, measured after the run) subtracted"}
+                                  "launches_note": "every %d-th launch of this kernel inside the timed region is bracketed by "
+                                                   "HIP events (sampling keeps the events' own cost out of `value`), the phase moving by one "
+                                                   "launch site per step; durations have an empty bracket (empty_bracket_us, measured after the "
+                                                   "run) subtracted and are averaged per launch site first, so every site of the step weighs the "
+                                                   "same for any --steps" % args.event_stride}
             # The GEMM launches run on two streams (weight-gradient products overlap the rest of the backward pass), so a
             # launch's own duration includes the time it shares the chip.  All GEMM launches together: flops over the
             # UNION of their execution intervals = the MFMA throughput the step actually gets out of the chip.

@@ -1099,7 +1099,7 @@ __device__ unsigned long long* g_pair_dbg_dev = nullptr;
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
 
-template <bool ACC, bool XF, int TAG = 0, bool STAMP = false>
+template <bool ACC, bool XF, int TAG = 0, bool STAMP = false, bool ILV = false>
 __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* __restrict__ A, int64_t lda,
                                                                    const float* __restrict__ B, int64_t ldb,
                                                                    const float* __restrict__ bias, float* __restrict__ C,
@@ -1216,6 +1216,44 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       it_tile = tile_of(++it_j);
     }
   };
+  // ---- the same cursor in three steps (ILV): set-up at the slice top, one pair of copies per call, advance
+  float* is_st = nullptr;
+  int64_t is_k0 = 0;
+  auto issue_begin = [&]() -> bool {
+    if (it_tile >= tiles) return false;
+    if (it_u >= T) {          // K remainder slice: the register path, whole
+      issue_next();
+      return false;
+    }
+    if (it_u == 0) {
+      im0 = tile_row(it_tile) * PR_BM;
+      in0 = tile_col(it_tile) * PR_BN;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const int r = 8 * (wave * NC + q) + lr;
+        int64_t row = im0 + r;
+        row = row < M ? row : M - 1;
+        a_src[q] = A + row * lda + 4 * (lc ^ ((r >> 1) & 7));
+        row = in0 + r;
+        row = row < N ? row : N - 1;
+        b_src[q] = B + row * ldb + 4 * (lc ^ ((r >> 1) & 7));
+      }
+    }
+    is_st = lds + (gi & 1) * STAGE;
+    is_k0 = (int64_t)it_u * BK;
+    return true;
+  };
+  auto issue_piece = [&](int q) {
+    glds16(a_src[q] + is_k0, is_st + (8 * (wave * NC + q)) * BK);
+    glds16(b_src[q] + is_k0, is_st + AF + (8 * (wave * NC + q)) * BK);
+  };
+  auto issue_end = [&]() {
+    ++gi;
+    if (++it_u == TT) {
+      it_u = 0;
+      it_tile = tile_of(++it_j);
+    }
+  };
   // experiments (A/B hook; profiles/r02_pair_kernel_experiments.txt: none of them pays): bit 3 = the second workgroup of a CU
   // starts (opt >> 8) x 3.6 us late, bit 4 = ... and runs at low instruction priority; bit 2 (host side) = one workgroup per CU
   if ((opt & 8) && blockIdx.x >= 256)
@@ -1290,7 +1328,9 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       }
       __builtin_amdgcn_s_barrier();
       if (STAMP) { PR_STAMP(st_a); sum_b += (uint32_t)(st_a - st_b); }
-      issue_next();
+      bool dma_now = false;
+      if (ILV) dma_now = issue_begin();
+      else issue_next();
       if (u == 0 && stat_tile >= 0) stats_readout();
       if (STAMP) { PR_STAMP(st_b); sum_i += (uint32_t)(st_b - st_a); }
       const uint32_t stage_b = lds_base + (uint32_t)((g & 1) * STAGE * 4);
@@ -1387,7 +1427,23 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        mfma_group(q & 1);
+        if (ILV && q == 0) {
+#pragma unroll
+          for (int comp = 0; comp < 4; ++comp) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+                acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][ab][comp], fb[0][t][comp], acc[ab][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (dma_now) issue_piece(comp);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (dma_now) issue_end();
+        } else {
+          mfma_group(q & 1);
+        }
       }
       if (STAMP) { PR_STAMP(st_a); sum_c += (uint32_t)(st_a - st_b); ++n_sl; }
     }
@@ -1479,7 +1535,14 @@ int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, c
   }
   const int64_t slots = (g_pair_opt & 4) ? 256 : 512;
   const int64_t grid = tiles < slots ? tiles : slots;  // two workgroups per CU
-  if (g_pair_dbg_host != nullptr && xf_scale == nullptr && !accumulate && !split_part)
+  if ((g_pair_opt & 32) && xf_scale == nullptr && !accumulate && !split_part) {
+    if (g_pair_dbg_host != nullptr)
+      hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 0, true, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y,
+                         ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, nullptr, nullptr, 0, 0.f);
+    else
+      hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 0, false, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y,
+                         ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, nullptr, nullptr, 0, 0.f);
+  } else if (g_pair_dbg_host != nullptr && xf_scale == nullptr && !accumulate && !split_part)
     hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 0, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y,
                        ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, nullptr, nullptr, 0, 0.f);
   else if (xf_scale != nullptr)

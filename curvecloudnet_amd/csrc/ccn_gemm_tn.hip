@@ -49,10 +49,12 @@ __global__ __launch_bounds__(TN_TPB, 2) void gemm_tn_glds_kernel(const float* __
                                                                  float* __restrict__ C, int64_t ldc, int64_t M, int64_t N,
                                                                  int64_t K, int tiles_k, int tiles, int split,
                                                                  int64_t slices_per_chunk, int64_t n_ids, int xcd_order,
-                                                                 float* __restrict__ slabs, int64_t b_extent,
-                                                                 const float* __restrict__ xf_scale,
+                                                                 float* __restrict__ slabs, int64_t a_extent,
+                                                                 int64_t b_extent, const float* __restrict__ xf_scale,
                                                                  const float* __restrict__ xf_shift, float xf_neg) {
-  // b_extent: floats readable from the start of a B row (= ldb, or K when the rows overlap: ccn_conv_rows_tn)
+  // a_extent / b_extent: floats readable from the start of an A / B row as the kernel sees it -- the leading dimension minus the
+  // column offset of this launch's block (tn_ws_impl splits N and K into a 128-multiple part and a remainder block whose
+  // operand pointers are shifted by n0 / k0), or K when the B rows overlap (ccn_conv_rows_tn)
   constexpr int QN = TN / 64, QK = TK / 64, WC = 4 / (QN * QK);   // quadrants, waves sharing a quadrant
   constexpr int STEPS = TN_SLICE / 2 / WC;                          // 2-row MFMA steps per wave and slice
   constexpr int AF = TN_SLICE * TN, BF = TN_SLICE * TK, STAGE = AF + BF;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(TN_TPB, 2) void gemm_tn_glds_kernel(const float* __
         const int g = wave * NIA + q;
         a_row[q] = g * RPI_A + lane / (TN / 4);
         int64_t c = n0 + 4 * (lane % (TN / 4));
-        a_col[q] = c <= lda - 4 ? c : lda - 4;
+        a_col[q] = c <= a_extent - 4 ? c : a_extent - 4;
       }
 #pragma unroll
       for (int q = 0; q < NIB; ++q) {
@@ -387,15 +389,16 @@ struct TnXf {
 
 template <int TN, int TK>
 int launch_tn(const TnPlan& p, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw,
-              int64_t M, int64_t N, int64_t K, float* slabs, hipStream_t s, int64_t b_extent, const TnXf* xf) {
+              int64_t M, int64_t N, int64_t K, float* slabs, hipStream_t s, int64_t a_extent, int64_t b_extent,
+              const TnXf* xf) {
   const int64_t grid = p.n_ids < 512 ? p.n_ids : 512;
   const float* xs = xf ? xf->scale : nullptr;
   const float* xh = xf ? xf->shift : nullptr;
   const float xn = xf ? xf->neg : 1.f;
 #define CCN_TN_LAUNCH(EPI_, XF_, SLABS_)                                                                                       \
   hipLaunchKernelGGL((gemm_tn_glds_kernel<TN, TK, EPI_, XF_>), dim3((unsigned)grid), dim3(TN_TPB), 0, s, dY, lddy, X, ldx, dW,   \
-                     lddw, M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, SLABS_, b_extent, \
-                     xs, xh, xn)
+                     lddw, M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, SLABS_, a_extent, \
+                     b_extent, xs, xh, xn)
   if (p.split == 1) {
     if (xf) CCN_TN_LAUNCH(2, true, (float*)nullptr);
     else CCN_TN_LAUNCH(2, false, (float*)nullptr);
@@ -451,8 +454,8 @@ int ccn_gemm_tn_generic(const float* dY, int64_t lddy, const float* X, int64_t l
 
 // one launch (+ its slab reduction) of the LDS-DMA kernel over an N x K block of the output
 static int tn_launch_block(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
-                           int64_t N, int64_t K, void* workspace, size_t workspace_bytes, hipStream_t s, int64_t ext,
-                           const TnXf* xf) {
+                           int64_t N, int64_t K, void* workspace, size_t workspace_bytes, hipStream_t s, int64_t aext,
+                           int64_t ext, const TnXf* xf) {
   const TnPlan p = tn_plan(M, N, K);
   float* slabs = nullptr;
   if (p.slab_floats > 0 && workspace != nullptr) {
@@ -461,10 +464,10 @@ static int tn_launch_block(const float* dY, int64_t lddy, const float* X, int64_
                 (size_t)p.slab_floats * sizeof(float));
     slabs = (float*)workspace;
   }
-  if (p.tn == 128 && p.tk == 128) return launch_tn<128, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext, xf);
-  if (p.tn == 128) return launch_tn<128, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext, xf);
-  if (p.tk == 128) return launch_tn<64, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext, xf);
-  return launch_tn<64, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, ext, xf);
+  if (p.tn == 128 && p.tk == 128) return launch_tn<128, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, aext, ext, xf);
+  if (p.tn == 128) return launch_tn<128, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, aext, ext, xf);
+  if (p.tk == 128) return launch_tn<64, 128>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, aext, ext, xf);
+  return launch_tn<64, 64>(p, dY, lddy, X, ldx, dW, lddw, M, N, K, slabs, s, aext, ext, xf);
 }
 
 static int tn_ws_impl(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
@@ -487,7 +490,7 @@ static int tn_ws_impl(const float* dY, int64_t lddy, const float* X, int64_t ldx
       TnXf part;
       if (xf) part = TnXf{xf->scale + k0, xf->shift + k0, xf->neg};
       const int rc = tn_launch_block(dY + n0, lddy, X + k0, ldx, dW + n0 * lddw + k0, lddw, M, n, k, workspace,
-                                     workspace_bytes, s, ext - k0, xf ? &part : nullptr);
+                                     workspace_bytes, s, lddy - n0, ext - k0, xf ? &part : nullptr);
       if (rc) return rc;
     }
   CCN_LAUNCH_OK("gemm_tn_ws");

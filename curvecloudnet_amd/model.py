@@ -240,8 +240,31 @@ def build_model(model_cfg, in_dim, n_out):
     return ModelBase(in_dim, n_out, **cfg)
 
 
-def segmentation_loss(logits, target, ignore_index=-100):
-    """Harness counterpart of ref src/run/kitti_seg.py:184-192 (mean NLL over points): F.nll_loss(F.log_softmax(logits),
-    target) as one fused forward and one backward pass (ops.NLLLoss)."""
+def segmentation_loss(logits, target, ignore_index=-100, reduction="mean", check_targets=None):
+    """Harness counterpart of ref src/run/kitti_seg.py:184-192: F.nll_loss(F.log_softmax(logits), target) as one fused
+    forward and one backward pass (ops.NLLLoss).
+
+    ``reduction="mean"`` (default) divides by the number of rows whose target is not ``ignore_index`` -- torch's
+    ``reduction='mean'``, what the nuScenes / A2D2 runners and the benchmark use.  ``reduction="mean_all"`` is the KITTI
+    runner's form (kitti_seg.py:184-192: ``nll_loss(reduction='none', ignore_index=0)`` followed by ``torch.mean`` over
+    ALL points): ignored rows contribute zero but stay in the denominator.
+
+    A target outside [0, C) that is not ``ignore_index`` contributes nothing in the kernel (torch raises a device-side
+    assertion there).  ``check_targets=True`` (or CCN_CHECK_TARGETS=1) validates the range on the host first, at the
+    price of one device synchronisation, and raises IndexError like torch's CPU path."""
+    import os
     from . import ops
-    return ops.NLLLoss.apply(logits, target, ignore_index)
+    if reduction not in ("mean", "mean_all"):
+        raise ValueError("reduction must be 'mean' or 'mean_all'")
+    if check_targets is None:
+        check_targets = os.environ.get("CCN_CHECK_TARGETS") == "1"
+    if check_targets:
+        c = logits.size(-1)
+        bad = (target != ignore_index) & ((target < 0) | (target >= c))
+        if bool(bad.any()):
+            raise IndexError("Target %d is out of bounds." % int(target[bad][0]))
+    loss = ops.NLLLoss.apply(logits, target, ignore_index)
+    if reduction == "mean_all":
+        counted = (target != ignore_index).sum().to(loss.dtype)
+        loss = loss * (counted / max(target.numel(), 1))
+    return loss

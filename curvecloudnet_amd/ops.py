@@ -764,16 +764,17 @@ class LinearBNAct(torch.autograd.Function):
             dw = into if into is not None else _rows(n, k, dev, zero=True)
             if ctx.gemm_nt in ("gemm_nt_bf16", "gemm_nt_f16"):
                 dy = _aligned_rows(dy)
-            if ctx.xf_act is not None and not lib().ccn_gemm_tn_xf_ok(ptr(dy), _ld(dy), ptr(x), _ld(x), m, n, k):
+            xf_act = ctx.xf_act           # (a local: ctx must read the same on a second backward over a retained graph)
+            if xf_act is not None and not lib().ccn_gemm_tn_xf_ok(ptr(dy), _ld(dy), ptr(x), _ld(x), m, n, k):
                 # (an unaligned incoming gradient: the input activation is written for this product after all)
                 z_in = _rows(m, k, dev)
-                call("bn_act_fwd", ptr(x), _ld(x), m, k, ptr(xf_par[0]), ptr(xf_par[1]), ctx.xf_act, LEAKY_SLOPE, ptr(z_in), _ld(z_in))
-                x, ctx.xf_act = z_in, None
+                call("bn_act_fwd", ptr(x), _ld(x), m, k, ptr(xf_par[0]), ptr(xf_par[1]), xf_act, LEAKY_SLOPE, ptr(z_in), _ld(z_in))
+                x, xf_act = z_in, None
             with _WgradScope(into, dy, x, xf_par):
-                if ctx.xf_act is not None:
+                if xf_act is not None:
                     nb = lib().ccn_gemm_tn_workspace_bytes(m, n, k)
                     ws = _tn_scratch(nb, dev)
-                    call("gemm_tn_ws_xf", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(xf_par[0]), ptr(xf_par[1]), ctx.xf_act,
+                    call("gemm_tn_ws_xf", ptr(dy), _ld(dy), ptr(x), _ld(x), ptr(xf_par[0]), ptr(xf_par[1]), xf_act,
                          LEAKY_SLOPE, ptr(dw), _ld(dw), m, n, k, ptr(ws), nb)
                 else:
                     _wgrad(ctx.gemm_nt, dy, x, dw, m, n, k)
@@ -1136,13 +1137,17 @@ class SegSoftmaxAgg(torch.autograd.Function):
     """scatter_add(msg * softmax_per_destination(att))  (ref point_conv.py:89-93)."""
 
     @staticmethod
-    def forward(ctx, msg, att, offsets, num_dst):
+    def forward(ctx, msg, att, offsets, num_dst, owns_msg=False):
+        # owns_msg: the caller made ``msg`` itself and hands it to exactly two consumers -- the MLP that produced ``att`` and
+        # this aggregation (PointNetConv2 / the sparse SGCNN path).  Only then may the gradient sink be used: with a third
+        # consumer autograd would accumulate out of place and the in-place add into dmsg would be lost (ADVICE r2).
         msg, att = _mat(msg), _mat(att)
         c = msg.size(1)
         out = _rows(num_dst, c, msg.device)
         call("seg_softmax_agg_fwd", ptr(msg), _ld(msg), ptr(att), _ld(att), ptr(offsets), num_dst, c, ptr(out), _ld(out))
         _GRAD_SINK.clear()                   # (nothing of an earlier backward pass may survive into this one)
         ctx.save_for_backward(msg, att, offsets)
+        ctx.owns_msg = bool(owns_msg)
         return out
 
     @staticmethod
@@ -1153,8 +1158,9 @@ class SegSoftmaxAgg(torch.autograd.Function):
         dmsg, datt = _rows(msg.size(0), c, g.device), _rows(att.size(0), c, g.device)
         call("seg_softmax_agg_bwd", ptr(msg), _ld(msg), ptr(att), _ld(att), ptr(offsets), m, c, ptr(g), _ld(g),
              ptr(dmsg), _ld(dmsg), ptr(datt), _ld(datt))
-        _grad_sink_offer(msg, dmsg)          # attend_nn's first layer adds its data gradient into dmsg (see _GRAD_SINK)
-        return dmsg, datt, None, None
+        if ctx.owns_msg:
+            _grad_sink_offer(msg, dmsg)      # attend_nn's first layer adds its data gradient into dmsg (see _GRAD_SINK)
+        return dmsg, datt, None, None, None
 
 
 class SegWSum(torch.autograd.Function):

@@ -103,6 +103,10 @@ class GradientAllReduce:
         self._handles = []
         self._quiet = False
         self.reduce_calls = 0      # collectives launched since construction (tests)
+        # what a multi-rank run reports about itself (bench.py): bytes handed to all_reduce, buckets that had to be reduced
+        # in finish() because not every parameter had reported during backward (no overlap for those), host time finish()
+        # spent waiting for the collectives
+        self.stats = {"steps": 0, "bytes_reduced": 0, "buckets_reduced_in_finish": 0, "finish_wait_s": 0.0}
         if self.reduces:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
@@ -148,8 +152,10 @@ class GradientAllReduce:
         self._uses[id(p)] = max(self._uses.get(id(p), 0) - 1, 0)
 
     def _on_grad(self, p):
-        """autograd's post-accumulate hook (fires once per backward pass, after the parameter's last use -- also for a
-        parameter whose layers returned no gradient tensor because they had added it into the bucket themselves)."""
+        """autograd's post-accumulate hook: fires once per backward pass after the parameter's last use, when autograd
+        itself accumulated a gradient tensor for it.  (AccumulateGrad skips its hooks for an undefined gradient, so a
+        parameter whose layers all added their product into the bucket view and returned None is reported by
+        ``use_done`` alone; where both fire in one pass, ``_mark`` recognises the second report.)"""
         if self._uses.get(id(p), 0) > 0:
             return                  # a fused use is still outstanding: use_done reports
         self._mark(p, True)
@@ -173,6 +179,7 @@ class GradientAllReduce:
         self._launched[b] = True
         self.reduce_calls += 1
         flat = self.buckets[b][0]
+        self.stats["bytes_reduced"] += flat.numel() * flat.element_size()
         if os.environ.get("CCN_DP_DRYRUN"):       # diagnostic: hooks and bookkeeping without the collective itself
             return
         from .ops import wgrad_stream_of
@@ -195,11 +202,16 @@ class GradientAllReduce:
         _join_wgrad()
         if self.reduces:
             # buckets whose parameters did not all report a gradient this step are reduced here
+            import time
             for b in range(len(self.buckets)):
                 if not self._launched[b]:
+                    self.stats["buckets_reduced_in_finish"] += 1
                     self._reduce(b)
+            t0 = time.perf_counter()
             for h in self._handles:
                 h.wait()
+            self.stats["finish_wait_s"] += time.perf_counter() - t0
+            self.stats["steps"] += 1
             for flat, _, _ in self.buckets:
                 flat.div_(self.world)
         self._handles = []

@@ -360,7 +360,7 @@ class PointNetConv2(nn.Module):
         elif self.aggr_type == "weighted-sum":
             out = ops.SegWSum.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst, 1)
         else:
-            out = ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst)
+            out = ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst, True)
         if self.global_nn is not None:
             out = self.global_nn(out)
         return out
@@ -551,7 +551,7 @@ class SGCNNLayer(nn.Module):
             if self.aggr_type == "max":
                 return ops.SegMax.apply(msg, edges.offsets, edges.num_dst, edges.col)
             # ref dgcnn.py:239-244: every other aggr_type takes the softmax-attention branch
-            return ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst)
+            return ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst, True)
         topo, nbr, comp = g.topo, g.nbr, g.comp
         algebraic, _ = self._mode()
         lin0 = self.nn.lins[0]

@@ -347,3 +347,31 @@ def test_transforming_gemms_match_written_activation(M, N, K, act):
     assert lib().ccn_gemm_tn_xf_ok(ptr(dy), N, ptr(y0), K, M, N, K)
     call("gemm_tn_ws_xf", ptr(dy), N, ptr(y0), K, ptr(par[0]), ptr(par[1]), act, 0.01, ptr(d2), K, M, N, K, ptr(ws), nb)
     assert torch.equal(d1, d2), "weight gradient"
+
+
+@pytest.mark.parametrize("M,N,K", [(2051, 130, 96), (4099, 131, 259), (1033, 192, 67)])
+def test_weight_gradient_remainder_block_on_a_tight_allocation(M, N, K):
+    """ccn_gemm_tn_ws splits an output width like 130 / 131 / 259 into a 128-multiple block and a remainder block whose
+    operand pointers are shifted by n0 / k0.  The remainder block's LDS-DMA columns must be clamped against what is left
+    of the row (ld - n0), not against ld (up to 240 B past the end of dY on the last row).  The operands sit at
+    the very END of their allocations, with a sentinel buffer behind them that must stay untouched, and the result is
+    held against an fp64 product."""
+    ops, call, lib, ptr, workspace = _api()
+    gen = torch.Generator().manual_seed(M + N + K)
+    ldn, ldk = (N + 3) // 4 * 4, (K + 3) // 4 * 4
+    pool = torch.full((M * ldn + M * ldk + 4096,), float("nan"), device=DEV)       # [guard | dY | X], both flush right
+    dy = pool[4096:4096 + M * ldn].view(M, ldn)
+    x = pool[4096 + M * ldn:].view(M, ldk)
+    dy.copy_(torch.randn(M, ldn, generator=gen))
+    x.copy_(torch.randn(M, ldk, generator=gen))
+    assert x.data_ptr() + x.numel() * 4 == pool.data_ptr() + pool.numel() * 4       # X ends with the allocation
+    dw = torch.zeros(N, ldk, device=DEV)
+    nb = lib().ccn_gemm_tn_workspace_bytes(M, N, K)
+    ws = workspace(max(nb, 16), DEV)
+    call("gemm_tn_ws", ptr(dy), ldn, ptr(x), ldk, ptr(dw), ldk, M, N, K, ptr(ws), nb)
+    torch.cuda.synchronize()
+    ref = dy[:, :N].double().t() @ x[:, :K].double()
+    bound = (dy[:, :N].double().abs().t() @ x[:, :K].double().abs())
+    err = float(((dw[:, :K].double() - ref).abs() / bound).max())
+    assert err < 5e-6, err
+    assert bool((dw[:, K:] == 0).all())                                              # padding columns of dW untouched

@@ -884,3 +884,26 @@ def test_nll_loss_matches_torch(rows, C, ignore):
     if ignore >= 0:
         assert float(gd[t.to(DEV) == ignore].abs().max()) == 0.0
 
+
+
+def test_nll_loss_kitti_runner_form_and_target_check():
+    """reduction="mean_all": the KITTI runner's literal form (ref kitti_seg.py:184-192: nll_loss(reduction='none',
+    ignore_index=0) then torch.mean over ALL points -- ignored rows stay in the denominator); check_targets raises on a
+    target outside [0, C) that is not the ignore index (torch asserts on the device there)."""
+    from curvecloudnet_amd.model import segmentation_loss
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(5000, 20, generator=gen) * 2
+    t = torch.randint(0, 20, (5000,), generator=gen)
+    xr = x.clone().requires_grad_(True)
+    lr = torch.mean(F.nll_loss(F.log_softmax(xr, dim=-1), t, reduction="none", ignore_index=0))
+    (gr,) = torch.autograd.grad(lr, xr)
+    xd = x.to(DEV).requires_grad_(True)
+    ld = segmentation_loss(xd, t.to(DEV), ignore_index=0, reduction="mean_all")
+    (gd,) = torch.autograd.grad(ld, xd)
+    assert abs(float(ld) - float(lr)) <= 2e-6 * max(1.0, abs(float(lr)))
+    _close(gd, gr, 1e-6, "dlogits")
+    bad = t.clone()
+    bad[17] = 20
+    with pytest.raises(IndexError):
+        segmentation_loss(xd, bad.to(DEV), ignore_index=0, check_targets=True)
+    segmentation_loss(xd, t.to(DEV), ignore_index=0, check_targets=True)       # in range: passes

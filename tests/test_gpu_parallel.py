@@ -167,3 +167,31 @@ def test_flat_adam_state_matches_torch_adam():
     for k in sa["state"]:
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 3.0
         assert float((sa["state"][k]["exp_avg"] - sb["state"][k]["exp_avg"]).abs().max()) < 1e-6
+
+
+def test_bench_two_ranks_describes_itself(tmp_path):
+    """`python bench.py --gpus 2` starts its own ranks (fresh torch.distributed.run children) and rank 0's JSON line
+    carries what SURVEY section 8(e) asks of a data-parallel run: the world size the process group reports, the points per
+    rank and the load imbalance (max / mean), the bytes all-reduced per step (= the gradient buckets: gradients only),
+    the time finish() waits.  Rehearsed here with two gloo ranks sharing device 0 on a reduced network; a failing rank
+    makes the launcher exit non-zero."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config",
+           "hotpath", "--width", "0.25", "--clouds-per-gpu", "2", "--curves", "96", "--no-cpu-baseline", "--no-kernel-timing"]
+    env = _env(CCN_DIST_BACKEND="gloo")
+    env.pop("MASTER_ADDR", None)
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode(errors="replace")[-3000:]
+    line = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["value"] > 0
+    mg = res["multi_gpu"]
+    assert mg["world_size"] == 2 and mg["world_size_observed"] == 2 and mg["backend"] == "gloo"
+    assert len(mg["points_per_rank"]) == 2 and all(p > 0 for p in mg["points_per_rank"])
+    assert 1.0 <= mg["load_imbalance_max_over_mean"] < 1.5
+    assert mg["gradient_bytes"] > 0 and abs(mg["allreduce_bytes_per_step"] - mg["gradient_bytes"]) < 1e-6 * mg["gradient_bytes"]
+    assert mg["finish_wait_ms_per_step"] >= 0.0
+    # a rank that fails takes the launcher's exit code with it
+    bad = subprocess.run(cmd, env=dict(env, CCN_BENCH_FAIL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=600)
+    assert bad.returncode != 0

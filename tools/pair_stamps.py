@@ -57,5 +57,9 @@ mf = nsl * 64 * 64
 print("  MFMA cycles of the wave itself: %.1f %% of its lifetime (x2 waves per SIMD)" % (float((mf / tot).median()) * 100))
 # kernel span in real time (100 MHz ticks) and the start spread
 r0, r1 = d[..., 10][live], d[..., 11][live]
-print("  real-time span of all waves: %.3f ms; start spread %.1f us; end spread %.1f us"
-      % ((r1.max() - r0.min()) / 1e5, (r0.max() - r0.min()) / 100, (r1.max() - r1.min()) / 100))
+span = float(r1.max() - r0.min())
+alive = float((r1 - r0).sum()) / float(live.sum())
+print("  real-time span of all waves: %.3f ms; start spread %.1f us; end spread %.1f us; mean wave lifetime %.3f ms = %.1f %% "
+      "of the span (the rest: slots idle behind the last tiles); workgroups %d"
+      % (span / 1e5, (r0.max() - r0.min()) / 100, (r1.max() - r1.min()) / 100, alive / 1e5, 100 * alive / span,
+         int(live.sum()) // 4))
