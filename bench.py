@@ -448,6 +448,19 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # Allocator headroom, still outside the timed region: the caching allocator keeps one pool per stream, and in the timed
+    # region the host runs further ahead of the GPU than during warm-up (nothing synchronises there), so a pool can need a
+    # little more than its warm-up peak -- a hipMalloc in mid-run (3-4 per 20 steps in round 2).  A block of headroom is
+    # allocated and freed once on every stream the step allocates on: it stays cached in that stream's pool and is split
+    # on demand.
+    from curvecloudnet_amd import steps as _steps
+    pools = [torch.cuda.current_stream(dev)] + list(_steps._GEOMETRY_STREAMS.values()) + list(ops._WGRAD_STREAMS.values())
+    for st in pools:
+        with torch.cuda.stream(st):
+            held = [torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                    for nbytes in (1 << 30, 1 << 30, 256 << 20, 256 << 20, 64 << 20, 64 << 20, 16 << 20, 16 << 20)]
+            del held
+    barrier()
     if os.environ.get("CCN_BENCH_LAZY_LOG") == "1":             # diagnostics: which layers hand over deferred activations
         from curvecloudnet_amd import ops as _ops
         _ops.LAZY_ACT_LOG = []

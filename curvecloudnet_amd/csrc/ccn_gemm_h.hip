@@ -1,0 +1,909 @@
+// 16-bit operand GEMMs on the LDS-DMA pipeline (BASELINE configs[2] "bf16 MLP MFMA path", configs[4] "fp16 features").
+//
+// Replaces, for the 16-bit MLP modes, the products of PyG MLP layers as the reference uses them (base.py:90-125; autograd of
+// F.linear): the hidden activations of an MLP, the BatchNorm-backward gradient dY and the (cast) weights are STORED as
+// bf16 / fp16 in HBM, so that these products stream half the operand bytes and need no conversion on the way to the
+// matrix cores.  At the widths of the shipped networks (K, N <= 1024, mostly 64..256) the products are HBM-bound on
+// v_mfma_f32_32x32x16_{bf16,f16} (16x the fp32 MFMA rate): the kernels are built around bytes in flight, not MFMA issue.
+//
+//   ccn_gemm_nt_h   Y[M x N] = A[M x K] W[N x K]^T (+ bias), fp32 accumulate; Y fp32 (+ BatchNorm column statistics of
+//                   the fp32 result) or 16-bit (the data gradient handed to a 16-bit activation)
+//   ccn_gemm_tn_h   dW[N x K] += dY[M x N]^T X[M x K]   (fp32 accumulation target)
+//
+// NT kernel = the fp32 paired kernel's structure (ccn_gemm.hip: two independent 4-wave workgroups per CU on 128 x 128
+// tiles, two-stage LDS-DMA ring, XOR swizzle on the DMA source + ds_read_b128, persistent XCD-aware tile loop) with 64
+// 16-bit elements per slice and row instead of 32 floats: the same 128-byte rows, the same LDS image, the same swizzle; a
+// lane's fragment of k-step s (16 contraction elements per 32x32x16 MFMA, k = 16 s + 8 h .. + 7) is the 16-byte chunk
+// 2 s + h of its row -- one ds_read_b128, no permutation.
+#include "ccn_common.h"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using u16 = uint16_t;
+
+constexpr int HB_TPB = 256;
+constexpr int HB_BM = 128, HB_BN = 128;
+constexpr int HB_BK = 64;      // 16-bit elements per slice and row (128 bytes)
+
+__device__ __forceinline__ void glds16h(const u16* src, u16* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma_h(const f32x4& a, const f32x4& b, f32x16 c) {
+  if (F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <bool F16>
+__device__ __forceinline__ u16 to_h(float v) {
+  if (F16) {
+    const _Float16 x = (_Float16)v;
+    return __builtin_bit_cast(u16, x);
+  }
+  const __bf16 x = (__bf16)v;          // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+  return __builtin_bit_cast(u16, x);
+}
+
+template <bool F16>
+__device__ __forceinline__ float from_h(u16 v) {
+  if (F16) return (float)__builtin_bit_cast(_Float16, v);
+  return __builtin_bit_cast(float, (uint32_t)v << 16);
+}
+
+// OUT16: the result is written as 16-bit (a data gradient): the MFMA operands are SWAPPED, so that a lane holds one output
+// ROW and four consecutive COLUMNS per register quad -- 16 eight-byte stores per lane and tile instead of 64 two-byte ones
+// (the sums per output element are the same fma chains in the same k order: a*b commutes).  No statistics in that form.
+template <bool F16, bool OUT16>
+__global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __restrict__ A, int64_t lda,
+                                                                const u16* __restrict__ B, int64_t ldb,
+                                                                const float* __restrict__ bias, void* __restrict__ Cv,
+                                                                int64_t ldc, int64_t M, int64_t N, int64_t K, int64_t tiles,
+                                                                int64_t gn, int xcd_order, double* __restrict__ colstats) {
+  constexpr int AF = HB_BM * HB_BK, BF = HB_BN * HB_BK, STAGE = AF + BF;   // 16-bit elements
+  constexpr int NC = 4;   // LDS-DMA copies (8 rows x 128 B) per wave, slice and operand
+  __shared__ __attribute__((aligned(16))) u16 lds[2 * STAGE];
+  __shared__ float stat_part[2 * HB_BN * 2];   // [wm][column][sum, sum of squares] of the finished tile
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int i = lane & 31, h = lane >> 5;
+  const int swz = (i >> 1) & 7;
+  const int lr = lane >> 3, lc = lane & 7;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+  const uint32_t a_off = (uint32_t)((wm * 64 + i) * HB_BK * 2);            // bytes: A fragment row of block ab = 0
+  const uint32_t b_off = (uint32_t)((AF + (wn * 64 + i) * HB_BK) * 2);     // bytes: B fragment row of block t = 0
+  const int T = (int)(K / HB_BK);
+  const int has_tail = (K % HB_BK) != 0;
+  const int TT = T + has_tail;
+
+  const uint32_t gnu = (uint32_t)gn;
+  const uint32_t gm_tiles = (uint32_t)tiles / gnu;
+  const bool xcd_map = xcd_order && gridDim.x == 512 && gnu <= 64 && 64 % gnu == 0;
+  const uint32_t slot = blockIdx.x >> 3;
+  const uint32_t rows_per_step = 512u / gnu, slot_row = (slot / gnu) * 8 + (blockIdx.x & 7), slot_col = slot % gnu;
+  auto tile_of = [&](int64_t j) -> int64_t {
+    if (xcd_map) {
+      const uint32_t m = (uint32_t)j * rows_per_step + slot_row;
+      return m < gm_tiles ? (int64_t)(m * gnu + slot_col) : tiles;
+    }
+    return j * gridDim.x + blockIdx.x;
+  };
+  auto tile_row = [&](int64_t t) -> int64_t { return (int64_t)((uint32_t)t / gnu); };
+  auto tile_col = [&](int64_t t) -> int64_t { return (int64_t)((uint32_t)t % gnu); };
+
+  // ---- issue cursor: one slice ahead of the compute cursor, across tile boundaries
+  const u16* a_src[NC];
+  const u16* b_src[NC];
+  int64_t it_j = 0, it_tile = tile_of(0), gi = 0;
+  int64_t im0 = 0, in0 = 0;
+  int it_u = 0;
+  auto issue_next = [&]() {
+    if (it_tile >= tiles) return;
+    if (it_u == 0) {
+      im0 = tile_row(it_tile) * HB_BM;
+      in0 = tile_col(it_tile) * HB_BN;
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const int r = 8 * (wave * NC + q) + lr;
+        int64_t row = im0 + r;
+        row = row < M ? row : M - 1;
+        a_src[q] = A + row * lda + 8 * (lc ^ ((r >> 1) & 7));
+        row = in0 + r;
+        row = row < N ? row : N - 1;
+        b_src[q] = B + row * ldb + 8 * (lc ^ ((r >> 1) & 7));
+      }
+    }
+    u16* st = lds + (gi & 1) * STAGE;
+    const int64_t k0 = (int64_t)it_u * HB_BK;
+    if (it_u < T) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) glds16h(a_src[q] + k0, st + (8 * (wave * NC + q)) * HB_BK);
+#pragma unroll
+      for (int q = 0; q < NC; ++q) glds16h(b_src[q] + k0, st + AF + (8 * (wave * NC + q)) * HB_BK);
+    } else {
+      // K remainder (< 64 elements): both operands through registers, zero filled beyond K, into the same swizzled image
+      // (nothing else is in flight here: every iteration waits vmcnt(0))
+#pragma unroll
+      for (int it = 0; it < 2 * HB_BM * 8 / HB_TPB; ++it) {
+        const int sl0 = threadIdx.x + it * HB_TPB;
+        const bool isA = sl0 < HB_BM * 8;
+        const int sl = isA ? sl0 : sl0 - HB_BM * 8;
+        const int r = sl >> 3, kq = sl & 7;
+        const u16* p = isA ? A : B;
+        const int64_t ld = isA ? lda : ldb;
+        int64_t row = (isA ? im0 : in0) + r;
+        const int64_t lim = isA ? M : N;
+        row = row < lim ? row : lim - 1;
+        const int64_t k = k0 + kq * 8;
+        const int64_t kc = k <= ld - 8 ? k : ld - 8;     // (k > ld - 8 implies k >= K: everything is zeroed below)
+        uint4 v = *reinterpret_cast<const uint4*>(p + row * ld + kc);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t lo = (k + 2 * e < K) ? (w[e] & 0xffffu) : 0u;
+          const uint32_t hi = (k + 2 * e + 1 < K) ? (w[e] & 0xffff0000u) : 0u;
+          w[e] = lo | hi;
+        }
+        *reinterpret_cast<uint4*>(st + (isA ? 0 : AF) + r * HB_BK + 8 * (kq ^ ((r >> 1) & 7))) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written before this wave reaches the next barrier
+    }
+    ++gi;
+    if (++it_u == TT) {
+      it_u = 0;
+      it_tile = tile_of(++it_j);
+    }
+  };
+  issue_next();
+
+  int64_t stat_tile = -1;
+  auto stats_readout = [&]() {
+    const int64_t pm = tile_row(stat_tile), pn0 = tile_col(stat_tile) * HB_BN;
+    for (int c = threadIdx.x; c < HB_BN; c += HB_TPB) {
+      const int64_t n = pn0 + c;
+      if (n < N) {
+        double* dst = colstats + pm * 2 * N;   // one partial row per 128-row block (ccn_stats_rows)
+        dst[n] = (double)stat_part[c * 2] + (double)stat_part[(HB_BN + c) * 2];
+        dst[N + n] = (double)stat_part[c * 2 + 1] + (double)stat_part[(HB_BN + c) * 2 + 1];
+      }
+    }
+    stat_tile = -1;
+  };
+
+  int64_t g = 0;
+  for (int64_t j = 0, tile; (tile = tile_of(j)) < tiles; ++j) {
+    const int64_t m0 = tile_row(tile) * HB_BM, n0 = tile_col(tile) * HB_BN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float bv = 0.f;
+      if (!OUT16) {
+        const int64_t n = n0 + wn * 64 + t * 32 + i;
+        bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+      }
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ab][t][r] = bv;
+    }
+
+    for (int u = 0; u < TT; ++u, ++g) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice g has landed (and the previous tile's stores retired)
+      __builtin_amdgcn_s_barrier();
+      issue_next();
+      if (u == 0 && stat_tile >= 0) stats_readout();
+      const uint32_t stage_b = lds_base + (uint32_t)((g & 1) * STAGE * 2);
+      f32x4 fa[2][2], fb[2][2];   // [k-step parity][block]
+      auto read_group = [&](int s, f32x4 (&da)[2], f32x4 (&db)[2]) {
+        const uint32_t ch = 16u * (uint32_t)((2 * s + h) ^ swz);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(da[0]) : "v"(stage_b + a_off + ch) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(da[1]) : "v"(stage_b + a_off + ch), "n"(32 * HB_BK * 2) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(db[0]) : "v"(stage_b + b_off + ch) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(db[1]) : "v"(stage_b + b_off + ch), "n"(32 * HB_BK * 2) : "memory");
+      };
+      read_group(0, fa[0], fb[0]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (s < 3) {
+          read_group(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+          asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            if (OUT16) acc[ab][t] = mfma_h<F16>(fb[s & 1][t], fa[s & 1][ab], acc[ab][t]);
+            else acc[ab][t] = mfma_h<F16>(fa[s & 1][ab], fb[s & 1][t], acc[ab][t]);
+          }
+      }
+    }
+
+    // ---- tile epilogue
+    if (OUT16) {
+      // D[p][q] of mfma(B-fragment, A-fragment): p = column n (registers: (r&3) + 8*(r>>2) + 4*h), q = row m (lane i)
+      u16* const C = reinterpret_cast<u16*>(Cv);
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab) {
+        const int64_t m = m0 + wm * 64 + ab * 32 + i;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int64_t n = n0 + wn * 64 + t * 32 + 8 * q4 + 4 * h;
+            if (m < M) {
+              u16* const dst = C + m * ldc + n;
+              const u16 v0 = to_h<F16>(acc[ab][t][4 * q4 + 0]), v1 = to_h<F16>(acc[ab][t][4 * q4 + 1]);
+              const u16 v2 = to_h<F16>(acc[ab][t][4 * q4 + 2]), v3 = to_h<F16>(acc[ab][t][4 * q4 + 3]);
+              if (n + 3 < N) {
+                *reinterpret_cast<uint2*>(dst) = make_uint2((uint32_t)v0 | ((uint32_t)v1 << 16), (uint32_t)v2 | ((uint32_t)v3 << 16));
+              } else {
+                if (n + 0 < N) dst[0] = v0;
+                if (n + 1 < N) dst[1] = v1;
+                if (n + 2 < N) dst[2] = v2;
+              }
+            }
+          }
+      }
+      continue;
+    }
+    float* const C = reinterpret_cast<float*>(Cv);
+    const bool interior = m0 + HB_BM <= M && n0 + HB_BN <= N;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ncol = wn * 64 + t * 32 + i;
+      const int64_t n = n0 + ncol;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab) {
+        float* const crow = C + (m0 + wm * 64 + ab * 32 + 4 * h) * ldc + n;
+        if (interior) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[ab][t][r];
+            crow[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;
+            s1 += v;
+            s2 += v * v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * 64 + ab * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < M && n < N) {
+              const float v = acc[ab][t][r];
+              C[m * ldc + n] = v;
+              s1 += v;
+              s2 += v * v;
+            }
+          }
+        }
+      }
+      if (colstats != nullptr) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0) {
+          stat_part[(wm * HB_BN + ncol) * 2] = s1;
+          stat_part[(wm * HB_BN + ncol) * 2 + 1] = s2;
+        }
+      }
+    }
+    if (colstats != nullptr) {
+      stat_tile = tile;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // table written before this wave reaches the next barrier
+    }
+  }
+  if (stat_tile >= 0) {  // statistics of the last tile
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stats_readout();
+  }
+}
+
+// ---- element-wise companions: casts and the BatchNorm passes that read or write 16-bit rows ----------------------------
+// fp32 rows -> 16-bit rows (8 elements per thread: two 16-byte loads, one 16-byte store); columns [C, ld16) are zeroed.
+template <bool F16>
+__global__ __launch_bounds__(256) void cast_rows_h_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int64_t C,
+                                                          u16* __restrict__ Y, int64_t ldy) {
+  const int64_t per_row = ldy / 8;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * per_row) return;
+  const int64_t r = t / per_row, c0 = (t - r * per_row) * 8;
+  float v[8];
+  const float* src = X + r * ldx + c0;
+  if (c0 + 8 <= C && (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0) {
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? src[e] : 0.f;
+  }
+  uint32_t w[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w[e] = (uint32_t)to_h<F16>(v[2 * e]) | ((uint32_t)to_h<F16>(v[2 * e + 1]) << 16);
+  *reinterpret_cast<uint4*>(Y + r * ldy + c0) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// W[n][k] fp32 -> Wt[k][n] 16-bit (the data-gradient product's "weight"), LDS-tiled 32 x 32; columns [N, ldt) zeroed
+template <bool F16>
+__global__ __launch_bounds__(256) void transpose_cast_h_kernel(const float* __restrict__ W, int64_t ldw, int64_t N, int64_t K,
+                                                               u16* __restrict__ Wt, int64_t ldt) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  const int64_t n0 = (int64_t)blockIdx.x * 32, k0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int64_t n = n0 + ty + 8 * rr, k = k0 + tx;
+    tile[ty + 8 * rr][tx] = (n < N && k < K) ? W[n * ldw + k] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int64_t k = k0 + ty + 8 * rr, n = n0 + tx;
+    if (k < K && n < ldt) Wt[k * ldt + n] = to_h<F16>(tile[tx][ty + 8 * rr]);
+  }
+}
+
+__device__ __forceinline__ float act_fwd_h(float z, int act, float slope) {
+  if (act == CCN_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (act == CCN_ACT_LEAKY) return z > 0.f ? z : z * slope;
+  return z;
+}
+__device__ __forceinline__ float act_grad_h(float z, int act, float slope) {
+  if (act == CCN_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == CCN_ACT_LEAKY) return z > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+// z = act(y * scale + shift) written as 16-bit rows (the expression of ccn_bn_act_fwd, then ONE rounding); 8 columns per
+// thread; padding columns [C, ldz) zeroed
+template <bool F16>
+__global__ __launch_bounds__(256) void bn_act_fwd_h_kernel(const float* __restrict__ Y, int64_t ldy, int64_t rows, int64_t C,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           int act, float slope, u16* __restrict__ Z, int64_t ldz) {
+  const int64_t per_row = ldz / 8;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * per_row) return;
+  const int64_t r = t / per_row, c0 = (t - r * per_row) * 8;
+  float v[8];
+  const float* src = Y + r * ldy + c0;
+  const bool full = c0 + 8 <= C;
+  if (full && (ldy & 3) == 0 && ((uintptr_t)Y & 15) == 0) {
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? src[e] : 0.f;
+  }
+  uint32_t w[4];
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    float z0 = 0.f, z1 = 0.f;
+    if (c0 + e < C) z0 = act_fwd_h(v[e] * scale[c0 + e] + shift[c0 + e], act, slope);
+    if (c0 + e + 1 < C) z1 = act_fwd_h(v[e + 1] * scale[c0 + e + 1] + shift[c0 + e + 1], act, slope);
+    w[e >> 1] = (uint32_t)to_h<F16>(z0) | ((uint32_t)to_h<F16>(z1) << 16);
+  }
+  *reinterpret_cast<uint4*>(Z + r * ldz + c0) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// BatchNorm + activation backward, second pass: dY (16-bit rows) from dZ (fp32 or 16-bit), y and the column sums of the first
+// pass -- the expression of bn_act_bwd_apply_kernel, then ONE rounding (both consumers of dY, the data- and the weight-
+// gradient product, round it to bf16 anyway in the 16-bit modes).  DZ16: dZ is 16-bit (a 16-bit activation's gradient).
+template <bool F16, bool DZ16>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_h_kernel(
+    const void* __restrict__ dZv, int64_t lddz, const float* __restrict__ Y, int64_t ldy, int64_t rows, int64_t C,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ rstd, int act, float slope, const double* __restrict__ sums, int training, float inv_n,
+    u16* __restrict__ dY, int64_t lddy, float* __restrict__ dgamma, float* __restrict__ dbeta, int acc_params) {
+  const int64_t per_row = lddy / 8;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < C) {      // parameter gradients from the column sums (acc_params: add into gradient-bucket views)
+    if (dgamma) dgamma[t] = (acc_params ? dgamma[t] : 0.f) + (float)sums[C + t];
+    if (dbeta) dbeta[t] = (acc_params ? dbeta[t] : 0.f) + (float)sums[t];
+  }
+  if (t >= rows * per_row) return;
+  const int64_t r = t / per_row, c0 = (t - r * per_row) * 8;
+  float y[8], gz[8];
+  const bool full = c0 + 8 <= C;
+  const float* ysrc = Y + r * ldy + c0;
+  if (full && (ldy & 3) == 0 && ((uintptr_t)Y & 15) == 0) {
+    const float4 a = *reinterpret_cast<const float4*>(ysrc), b = *reinterpret_cast<const float4*>(ysrc + 4);
+    y[0] = a.x; y[1] = a.y; y[2] = a.z; y[3] = a.w; y[4] = b.x; y[5] = b.y; y[6] = b.z; y[7] = b.w;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = c0 + e < C ? ysrc[e] : 0.f;
+  }
+  if (DZ16) {
+    const u16* gsrc = reinterpret_cast<const u16*>(dZv) + r * lddz + c0;
+    if (full && (lddz & 7) == 0 && ((uintptr_t)dZv & 15) == 0) {
+      const uint4 q = *reinterpret_cast<const uint4*>(gsrc);
+      const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        gz[2 * e] = __builtin_bit_cast(float, qq[e] << 16);
+        gz[2 * e + 1] = __builtin_bit_cast(float, qq[e] & 0xffff0000u);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gz[e] = c0 + e < C ? from_h<false>(gsrc[e]) : 0.f;
+    }
+  } else {
+    const float* gsrc = reinterpret_cast<const float*>(dZv) + r * lddz + c0;
+    if (full && (lddz & 3) == 0 && ((uintptr_t)dZv & 15) == 0) {
+      const float4 a = *reinterpret_cast<const float4*>(gsrc), b = *reinterpret_cast<const float4*>(gsrc + 4);
+      gz[0] = a.x; gz[1] = a.y; gz[2] = a.z; gz[3] = a.w; gz[4] = b.x; gz[5] = b.y; gz[6] = b.z; gz[7] = b.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gz[e] = c0 + e < C ? gsrc[e] : 0.f;
+    }
+  }
+  uint32_t w[4];
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    float o[2] = {0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int64_t c = c0 + e + d;
+      if (c < C) {
+        const float sc = scale[c];
+        const float g = gz[e + d] * act_grad_h(y[e + d] * sc + shift[c], act, slope);
+        const float m1 = (float)sums[c] * inv_n, m2 = (float)sums[C + c] * inv_n;
+        o[d] = training ? sc * (g - m1 - (y[e + d] - mean[c]) * rstd[c] * m2) : sc * g;
+      }
+    }
+    w[e >> 1] = (uint32_t)to_h<F16>(o[0]) | ((uint32_t)to_h<F16>(o[1]) << 16);
+  }
+  *reinterpret_cast<uint4*>(dY + r * lddy + c0) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// first pass with a 16-bit dZ: column sums of g = dZ * act'(u) and of g * xhat (fp64 partial rows, as col_partial_vec<1>)
+constexpr int HR_ROWS = 128;    // rows per workgroup = one partial row (ccn_stats_rows)
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_h_kernel(const u16* __restrict__ dZ, int64_t lddz,
+                                                                  const float* __restrict__ Y, int64_t ldy, int64_t rows,
+                                                                  int64_t C, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, int act, float slope,
+                                                                  double* __restrict__ partial) {
+  // 256 threads: 64 column lanes x 4 row groups; every thread walks its columns c = cx, cx + 64, ... over 32 of the 128 rows
+  __shared__ double red[4][64][2];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * HR_ROWS;
+  for (int64_t cb = 0; cb < C; cb += 64) {
+    const int64_t c = cb + cx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+      const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
+      float a1 = 0.f, a2 = 0.f;
+      for (int64_t r = r0 + ry; r < r0 + HR_ROWS && r < rows; r += 4) {
+        const float y = Y[r * ldy + c];
+        const float g = from_h<false>(dZ[r * lddz + c]) * act_grad_h(y * sc + sh, act, slope);
+        a1 += g;
+        a2 += g * ((y - mu) * rs);
+      }
+      s1 = (double)a1;
+      s2 = (double)a2;
+    }
+    red[ry][cx][0] = s1;
+    red[ry][cx][1] = s2;
+    __syncthreads();
+    if (ry == 0 && c < C) {
+      double* dst = partial + (int64_t)blockIdx.x * 2 * C;
+      dst[c] = red[0][cx][0] + red[1][cx][0] + red[2][cx][0] + red[3][cx][0];
+      dst[C + c] = red[0][cx][1] + red[1][cx][1] + red[2][cx][1] + red[3][cx][1];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ weight gradient: dW[N x K] += dY[M x N]^T X[M x K]
+// Both operands are CONTRACTION-major in HBM (the contraction index m is their row), the 32x32x16 MFMA wants 8 consecutive
+// contraction elements per lane: the slice images [64 rows m][128 columns] (256-byte rows, filled by LDS-DMA, 4 rows per
+// wave instruction) are read with ds_read_b64_tr_b16 -- per 16-lane group a block of 4 rows x 16 columns, delivered
+// column-major: lane i of the group receives column i of the 4 rows.  Two such reads (rows 8h + 0..3 and 8h + 4..7 of the
+// k-step) are a lane's operand of one MFMA.  16-byte chunk c of image row R sits at chunk c ^ f(R), f(R) = ((R & 3) << 2) |
+// ((R >> 2) & 3) (applied to the DMA source column and to the read address): the four rows of a block, and the two blocks
+// of a 32-lane half, then fall on different banks.
+// Work decomposition as the fp32 kernel (ccn_gemm_tn.hip): a workgroup owns a (128 x 128 tile of dW, chunk of rows) item,
+// partial tiles go to caller-owned slabs, ccn_tn_reduce-style summation in chunk order (deterministic).
+constexpr int HT_TPB = 256;
+constexpr int HT_T = 128;     // tile edge (columns of both slice images)
+constexpr int HT_SL = 64;     // contraction rows per slice (4 MFMA k-steps)
+
+// (transposed-read results are held as 64-bit scalars: an ext_vector(2) inline-asm output came back with its second dword
+// treated as a copy of the first by hipcc 7.2 -- v_mov v89, v88 in front of the MFMAs)
+using u64 = unsigned long long;
+
+template <int EPI>   // 0: slab store, 2: plain add into dW (one chunk)
+__global__ __launch_bounds__(HT_TPB, 2) void gemm_h_tn_kernel(const u16* __restrict__ A, int64_t lda,
+                                                              const u16* __restrict__ B, int64_t ldb, float* __restrict__ C,
+                                                              int64_t ldc, int64_t M, int64_t N, int64_t K, int tiles_k,
+                                                              int tiles, int split, int64_t slices_per_chunk, int64_t n_ids,
+                                                              int xcd_order, float* __restrict__ slabs) {
+  constexpr int AF = HT_SL * HT_T, STAGE = 2 * AF;      // 16-bit elements: 16 KB per operand image, 32 KB per stage
+  __shared__ __attribute__((aligned(16))) u16 lds[2 * STAGE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wn = wave >> 1, wk = wave & 1;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+  // transposed-read geometry: lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p + 3 of the group's block
+  const int L = lane & 15, q = L >> 2, p = L & 3, gsel = (lane >> 4) & 1;
+  uint32_t a_addr[2][2], b_addr[2][2];     // [column block ta / tb][row half]: bytes inside a stage, k-step 0
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const int R = 8 * h + 4 * half + q;                        // (+ 16 s per k-step: leaves f(R) unchanged)
+    const int f = ((R & 3) << 2) | ((R >> 2) & 3);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int cha = 8 * wn + 4 * t + 2 * gsel + (p >> 1), chb = 8 * wk + 4 * t + 2 * gsel + (p >> 1);
+      a_addr[t][half] = (uint32_t)(256 * R + 16 * (cha ^ f) + 8 * (p & 1));
+      b_addr[t][half] = (uint32_t)(AF * 2 + 256 * R + 16 * (chb ^ f) + 8 * (p & 1));
+    }
+  }
+  const int64_t total_slices = (M + HT_SL - 1) / HT_SL;
+
+  for (int64_t id = blockIdx.x; id < n_ids; id += gridDim.x) {
+    int64_t chunk, tile;
+    if (xcd_order) {
+      const int64_t slot = id >> 3;
+      chunk = (slot / tiles) * 8 + (id & 7);
+      tile = slot % tiles;
+    } else {
+      chunk = id / tiles;
+      tile = id % tiles;
+    }
+    if (chunk >= split) continue;
+    const int64_t s_beg = chunk * slices_per_chunk;
+    int64_t s_end = s_beg + slices_per_chunk;
+    if (s_end > total_slices) s_end = total_slices;
+    const int64_t n0 = (tile / tiles_k) * HT_T, k0 = (tile % tiles_k) * HT_T;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ta][tb][r] = 0.f;
+
+    if (s_beg < s_end) {
+      // ---- DMA sources: instruction g = 4 wave + qn copies image rows 4 g .. 4 g + 3 (lane: row lane >> 4, LDS chunk lane & 15)
+      int64_t a_col[4], b_col[4];
+#pragma unroll
+      for (int qn = 0; qn < 4; ++qn) {
+        const int f = ((lane >> 4) << 2) | qn;                 // f(R) of image row R = 4 (4 wave + qn) + (lane >> 4)
+        const int64_t ca = n0 + 8 * ((lane & 15) ^ f), cb = k0 + 8 * ((lane & 15) ^ f);
+        a_col[qn] = ca <= lda - 8 ? ca : lda - 8;              // (clamped columns only feed elements that are never stored)
+        b_col[qn] = cb <= ldb - 8 ? cb : ldb - 8;
+      }
+      auto issue = [&](int64_t sl, int stage) {
+        u16* st = lds + stage * STAGE;
+        const int64_t mrow0 = sl * HT_SL;
+#pragma unroll
+        for (int qn = 0; qn < 4; ++qn) {
+          int64_t row = mrow0 + 4 * (4 * wave + qn) + (lane >> 4);
+          row = row < M ? row : M - 1;
+          glds16h(A + row * lda + a_col[qn], st + (4 * wave + qn) * 512);
+        }
+#pragma unroll
+        for (int qn = 0; qn < 4; ++qn) {
+          int64_t row = mrow0 + 4 * (4 * wave + qn) + (lane >> 4);
+          row = row < M ? row : M - 1;
+          glds16h(B + row * ldb + b_col[qn], st + AF + (4 * wave + qn) * 512);
+        }
+      };
+      __builtin_amdgcn_s_barrier();          // every wave is done with the previous item's LDS reads
+      issue(s_beg, 0);
+      int stage = 0;
+      for (int64_t sl = s_beg; sl < s_end; ++sl, stage ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice sl has landed (this wave's share)
+        __builtin_amdgcn_s_barrier();                      // ... and everybody else's; the other stage is free again
+        if (sl + 1 < s_end) issue(sl + 1, stage ^ 1);
+        const uint32_t sb = lds_base + (uint32_t)(stage * STAGE * 2);
+        const int64_t rl64 = M - sl * HT_SL;
+        const int rows_left = rl64 < HT_SL ? (int)rl64 : HT_SL;
+        u64 fa[2][2][2], fb[2][2][2];      // [k-step parity][column block][row half]
+        // (immediate offsets must be literals: the four k-steps are written out)
+#define HT_READ(S, PAR)                                                                                                         \
+  _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int half = 0; half < 2; ++half) {                        \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fa[PAR][t][half]) : "v"(sb + a_addr[t][half]), "n"((S) * 4096) : "memory"); \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fb[PAR][t][half]) : "v"(sb + b_addr[t][half]), "n"((S) * 4096) : "memory"); \
+  }
+#define HT_MFMA(S, PAR)                                                                                                  \
+  {                                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    f32x4 oa[2], ob[2];                                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                      \
+      uint32_t l0 = (uint32_t)fa[PAR][t][0], l1 = (uint32_t)(fa[PAR][t][0] >> 32);                                      \
+      uint32_t h0 = (uint32_t)fa[PAR][t][1], h1 = (uint32_t)(fa[PAR][t][1] >> 32);                                      \
+      if (rows_left < HT_SL) {      /* rows beyond M (clamped source rows): their dY elements are zeroed */              \
+        const int m = 16 * (S) + 8 * h;                                                                                  \
+        l0 = (m + 0 < rows_left ? l0 & 0xffffu : 0u) | (m + 1 < rows_left ? l0 & 0xffff0000u : 0u);                     \
+        l1 = (m + 2 < rows_left ? l1 & 0xffffu : 0u) | (m + 3 < rows_left ? l1 & 0xffff0000u : 0u);                     \
+        h0 = (m + 4 < rows_left ? h0 & 0xffffu : 0u) | (m + 5 < rows_left ? h0 & 0xffff0000u : 0u);                     \
+        h1 = (m + 6 < rows_left ? h1 & 0xffffu : 0u) | (m + 7 < rows_left ? h1 & 0xffff0000u : 0u);                     \
+      }                                                                                                                  \
+      oa[t] = f32x4{__builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1), __builtin_bit_cast(float, h0),        \
+                    __builtin_bit_cast(float, h1)};                                                                      \
+      ob[t] = f32x4{__builtin_bit_cast(float, (uint32_t)fb[PAR][t][0]), __builtin_bit_cast(float, (uint32_t)(fb[PAR][t][0] >> 32)), \
+                    __builtin_bit_cast(float, (uint32_t)fb[PAR][t][1]), __builtin_bit_cast(float, (uint32_t)(fb[PAR][t][1] >> 32))}; \
+    }                                                                                                                    \
+    _Pragma("unroll") for (int ta = 0; ta < 2; ++ta) _Pragma("unroll") for (int tb = 0; tb < 2; ++tb)                    \
+        acc[ta][tb] = mfma_h<false>(oa[ta], ob[tb], acc[ta][tb]);                                                        \
+  }
+        HT_READ(0, 0)
+        HT_READ(1, 1)
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]),
+                     "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1]) : : "memory");
+        HT_MFMA(0, 0)
+        HT_READ(2, 0)
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]),
+                     "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][1][0]), "+v"(fb[1][1][1]) : : "memory");
+        HT_MFMA(1, 1)
+        HT_READ(3, 1)
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(fa[0][0][0]), "+v"(fa[0][0][1]), "+v"(fa[0][1][0]), "+v"(fa[0][1][1]),
+                     "+v"(fb[0][0][0]), "+v"(fb[0][0][1]), "+v"(fb[0][1][0]), "+v"(fb[0][1][1]) : : "memory");
+        HT_MFMA(2, 0)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0][0]), "+v"(fa[1][0][1]), "+v"(fa[1][1][0]), "+v"(fa[1][1][1]),
+                     "+v"(fb[1][0][0]), "+v"(fb[1][0][1]), "+v"(fb[1][1][0]), "+v"(fb[1][1][1]) : : "memory");
+        HT_MFMA(3, 1)
+#undef HT_READ
+#undef HT_MFMA
+      }
+    }
+
+    // ---- epilogue.  C/D layout: col = lane & 31 (k), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (n)
+    if (EPI == 0) {
+      float* slab = slabs + ((int64_t)tile * split + chunk) * (HT_T * HT_T);
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int nl = wn * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            slab[nl * HT_T + wk * 64 + tb * 32 + i] = acc[ta][tb][r];
+          }
+    } else {
+#pragma unroll
+      for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t n = n0 + wn * 64 + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int64_t k = k0 + wk * 64 + tb * 32 + i;
+            if (n < N && k < K) C[n * ldc + k] += acc[ta][tb][r];
+          }
+    }
+  }
+}
+
+// dW[n][k] += sum over the chunks of the tile's slabs, in chunk order (the reduction of ccn_gemm_tn.hip, 128 x 128 tiles)
+constexpr int HRED_WAVES = 16;
+__global__ __launch_bounds__(64 * HRED_WAVES) void tn_h_reduce_kernel(const float* __restrict__ slabs, int split, int tiles_k,
+                                                                      int tiles, int64_t N, int64_t K, float* __restrict__ C,
+                                                                      int64_t ldc) {
+  constexpr int Q = HT_T * HT_T / 4;                  // float4 per slab
+  __shared__ float4 red[HRED_WAVES][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = e < (int64_t)tiles * Q;
+  const int64_t tile = live ? e / Q : 0;
+  const int within = live ? (int)(e - tile * Q) : 0;
+  const float* src = slabs + tile * split * (int64_t)(HT_T * HT_T) + (int64_t)within * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    for (int c = w; c < split; c += 4 * HRED_WAVES) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cc = c + u * HRED_WAVES;
+        v[u] = cc < split ? *reinterpret_cast<const float4*>(src + (int64_t)cc * (HT_T * HT_T)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s.x += v[u].x;
+        s.y += v[u].y;
+        s.z += v[u].z;
+        s.w += v[u].w;
+      }
+    }
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w != 0 || !live) return;
+#pragma unroll
+  for (int u = 1; u < HRED_WAVES; ++u) {
+    const float4 t = red[u][lane];
+    s.x += t.x;
+    s.y += t.y;
+    s.z += t.z;
+    s.w += t.w;
+  }
+  const int64_t n = (tile / tiles_k) * HT_T + (within * 4) / HT_T;
+  const int64_t k = (tile % tiles_k) * HT_T + (within * 4) % HT_T;
+  if (n >= N || k >= K) return;
+  float* dst = C + n * ldc + k;
+  dst[0] += s.x;
+  if (k + 1 < K) dst[1] += s.y;
+  if (k + 2 < K) dst[2] += s.z;
+  if (k + 3 < K) dst[3] += s.w;
+}
+
+struct HtPlan {
+  int tiles_n, tiles_k, tiles, split;
+  int64_t slices_per_chunk, n_ids, slab_floats;
+  bool xcd;
+};
+
+inline HtPlan ht_plan(int64_t M, int64_t N, int64_t K) {
+  HtPlan p;
+  p.tiles_n = (int)((N + HT_T - 1) / HT_T);
+  p.tiles_k = (int)((K + HT_T - 1) / HT_T);
+  p.tiles = p.tiles_n * p.tiles_k;
+  const int64_t slices = (M + HT_SL - 1) / HT_SL;
+  // ~1024 work items (two workgroups per CU, two rounds: the products are HBM-bound, tails are cheap) of >= 4 slices each
+  int64_t split = (1024 + p.tiles - 1) / p.tiles;
+  if (split > slices / 4) split = slices / 4;
+  if (split < 1) split = 1;
+  p.slices_per_chunk = (slices + split - 1) / split;
+  split = (slices + p.slices_per_chunk - 1) / p.slices_per_chunk;
+  p.split = (int)split;
+  p.xcd = split >= 8 && p.tiles > 1;
+  p.n_ids = p.xcd ? (int64_t)p.tiles * ((split + 7) / 8 * 8) : (int64_t)p.tiles * split;
+  p.slab_floats = split > 1 ? (int64_t)p.tiles * split * HT_T * HT_T : 0;
+  return p;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+template <bool F16, bool OUT16>
+int launch_nt_h(const u16* A, int64_t lda, const u16* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
+                int64_t N, int64_t K, double* colstats, hipStream_t s) {
+  const int64_t gm = (M + HB_BM - 1) / HB_BM, gn = (N + HB_BN - 1) / HB_BN;
+  const int64_t tiles = gm * gn;
+  if (tiles >= ((int64_t)1 << 31)) {
+    ccn_set_error("gemm_nt_h: more than 2^31 output tiles");
+    return CCN_ERR_ARG;
+  }
+  const int64_t grid = tiles < 512 ? tiles : 512;  // two workgroups per CU
+  hipLaunchKernelGGL((gemm_h_pair_kernel<F16, OUT16>), dim3((unsigned)grid), dim3(HB_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy, M,
+                     N, K, tiles, gn, 1, colstats);
+  return CCN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ccn_gemm_nt_h(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
+                  int64_t N, int64_t K, double* colstats, int f16, int out16, void* stream) {
+  CCN_REQUIRE(A && W && Y, "gemm_nt_h: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, "gemm_nt_h: bad sizes");
+  CCN_REQUIRE(aligned16(A) && aligned16(W) && lda % 8 == 0 && ldw % 8 == 0,
+              "gemm_nt_h: 16-bit operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+  CCN_REQUIRE(!out16 || (colstats == nullptr && bias == nullptr && ((uintptr_t)Y & 7) == 0 && ldy % 4 == 0),
+              "gemm_nt_h: a 16-bit result takes no bias / statistics and needs 8-byte aligned rows");
+  if (M == 0) return CCN_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const u16* a = (const u16*)A;
+  const u16* w = (const u16*)W;
+  int rc;
+  if (f16) rc = out16 ? launch_nt_h<true, true>(a, lda, w, ldw, bias, Y, ldy, M, N, K, colstats, s)
+                      : launch_nt_h<true, false>(a, lda, w, ldw, bias, Y, ldy, M, N, K, colstats, s);
+  else rc = out16 ? launch_nt_h<false, true>(a, lda, w, ldw, bias, Y, ldy, M, N, K, colstats, s)
+                  : launch_nt_h<false, false>(a, lda, w, ldw, bias, Y, ldy, M, N, K, colstats, s);
+  if (rc) return rc;
+  CCN_LAUNCH_OK("gemm_nt_h");
+  return CCN_OK;
+}
+
+size_t ccn_gemm_tn_h_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (size_t)ht_plan(M, N, K).slab_floats * sizeof(float);
+}
+
+int ccn_gemm_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
+                  int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  CCN_REQUIRE(dY && X && dW, "gemm_tn_h: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "gemm_tn_h: bad sizes");
+  CCN_REQUIRE(aligned16(dY) && aligned16(X) && lddy % 8 == 0 && ldx % 8 == 0 && lddy >= 8 && ldx >= 8,
+              "gemm_tn_h: bf16 operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+  if (M == 0) return CCN_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const HtPlan p = ht_plan(M, N, K);
+  const int64_t grid = p.n_ids < 512 ? p.n_ids : 512;
+  const u16* a = (const u16*)dY;
+  const u16* b = (const u16*)X;
+  if (p.split == 1) {
+    hipLaunchKernelGGL(gemm_h_tn_kernel<2>, dim3((unsigned)grid), dim3(HT_TPB), 0, s, a, lddy, b, ldx, dW, lddw, M, N, K, p.tiles_k,
+                       p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, (float*)nullptr);
+  } else {
+    CCN_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)p.slab_floats * sizeof(float) && aligned16(workspace),
+                "gemm_tn_h: workspace too small (%zu < %zu bytes) or unaligned", workspace_bytes,
+                (size_t)p.slab_floats * sizeof(float));
+    float* slabs = (float*)workspace;
+    hipLaunchKernelGGL(gemm_h_tn_kernel<0>, dim3((unsigned)grid), dim3(HT_TPB), 0, s, a, lddy, b, ldx, dW, lddw, M, N, K, p.tiles_k,
+                       p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, slabs);
+    const int64_t work = (int64_t)p.tiles * (HT_T * HT_T / 4);
+    hipLaunchKernelGGL(tn_h_reduce_kernel, dim3((unsigned)((work + 63) / 64)), dim3(64 * HRED_WAVES), 0, s, slabs, p.split,
+                       p.tiles_k, p.tiles, N, K, dW, lddw);
+  }
+  CCN_LAUNCH_OK("gemm_tn_h");
+  return CCN_OK;
+}
+
+int ccn_cast_rows_h(const float* X, int64_t ldx, int64_t rows, int64_t C, void* Y, int64_t ldy, int f16, void* stream) {
+  CCN_REQUIRE(X && Y && rows >= 0 && C > 0 && ldx >= C && ldy >= C && ldy % 8 == 0 && aligned16(Y), "cast_rows_h: bad arguments");
+  if (rows == 0) return CCN_OK;
+  const int64_t n = rows * (ldy / 8);
+  if (f16) hipLaunchKernelGGL(cast_rows_h_kernel<true>, dim3(ccn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy);
+  else hipLaunchKernelGGL(cast_rows_h_kernel<false>, dim3(ccn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy);
+  CCN_LAUNCH_OK("cast_rows_h");
+  return CCN_OK;
+}
+
+int ccn_transpose_cast_h(const float* W, int64_t ldw, int64_t N, int64_t K, void* Wt, int64_t ldt, int f16, void* stream) {
+  CCN_REQUIRE(W && Wt && N > 0 && K > 0 && ldw >= K && ldt >= N && ldt % 8 == 0 && aligned16(Wt), "transpose_cast_h: bad arguments");
+  const dim3 grid((unsigned)((ldt + 31) / 32), (unsigned)((K + 31) / 32));
+  if (f16) hipLaunchKernelGGL(transpose_cast_h_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, (u16*)Wt, ldt);
+  else hipLaunchKernelGGL(transpose_cast_h_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, (u16*)Wt, ldt);
+  CCN_LAUNCH_OK("transpose_cast_h");
+  return CCN_OK;
+}
+
+int ccn_bn_act_fwd_h(const float* Y, int64_t ldy, int64_t rows, int64_t C, const float* scale, const float* shift, int act,
+                     float slope, void* Z, int64_t ldz, int f16, void* stream) {
+  CCN_REQUIRE(Y && Z && scale && shift && rows >= 0 && C > 0 && ldy >= C && ldz >= C && ldz % 8 == 0 && aligned16(Z),
+              "bn_act_fwd_h: bad arguments");
+  if (rows == 0) return CCN_OK;
+  const int64_t n = rows * (ldz / 8);
+  if (f16) hipLaunchKernelGGL(bn_act_fwd_h_kernel<true>, dim3(ccn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, Y, ldy, rows, C, scale, shift, act, slope, (u16*)Z, ldz);
+  else hipLaunchKernelGGL(bn_act_fwd_h_kernel<false>, dim3(ccn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, Y, ldy, rows, C, scale, shift, act, slope, (u16*)Z, ldz);
+  CCN_LAUNCH_OK("bn_act_fwd_h");
+  return CCN_OK;
+}
+
+int ccn_bn_act_bwd_reduce_h(const void* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C,
+                            const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                            double* sums, void* stream) {
+  // dZ: bf16 rows.  sums: 2*C totals followed by [ccn_stats_rows(rows)][2*C] doubles of scratch (as ccn_bn_act_bwd_reduce)
+  CCN_REQUIRE(dZ && Y && sums && rows > 0 && C > 0 && lddz >= C && ldy >= C, "bn_act_bwd_reduce_h: bad arguments");
+  const int64_t nparts = ccn_stats_rows(rows);
+  double* partial = sums + 2 * C;
+  hipLaunchKernelGGL(bn_act_bwd_reduce_h_kernel, dim3((unsigned)nparts), dim3(256), 0, (hipStream_t)stream, (const u16*)dZ, lddz,
+                     Y, ldy, rows, C, scale, shift, mean, rstd, act, slope, partial);
+  CCN_LAUNCH_OK("bn_act_bwd_reduce_h");
+  return ccn_reduce_partials(partial, nparts, 2 * C, sums, stream);
+}
+
+int ccn_bn_act_bwd_apply_h(const void* dZ, int dz16, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C,
+                           const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                           const double* sums, float count, int training, int acc_params, void* dY, int64_t lddy, float* dgamma,
+                           float* dbeta, int f16, void* stream) {
+  CCN_REQUIRE(dZ && Y && dY && sums && rows > 0 && C > 0 && lddz >= C && ldy >= C && lddy >= C && lddy % 8 == 0 && aligned16(dY),
+              "bn_act_bwd_apply_h: bad arguments");
+  const int64_t n = rows * (lddy / 8);
+  const int64_t work = n > C ? n : C;
+  const float inv_n = 1.f / count;
+#define CCN_APPLY_H(F16_, DZ16_)                                                                                              \
+  hipLaunchKernelGGL((bn_act_bwd_apply_h_kernel<F16_, DZ16_>), dim3(ccn_blocks(work, 256)), dim3(256), 0, (hipStream_t)stream, \
+                     dZ, lddz, Y, ldy, rows, C, scale, shift, mean, rstd, act, slope, sums, training, inv_n, (u16*)dY, lddy,  \
+                     dgamma, dbeta, acc_params)
+  if (f16) { if (dz16) CCN_APPLY_H(true, true); else CCN_APPLY_H(true, false); }
+  else { if (dz16) CCN_APPLY_H(false, true); else CCN_APPLY_H(false, false); }
+#undef CCN_APPLY_H
+  CCN_LAUNCH_OK("bn_act_bwd_apply_h");
+  return CCN_OK;
+}
+
+}  // extern "C"

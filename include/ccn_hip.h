@@ -243,6 +243,35 @@ int ccn_gemm_nt_f16(const float* A, int64_t lda, const float* W, int64_t ldw, co
 int ccn_gemm_tn_bf16(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
                      int64_t N, int64_t K, void* stream); /* dW += dY^T X (dW pre-zeroed by caller) */
 
+/* ---- 16-bit STORAGE path of the 16-bit MLP modes (csrc/ccn_gemm_h.hip; BASELINE configs[2] "bf16 MLP MFMA path").
+ * Replaces the products of PyG MLP layers (reference base.py:90-125, autograd of F.linear) where the hidden activation, the
+ * BatchNorm-backward gradient dY and the cast weight are kept as bf16 / fp16 rows in HBM: operands reach LDS by LDS-DMA with
+ * no conversion, v_mfma_f32_32x32x16_{bf16,f16}, fp32 accumulation.  16-bit rows: 16-byte aligned, leading dimension (in
+ * elements) a multiple of 8, padding columns zero.  f16 != 0 selects fp16 (forward operands of the fp16 mode), else bf16.
+ *   ccn_gemm_nt_h: Y = A W^T (+ bias).  out16 == 0: Y fp32 (+ colstats as ccn_gemm_nt); out16 != 0: Y 16-bit rows (ldy in
+ *                  elements, % 4 == 0), no bias / statistics -- the data gradient of a 16-bit activation.
+ *   ccn_gemm_tn_h: dW (fp32) += dY^T X, both operands bf16 rows; caller-owned scratch for the partial tiles
+ *                  (ccn_gemm_tn_h_workspace_bytes), summed in chunk order (deterministic). */
+int ccn_gemm_nt_h(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
+                  int64_t N, int64_t K, double* colstats, int f16, int out16, void* stream);
+size_t ccn_gemm_tn_h_workspace_bytes(int64_t M, int64_t N, int64_t K);
+int ccn_gemm_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
+                  int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+/* fp32 rows -> 16-bit rows (round to nearest even), padding columns [C, ldy) zeroed; W (N x K fp32) -> W^T (K x N 16-bit) */
+int ccn_cast_rows_h(const float* X, int64_t ldx, int64_t rows, int64_t C, void* Y, int64_t ldy, int f16, void* stream);
+int ccn_transpose_cast_h(const float* W, int64_t ldw, int64_t N, int64_t K, void* Wt, int64_t ldt, int f16, void* stream);
+/* ccn_bn_act_fwd writing z as 16-bit rows; ccn_bn_act_bwd_reduce reading a bf16 dZ; ccn_bn_act_bwd_apply_ex reading an fp32
+ * (dz16 == 0) or bf16 dZ and writing dY as bf16 rows (same expressions, one rounding at the store) */
+int ccn_bn_act_fwd_h(const float* Y, int64_t ldy, int64_t rows, int64_t C, const float* scale, const float* shift, int act,
+                     float slope, void* Z, int64_t ldz, int f16, void* stream);
+int ccn_bn_act_bwd_reduce_h(const void* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C,
+                            const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                            double* sums, void* stream);
+int ccn_bn_act_bwd_apply_h(const void* dZ, int dz16, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C,
+                           const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                           const double* sums, float count, int training, int acc_params, void* dY, int64_t lddy, float* dgamma,
+                           float* dbeta, int f16, void* stream);
+
 int ccn_bn_finalize(const double* colstats, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
                     float momentum, float* running_mean, float* running_var, float* scale, float* shift,
                     float* save_mean, float* save_rstd, void* stream);

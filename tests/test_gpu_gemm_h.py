@@ -1,0 +1,205 @@
+"""The 16-bit STORAGE kernels (csrc/ccn_gemm_h.hip) through the C-ABI with raw pointers: casts, ccn_gemm_nt_h (fp32 and
+16-bit results, statistics, K remainders), ccn_gemm_tn_h (transposed LDS reads), the 16-bit BatchNorm passes.
+
+Operand lane maps are checked with EXACT small-integer data that is asymmetric in every index (a swapped row / column /
+contraction map cannot pass), then random data is held against fp64 products of the rounded operands."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _api():
+    from curvecloudnet_amd._lib import call, lib, ptr, workspace
+    return call, lib, ptr, workspace
+
+
+def _rows16(rows, cols, dtype=torch.bfloat16):
+    ld = (cols + 7) // 8 * 8
+    buf = torch.zeros((rows, ld), dtype=dtype, device=DEV)
+    return buf, ld
+
+
+def _to16(x, dtype=torch.bfloat16):
+    """fp32 (rows, cols) on the CPU -> zero-padded 16-bit rows on the GPU via ccn_cast_rows_h, checked against torch's cast."""
+    call, lib, ptr, _ = _api()
+    rows, cols = x.shape
+    xd = x.to(DEV).contiguous()
+    buf, ld = _rows16(rows, cols, dtype)
+    buf.fill_(7.0)                                            # (the cast must overwrite the padding columns with zeros)
+    call("cast_rows_h", ptr(xd), cols, rows, cols, ptr(buf), ld, 1 if dtype == torch.float16 else 0)
+    assert torch.equal(buf[:, :cols].cpu(), x.to(dtype)), "cast_rows_h differs from torch's round-to-nearest-even"
+    assert bool((buf[:, cols:] == 0).all())
+    return buf, ld
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 3), (1000, 64), (777, 259), (33, 8)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_cast_rows(rows, cols, dtype):
+    gen = torch.Generator().manual_seed(rows + cols)
+    _to16(torch.randn(rows, cols, generator=gen) * 3, dtype)
+
+
+def _int_matrix(rows, cols, seed, lo=-3, hi=4):
+    gen = torch.Generator().manual_seed(seed)
+    m = torch.randint(lo, hi, (rows, cols), generator=gen).float()
+    # asymmetric in both indices: a distinct ramp per row and per column
+    return m + (torch.arange(rows)[:, None] % 5).float() - (torch.arange(cols)[None, :] % 3).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 192, 128), (1000, 259, 72), (129, 64, 200), (5000, 256, 256),
+                                   (70000, 128, 320)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_nt_h_exact_integers_and_statistics(M, N, K, dtype):
+    """Small integers are exact in bf16 / fp16 and their sums exact in fp32: the product must EQUAL the integer result, for
+    M / N / K that are not multiples of the tile and slice (clamped rows, zero-filled K remainder), with and without
+    bias and statistics, as fp32 rows and as 16-bit rows."""
+    call, lib, ptr, _ = _api()
+    f16 = 1 if dtype == torch.float16 else 0
+    a, w = _int_matrix(M, K, 1), _int_matrix(N, K, 2)
+    a16, lda = _to16(a, dtype)
+    w16, ldw = _to16(w, dtype)
+    bias = torch.arange(N, dtype=torch.float32) % 7
+    want = (a.double() @ w.double().t())
+    assert float(want.abs().max()) < 2 ** 23
+    y = torch.full((M, N + 5), -1.0, device=DEV)
+    nparts = lib().ccn_stats_rows(M)
+    stats = torch.zeros((nparts + 1) * 2 * N, dtype=torch.float64, device=DEV)
+    call("gemm_nt_h", ptr(a16), lda, ptr(w16), ldw, ptr(bias.to(DEV)), ptr(y), N + 5, M, N, K, ptr(stats), f16, 0)
+    got = y[:, :N].cpu().double()
+    assert torch.equal(got, want + bias.double()[None, :]), "fp32 result"
+    assert bool((y[:, N:] == -1.0).all()), "columns beyond N were written"
+    parts = stats[: nparts * 2 * N].view(nparts, 2, N).sum(0).cpu()
+    assert torch.allclose(parts[0], got.sum(0), rtol=1e-6, atol=1e-3)
+    assert torch.allclose(parts[1], (got * got).sum(0), rtol=1e-5, atol=1e-2)
+    # 16-bit result (the data-gradient form: swapped MFMA operands, 8-byte stores): the rounding of the exact product
+    ld16 = (N + 3) // 4 * 4
+    y16 = torch.full((M, ld16), -1.0, dtype=dtype, device=DEV)
+    call("gemm_nt_h", ptr(a16), lda, ptr(w16), ldw, None, ptr(y16), ld16, M, N, K, None, f16, 1)
+    assert torch.equal(y16[:, :N].cpu(), want.float().to(dtype)), "16-bit result"
+    assert bool((y16[:, N:] == -1.0).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 256), (100000, 128, 192), (3000, 1024, 1024), (50000, 64, 64)])
+def test_gemm_nt_h_random_against_fp64(M, N, K):
+    call, lib, ptr, _ = _api()
+    gen = torch.Generator().manual_seed(M + N + K)
+    a, w = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) / K ** 0.5
+    a16, lda = _to16(a)
+    w16, ldw = _to16(w)
+    y = torch.empty(M, N, device=DEV)
+    call("gemm_nt_h", ptr(a16), lda, ptr(w16), ldw, None, ptr(y), N, M, N, K, None, 0, 0)
+    ar, wr = a.bfloat16().double(), w.bfloat16().double()
+    want, bound = ar @ wr.t(), ar.abs() @ wr.abs().t()
+    err = float(((y.cpu().double() - want).abs() / bound).max())
+    assert err < 3e-6, err             # fp32 accumulation of exact bf16 products
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1000, 128, 128), (777, 256, 192), (5000, 64, 320), (200000, 256, 256),
+                                   (9000, 259, 131)])
+def test_gemm_tn_h_exact_integers(M, N, K):
+    """dW += dY^T X with transposed LDS reads: exact integer data (asymmetric in m, n and k), accumulation into a non-zero
+    dW, rows beyond M, columns beyond N / K."""
+    call, lib, ptr, workspace = _api()
+    dy, x = _int_matrix(M, N, 3, -2, 3), _int_matrix(M, K, 4, -2, 3)
+    # keep the exact sums inside fp32's integer range
+    scale = max(1, int((M * 36) // 2 ** 23) + 1)
+    if scale > 1:
+        keep = (torch.arange(M) % scale == 0).float()[:, None]
+        dy = dy * keep
+    dy16, lddy = _to16(dy)
+    x16, ldx = _to16(x)
+    want = dy.double().t() @ x.double()
+    assert float(want.abs().max()) < 2 ** 23
+    base = (torch.arange(N * K).view(N, K) % 11).float()
+    ldw = K + 3
+    dw = torch.full((N, ldw), -2.0, device=DEV)
+    dw[:, :K] = base.to(DEV)
+    nb = lib().ccn_gemm_tn_h_workspace_bytes(M, N, K)
+    ws = workspace(nb, DEV)
+    call("gemm_tn_h", ptr(dy16), lddy, ptr(x16), ldx, ptr(dw), ldw, M, N, K, ptr(ws), nb)
+    assert torch.equal(dw[:, :K].cpu().double(), want + base.double())
+    assert bool((dw[:, K:] == -2.0).all())
+
+
+@pytest.mark.parametrize("M,N,K", [(100000, 256, 256), (33333, 128, 64), (8000, 1024, 512)])
+def test_gemm_tn_h_random_against_fp64(M, N, K):
+    call, lib, ptr, workspace = _api()
+    gen = torch.Generator().manual_seed(M + N + K)
+    dy, x = torch.randn(M, N, generator=gen), torch.randn(M, K, generator=gen)
+    dy16, lddy = _to16(dy)
+    x16, ldx = _to16(x)
+    dw = torch.zeros(N, K, device=DEV)
+    nb = lib().ccn_gemm_tn_h_workspace_bytes(M, N, K)
+    ws = workspace(nb, DEV)
+    call("gemm_tn_h", ptr(dy16), lddy, ptr(x16), ldx, ptr(dw), K, M, N, K, ptr(ws), nb)
+    a, b = dy.bfloat16().double(), x.bfloat16().double()
+    want, bound = a.t() @ b, a.abs().t() @ b.abs()
+    err = float(((dw.cpu().double() - want).abs() / bound).max())
+    assert err < 3e-6, err
+    # deterministic: the slabs are summed in chunk order
+    dw2 = torch.zeros(N, K, device=DEV)
+    call("gemm_tn_h", ptr(dy16), lddy, ptr(x16), ldx, ptr(dw2), K, M, N, K, ptr(ws), nb)
+    assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize("N,K", [(128, 256), (67, 131), (1024, 40)])
+def test_transpose_cast(N, K):
+    call, lib, ptr, _ = _api()
+    gen = torch.Generator().manual_seed(N + K)
+    w = torch.randn(N, K + 2, generator=gen).to(DEV)
+    wt, ldt = _rows16(K, N)
+    wt.fill_(3.0)
+    call("transpose_cast_h", ptr(w), K + 2, N, K, ptr(wt), ldt, 0)
+    assert torch.equal(wt[:, :N], w[:, :K].t().to(torch.bfloat16))
+    assert bool((wt[:, N:] == 0).all())
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 64), (4099, 259), (300, 8), (70000, 128)])
+@pytest.mark.parametrize("act", [1, 2])
+def test_batchnorm_passes_with_16bit_rows(rows, C, act):
+    """ccn_bn_act_fwd_h = ccn_bn_act_fwd followed by ONE rounding; ccn_bn_act_bwd_reduce_h / _apply_h = the fp32 passes on
+    the same (bf16-valued) dZ, dY rounded once at the store."""
+    call, lib, ptr, _ = _api()
+    gen = torch.Generator().manual_seed(rows + C + act)
+    y = torch.randn(rows, C, generator=gen).to(DEV)
+    par = torch.stack([torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.3,
+                       torch.randn(C, generator=gen) * 0.1, torch.rand(C, generator=gen) + 0.5]).to(DEV)   # scale shift mean rstd
+    z32 = torch.empty(rows, C, device=DEV)
+    call("bn_act_fwd", ptr(y), C, rows, C, ptr(par[0]), ptr(par[1]), act, 0.01, ptr(z32), C)
+    for dtype, f16 in ((torch.bfloat16, 0), (torch.float16, 1)):
+        z16, ldz = _rows16(rows, C, dtype)
+        z16.fill_(5.0)
+        call("bn_act_fwd_h", ptr(y), C, rows, C, ptr(par[0]), ptr(par[1]), act, 0.01, ptr(z16), ldz, f16)
+        assert torch.equal(z16[:, :C], z32.to(dtype))
+        assert bool((z16[:, C:] == 0).all())
+    # backward: dZ held in bf16
+    g16, ldg = _to16(torch.randn(rows, C, generator=gen))
+    g32 = g16[:, :C].float().contiguous()
+    nparts = lib().ccn_stats_rows(rows)
+    s_ref = torch.zeros((nparts + 1) * 2 * C, dtype=torch.float64, device=DEV)
+    s_h = torch.zeros_like(s_ref)
+    call("bn_act_bwd_reduce", ptr(g32), C, ptr(y), C, rows, C, ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]), act, 0.01,
+         ptr(s_ref))
+    call("bn_act_bwd_reduce_h", ptr(g16), ldg, ptr(y), C, rows, C, ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]), act,
+         0.01, ptr(s_h))
+    tot_ref, tot_h = s_ref[: 2 * C].cpu(), s_h[: 2 * C].cpu()
+    assert torch.allclose(tot_h, tot_ref, rtol=1e-5, atol=1e-4 * rows ** 0.5), float((tot_h - tot_ref).abs().max())
+    dy32 = torch.empty(rows, C, device=DEV)
+    dgb = torch.zeros(2, C, device=DEV)
+    call("bn_act_bwd_apply_ex", ptr(g32), C, ptr(y), C, rows, C, ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]), act, 0.01,
+         ptr(s_ref), float(rows), 1, 0, ptr(dy32), C, ptr(dgb[0]), ptr(dgb[1]))
+    for dz16, gsrc, ldsrc in ((1, g16, ldg), (0, g32, C)):
+        dy16, lddy = _rows16(rows, C)
+        dgb2 = torch.full((2, C), 9.0, device=DEV)
+        call("bn_act_bwd_apply_h", ptr(gsrc), dz16, ldsrc, ptr(y), C, rows, C, ptr(par[0]), ptr(par[1]), ptr(par[2]),
+             ptr(par[3]), act, 0.01, ptr(s_ref), float(rows), 1, 0, ptr(dy16), lddy, ptr(dgb2[0]), ptr(dgb2[1]), 0)
+        # the same expression, but the two kernels may contract multiply-adds differently: equal up to one bf16 rounding
+        # boundary crossed by a last-bit fp32 difference
+        diff = (dy16[:, :C].float() - dy32.to(torch.bfloat16).float()).abs()
+        tol = dy32.abs() * 2 ** -7 + 2e-6            # (+ fp32 cancellation noise of g - m1 - xhat m2 where it is ~0)
+        assert bool((diff <= tol).all())
+        assert float((diff > 0).float().mean()) < 1e-3
+        assert torch.equal(dgb2, dgb)
+        assert bool((dy16[:, C:] == 0).all())
