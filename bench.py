@@ -30,10 +30,15 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 def gemm_label(name, ints, nulls=()):
     """(kernel symbol as rocprofv3 prints it, flops) of a GEMM launch; mirrors the dispatch in csrc/ccn_gemm.hip."""
-    if name not in ("gemm_nt", "gemm_nn", "gemm_tn", "gemm_tn_ws", "gemm_nt_bf16", "gemm_nt_f16", "gemm_tn_bf16", "gemm_nt_x3"):
+    if name not in ("gemm_nt", "gemm_nn", "gemm_tn", "gemm_tn_ws", "gemm_nt_bf16", "gemm_nt_f16", "gemm_tn_bf16", "gemm_nt_x3",
+                    "gemm_nt_h", "gemm_tn_h"):
         return None, 0.0
     ld_a, ld_b, _, m, n, k = ints[:6]
     flops = 2.0 * m * n * k
+    if name == "gemm_nt_h":       # (16-bit rows: the LDS-DMA kernels of csrc/ccn_gemm_h.hip)
+        return "gemm_h_pair_kernel<%s, %s>" % ("true" if ints[6] else "false", "true" if ints[7] else "false"), flops
+    if name == "gemm_tn_h":
+        return "gemm_h_tn_kernel", flops
     if name == "gemm_tn_ws":
         def tile(d):        # (a small remainder over 128 goes to a second, 64-wide launch: the label is the main one's)
             return 64 if d <= 64 else 128
@@ -73,6 +78,19 @@ def gemm_label(name, ints, nulls=()):
         return "gemm_fast_kernel<128, %d, 4, 0, 1, 0>" % bn, flops
     tile = "32, 128, 1" if n <= 32 else ("64, 64, 2" if k <= 64 else ("128, 128, 4" if n > 64 and m >= 50000 else "64, 128, 2"))
     return "gemm_fast_kernel<%s, 1, 1, 1, true>" % tile, flops
+
+
+def gemm_bytes(name, ints):
+    """Algorithmic HBM bytes of a 16-bit-storage GEMM launch (operands read once, result written once):
+    ccn_gemm_nt_h reads A (2 B) and the weight (2 B), writes Y (4 B, or 2 B for a 16-bit result); ccn_gemm_tn_h reads dY and
+    X (2 B each) and adds into dW (4 B read + 4 B written)."""
+    if name == "gemm_nt_h":
+        _, _, _, m, n, k, _, out16 = ints[:8]
+        return m * (2.0 * k + (2.0 if out16 else 4.0) * n) + 2.0 * n * k
+    if name == "gemm_tn_h":
+        _, _, _, m, n, k = ints[:6]
+        return 2.0 * m * (n + k) + 8.0 * n * k
+    return 0.0
 
 
 def pmc_traffic(kernel):
@@ -476,7 +494,9 @@ def main():
         # inside the timed region only the launches of the DOMINANT kernel are bracketed by HIP events (on the stream they
         # run on): an event pair costs ~3 us of GPU time -- over all ~2300 launches of a step 4 % of the step, over every
         # GEMM launch of both streams, or over all ~130 launches of the dominant kernel, still ~1 % (70.8 vs 71.5 clouds/s)
-        dominant = {"fp32": "gemm_glds_pair_kernel", "bf16": "gemm_bf16_kernel<128, 128", "fp16": "gemm_bf16_kernel<128, 128",
+        dominant = {"fp32": "gemm_glds_pair_kernel",
+                    "bf16": "gemm_h_pair_kernel<false, false>" if ops.STORE16 else "gemm_bf16_kernel<128, 128",
+                    "fp16": "gemm_bf16_kernel<128, 128",
                     "bf16x3": "gemm_x3_pair_kernel"}[args.mlp_dtype]
 
         def only_dominant(name, cargs):
@@ -587,12 +607,14 @@ def main():
             per_site = {}
             if len(sampled_sites) == len(records):
                 for st, (rname, ints, beg, end, nulls) in zip(sampled_sites, records):
-                    e = per_site.setdefault(st, [0.0, 0, gemm_label(rname, ints, nulls)[1]])
+                    e = per_site.setdefault(st, [0.0, 0, gemm_label(rname, ints, nulls)[1], gemm_bytes(rname, ints)])
                     e[0] += max(beg.elapsed_time(end) - bracket, 0.0)
                     e[1] += 1
+            site_bytes = 0.0
             if per_site:
-                site_ms = sum(ms / cnt for ms, cnt, _ in per_site.values())
-                site_flops = sum(fl for _, _, fl in per_site.values())
+                site_ms = sum(v[0] / v[1] for v in per_site.values())
+                site_flops = sum(v[2] for v in per_site.values())
+                site_bytes = sum(v[3] for v in per_site.values())
                 achieved = site_flops / (site_ms * 1e-3) / 1e12
                 top = dict(top, flops_per_launch=site_flops / len(per_site), avg_launch_ms=site_ms / len(per_site),
                            sites=len(per_site))
@@ -615,6 +637,13 @@ def main():
                                                    "launch site per step; durations have an empty bracket (empty_bracket_us, measured after the "
                                                    "run) subtracted and are averaged per launch site first, so every site of the step weighs the "
                                                    "same for any --steps" % args.event_stride}
+            if site_bytes > 0:
+                # the 16-bit storage products are HBM-bound at the network's widths (128 FLOP per byte at K = N = 256 against
+                # 2500 / 8 = 312 at the ridge): the binding roof is HBM; the matrix-core figure stays alongside
+                gbs = site_bytes / (site_ms * 1e-3) / 1e9
+                result["roofline"].update({"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                           "frac": gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": site_bytes / len(per_site),
+                                           "mfma": {"achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak}})
             # The GEMM launches run on two streams (weight-gradient products overlap the rest of the backward pass), so a
             # launch's own duration includes the time it shares the chip.  All GEMM launches together: flops over the
             # UNION of their execution intervals = the MFMA throughput the step actually gets out of the chip.

@@ -309,27 +309,72 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
 }
 
 // ---- element-wise companions: casts and the BatchNorm passes that read or write 16-bit rows ----------------------------
-// fp32 rows -> 16-bit rows (8 elements per thread: two 16-byte loads, one 16-byte store); columns [C, ld16) are zeroed.
-template <bool F16>
-__global__ __launch_bounds__(256) void cast_rows_h_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int64_t C,
-                                                          u16* __restrict__ Y, int64_t ldy) {
-  const int64_t per_row = ldy / 8;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * per_row) return;
-  const int64_t r = t / per_row, c0 = (t - r * per_row) * 8;
-  float v[8];
-  const float* src = X + r * ldx + c0;
-  if (c0 + 8 <= C && (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0) {
-    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+// Common shape: a thread owns ONE 8-column chunk (16 bytes of 16-bit data, 32 bytes of fp32) and walks rows; the per-column
+// BatchNorm constants live in registers for the whole walk (a first form that re-read six of them per element was
+// instruction-bound: 18 ms per step on BASELINE configs[2] against 5 ms for the fp32 pass it replaced).  A workgroup of
+// 256 threads covers CPB = min(chunks per row, 256) chunks x RPP = 256 / CPB rows per pass; gridDim.y covers wider rows.
+constexpr int EW_TPB = 256;
+constexpr int EW_ROWS = 128;      // rows per workgroup (= one partial row of the statistics passes: ccn_stats_rows)
+
+struct EwGeom {
+  int cpb, rpp;            // chunks per workgroup row, rows per pass
+  unsigned gy;             // workgroups along the columns
+};
+inline EwGeom ew_geom(int64_t ld16) {
+  const int64_t cpr = ld16 / 8;
+  EwGeom g;
+  g.cpb = (int)(cpr < EW_TPB ? cpr : EW_TPB);
+  g.rpp = EW_TPB / g.cpb;
+  g.gy = (unsigned)((cpr + g.cpb - 1) / g.cpb);
+  return g;
+}
+
+__device__ __forceinline__ void load8(const float* __restrict__ p, bool vec, int64_t c0, int64_t C, float (&v)[8]) {
+  if (vec) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
   } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? src[e] : 0.f;
+    for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? p[e] : 0.f;
   }
+}
+__device__ __forceinline__ void load8h(const u16* __restrict__ p, bool vec, int64_t c0, int64_t C, float (&v)[8]) {   // bf16
+  if (vec) {
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+    const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = __builtin_bit_cast(float, qq[e] << 16);
+      v[2 * e + 1] = __builtin_bit_cast(float, qq[e] & 0xffff0000u);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? from_h<false>(p[e]) : 0.f;
+  }
+}
+template <bool F16>
+__device__ __forceinline__ void store8h(u16* __restrict__ p, const float (&v)[8]) {
   uint32_t w[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) w[e] = (uint32_t)to_h<F16>(v[2 * e]) | ((uint32_t)to_h<F16>(v[2 * e + 1]) << 16);
-  *reinterpret_cast<uint4*>(Y + r * ldy + c0) = make_uint4(w[0], w[1], w[2], w[3]);
+  *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// fp32 rows -> 16-bit rows; columns [C, ld16) are zeroed
+template <bool F16>
+__global__ __launch_bounds__(EW_TPB) void cast_rows_h_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int64_t C,
+                                                             u16* __restrict__ Y, int64_t ldy, int cpb, int rpp) {
+  const int ch = threadIdx.x % cpb, rr = threadIdx.x / cpb;
+  const int64_t c0 = ((int64_t)blockIdx.y * cpb + ch) * 8;
+  if (rr >= rpp || c0 >= ldy) return;
+  const bool vec = c0 + 8 <= C && (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0;
+  const int64_t r0 = (int64_t)blockIdx.x * EW_ROWS;
+  const int64_t r1 = r0 + EW_ROWS < rows ? r0 + EW_ROWS : rows;
+  for (int64_t r = r0 + rr; r < r1; r += rpp) {
+    float v[8];
+    load8(X + r * ldx + c0, vec, c0, C, v);
+    store8h<F16>(Y + r * ldy + c0, v);
+  }
 }
 
 // W[n][k] fp32 -> Wt[k][n] 16-bit (the data-gradient product's "weight"), LDS-tiled 32 x 32; columns [N, ldt) zeroed
@@ -363,144 +408,136 @@ __device__ __forceinline__ float act_grad_h(float z, int act, float slope) {
   return 1.f;
 }
 
-// z = act(y * scale + shift) written as 16-bit rows (the expression of ccn_bn_act_fwd, then ONE rounding); 8 columns per
-// thread; padding columns [C, ldz) zeroed
+// z = act(y * scale + shift) written as 16-bit rows (the expression of ccn_bn_act_fwd, then ONE rounding); padding columns
+// [C, ldz) zeroed
 template <bool F16>
-__global__ __launch_bounds__(256) void bn_act_fwd_h_kernel(const float* __restrict__ Y, int64_t ldy, int64_t rows, int64_t C,
-                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           int act, float slope, u16* __restrict__ Z, int64_t ldz) {
-  const int64_t per_row = ldz / 8;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= rows * per_row) return;
-  const int64_t r = t / per_row, c0 = (t - r * per_row) * 8;
-  float v[8];
-  const float* src = Y + r * ldy + c0;
-  const bool full = c0 + 8 <= C;
-  if (full && (ldy & 3) == 0 && ((uintptr_t)Y & 15) == 0) {
-    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-  } else {
+__global__ __launch_bounds__(EW_TPB) void bn_act_fwd_h_kernel(const float* __restrict__ Y, int64_t ldy, int64_t rows, int64_t C,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              int act, float slope, u16* __restrict__ Z, int64_t ldz, int cpb,
+                                                              int rpp) {
+  const int ch = threadIdx.x % cpb, rr = threadIdx.x / cpb;
+  const int64_t c0 = ((int64_t)blockIdx.y * cpb + ch) * 8;
+  if (rr >= rpp || c0 >= ldz) return;
+  float sc[8], sh[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? src[e] : 0.f;
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = c0 + e < C ? scale[c0 + e] : 0.f;
+    sh[e] = c0 + e < C ? shift[c0 + e] : 0.f;
   }
-  uint32_t w[4];
+  const bool vec = c0 + 8 <= C && (ldy & 3) == 0 && ((uintptr_t)Y & 15) == 0;
+  const int64_t r0 = (int64_t)blockIdx.x * EW_ROWS;
+  const int64_t r1 = r0 + EW_ROWS < rows ? r0 + EW_ROWS : rows;
+  for (int64_t r = r0 + rr; r < r1; r += rpp) {
+    float v[8];
+    load8(Y + r * ldy + c0, vec, c0, C, v);
 #pragma unroll
-  for (int e = 0; e < 8; e += 2) {
-    float z0 = 0.f, z1 = 0.f;
-    if (c0 + e < C) z0 = act_fwd_h(v[e] * scale[c0 + e] + shift[c0 + e], act, slope);
-    if (c0 + e + 1 < C) z1 = act_fwd_h(v[e + 1] * scale[c0 + e + 1] + shift[c0 + e + 1], act, slope);
-    w[e >> 1] = (uint32_t)to_h<F16>(z0) | ((uint32_t)to_h<F16>(z1) << 16);
+    for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? act_fwd_h(v[e] * sc[e] + sh[e], act, slope) : 0.f;
+    store8h<F16>(Z + r * ldz + c0, v);
   }
-  *reinterpret_cast<uint4*>(Z + r * ldz + c0) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// BatchNorm + activation backward, second pass: dY (16-bit rows) from dZ (fp32 or 16-bit), y and the column sums of the first
+// BatchNorm + activation backward, second pass: dY (bf16 rows) from dZ (fp32 or bf16), y and the column sums of the first
 // pass -- the expression of bn_act_bwd_apply_kernel, then ONE rounding (both consumers of dY, the data- and the weight-
-// gradient product, round it to bf16 anyway in the 16-bit modes).  DZ16: dZ is 16-bit (a 16-bit activation's gradient).
+// gradient product, round it to bf16 anyway in the 16-bit modes).  DZ16: dZ is bf16 (a 16-bit activation's gradient).
 template <bool F16, bool DZ16>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_h_kernel(
+__global__ __launch_bounds__(EW_TPB) void bn_act_bwd_apply_h_kernel(
     const void* __restrict__ dZv, int64_t lddz, const float* __restrict__ Y, int64_t ldy, int64_t rows, int64_t C,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ rstd, int act, float slope, const double* __restrict__ sums, int training, float inv_n,
-    u16* __restrict__ dY, int64_t lddy, float* __restrict__ dgamma, float* __restrict__ dbeta, int acc_params) {
-  const int64_t per_row = lddy / 8;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < C) {      // parameter gradients from the column sums (acc_params: add into gradient-bucket views)
-    if (dgamma) dgamma[t] = (acc_params ? dgamma[t] : 0.f) + (float)sums[C + t];
-    if (dbeta) dbeta[t] = (acc_params ? dbeta[t] : 0.f) + (float)sums[t];
+    u16* __restrict__ dY, int64_t lddy, float* __restrict__ dgamma, float* __restrict__ dbeta, int acc_params, int cpb, int rpp) {
+  const int ch = threadIdx.x % cpb, rr = threadIdx.x / cpb;
+  const int64_t c0 = ((int64_t)blockIdx.y * cpb + ch) * 8;
+  if (rr >= rpp || c0 >= lddy) return;
+  float sc[8], sh[8], mu[8], rs[8], m1[8], m2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int64_t c = c0 + e < C ? c0 + e : C - 1;
+    sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; rs[e] = rstd[c];
+    m1[e] = (float)sums[c] * inv_n;
+    m2[e] = (float)sums[C + c] * inv_n;
+    if (blockIdx.x == 0 && rr == 0 && c0 + e < C) {   // parameter gradients (acc_params: add into gradient-bucket views)
+      if (dgamma) dgamma[c] = (acc_params ? dgamma[c] : 0.f) + (float)sums[C + c];
+      if (dbeta) dbeta[c] = (acc_params ? dbeta[c] : 0.f) + (float)sums[c];
+    }
   }
-  if (t >= rows * per_row) return;
-  const int64_t r = t / per_row, c0 = (t - r * per_row) * 8;
-  float y[8], gz[8];
   const bool full = c0 + 8 <= C;
-  const float* ysrc = Y + r * ldy + c0;
-  if (full && (ldy & 3) == 0 && ((uintptr_t)Y & 15) == 0) {
-    const float4 a = *reinterpret_cast<const float4*>(ysrc), b = *reinterpret_cast<const float4*>(ysrc + 4);
-    y[0] = a.x; y[1] = a.y; y[2] = a.z; y[3] = a.w; y[4] = b.x; y[5] = b.y; y[6] = b.z; y[7] = b.w;
-  } else {
+  const bool yvec = full && (ldy & 3) == 0 && ((uintptr_t)Y & 15) == 0;
+  const bool gvec = full && (DZ16 ? ((lddz & 7) == 0) : ((lddz & 3) == 0)) && ((uintptr_t)dZv & 15) == 0;
+  const int64_t r0 = (int64_t)blockIdx.x * EW_ROWS;
+  const int64_t r1 = r0 + EW_ROWS < rows ? r0 + EW_ROWS : rows;
+  for (int64_t r = r0 + rr; r < r1; r += rpp) {
+    float y[8], gz[8], o[8];
+    load8(Y + r * ldy + c0, yvec, c0, C, y);
+    if (DZ16) load8h(reinterpret_cast<const u16*>(dZv) + r * lddz + c0, gvec, c0, C, gz);
+    else load8(reinterpret_cast<const float*>(dZv) + r * lddz + c0, gvec, c0, C, gz);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) y[e] = c0 + e < C ? ysrc[e] : 0.f;
-  }
-  if (DZ16) {
-    const u16* gsrc = reinterpret_cast<const u16*>(dZv) + r * lddz + c0;
-    if (full && (lddz & 7) == 0 && ((uintptr_t)dZv & 15) == 0) {
-      const uint4 q = *reinterpret_cast<const uint4*>(gsrc);
-      const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        gz[2 * e] = __builtin_bit_cast(float, qq[e] << 16);
-        gz[2 * e + 1] = __builtin_bit_cast(float, qq[e] & 0xffff0000u);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) gz[e] = c0 + e < C ? from_h<false>(gsrc[e]) : 0.f;
+    for (int e = 0; e < 8; ++e) {
+      const float g = gz[e] * act_grad_h(y[e] * sc[e] + sh[e], act, slope);
+      const float v = training ? sc[e] * (g - m1[e] - (y[e] - mu[e]) * rs[e] * m2[e]) : sc[e] * g;
+      o[e] = c0 + e < C ? v : 0.f;
     }
-  } else {
-    const float* gsrc = reinterpret_cast<const float*>(dZv) + r * lddz + c0;
-    if (full && (lddz & 3) == 0 && ((uintptr_t)dZv & 15) == 0) {
-      const float4 a = *reinterpret_cast<const float4*>(gsrc), b = *reinterpret_cast<const float4*>(gsrc + 4);
-      gz[0] = a.x; gz[1] = a.y; gz[2] = a.z; gz[3] = a.w; gz[4] = b.x; gz[5] = b.y; gz[6] = b.z; gz[7] = b.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) gz[e] = c0 + e < C ? gsrc[e] : 0.f;
-    }
+    store8h<F16>(dY + r * lddy + c0, o);
   }
-  uint32_t w[4];
-#pragma unroll
-  for (int e = 0; e < 8; e += 2) {
-    float o[2] = {0.f, 0.f};
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      const int64_t c = c0 + e + d;
-      if (c < C) {
-        const float sc = scale[c];
-        const float g = gz[e + d] * act_grad_h(y[e + d] * sc + shift[c], act, slope);
-        const float m1 = (float)sums[c] * inv_n, m2 = (float)sums[C + c] * inv_n;
-        o[d] = training ? sc * (g - m1 - (y[e + d] - mean[c]) * rstd[c] * m2) : sc * g;
-      }
-    }
-    w[e >> 1] = (uint32_t)to_h<F16>(o[0]) | ((uint32_t)to_h<F16>(o[1]) << 16);
-  }
-  *reinterpret_cast<uint4*>(dY + r * lddy + c0) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// first pass with a 16-bit dZ: column sums of g = dZ * act'(u) and of g * xhat (fp64 partial rows, as col_partial_vec<1>)
-constexpr int HR_ROWS = 128;    // rows per workgroup = one partial row (ccn_stats_rows)
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce_h_kernel(const u16* __restrict__ dZ, int64_t lddz,
-                                                                  const float* __restrict__ Y, int64_t ldy, int64_t rows,
-                                                                  int64_t C, const float* __restrict__ scale,
-                                                                  const float* __restrict__ shift,
-                                                                  const float* __restrict__ mean,
-                                                                  const float* __restrict__ rstd, int act, float slope,
-                                                                  double* __restrict__ partial) {
-  // 256 threads: 64 column lanes x 4 row groups; every thread walks its columns c = cx, cx + 64, ... over 32 of the 128 rows
-  __shared__ double red[4][64][2];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int64_t r0 = (int64_t)blockIdx.x * HR_ROWS;
-  for (int64_t cb = 0; cb < C; cb += 64) {
-    const int64_t c = cb + cx;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C) {
-      const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
-      float a1 = 0.f, a2 = 0.f;
-      for (int64_t r = r0 + ry; r < r0 + HR_ROWS && r < rows; r += 4) {
-        const float y = Y[r * ldy + c];
-        const float g = from_h<false>(dZ[r * lddz + c]) * act_grad_h(y * sc + sh, act, slope);
-        a1 += g;
-        a2 += g * ((y - mu) * rs);
+// first pass with a bf16 dZ: column sums of g = dZ * act'(u) and of g * xhat; one fp64 partial row per 128-row workgroup
+__global__ __launch_bounds__(EW_TPB) void bn_act_bwd_reduce_h_kernel(const u16* __restrict__ dZ, int64_t lddz,
+                                                                     const float* __restrict__ Y, int64_t ldy, int64_t rows,
+                                                                     int64_t C, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ rstd, int act, float slope,
+                                                                     double* __restrict__ partial, int cpb, int rpp) {
+  __shared__ float red[2][EW_TPB * 8];          // [sum | sum * xhat][row group rr][chunk ch][8]
+  const int ch = threadIdx.x % cpb, rr = threadIdx.x / cpb;
+  const int64_t c0 = ((int64_t)blockIdx.y * cpb + ch) * 8;
+  const bool live = rr < rpp && c0 < C;
+  float a1[8], a2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a1[e] = a2[e] = 0.f;
+  if (live) {
+    float sc[8], sh[8], mu[8], rs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int64_t c = c0 + e < C ? c0 + e : C - 1;
+      sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; rs[e] = rstd[c];
+    }
+    const bool full = c0 + 8 <= C;
+    const bool yvec = full && (ldy & 3) == 0 && ((uintptr_t)Y & 15) == 0;
+    const bool gvec = full && (lddz & 7) == 0 && ((uintptr_t)dZ & 15) == 0;
+    const int64_t r0 = (int64_t)blockIdx.x * EW_ROWS;
+    const int64_t r1 = r0 + EW_ROWS < rows ? r0 + EW_ROWS : rows;
+    for (int64_t r = r0 + rr; r < r1; r += rpp) {
+      float y[8], gz[8];
+      load8(Y + r * ldy + c0, yvec, c0, C, y);
+      load8h(dZ + r * lddz + c0, gvec, c0, C, gz);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float g = gz[e] * act_grad_h(y[e] * sc[e] + sh[e], act, slope);
+        a1[e] += g;
+        a2[e] += g * ((y[e] - mu[e]) * rs[e]);
       }
-      s1 = (double)a1;
-      s2 = (double)a2;
     }
-    red[ry][cx][0] = s1;
-    red[ry][cx][1] = s2;
-    __syncthreads();
-    if (ry == 0 && c < C) {
-      double* dst = partial + (int64_t)blockIdx.x * 2 * C;
-      dst[c] = red[0][cx][0] + red[1][cx][0] + red[2][cx][0] + red[3][cx][0];
-      dst[C + c] = red[0][cx][1] + red[1][cx][1] + red[2][cx][1] + red[3][cx][1];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[0][threadIdx.x * 8 + e] = a1[e];
+    red[1][threadIdx.x * 8 + e] = a2[e];
+  }
+  __syncthreads();
+  if (rr == 0 && c0 < C) {
+    double* dst = partial + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (c0 + e >= C) break;
+      double s1 = 0.0, s2 = 0.0;
+      for (int q = 0; q < rpp; ++q) {
+        s1 += (double)red[0][(q * cpb + ch) * 8 + e];
+        s2 += (double)red[1][(q * cpb + ch) * 8 + e];
+      }
+      dst[c0 + e] = s1;
+      dst[C + c0 + e] = s2;
     }
-    __syncthreads();
   }
 }
 
@@ -845,9 +882,10 @@ int ccn_gemm_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, floa
 int ccn_cast_rows_h(const float* X, int64_t ldx, int64_t rows, int64_t C, void* Y, int64_t ldy, int f16, void* stream) {
   CCN_REQUIRE(X && Y && rows >= 0 && C > 0 && ldx >= C && ldy >= C && ldy % 8 == 0 && aligned16(Y), "cast_rows_h: bad arguments");
   if (rows == 0) return CCN_OK;
-  const int64_t n = rows * (ldy / 8);
-  if (f16) hipLaunchKernelGGL(cast_rows_h_kernel<true>, dim3(ccn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy);
-  else hipLaunchKernelGGL(cast_rows_h_kernel<false>, dim3(ccn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy);
+  const EwGeom g = ew_geom(ldy);
+  const dim3 grid((unsigned)ccn_blocks(rows, EW_ROWS), g.gy);
+  if (f16) hipLaunchKernelGGL(cast_rows_h_kernel<true>, grid, dim3(EW_TPB), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy, g.cpb, g.rpp);
+  else hipLaunchKernelGGL(cast_rows_h_kernel<false>, grid, dim3(EW_TPB), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy, g.cpb, g.rpp);
   CCN_LAUNCH_OK("cast_rows_h");
   return CCN_OK;
 }
@@ -866,9 +904,10 @@ int ccn_bn_act_fwd_h(const float* Y, int64_t ldy, int64_t rows, int64_t C, const
   CCN_REQUIRE(Y && Z && scale && shift && rows >= 0 && C > 0 && ldy >= C && ldz >= C && ldz % 8 == 0 && aligned16(Z),
               "bn_act_fwd_h: bad arguments");
   if (rows == 0) return CCN_OK;
-  const int64_t n = rows * (ldz / 8);
-  if (f16) hipLaunchKernelGGL(bn_act_fwd_h_kernel<true>, dim3(ccn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, Y, ldy, rows, C, scale, shift, act, slope, (u16*)Z, ldz);
-  else hipLaunchKernelGGL(bn_act_fwd_h_kernel<false>, dim3(ccn_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, Y, ldy, rows, C, scale, shift, act, slope, (u16*)Z, ldz);
+  const EwGeom g = ew_geom(ldz);
+  const dim3 grid((unsigned)ccn_blocks(rows, EW_ROWS), g.gy);
+  if (f16) hipLaunchKernelGGL(bn_act_fwd_h_kernel<true>, grid, dim3(EW_TPB), 0, (hipStream_t)stream, Y, ldy, rows, C, scale, shift, act, slope, (u16*)Z, ldz, g.cpb, g.rpp);
+  else hipLaunchKernelGGL(bn_act_fwd_h_kernel<false>, grid, dim3(EW_TPB), 0, (hipStream_t)stream, Y, ldy, rows, C, scale, shift, act, slope, (u16*)Z, ldz, g.cpb, g.rpp);
   CCN_LAUNCH_OK("bn_act_fwd_h");
   return CCN_OK;
 }
@@ -880,8 +919,9 @@ int ccn_bn_act_bwd_reduce_h(const void* dZ, int64_t lddz, const float* Y, int64_
   CCN_REQUIRE(dZ && Y && sums && rows > 0 && C > 0 && lddz >= C && ldy >= C, "bn_act_bwd_reduce_h: bad arguments");
   const int64_t nparts = ccn_stats_rows(rows);
   double* partial = sums + 2 * C;
-  hipLaunchKernelGGL(bn_act_bwd_reduce_h_kernel, dim3((unsigned)nparts), dim3(256), 0, (hipStream_t)stream, (const u16*)dZ, lddz,
-                     Y, ldy, rows, C, scale, shift, mean, rstd, act, slope, partial);
+  const EwGeom g = ew_geom((C + 7) / 8 * 8);
+  hipLaunchKernelGGL(bn_act_bwd_reduce_h_kernel, dim3((unsigned)nparts, g.gy), dim3(EW_TPB), 0, (hipStream_t)stream,
+                     (const u16*)dZ, lddz, Y, ldy, rows, C, scale, shift, mean, rstd, act, slope, partial, g.cpb, g.rpp);
   CCN_LAUNCH_OK("bn_act_bwd_reduce_h");
   return ccn_reduce_partials(partial, nparts, 2 * C, sums, stream);
 }
@@ -892,13 +932,13 @@ int ccn_bn_act_bwd_apply_h(const void* dZ, int dz16, int64_t lddz, const float* 
                            float* dbeta, int f16, void* stream) {
   CCN_REQUIRE(dZ && Y && dY && sums && rows > 0 && C > 0 && lddz >= C && ldy >= C && lddy >= C && lddy % 8 == 0 && aligned16(dY),
               "bn_act_bwd_apply_h: bad arguments");
-  const int64_t n = rows * (lddy / 8);
-  const int64_t work = n > C ? n : C;
+  const EwGeom g = ew_geom(lddy);
+  const dim3 grid((unsigned)ccn_blocks(rows, EW_ROWS), g.gy);
   const float inv_n = 1.f / count;
 #define CCN_APPLY_H(F16_, DZ16_)                                                                                              \
-  hipLaunchKernelGGL((bn_act_bwd_apply_h_kernel<F16_, DZ16_>), dim3(ccn_blocks(work, 256)), dim3(256), 0, (hipStream_t)stream, \
+  hipLaunchKernelGGL((bn_act_bwd_apply_h_kernel<F16_, DZ16_>), grid, dim3(EW_TPB), 0, (hipStream_t)stream,                    \
                      dZ, lddz, Y, ldy, rows, C, scale, shift, mean, rstd, act, slope, sums, training, inv_n, (u16*)dY, lddy,  \
-                     dgamma, dbeta, acc_params)
+                     dgamma, dbeta, acc_params, g.cpb, g.rpp)
   if (f16) { if (dz16) CCN_APPLY_H(true, true); else CCN_APPLY_H(true, false); }
   else { if (dz16) CCN_APPLY_H(false, true); else CCN_APPLY_H(false, false); }
 #undef CCN_APPLY_H

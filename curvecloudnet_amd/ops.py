@@ -788,6 +788,176 @@ class LinearBNAct(torch.autograd.Function):
         return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
+# ---- 16-bit STORAGE form of the bf16 MLP mode (BASELINE configs[2]; csrc/ccn_gemm_h.hip) -------------------------------
+# In the bf16 mode every product rounds its operands to bf16 anyway.  Here the rounded values are what is STORED: the layer
+# input is cast once (or arrives as bf16 rows from the previous layer of the same MLP), the weight is cast per call, the
+# BatchNorm-backward gradient dY is written as bf16 rows, and a hidden activation whose only consumer is the next Linear
+# is written as bf16 rows (and receives its gradient as bf16 rows).  The products then stream half the bytes through the
+# LDS-DMA kernels ccn_gemm_nt_h / ccn_gemm_tn_h.  Forward values are those of the fp32-storage form (one rounding of the
+# same fp32 number, earlier); the gradient of a 16-bit hidden activation is rounded to bf16 once more than there
+# (oracle.torch_ref mirrors it).  CCN_STORE16=0 keeps the fp32-storage kernels (A/B).
+STORE16 = os.environ.get("CCN_STORE16", "1") != "0"
+
+
+def _rows16(rows, cols, device, dtype=torch.bfloat16):
+    """(rows, cols) 16-bit matrix whose rows start 16-byte aligned: leading dimension a multiple of 8 elements."""
+    ld = (cols + 7) // 8 * 8
+    buf = torch.empty((rows, ld), dtype=dtype, device=device)
+    return buf if ld == cols else buf[:, :cols]
+
+
+def _is_rows16(t):
+    return (t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0
+            and t.stride(0) >= t.size(1) and t.data_ptr() % 16 == 0)
+
+
+def _cast16(x):
+    """fp32 rows -> bf16 rows (ccn_cast_rows_h); a bf16 row matrix passes through."""
+    if _is_rows16(x):
+        return x
+    if x.dtype == torch.bfloat16:
+        x = x.float()
+    x = _mat(x)
+    out = _rows16(x.size(0), x.size(1), x.device)
+    if x.size(0):
+        call("cast_rows_h", ptr(x), _ld(x), x.size(0), x.size(1), ptr(out), _ld(out), 0)
+    return out
+
+
+class LinearBNActH(torch.autograd.Function):
+    """LinearBNAct on 16-bit rows (see STORE16 above): y = act(BN(bf16(x) bf16(W)^T + b)), fp32 accumulation and statistics."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum, grad_on, out16):
+        require_gpu(x, weight)
+        m, k = x.shape
+        n = weight.size(0)
+        if weight.size(1) != k:
+            raise ValueError("linear: input has %d channels, weight expects %d" % (k, weight.size(1)))
+        dev = x.device
+        ctx.x16_in = x.dtype == torch.bfloat16
+        x16 = _cast16(x)
+        w16 = _cast16(weight.detach())
+        y = _rows(m, n, dev)
+        has_bn = gamma is not None
+        ctx.has_bn, ctx.act, ctx.training, ctx.has_bias = has_bn, ACT[act], bool(training), bias is not None
+        ctx.out16 = bool(out16 and has_bn)
+        none = y.new_empty(0)
+        ctx.main_grad_of = weight if (grad_on and ctx.needs_input_grad[1] and _main_grad(weight, n, k) is not None) else None
+        ctx.bn_refs = ((gamma, beta) if has_bn and grad_on and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]
+                       and _main_grad_vec(gamma, n) is not None and _main_grad_vec(beta, n) is not None else None)
+        _main_grad_note(ctx.main_grad_of, *(ctx.bn_refs or ()))
+        ctx.shape = (m, n, k)
+
+        def product(stats):
+            if m:
+                call("gemm_nt_h", ptr(x16), _ld(x16), ptr(w16), _ld(w16), ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats), 0, 0)
+
+        if not has_bn:
+            product(None)
+            ctx.save_for_backward(x16, weight)
+            return y
+        par = torch.empty((4, n), dtype=torch.float32, device=dev)      # scale, shift, mean, rstd
+        if training:
+            if m < 2:
+                raise ValueError("Expected more than 1 value per channel when training")
+            stats = _stats_buffer(m, n, dev)
+            product(stats)
+            call("bn_finalize", ptr(stats), m, n, ptr(gamma), ptr(beta), float(eps), float(momentum),
+                 ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        else:
+            product(None)
+            call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), n,
+                 ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        ctx.save_for_backward(x16, weight, y, par)
+        if ctx.out16:
+            z = _rows16(m, n, dev)
+            call("bn_act_fwd_h", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z), 0)
+            return z
+        z = _rows(m, n, dev)
+        call("bn_act_fwd", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
+        _trace_act(z, ctx.act)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        m, n, k = ctx.shape
+        dev = g.device
+        dgamma = dbeta = None
+        if ctx.has_bn:
+            x16, weight, y, par = ctx.saved_tensors
+            g16 = g.dtype == torch.bfloat16
+            if g16 and not _is_rows16(g):
+                g, g16 = g.float(), False
+            g = g if g16 else _mat(g)
+            sums = _stats_buffer(m, n, dev)
+            if g16:
+                call("bn_act_bwd_reduce_h", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                     ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums))
+            else:
+                call("bn_act_bwd_reduce", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                     ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums))
+            dy16 = _rows16(m, n, dev)
+            refs = ctx.bn_refs
+            gview = _main_grad_vec(refs[0], n) if refs else None
+            bview = _main_grad_vec(refs[1], n) if refs else None
+            if refs and (gview is None or bview is None):
+                _main_grad_cancel(*refs)
+                gview = bview = None
+            fused = gview is not None
+            if not fused:
+                dgb = torch.empty((2, n), dtype=torch.float32, device=dev)
+                gview, bview = dgb[0], dgb[1]
+            call("bn_act_bwd_apply_h", ptr(g), 1 if g16 else 0, _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]),
+                 ptr(par[2]), ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums), float(m), 1 if ctx.training else 0,
+                 1 if fused else 0, ptr(dy16), _ld(dy16), ptr(gview), ptr(bview), 0)
+            if fused:
+                dgamma, dbeta = _main_grad_done(refs[0]), _main_grad_done(refs[1])
+            else:
+                dgamma, dbeta = gview, bview
+        else:
+            x16, weight = ctx.saved_tensors
+            sums = par = None
+            dy16 = _cast16(g)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt16 = _rows16(k, n, dev)
+            call("transpose_cast_h", ptr(weight), _ld(weight), n, k, ptr(wt16), _ld(wt16), 0)
+            if ctx.x16_in:       # the gradient of a 16-bit activation: written as bf16 rows
+                dx = _rows16(m, k, dev)
+                if m:
+                    call("gemm_nt_h", ptr(dy16), _ld(dy16), ptr(wt16), _ld(wt16), None, ptr(dx), _ld(dx), m, k, n, None, 0, 1)
+            else:
+                dx = _rows(m, k, dev)
+                if m:
+                    call("gemm_nt_h", ptr(dy16), _ld(dy16), ptr(wt16), _ld(wt16), None, ptr(dx), _ld(dx), m, k, n, None, 0, 0)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            into = _main_grad(ctx.main_grad_of, n, k)
+            if into is None and ctx.main_grad_of is not None:
+                _main_grad_cancel(ctx.main_grad_of)
+            dw = into if into is not None else _rows(n, k, dev, zero=True)
+            if m:
+                with _WgradScope(into, dy16, x16):
+                    nb = lib().ccn_gemm_tn_h_workspace_bytes(m, n, k)
+                    ws = _tn_scratch(nb, dev)
+                    call("gemm_tn_h", ptr(dy16), _ld(dy16), ptr(x16), _ld(x16), ptr(dw), _ld(dw), m, n, k, ptr(ws), nb)
+            if into is not None:
+                dw = _main_grad_done(ctx.main_grad_of)
+        db = None
+        if ctx.has_bias:
+            if ctx.has_bn:
+                # the bias sits in front of the BatchNorm: with batch statistics its gradient is identically zero, with
+                # running statistics it is scale * sum(g act'): both from the column sums of the first pass
+                db = torch.zeros(n, dtype=torch.float32, device=dev) if ctx.training else par[0] * sums[:n].float()
+            else:
+                gf = _mat(g.float()) if g.dtype != torch.float32 else _mat(g)
+                acc = _stats_buffer(m, n, dev)
+                db = torch.empty(n, dtype=torch.float32, device=dev)
+                call("colsum", ptr(gf), _ld(gf), m, n, ptr(acc), ptr(db))
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
 # A hidden MLP layer whose only consumer is the next Linear of the same MLP hands over its PRE-normalisation product; the
 # consumer applies BatchNorm + activation to the A fragments inside its GEMM (ccn_gemm_nt_xf, and ccn_gemm_tn_ws_xf for its
 # weight gradient), so the activation tensor is never written or read: same bits, one pass over rows x K saved per layer
@@ -803,6 +973,18 @@ def linear_bn_act(x, weight, bias, bn, training, act, defer=False):
     """bn: a torch.nn.BatchNorm1d used as parameter/buffer container, or None.  ``defer``: the caller feeds the result to
     another linear_bn_act and nothing else (nn.MLP); the result may then be a deferred activation (see LAZY_ACT)."""
     grad_on = torch.is_grad_enabled()
+    if _MLP_DTYPE == "bf16" and STORE16 and x.dim() == 2 and x.size(0) > 0:
+        if bn is None:
+            return LinearBNActH.apply(x, weight, bias, None, None, None, None, False, None, 0.0, 0.0, grad_on, False)
+        if training and bn.track_running_stats:
+            bn.num_batches_tracked += 1
+        use_batch_stats = training or not bn.track_running_stats
+        # (the parity tests read sign tables off the fp32 activation: no 16-bit activation while they are recorded)
+        out16 = bool(defer and ACT_TRACE is None and ACT[act] != 0)
+        return LinearBNActH.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats, act,
+                                  bn.eps, bn.momentum if bn.momentum is not None else 0.1, grad_on, out16)
+    if x.dtype == torch.bfloat16:
+        x = x.float()
     pend = getattr(x, "_ccn_deferred", None)
     xf_par, xf_act = pend if pend is not None else (None, 0)
     if bn is None:

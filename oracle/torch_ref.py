@@ -125,6 +125,22 @@ def _bf16(t):
     return t.to(torch.bfloat16).to(t.dtype)
 
 
+# 16-bit STORAGE form of the bf16 mode (the product's ops.STORE16): a hidden MLP activation whose only consumer is the next
+# Linear is kept as bf16 rows.  Its forward value is the one both forms round before the product anyway; its GRADIENT is
+# stored as bf16 too, i.e. rounded once more than in the fp32-storage form.
+STORE16 = True
+
+
+class _RoundGradBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
 def _fwd16(t):
     return t.to(torch.float16 if MLP_DTYPE == "fp16" else torch.bfloat16).to(t.dtype)
 
@@ -619,6 +635,9 @@ class MLP(nn.Module):
     def forward(self, x):
         for i, (lin, norm) in enumerate(zip(self.lins, self.norms)):
             x = F.dropout(activation(norm(linear(x, lin)), self.act), p=self.dropout[i], training=self.training)
+            if (MLP_DTYPE == "bf16" and STORE16 and ACT_TRACE is None and self.dropout[i] == 0.0
+                    and (i + 1 < len(self.norms) or self.plain_last)):
+                x = _RoundGradBF16.apply(x)          # (stored as bf16 rows in the product: see STORE16)
         if self.plain_last:
             x = F.dropout(linear(x, self.lins[-1]), p=self.dropout[-1], training=self.training)
         return x

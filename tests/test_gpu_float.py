@@ -907,3 +907,69 @@ def test_nll_loss_kitti_runner_form_and_target_check():
     with pytest.raises(IndexError):
         segmentation_loss(xd, bad.to(DEV), ignore_index=0, check_targets=True)
     segmentation_loss(xd, t.to(DEV), ignore_index=0, check_targets=True)       # in range: passes
+
+
+@pytest.mark.parametrize("dims,bias,plain_last", [([67, 128, 192, 64], False, True), ([40, 64, 64], True, False),
+                                                  ([259, 256, 128, 128, 64], False, False)])
+def test_bf16_storage_mlp_chain(dims, bias, plain_last):
+    """ops.STORE16: in the bf16 mode the hidden activations of an MLP, the BatchNorm-backward gradients and the cast
+    weights are stored as bf16 rows and multiplied by the LDS-DMA kernels (ccn_gemm_nt_h / ccn_gemm_tn_h).  Against the
+    CPU emulation (operands rounded to bf16, fp32 accumulation; hidden-activation gradients rounded to bf16): output
+    and every gradient in the max norm relative to the tensor's largest entry; against the fp32-storage kernels
+    (CCN_STORE16=0 form): the same forward values up to fp32 summation order."""
+    from oracle import torch_ref as R
+    from curvecloudnet_amd.nn import MLP
+    ops = _ops()
+    M = 6000
+    gen = torch.Generator().manual_seed(sum(dims))
+    x = torch.randn(M, dims[0], generator=gen) + 0.2
+    cot = torch.randn(M, dims[-1], generator=gen)
+    torch.manual_seed(1)
+    ref = R.MLP(dims, act="leaky_relu", bias=bias, plain_last=plain_last).train()
+    for m_ in ref.modules():
+        if isinstance(m_, torch.nn.BatchNorm1d):
+            m_.weight.data.uniform_(0.5, 1.5)
+            m_.bias.data.uniform_(-0.2, 0.2)
+    mine = MLP(dims, act="leaky_relu", bias=bias, plain_last=plain_last)
+    mine.load_state_dict(ref.state_dict())
+    mine = mine.to(DEV).train()
+    ops.set_mlp_dtype("bf16")
+    R.set_mlp_dtype("bf16")
+    try:
+        assert ops.STORE16 and R.STORE16
+        xr = x.clone().requires_grad_(True)
+        yr = ref(xr)
+        gr = torch.autograd.grad((yr * cot).sum(), [xr] + list(ref.parameters()))
+        xd = x.to(DEV).requires_grad_(True)
+        yd = mine(xd)
+        assert yd.dtype == torch.float32
+        gd = torch.autograd.grad((yd * cot.to(DEV)).sum(), [xd] + list(mine.parameters()))
+        ops.STORE16 = False
+        try:
+            y_plain = mine(x.to(DEV))
+        finally:
+            ops.STORE16 = True
+    finally:
+        ops.set_mlp_dtype("fp32")
+        R.set_mlp_dtype("fp32")
+
+    def rel(a, b):
+        return float((a.detach().cpu() - b.detach()).abs().max() / b.detach().abs().max().clamp_min(1e-12))
+    # a 1e-7 CPU / GPU difference of an activation that sits on a bf16 rounding boundary becomes one bf16 ulp (0.4 %) of
+    # that element: per-tensor max-norm bounds a little above that
+    assert rel(yd, yr) < 6e-3, rel(yd, yr)
+    assert rel(y_plain.cpu(), yd.cpu()) < 6e-3
+    names = ["dx"] + [n for n, _ in ref.named_parameters()]
+    gmax = max(float(b.abs().max()) for b in gr[1:])
+    for a, b, nme in zip(gd, gr, names):
+        assert a.dtype == torch.float32 and a.shape == b.shape
+        # (a bias in front of a BatchNorm has a mathematically zero gradient: what the reference holds there is summation
+        # noise, the product returns exact zeros -- compared on the scale of the model's gradients)
+        denom = max(float(b.abs().max()), 1e-3 * gmax)
+        diff = a.detach().cpu() - b.detach()
+        # LeakyReLU kinks: a pre-activation within bf16 noise (0.4 %) of zero takes the other slope on one side, which moves
+        # single entries by several per cent in a four-layer chain -- the bound on the max norm is loose, the one on the
+        # l2 norm is the sharp one
+        assert float(diff.abs().max()) / denom < 0.25, (nme, float(diff.abs().max()) / denom)
+        l2 = float(diff.norm() / max(float(b.norm()), 1e-3 * gmax * b.numel() ** 0.5))
+        assert l2 < 3e-2, (nme, l2)
