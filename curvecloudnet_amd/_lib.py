@@ -12,7 +12,8 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "libccn_hip.so")
+# (CCN_LIB_PATH: another build of the SAME library for one-box A/B runs of a kernel change -- tools/ only)
+LIB_PATH = os.environ.get("CCN_LIB_PATH") or os.path.join(_PKG, "libccn_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "ccn_hip.h")
 
 _CTYPES = {

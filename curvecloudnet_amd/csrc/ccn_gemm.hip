@@ -1099,7 +1099,7 @@ __device__ unsigned long long* g_pair_dbg_dev = nullptr;
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
 
-template <bool ACC, bool XF, int TAG = 0, bool STAMP = false, bool ILV = false>
+template <bool ACC, bool XF, int TAG = 0, bool STAMP = false>
 __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* __restrict__ A, int64_t lda,
                                                                    const float* __restrict__ B, int64_t ldb,
                                                                    const float* __restrict__ bias, float* __restrict__ C,
@@ -1126,7 +1126,8 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   const uint32_t xf_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)xf_tab;
   const float xf_neg = xf_act == CCN_ACT_RELU ? 0.f : (xf_act == CCN_ACT_LEAKY ? xf_slope : 1.f);   // multiplier of v <= 0
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wave index as a SCALAR: LDS-DMA destinations and tile bases then stay in SGPRs -- three vector instructions fewer per copy)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int wm = wave & 1, wn = wave >> 1;
   const int i = lane & 31, h = lane >> 5;
   const int swz = (i >> 1) & 7;
@@ -1156,8 +1157,11 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   auto tile_col = [&](int64_t t) -> int64_t { return (int64_t)((uint32_t)t % gnu); };
 
   // ---- issue cursor: one slice ahead of the compute cursor, across tile boundaries
-  const float* a_src[NC];
-  const float* b_src[NC];
+  // a copy's source = tile base (scalar, 64 bit) + this lane's byte offset inside the tile (32 bit: row * ld + swizzled chunk;
+  // a tile spans 128 rows, so the offset fits whatever the matrix size)
+  uint32_t a_off32[NC], b_off32[NC];
+  const char* a_tile = reinterpret_cast<const char*>(A);
+  const char* b_tile = reinterpret_cast<const char*>(B);
   int64_t it_j = 0, it_tile = tile_of(0), gi = 0;
   int64_t im0 = 0, in0 = 0;
   int it_u = 0;
@@ -1166,24 +1170,28 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     if (it_u == 0) {
       im0 = tile_row(it_tile) * PR_BM;
       in0 = tile_col(it_tile) * PR_BN;
+      a_tile = reinterpret_cast<const char*>(A + im0 * lda);
+      b_tile = reinterpret_cast<const char*>(B + in0 * ldb);
+      const int64_t a_rows = M - im0, b_rows = N - in0;       // rows of the matrix from the tile's first row on (>= 1)
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
         const int r = 8 * (wave * NC + q) + lr;
-        int64_t row = im0 + r;
-        row = row < M ? row : M - 1;
-        a_src[q] = A + row * lda + 4 * (lc ^ ((r >> 1) & 7));
-        row = in0 + r;
-        row = row < N ? row : N - 1;
-        b_src[q] = B + row * ldb + 4 * (lc ^ ((r >> 1) & 7));
+        const int64_t ra = r < a_rows ? r : a_rows - 1, rb = r < b_rows ? r : b_rows - 1;
+        a_off32[q] = (uint32_t)((ra * lda + 4 * (lc ^ ((r >> 1) & 7))) * 4);
+        b_off32[q] = (uint32_t)((rb * ldb + 4 * (lc ^ ((r >> 1) & 7))) * 4);
       }
     }
     float* st = lds + (gi & 1) * STAGE;
     const int64_t k0 = (int64_t)it_u * BK;
     if (it_u < T) {
+      const char* const a_sl = a_tile + k0 * 4;
+      const char* const b_sl = b_tile + k0 * 4;
 #pragma unroll
-      for (int q = 0; q < NC; ++q) glds16(a_src[q] + k0, st + (8 * (wave * NC + q)) * BK);
+      for (int q = 0; q < NC; ++q)
+        glds16(reinterpret_cast<const float*>(a_sl + a_off32[q]), st + (8 * (wave * NC + q)) * BK);
 #pragma unroll
-      for (int q = 0; q < NC; ++q) glds16(b_src[q] + k0, st + AF + (8 * (wave * NC + q)) * BK);
+      for (int q = 0; q < NC; ++q)
+        glds16(reinterpret_cast<const float*>(b_sl + b_off32[q]), st + AF + (8 * (wave * NC + q)) * BK);
     } else {
       // K remainder (< 32 columns, e.g. the 3 xyz columns of a 259-wide concat): both operands through registers, zero
       // filled beyond K, into the same swizzled image.  (Nothing else is in flight here: every iteration waits vmcnt(0).)
@@ -1210,44 +1218,6 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written before this wave reaches the next barrier
     }
-    ++gi;
-    if (++it_u == TT) {
-      it_u = 0;
-      it_tile = tile_of(++it_j);
-    }
-  };
-  // ---- the same cursor in three steps (ILV): set-up at the slice top, one pair of copies per call, advance
-  float* is_st = nullptr;
-  int64_t is_k0 = 0;
-  auto issue_begin = [&]() -> bool {
-    if (it_tile >= tiles) return false;
-    if (it_u >= T) {          // K remainder slice: the register path, whole
-      issue_next();
-      return false;
-    }
-    if (it_u == 0) {
-      im0 = tile_row(it_tile) * PR_BM;
-      in0 = tile_col(it_tile) * PR_BN;
-#pragma unroll
-      for (int q = 0; q < NC; ++q) {
-        const int r = 8 * (wave * NC + q) + lr;
-        int64_t row = im0 + r;
-        row = row < M ? row : M - 1;
-        a_src[q] = A + row * lda + 4 * (lc ^ ((r >> 1) & 7));
-        row = in0 + r;
-        row = row < N ? row : N - 1;
-        b_src[q] = B + row * ldb + 4 * (lc ^ ((r >> 1) & 7));
-      }
-    }
-    is_st = lds + (gi & 1) * STAGE;
-    is_k0 = (int64_t)it_u * BK;
-    return true;
-  };
-  auto issue_piece = [&](int q) {
-    glds16(a_src[q] + is_k0, is_st + (8 * (wave * NC + q)) * BK);
-    glds16(b_src[q] + is_k0, is_st + AF + (8 * (wave * NC + q)) * BK);
-  };
-  auto issue_end = [&]() {
     ++gi;
     if (++it_u == TT) {
       it_u = 0;
@@ -1328,9 +1298,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       }
       __builtin_amdgcn_s_barrier();
       if (STAMP) { PR_STAMP(st_a); sum_b += (uint32_t)(st_a - st_b); }
-      bool dma_now = false;
-      if (ILV) dma_now = issue_begin();
-      else issue_next();
+      issue_next();
       if (u == 0 && stat_tile >= 0) stats_readout();
       if (STAMP) { PR_STAMP(st_b); sum_i += (uint32_t)(st_b - st_a); }
       const uint32_t stage_b = lds_base + (uint32_t)((g & 1) * STAGE * 4);
@@ -1427,23 +1395,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        if (ILV && q == 0) {
-#pragma unroll
-          for (int comp = 0; comp < 4; ++comp) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ab = 0; ab < 2; ++ab)
-#pragma unroll
-              for (int t = 0; t < 2; ++t)
-                acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][ab][comp], fb[0][t][comp], acc[ab][t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (dma_now) issue_piece(comp);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          if (dma_now) issue_end();
-        } else {
-          mfma_group(q & 1);
-        }
+        mfma_group(q & 1);
       }
       if (STAMP) { PR_STAMP(st_a); sum_c += (uint32_t)(st_a - st_b); ++n_sl; }
     }
@@ -1459,12 +1411,17 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int ab = 0; ab < 2; ++ab) {
-        float* const crow = C + (m0 + wm * 64 + ab * 32 + 4 * h) * ldc + n;
         if (interior) {
+          // store address = a scalar row base (tile, wave quadrant, register's row) + this lane's 32-bit offset (its 4 h rows
+          // and its column): no vector address arithmetic per store
+          // (inline asm: hipcc folds a uniform base + lane offset back into 64-bit vector address arithmetic per store)
+          float* const cbase = C + (m0 + wm * 64 + ab * 32) * ldc + n0 + wn * 64 + t * 32;
+          const uint32_t lane_off = (uint32_t)((4 * h * ldc + i) * 4);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float v = acc[ab][t][r];
-            crow[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;
+            float* const rowp = cbase + (int64_t)((r & 3) + 8 * (r >> 2)) * ldc;
+            asm volatile("global_store_dword %0, %1, %2" : : "v"(lane_off), "v"(v), "s"(rowp) : "memory");
             s1 += v;
             s2 += v * v;
           }
@@ -1535,14 +1492,7 @@ int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, c
   }
   const int64_t slots = (g_pair_opt & 4) ? 256 : 512;
   const int64_t grid = tiles < slots ? tiles : slots;  // two workgroups per CU
-  if ((g_pair_opt & 32) && xf_scale == nullptr && !accumulate && !split_part) {
-    if (g_pair_dbg_host != nullptr)
-      hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 0, true, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y,
-                         ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, nullptr, nullptr, 0, 0.f);
-    else
-      hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 0, false, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y,
-                         ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, nullptr, nullptr, 0, 0.f);
-  } else if (g_pair_dbg_host != nullptr && xf_scale == nullptr && !accumulate && !split_part)
+  if (g_pair_dbg_host != nullptr && xf_scale == nullptr && !accumulate && !split_part)
     hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 0, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y,
                        ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, nullptr, nullptr, 0, 0.f);
   else if (xf_scale != nullptr)

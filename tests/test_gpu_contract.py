@@ -247,13 +247,25 @@ def test_linear_bn_act_entries_16bit(dtype, name):
     prev = ops.mlp_dtype()
     ops.set_mlp_dtype(name)
     try:
+        # the contract entry composes the fp32-STORAGE kernels: the Python mirror in that form gives the same bits ...
+        ops.STORE16 = False
         xa, wa = xd.clone().requires_grad_(True), wd.clone().requires_grad_(True)
         za = ops.linear_bn_act(xa, wa, None, bnm, True, "relu")
         ga = torch.autograd.grad((za * cot).sum(), [xa, wa])
+        # ... and the 16-bit storage form (ops.STORE16, the default of the bf16 mode) the same values up to the fp32
+        # summation order of its kernels (and, in the gradients, bf16 rounding boundaries crossed by that difference)
+        ops.STORE16 = True
+        xs, wsd = xd.clone().requires_grad_(True), wd.clone().requires_grad_(True)
+        zs = ops.linear_bn_act(xs, wsd, None, bnm, True, "relu")
+        gs = torch.autograd.grad((zs * cot).sum(), [xs, wsd])
     finally:
+        ops.STORE16 = True
         ops.set_mlp_dtype(prev)
     assert torch.equal(za, z) and torch.equal(ga[0], dx)
     _close(ga[1].cpu(), dw.cpu(), 1e-5, "dW vs the Python mirror (split-K atomics: order not fixed)")
+    _close(zs.cpu(), z.cpu(), 1e-4, "16-bit storage form: activation")
+    _close(gs[0].cpu(), dx.cpu(), 2e-2, "16-bit storage form: dx")
+    _close(gs[1].cpu(), dw.cpu(), 2e-2, "16-bit storage form: dW")
     y32 = xd @ wd.t()
     assert maxdiff(y.cpu(), y32.cpu()) < 5e-2 and maxdiff(y.cpu(), y32.cpu()) > 0          # 16-bit products, not fp32
 
