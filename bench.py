@@ -660,14 +660,12 @@ def main():
             busy += cur_e - cur_s
             fam_flops = sum(gemm_label(r[0], r[1], r[4])[1] for r in fam_records)
             fam = fam_flops / (busy * 1e-3) / 1e12
-            if world == 1 and os.environ.get("CCN_WGRAD_STREAM", "1") != "0":
-                result["roofline"]["note"] = ("launch durations include the time this kernel shares the chip with the "
-                                              "weight-gradient stream (ops._WgradScope); the same kernel without that stream "
-                                              "(CCN_WGRAD_STREAM=0, step ~5 % slower) and stand-alone: "
-                                              "profiles/r02*_kitti_bench_nows.json, DESIGN.md section 5")
+            if world == 1 and os.environ.get("CCN_WGRAD_STREAM", "0") != "0":
+                result["roofline"]["note"] = ("CCN_WGRAD_STREAM is on: launch durations include the time this kernel shares the "
+                                              "chip with the weight-gradient stream (ops._WgradScope)")
             result["roofline"]["all_gemm_launches"] = {
                 "achieved": fam, "frac": fam / peak, "busy_ms_per_step": busy / fam_steps,
-                "note": "flops of every GEMM launch / union of their execution intervals (two streams overlap)"
+                "note": "flops of every GEMM launch / union of their execution intervals"
                         + ("; from the 2 fully instrumented steps after the timed region" if full_records else "")}
         else:
             result["roofline"] = {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,

@@ -865,7 +865,8 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
   // add no workgroup barrier at all to the tile loop (two extra barriers per tile cost 13 % at K = 256).
   __shared__ float stat_part[8 * BN * 2];
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (wave index as a scalar, copies addressed as scalar tile base + 32-bit lane offset: see the paired kernel below)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int i = lane & 31, h = lane >> 5;
   const int swz = (i >> 1) & 7;
   const int lr = lane >> 3, lc = lane & 7;
@@ -875,8 +876,9 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
   const int T = (int)(K / BK);
 
   // ---- issue cursor (runs two slices ahead of the compute cursor, across tile boundaries)
-  const float* a_src[NA];
-  const float* b_src[NB];
+  uint32_t a_off32[NA], b_off32[NB];
+  const char* a_tile = reinterpret_cast<const char*>(A);
+  const char* b_tile = reinterpret_cast<const char*>(B);
   // Tile order.  With all 256 workgroups launched and gn dividing 32, the gn column tiles of one 256-row block go to
   // workgroups w, w + 8, ... of the SAME step: those ids sit on one XCD, so the row block is read from HBM once and from
   // that XCD's L2 by the other column tiles (measured on the split-bf16 twin of this kernel: 707 -> 379 MB read per
@@ -899,30 +901,33 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
     if (it_tile >= tiles) return;
     if (it_u == 0) {
       const int64_t im0 = (it_tile / gn) * GL_BM, in0 = (it_tile % gn) * BN;
+      a_tile = reinterpret_cast<const char*>(A + im0 * lda);
+      b_tile = reinterpret_cast<const char*>(B + in0 * ldb);
+      const int64_t a_rows = M - im0, b_rows = N - in0;
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
         const int r = 8 * (wave * NA + j) + lr;
-        int64_t row = im0 + r;
-        row = row < M ? row : M - 1;
-        a_src[j] = A + row * lda + 4 * (lc ^ ((r >> 1) & 7));
+        const int64_t ra = r < a_rows ? r : a_rows - 1;
+        a_off32[j] = (uint32_t)((ra * lda + 4 * (lc ^ ((r >> 1) & 7))) * 4);
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
         const int g = BN >= 64 ? wave * NB + j : (wave & 3);
         const int r = 8 * g + lr;
-        int64_t row = in0 + r;
-        row = row < N ? row : N - 1;
-        b_src[j] = B + row * ldb + 4 * (lc ^ ((r >> 1) & 7));
+        const int64_t rb = r < b_rows ? r : b_rows - 1;
+        b_off32[j] = (uint32_t)((rb * ldb + 4 * (lc ^ ((r >> 1) & 7))) * 4);
       }
     }
     float* st = lds + (gi % STAGES) * STAGE;
     const int64_t k0 = (int64_t)it_u * BK;
+    const char* const a_sl = a_tile + k0 * 4;
+    const char* const b_sl = b_tile + k0 * 4;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) glds16(a_src[j] + k0, st + (8 * (wave * NA + j)) * BK);
+    for (int j = 0; j < NA; ++j) glds16(reinterpret_cast<const float*>(a_sl + a_off32[j]), st + (8 * (wave * NA + j)) * BK);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int g = BN >= 64 ? wave * NB + j : (wave & 3);
-      glds16(b_src[j] + k0, st + AF + (8 * g) * BK);
+      glds16(reinterpret_cast<const float*>(b_sl + b_off32[j]), st + AF + (8 * g) * BK);
     }
     ++gi;
     if (++it_u == T) {

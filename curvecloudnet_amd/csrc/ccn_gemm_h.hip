@@ -71,7 +71,7 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
   __shared__ __attribute__((aligned(16))) u16 lds[2 * STAGE];
   __shared__ float stat_part[2 * HB_BN * 2];   // [wm][column][sum, sum of squares] of the finished tile
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: SGPR addressing)
   const int wm = wave & 1, wn = wave >> 1;
   const int i = lane & 31, h = lane >> 5;
   const int swz = (i >> 1) & 7;
@@ -99,8 +99,10 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
   auto tile_col = [&](int64_t t) -> int64_t { return (int64_t)((uint32_t)t % gnu); };
 
   // ---- issue cursor: one slice ahead of the compute cursor, across tile boundaries
-  const u16* a_src[NC];
-  const u16* b_src[NC];
+  // (a copy's source = scalar tile base + 32-bit lane offset: no vector address arithmetic per copy, as in ccn_gemm.hip)
+  uint32_t a_off32[NC], b_off32[NC];
+  const char* a_tile = reinterpret_cast<const char*>(A);
+  const char* b_tile = reinterpret_cast<const char*>(B);
   int64_t it_j = 0, it_tile = tile_of(0), gi = 0;
   int64_t im0 = 0, in0 = 0;
   int it_u = 0;
@@ -109,24 +111,26 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
     if (it_u == 0) {
       im0 = tile_row(it_tile) * HB_BM;
       in0 = tile_col(it_tile) * HB_BN;
+      a_tile = reinterpret_cast<const char*>(A + im0 * lda);
+      b_tile = reinterpret_cast<const char*>(B + in0 * ldb);
+      const int64_t a_rows = M - im0, b_rows = N - in0;
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
         const int r = 8 * (wave * NC + q) + lr;
-        int64_t row = im0 + r;
-        row = row < M ? row : M - 1;
-        a_src[q] = A + row * lda + 8 * (lc ^ ((r >> 1) & 7));
-        row = in0 + r;
-        row = row < N ? row : N - 1;
-        b_src[q] = B + row * ldb + 8 * (lc ^ ((r >> 1) & 7));
+        const int64_t ra = r < a_rows ? r : a_rows - 1, rb = r < b_rows ? r : b_rows - 1;
+        a_off32[q] = (uint32_t)((ra * lda + 8 * (lc ^ ((r >> 1) & 7))) * 2);
+        b_off32[q] = (uint32_t)((rb * ldb + 8 * (lc ^ ((r >> 1) & 7))) * 2);
       }
     }
     u16* st = lds + (gi & 1) * STAGE;
     const int64_t k0 = (int64_t)it_u * HB_BK;
     if (it_u < T) {
+      const char* const a_sl = a_tile + k0 * 2;
+      const char* const b_sl = b_tile + k0 * 2;
 #pragma unroll
-      for (int q = 0; q < NC; ++q) glds16h(a_src[q] + k0, st + (8 * (wave * NC + q)) * HB_BK);
+      for (int q = 0; q < NC; ++q) glds16h(reinterpret_cast<const u16*>(a_sl + a_off32[q]), st + (8 * (wave * NC + q)) * HB_BK);
 #pragma unroll
-      for (int q = 0; q < NC; ++q) glds16h(b_src[q] + k0, st + AF + (8 * (wave * NC + q)) * HB_BK);
+      for (int q = 0; q < NC; ++q) glds16h(reinterpret_cast<const u16*>(b_sl + b_off32[q]), st + AF + (8 * (wave * NC + q)) * HB_BK);
     } else {
       // K remainder (< 64 elements): both operands through registers, zero filled beyond K, into the same swizzled image
       // (nothing else is in flight here: every iteration waits vmcnt(0))
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(HT_TPB, 2) void gemm_h_tn_kernel(const u16* __restr
                                                               int xcd_order, float* __restrict__ slabs) {
   constexpr int AF = HT_SL * HT_T, STAGE = 2 * AF;      // 16-bit elements: 16 KB per operand image, 32 KB per stage
   __shared__ __attribute__((aligned(16))) u16 lds[2 * STAGE];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: SGPR addressing)
   const int i = lane & 31, h = lane >> 5;
   const int wn = wave >> 1, wk = wave & 1;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
@@ -621,9 +625,25 @@ __global__ __launch_bounds__(HT_TPB, 2) void gemm_h_tn_kernel(const u16* __restr
         a_col[qn] = ca <= lda - 8 ? ca : lda - 8;              // (clamped columns only feed elements that are never stored)
         b_col[qn] = cb <= ldb - 8 ? cb : ldb - 8;
       }
+      uint32_t a_off32[4], b_off32[4];      // lane offsets inside a slice: (row * ld + column) bytes
+#pragma unroll
+      for (int qn = 0; qn < 4; ++qn) {
+        const int64_t r = 4 * (4 * wave + qn) + (lane >> 4);
+        a_off32[qn] = (uint32_t)((r * lda + a_col[qn]) * 2);
+        b_off32[qn] = (uint32_t)((r * ldb + b_col[qn]) * 2);
+      }
       auto issue = [&](int64_t sl, int stage) {
         u16* st = lds + stage * STAGE;
         const int64_t mrow0 = sl * HT_SL;
+        if (mrow0 + HT_SL <= M) {      // scalar slice base + 32-bit lane offsets; only the matrix's last slice clamps rows per lane
+          const char* const a_sl = reinterpret_cast<const char*>(A + mrow0 * lda);
+          const char* const b_sl = reinterpret_cast<const char*>(B + mrow0 * ldb);
+#pragma unroll
+          for (int qn = 0; qn < 4; ++qn) glds16h(reinterpret_cast<const u16*>(a_sl + a_off32[qn]), st + (4 * wave + qn) * 512);
+#pragma unroll
+          for (int qn = 0; qn < 4; ++qn) glds16h(reinterpret_cast<const u16*>(b_sl + b_off32[qn]), st + AF + (4 * wave + qn) * 512);
+          return;
+        }
 #pragma unroll
         for (int qn = 0; qn < 4; ++qn) {
           int64_t row = mrow0 + 4 * (4 * wave + qn) + (lane >> 4);

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(TN_TPB, 2) void gemm_tn_glds_kernel(const float* __
   constexpr int LDS_FLOATS = 2 * STAGE > RED ? 2 * STAGE : RED;
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wave index as a scalar: LDS-DMA destinations and slice bases stay in SGPRs)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int i = lane & 31, h = lane >> 5;
   const int quad = wave / WC, wc = wave % WC;
   const int wn = quad / QK, wk = quad % QK;
@@ -132,9 +133,25 @@ __global__ __launch_bounds__(TN_TPB, 2) void gemm_tn_glds_kernel(const float* __
         int64_t c = k0 + 4 * (lane % (TK / 4));
         b_col[q] = c <= b_extent - 4 ? c : b_extent - 4;
       }
+      // a copy's source = slice base (scalar) + this lane's 32-bit byte offset inside the slice (row * ld + column): no vector
+      // address arithmetic per copy.  Only the last slice of the matrix (rows beyond M) takes the per-lane clamped form.
+      uint32_t a_off32[NIA], b_off32[NIB];
+#pragma unroll
+      for (int q = 0; q < NIA; ++q) a_off32[q] = (uint32_t)((a_row[q] * lda + a_col[q]) * 4);
+#pragma unroll
+      for (int q = 0; q < NIB; ++q) b_off32[q] = (uint32_t)((b_row[q] * ldb + b_col[q]) * 4);
       auto issue = [&](int64_t s, int stage) {
         float* st = lds + stage * STAGE;
         const int64_t m0 = s * TN_SLICE;
+        if (m0 + TN_SLICE <= M) {
+          const char* const a_sl = reinterpret_cast<const char*>(A + m0 * lda);
+          const char* const b_sl = reinterpret_cast<const char*>(B + m0 * ldb);
+#pragma unroll
+          for (int q = 0; q < NIA; ++q) glds16(reinterpret_cast<const float*>(a_sl + a_off32[q]), st + (wave * NIA + q) * 256);
+#pragma unroll
+          for (int q = 0; q < NIB; ++q) glds16(reinterpret_cast<const float*>(b_sl + b_off32[q]), st + AF + (wave * NIB + q) * 256);
+          return;
+        }
 #pragma unroll
         for (int q = 0; q < NIA; ++q) {
           int64_t row = m0 + a_row[q];

@@ -407,8 +407,11 @@ def _wgrad_stream(device):
     the backward pass consumes them, so they run concurrently with the (mostly HBM-bound) BatchNorm / gather passes and
     data-gradient products of the layers below.  ``join_wgrad()`` orders the current stream behind them; it runs as an
     autograd end-of-backward callback, and GradientAllReduce calls it before a bucket is reduced during the pass.
-    CCN_WGRAD_STREAM=0 keeps the products on the backward stream."""
-    if os.environ.get("CCN_WGRAD_STREAM", "1") == "0" or device.type != "cuda":
+    OFF BY DEFAULT since round 3 (CCN_WGRAD_STREAM=1 / force enables it): measured on the KITTI step it buys 1.4 % (106.8 vs 108.3 ms)
+    -- a weight-gradient product released next to a data-gradient product is two MFMA-bound grids taking turns on the CUs, not
+    an overlap -- and it costs a third stream, the join protocol below, the GPU_MAX_HW_QUEUES workaround and per-kernel
+    durations that are sharing artefacts (profiles/r03_wgrad_stream_ab.txt)."""
+    if os.environ.get("CCN_WGRAD_STREAM", "0") == "0" or device.type != "cuda":
         return None
     if (os.environ.get("CCN_WGRAD_STREAM") != "force" and torch.distributed.is_available()
             and torch.distributed.is_initialized()
