@@ -496,7 +496,7 @@ def main():
         # GEMM launch of both streams, or over all ~130 launches of the dominant kernel, still ~1 % (70.8 vs 71.5 clouds/s)
         dominant = {"fp32": "gemm_glds_pair_kernel",
                     "bf16": "gemm_h_pair_kernel<false, false>" if ops.STORE16 else "gemm_bf16_kernel<128, 128",
-                    "fp16": "gemm_bf16_kernel<128, 128",
+                    "fp16": "gemm_h_pair_kernel<true, false>" if ops.STORE16 else "gemm_bf16_kernel<128, 128",
                     "bf16x3": "gemm_x3_pair_kernel"}[args.mlp_dtype]
 
         def only_dominant(name, cargs):
@@ -575,8 +575,11 @@ def main():
         "metric": "point-clouds/sec fwd+bwd @50k pts", "value": world * b * args.steps / elapsed, "unit": "clouds/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"fp32": "f32", "bf16": "bf16 products, f32 accumulate / storage",
-                  "fp16": "fp16 products, f32 accumulate / storage",
+        "dtype": {"fp32": "f32",
+                  "bf16": ("bf16 products, f32 accumulate; hidden MLP activations, BatchNorm-backward gradients and cast weights "
+                           "stored as bf16 rows" if ops.STORE16 else "bf16 products, f32 accumulate / storage"),
+                  "fp16": ("fp16 forward products (activations stored as fp16 rows), bf16 gradient products, f32 accumulate"
+                           if ops.STORE16 else "fp16 products, f32 accumulate / storage"),
                   "bf16x3": "f32-grade products assembled from 3-way bf16 splits (6 bf16 MFMAs each; weight gradients "
                             "on the f32 MFMA), f32 accumulate / storage"}[args.mlp_dtype], "data": "synthetic",
         "config": {"workload": "%s; %d clouds/GPU x %d curves (~%dk points each, %d points on rank 0); curve-conv + HIP "

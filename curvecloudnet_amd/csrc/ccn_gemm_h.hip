@@ -381,6 +381,37 @@ __global__ __launch_bounds__(EW_TPB) void cast_rows_h_kernel(const float* __rest
   }
 }
 
+// fp16 rows -> bf16 rows (the fp16 mode keeps its activations as fp16 rows for the forward products; the weight-gradient
+// product, a bf16 product, takes bf16(fp16(x))): 8 elements per thread and row, same walk as the casts above
+__global__ __launch_bounds__(EW_TPB) void f16_to_bf16_rows_kernel(const u16* __restrict__ X, int64_t ldx, int64_t rows, int64_t C,
+                                                                  u16* __restrict__ Y, int64_t ldy, int cpb, int rpp) {
+  const int ch = threadIdx.x % cpb, rr = threadIdx.x / cpb;
+  const int64_t c0 = ((int64_t)blockIdx.y * cpb + ch) * 8;
+  if (rr >= rpp || c0 >= ldy) return;
+  const bool vec = c0 + 8 <= ldx && (ldx & 7) == 0 && ((uintptr_t)X & 15) == 0;
+  const int64_t r0 = (int64_t)blockIdx.x * EW_ROWS;
+  const int64_t r1 = r0 + EW_ROWS < rows ? r0 + EW_ROWS : rows;
+  for (int64_t r = r0 + rr; r < r1; r += rpp) {
+    float v[8];
+    const u16* src = X + r * ldx + c0;
+    if (vec) {
+      const uint4 q = *reinterpret_cast<const uint4*>(src);
+      const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[2 * e] = from_h<true>((u16)(qq[e] & 0xffffu));
+        v[2 * e + 1] = from_h<true>((u16)(qq[e] >> 16));
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? from_h<true>(src[e]) : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? v[e] : 0.f;
+    store8h<false>(Y + r * ldy + c0, v);
+  }
+}
+
 // W[n][k] fp32 -> Wt[k][n] 16-bit (the data-gradient product's "weight"), LDS-tiled 32 x 32; columns [N, ldt) zeroed
 template <bool F16>
 __global__ __launch_bounds__(256) void transpose_cast_h_kernel(const float* __restrict__ W, int64_t ldw, int64_t N, int64_t K,
@@ -907,6 +938,16 @@ int ccn_cast_rows_h(const float* X, int64_t ldx, int64_t rows, int64_t C, void* 
   if (f16) hipLaunchKernelGGL(cast_rows_h_kernel<true>, grid, dim3(EW_TPB), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy, g.cpb, g.rpp);
   else hipLaunchKernelGGL(cast_rows_h_kernel<false>, grid, dim3(EW_TPB), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy, g.cpb, g.rpp);
   CCN_LAUNCH_OK("cast_rows_h");
+  return CCN_OK;
+}
+
+int ccn_f16_to_bf16_rows(const void* X, int64_t ldx, int64_t rows, int64_t C, void* Y, int64_t ldy, void* stream) {
+  CCN_REQUIRE(X && Y && rows >= 0 && C > 0 && ldx >= C && ldy >= C && ldy % 8 == 0 && aligned16(Y), "f16_to_bf16_rows: bad arguments");
+  if (rows == 0) return CCN_OK;
+  const EwGeom g = ew_geom(ldy);
+  hipLaunchKernelGGL(f16_to_bf16_rows_kernel, dim3((unsigned)ccn_blocks(rows, EW_ROWS), g.gy), dim3(EW_TPB), 0, (hipStream_t)stream,
+                     (const u16*)X, ldx, rows, C, (u16*)Y, ldy, g.cpb, g.rpp);
+  CCN_LAUNCH_OK("f16_to_bf16_rows");
   return CCN_OK;
 }
 

@@ -802,6 +802,12 @@ class LinearBNAct(torch.autograd.Function):
 STORE16 = os.environ.get("CCN_STORE16", "1") != "0"
 
 
+def _fwd16():
+    """dtype of the FORWARD operands in the 16-bit storage form: bf16, or fp16 in the "fp16" mode (whose gradient products
+    stay bf16: gradients leave fp16's normal range without loss scaling)."""
+    return torch.float16 if _MLP_DTYPE == "fp16" else torch.bfloat16
+
+
 def _rows16(rows, cols, device, dtype=torch.bfloat16):
     """(rows, cols) 16-bit matrix whose rows start 16-byte aligned: leading dimension a multiple of 8 elements."""
     ld = (cols + 7) // 8 * 8
@@ -809,21 +815,31 @@ def _rows16(rows, cols, device, dtype=torch.bfloat16):
     return buf if ld == cols else buf[:, :cols]
 
 
-def _is_rows16(t):
-    return (t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0
+def _is_rows16(t, dtype=torch.bfloat16):
+    return (t.dtype == dtype and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 8 == 0
             and t.stride(0) >= t.size(1) and t.data_ptr() % 16 == 0)
 
 
-def _cast16(x):
-    """fp32 rows -> bf16 rows (ccn_cast_rows_h); a bf16 row matrix passes through."""
-    if _is_rows16(x):
+def _cast16(x, dtype=torch.bfloat16):
+    """fp32 rows -> 16-bit rows (ccn_cast_rows_h); a row matrix of that dtype passes through."""
+    if _is_rows16(x, dtype):
         return x
-    if x.dtype == torch.bfloat16:
+    if x.dtype != torch.float32:
         x = x.float()
     x = _mat(x)
-    out = _rows16(x.size(0), x.size(1), x.device)
+    out = _rows16(x.size(0), x.size(1), x.device, dtype)
     if x.size(0):
-        call("cast_rows_h", ptr(x), _ld(x), x.size(0), x.size(1), ptr(out), _ld(out), 0)
+        call("cast_rows_h", ptr(x), _ld(x), x.size(0), x.size(1), ptr(out), _ld(out), 1 if dtype == torch.float16 else 0)
+    return out
+
+
+def _bf16_of(x16):
+    """bf16 rows of a forward operand: itself in the bf16 mode, bf16(fp16(x)) in the fp16 mode (ccn_f16_to_bf16_rows)."""
+    if x16.dtype == torch.bfloat16:
+        return x16
+    out = _rows16(x16.size(0), x16.size(1), x16.device)
+    if x16.size(0):
+        call("f16_to_bf16_rows", ptr(x16), _ld(x16), x16.size(0), x16.size(1), ptr(out), _ld(out))
     return out
 
 
@@ -831,16 +847,23 @@ class LinearBNActH(torch.autograd.Function):
     """LinearBNAct on 16-bit rows (see STORE16 above): y = act(BN(bf16(x) bf16(W)^T + b)), fp32 accumulation and statistics."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum, grad_on, out16):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum, grad_on, out16,
+                x_f16_bits=False):
+        # x_f16_bits: ``x`` is a 16-bit activation of the fp16 mode -- fp16 bit patterns in a tensor TYPED bfloat16, so that
+        # autograd hands its gradient over as bf16 (an fp16-typed tensor would get an fp16 gradient: out of range)
         require_gpu(x, weight)
+        if x_f16_bits:
+            x = x.view(torch.float16)
         m, k = x.shape
         n = weight.size(0)
         if weight.size(1) != k:
             raise ValueError("linear: input has %d channels, weight expects %d" % (k, weight.size(1)))
         dev = x.device
-        ctx.x16_in = x.dtype == torch.bfloat16
-        x16 = _cast16(x)
-        w16 = _cast16(weight.detach())
+        fdt = _fwd16()                                   # forward operand dtype (bf16 / fp16)
+        f16 = 1 if fdt == torch.float16 else 0
+        ctx.x16_in = bool(x_f16_bits) or (x.dtype == torch.bfloat16 and fdt == torch.bfloat16)
+        x16 = _cast16(x, fdt)
+        w16 = _cast16(weight.detach(), fdt)
         y = _rows(m, n, dev)
         has_bn = gamma is not None
         ctx.has_bn, ctx.act, ctx.training, ctx.has_bias = has_bn, ACT[act], bool(training), bias is not None
@@ -854,7 +877,7 @@ class LinearBNActH(torch.autograd.Function):
 
         def product(stats):
             if m:
-                call("gemm_nt_h", ptr(x16), _ld(x16), ptr(w16), _ld(w16), ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats), 0, 0)
+                call("gemm_nt_h", ptr(x16), _ld(x16), ptr(w16), _ld(w16), ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats), f16, 0)
 
         if not has_bn:
             product(None)
@@ -874,9 +897,9 @@ class LinearBNActH(torch.autograd.Function):
                  ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
         ctx.save_for_backward(x16, weight, y, par)
         if ctx.out16:
-            z = _rows16(m, n, dev)
-            call("bn_act_fwd_h", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z), 0)
-            return z
+            z = _rows16(m, n, dev, fdt)
+            call("bn_act_fwd_h", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z), f16)
+            return z.view(torch.bfloat16) if f16 else z
         z = _rows(m, n, dev)
         call("bn_act_fwd", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
         _trace_act(z, ctx.act)
@@ -941,10 +964,11 @@ class LinearBNActH(torch.autograd.Function):
                 _main_grad_cancel(ctx.main_grad_of)
             dw = into if into is not None else _rows(n, k, dev, zero=True)
             if m:
-                with _WgradScope(into, dy16, x16):
+                xb = _bf16_of(x16)
+                with _WgradScope(into, dy16, xb):
                     nb = lib().ccn_gemm_tn_h_workspace_bytes(m, n, k)
                     ws = _tn_scratch(nb, dev)
-                    call("gemm_tn_h", ptr(dy16), _ld(dy16), ptr(x16), _ld(x16), ptr(dw), _ld(dw), m, n, k, ptr(ws), nb)
+                    call("gemm_tn_h", ptr(dy16), _ld(dy16), ptr(xb), _ld(xb), ptr(dw), _ld(dw), m, n, k, ptr(ws), nb)
             if into is not None:
                 dw = _main_grad_done(ctx.main_grad_of)
         db = None
@@ -958,7 +982,7 @@ class LinearBNActH(torch.autograd.Function):
                 acc = _stats_buffer(m, n, dev)
                 db = torch.empty(n, dtype=torch.float32, device=dev)
                 call("colsum", ptr(gf), _ld(gf), m, n, ptr(acc), ptr(db))
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 # A hidden MLP layer whose only consumer is the next Linear of the same MLP hands over its PRE-normalisation product; the
@@ -976,17 +1000,21 @@ def linear_bn_act(x, weight, bias, bn, training, act, defer=False):
     """bn: a torch.nn.BatchNorm1d used as parameter/buffer container, or None.  ``defer``: the caller feeds the result to
     another linear_bn_act and nothing else (nn.MLP); the result may then be a deferred activation (see LAZY_ACT)."""
     grad_on = torch.is_grad_enabled()
-    if _MLP_DTYPE == "bf16" and STORE16 and x.dim() == 2 and x.size(0) > 0:
+    if _MLP_DTYPE in ("bf16", "fp16") and STORE16 and x.dim() == 2 and x.size(0) > 0:
+        xbits = bool(getattr(x, "_ccn_f16_bits", False))
         if bn is None:
-            return LinearBNActH.apply(x, weight, bias, None, None, None, None, False, None, 0.0, 0.0, grad_on, False)
+            return LinearBNActH.apply(x, weight, bias, None, None, None, None, False, None, 0.0, 0.0, grad_on, False, xbits)
         if training and bn.track_running_stats:
             bn.num_batches_tracked += 1
         use_batch_stats = training or not bn.track_running_stats
         # (the parity tests read sign tables off the fp32 activation: no 16-bit activation while they are recorded)
         out16 = bool(defer and ACT_TRACE is None and ACT[act] != 0)
-        return LinearBNActH.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats, act,
-                                  bn.eps, bn.momentum if bn.momentum is not None else 0.1, grad_on, out16)
-    if x.dtype == torch.bfloat16:
+        out = LinearBNActH.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats, act,
+                                 bn.eps, bn.momentum if bn.momentum is not None else 0.1, grad_on, out16, xbits)
+        if out16 and _MLP_DTYPE == "fp16":
+            out._ccn_f16_bits = True
+        return out
+    if x.dtype in (torch.bfloat16, torch.float16):
         x = x.float()
     pend = getattr(x, "_ccn_deferred", None)
     xf_par, xf_act = pend if pend is not None else (None, 0)

@@ -260,6 +260,8 @@ int ccn_gemm_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, floa
 /* fp32 rows -> 16-bit rows (round to nearest even), padding columns [C, ldy) zeroed; W (N x K fp32) -> W^T (K x N 16-bit) */
 int ccn_cast_rows_h(const float* X, int64_t ldx, int64_t rows, int64_t C, void* Y, int64_t ldy, int f16, void* stream);
 int ccn_transpose_cast_h(const float* W, int64_t ldw, int64_t N, int64_t K, void* Wt, int64_t ldt, int f16, void* stream);
+/* fp16 rows -> bf16 rows (the fp16 mode's weight-gradient operand: bf16(fp16(x))) */
+int ccn_f16_to_bf16_rows(const void* X, int64_t ldx, int64_t rows, int64_t C, void* Y, int64_t ldy, void* stream);
 /* ccn_bn_act_fwd writing z as 16-bit rows; ccn_bn_act_bwd_reduce reading a bf16 dZ; ccn_bn_act_bwd_apply_ex reading an fp32
  * (dz16 == 0) or bf16 dZ and writing dY as bf16 rows (same expressions, one rounding at the store) */
 int ccn_bn_act_fwd_h(const float* Y, int64_t ldy, int64_t rows, int64_t C, const float* scale, const float* shift, int act,

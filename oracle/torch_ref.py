@@ -156,7 +156,10 @@ class _LinearBF16(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        return _bf16(g) @ _bf16(w), _bf16(g).t() @ _bf16(x), (g.sum(0) if ctx.has_bias else None)
+        # (16-bit storage form of the fp16 mode: the forward operand is KEPT as fp16 rows, the weight-gradient product -- a
+        # bf16 product -- takes bf16(fp16(x)))
+        xs = x.half().to(x.dtype) if (MLP_DTYPE == "fp16" and STORE16) else x
+        return _bf16(g) @ _bf16(w), _bf16(g).t() @ _bf16(xs), (g.sum(0) if ctx.has_bias else None)
 
 
 class _Conv1dBF16(torch.autograd.Function):
@@ -170,7 +173,8 @@ class _Conv1dBF16(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         dx = torch.nn.grad.conv1d_input(x.shape, _bf16(w), _bf16(g), stride=1, padding=ctx.pad)
-        dw = torch.nn.grad.conv1d_weight(_bf16(x), w.shape, _bf16(g), stride=1, padding=ctx.pad)
+        xs = x.half().to(x.dtype) if (MLP_DTYPE == "fp16" and STORE16) else x       # (see _LinearBF16.backward)
+        dw = torch.nn.grad.conv1d_weight(_bf16(xs), w.shape, _bf16(g), stride=1, padding=ctx.pad)
         return dx, dw, (g.sum(dim=(0, 2)) if ctx.has_bias else None), None
 
 
@@ -635,7 +639,7 @@ class MLP(nn.Module):
     def forward(self, x):
         for i, (lin, norm) in enumerate(zip(self.lins, self.norms)):
             x = F.dropout(activation(norm(linear(x, lin)), self.act), p=self.dropout[i], training=self.training)
-            if (MLP_DTYPE == "bf16" and STORE16 and ACT_TRACE is None and self.dropout[i] == 0.0
+            if (MLP_DTYPE in ("bf16", "fp16") and STORE16 and ACT_TRACE is None and self.dropout[i] == 0.0
                     and (i + 1 < len(self.norms) or self.plain_last)):
                 x = _RoundGradBF16.apply(x)          # (stored as bf16 rows in the product: see STORE16)
         if self.plain_last:

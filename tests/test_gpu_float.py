@@ -909,9 +909,10 @@ def test_nll_loss_kitti_runner_form_and_target_check():
     segmentation_loss(xd, t.to(DEV), ignore_index=0, check_targets=True)       # in range: passes
 
 
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("dims,bias,plain_last", [([67, 128, 192, 64], False, True), ([40, 64, 64], True, False),
                                                   ([259, 256, 128, 128, 64], False, False)])
-def test_bf16_storage_mlp_chain(dims, bias, plain_last):
+def test_bf16_storage_mlp_chain(dims, bias, plain_last, mode):
     """ops.STORE16: in the bf16 mode the hidden activations of an MLP, the BatchNorm-backward gradients and the cast
     weights are stored as bf16 rows and multiplied by the LDS-DMA kernels (ccn_gemm_nt_h / ccn_gemm_tn_h).  Against the
     CPU emulation (operands rounded to bf16, fp32 accumulation; hidden-activation gradients rounded to bf16): output
@@ -933,8 +934,8 @@ def test_bf16_storage_mlp_chain(dims, bias, plain_last):
     mine = MLP(dims, act="leaky_relu", bias=bias, plain_last=plain_last)
     mine.load_state_dict(ref.state_dict())
     mine = mine.to(DEV).train()
-    ops.set_mlp_dtype("bf16")
-    R.set_mlp_dtype("bf16")
+    ops.set_mlp_dtype(mode)
+    R.set_mlp_dtype(mode)
     try:
         assert ops.STORE16 and R.STORE16
         xr = x.clone().requires_grad_(True)

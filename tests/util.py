@@ -152,11 +152,13 @@ def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backwar
     return res
 
 
-def adjudicate(res):
-    """(d_gpu, d_cpu): max-norm distances of the GPU logits and of the fp32 CPU oracle's logits to the fp64 evaluation."""
+def adjudicate(res, rms=False):
+    """(d_gpu, d_cpu): max-norm (or rms) distances of the GPU logits and of the fp32 CPU oracle's logits to the fp64 evaluation."""
     o64 = res["out_64"]
-    return (float((res["out_d"].detach().cpu().double() - o64).abs().max()),
-            float((res["out_r"].detach().double() - o64).abs().max()))
+    eg, ec = res["out_d"].detach().cpu().double() - o64, res["out_r"].detach().double() - o64
+    if rms:
+        return float(eg.square().mean().sqrt()), float(ec.square().mean().sqrt())
+    return float(eg.abs().max()), float(ec.abs().max())
 
 
 GRAD_TOL = 3e-4          # routed gradients, per tensor (see routed_parity)

@@ -13,7 +13,7 @@ name = sys.argv[1]
 try:
     d = json.loads(open("gpurun_out/ab_%s.json" % name).read().strip().splitlines()[-1])
     r = d.get("roofline", {})
-    print("%-14s %7.2f clouds/s  %7.2f ms/step  dominant %.1f TFLOP/s  all-GEMM %.1f TFLOP/s busy %.1f ms  kernel time %.1f ms"
+    print("%-14s %7.2f clouds/s  %7.2f ms/step  dominant %.1f (TFLOP/s, or GB/s where HBM-bound)  all-GEMM %.1f TFLOP/s busy %.1f ms  kernel time %.1f ms"
           % (name, d["value"], d["ms_per_step"], r.get("achieved") or 0, r.get("all_gemm_launches", {}).get("achieved", 0),
              r.get("all_gemm_launches", {}).get("busy_ms_per_step", 0), d.get("kernel_time_ms_per_step", 0)))
 except Exception as e:
