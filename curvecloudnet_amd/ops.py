@@ -1581,13 +1581,21 @@ def voxel_fps(pos, batch, voxel_size, rnd=None):
     score = torch.empty(n, dtype=torch.float32, device=dev)
     bad = torch.empty(1, dtype=torch.int64, device=dev)
     call("voxel_keys", ptr(pos), ptr(batch), ptr(rnd), n, float(voxel_size), ptr(key), ptr(score), ptr(bad))
-    uniq, voxel_of = torch.unique(key, return_inverse=True)          # sorted keys (device radix sort: plumbing)
-    m = uniq.numel()
-    if int(bad.item()):
+    # dense rank of every point's (cloud, voxel) key among the sorted distinct keys = torch.unique(key, return_inverse=True)[1]:
+    # ccn_rank_keys (radix sort on the digits in which the keys differ at all)
+    meta = torch.empty(2, dtype=torch.int64, device=dev)              # [spread of the keys, number of distinct keys]
+    call("key_spread", ptr(key), n, ptr(meta))
+    spread, n_bad = int(meta[0].item()), int(bad.item())
+    if n_bad:
         raise ValueError("voxel_fps: voxel coordinates exceed the 18-bit key range")
+    digits = sum(1 << b for b in range(8) if (spread >> (8 * b)) & 255)
+    voxel_of = torch.empty(n, dtype=torch.int64, device=dev)
+    nb = lib().ccn_rank_keys_workspace_bytes(n)
+    ws = workspace(nb, dev)
+    call("rank_keys", ptr(key), n, digits, ptr(voxel_of), ptr(meta[1:]), ptr(ws), nb)
+    m = int(meta[1].item())
     scratch = torch.empty(m, dtype=torch.int64, device=dev)
     idx = torch.empty(m, dtype=torch.int64, device=dev)
-    voxel_of = voxel_of.contiguous()
     call("voxel_argmin", ptr(score), ptr(voxel_of), n, m, ptr(scratch), ptr(idx))
     return idx
 

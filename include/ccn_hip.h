@@ -481,6 +481,14 @@ int ccn_voxel_keys(const float* pos, const int64_t* batch, const float* rnd, int
                    float* score, int64_t* bad, void* stream);
 int ccn_voxel_argmin(const float* score, const int64_t* voxel_of, int64_t n, int64_t num_voxels, int64_t* scratch,
                      int64_t* idx, void* stream);
+/* Dense ranks of non-negative int64 keys: rank[i] = number of DISTINCT keys smaller than key[i] (torch.unique(sorted=True,
+ * return_inverse=True) as the reference's VoxelFPS uses it, fps_ops.py:51-60), count[0] = number of distinct keys.  LSD radix
+ * sort, 8-bit digits, stable and deterministic; digit_mask bit b = sort on digit b -- ccn_key_spread gives the OR of
+ * key[i] ^ key[0], only digits in which the keys differ need a pass.  Caller-owned workspace. */
+int ccn_key_spread(const int64_t* key, int64_t n, int64_t* spread, void* stream);
+size_t ccn_rank_keys_workspace_bytes(int64_t n);
+int ccn_rank_keys(const int64_t* key, int64_t n, int digit_mask, int64_t* rank, int64_t* count, void* workspace,
+                  size_t workspace_bytes, void* stream);
 /* sample_farthest_points (point_ops.py:57-70): per cloud out_ptr[b+1]-out_ptr[b] samples starting at start[b];
  * out = packed point indices in selection order; mind: float scratch (n); max_cloud: largest cloud size (clouds of up
  * to 16384 points are processed register-resident, 0 = unknown). */

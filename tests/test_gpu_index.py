@@ -403,3 +403,31 @@ def test_grid_knn_with_fewer_sources_than_k():
         ops.KNN_GRID_MIN_POINTS = keep
     assert torch.equal(nbr_g, nbr_e) and torch.equal(w_g, w_e)
     assert bool((nbr_e[:300, 2] == -1).all()) and bool((nbr_e[:300, :2] >= 0).all()) and bool((nbr_e[300:] >= 2).all())
+
+
+@pytest.mark.parametrize("n,hi", [(1, 10), (1000, 7), (5000, 1 << 40), (400070, 1 << 58), (70000, 1), (123457, 300)])
+def test_rank_keys_equals_torch_unique_inverse(n, hi):
+    """ccn_rank_keys (the hand-written radix sort behind VoxelFPS) = torch.unique(sorted=True, return_inverse=True): the dense
+    rank of every key among the distinct keys and their number, bit-exact; with all eight digit passes and with only the
+    digits ccn_key_spread reports."""
+    from curvecloudnet_amd._lib import call, lib, ptr, workspace
+    gen = torch.Generator().manual_seed(n)
+    key = torch.randint(0, hi, (n,), generator=gen, dtype=torch.int64)
+    if hi > 1000:
+        key[::3] = key[1::3][: key[::3].numel()]           # plenty of duplicates among wide keys too
+    uniq, inv = torch.unique(key, return_inverse=True)
+    kd = key.to(DEV)
+    meta = torch.zeros(2, dtype=torch.int64, device=DEV)
+    call("key_spread", ptr(kd), n, ptr(meta))
+    spread = int(meta[0].item())
+    want_spread = 0
+    for v in (key ^ key[0]).tolist()[:2000]:
+        want_spread |= v
+    assert spread & want_spread == want_spread
+    nb = lib().ccn_rank_keys_workspace_bytes(n)
+    ws = workspace(nb, DEV)
+    for digits in (0xff, sum(1 << b for b in range(8) if (spread >> (8 * b)) & 255)):
+        rank = torch.full((n,), -1, dtype=torch.int64, device=DEV)
+        call("rank_keys", ptr(kd), n, digits, ptr(rank), ptr(meta[1:]), ptr(ws), nb)
+        assert int(meta[1].item()) == uniq.numel()
+        assert torch.equal(rank.cpu(), inv)
