@@ -119,17 +119,9 @@ size_t ccn_rank_keys_workspace_bytes(int64_t n) {
          ccn_align256(ccn_scan_scratch_bytes(256 * tiles > n ? 256 * tiles : n)) + 1024;
 }
 
-// rank[i] = dense rank of key[i] (non-negative int64) among the distinct keys; count[0] = number of distinct keys.
-// digit_mask: bit b set = sort on the 8-bit digit b (0 = least significant); pass the digits in which the keys differ
-// (ccn_key_spread), or 0xff for all eight.
-int ccn_rank_keys(const int64_t* key, int64_t n, int digit_mask, int64_t* rank, int64_t* count, void* workspace,
-                  size_t workspace_bytes, void* stream) {
-  CCN_REQUIRE(key && rank && count && n >= 0 && n < ((int64_t)1 << 31), "rank_keys: bad arguments");
-  hipStream_t s = (hipStream_t)stream;
-  if (n == 0) {
-    CCN_HIP(hipMemsetAsync(count, 0, 8, s), "rank_keys");
-    return CCN_OK;
-  }
+// the LSD passes: on return *kout / *vout point at the sorted keys and their original indices (inside the workspace)
+static int rs_sort(const int64_t* key, int64_t n, int digit_mask, void* workspace, size_t workspace_bytes, hipStream_t s,
+                   const uint64_t** kout, const int32_t** vout, int32_t** flag_out, int32_t** idle_out, void** scan_out) {
   const int64_t tiles = rs_tiles(n);
   CcnArena ar(workspace, workspace_bytes);
   uint64_t* kbuf[2] = {ar.take<uint64_t>(n), ar.take<uint64_t>(n)};
@@ -138,12 +130,13 @@ int ccn_rank_keys(const int64_t* key, int64_t n, int digit_mask, int64_t* rank, 
   int32_t* hist = ar.take<int32_t>(256 * tiles);
   int32_t* offs = ar.take<int32_t>(256 * tiles);
   void* scan_ws = ar.take<char>(ccn_scan_scratch_bytes(256 * tiles > n ? 256 * tiles : n));
-  CCN_REQUIRE(ar.ok(), "rank_keys: workspace too small (%zu bytes given, %zu needed)", workspace_bytes,
+  CCN_REQUIRE(ar.ok(), "rank_keys / sort_keys: workspace too small (%zu bytes given, %zu needed)", workspace_bytes,
               ccn_rank_keys_workspace_bytes(n));
   const uint64_t* kin = (const uint64_t*)key;
   const int32_t* vin = nullptr;
   int cur = 0;
   bool first = true;
+  if ((digit_mask & 0xff) == 0) digit_mask = 1;   // all keys equal: one pass on digit 0 gives the identity payload
   for (int b = 0; b < 8; ++b) {
     if (!((digit_mask >> b) & 1)) continue;
     const int shift = 8 * b;
@@ -161,21 +154,53 @@ int ccn_rank_keys(const int64_t* key, int64_t n, int digit_mask, int64_t* rank, 
     cur ^= 1;
     first = false;
   }
-  if (first) {   // no digit differs: all keys equal -> one pass on digit 0 gives the identity payload
-    hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)tiles), dim3(RS_WAVE), 0, s, kin, n, 0, tiles, hist);
-    int rc = ccn_scan_i32(hist, offs, 256 * tiles, false, nullptr, scan_ws, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3((unsigned)tiles), dim3(RS_WAVE), 0, s, kin, vin, n, 0, tiles, offs, kbuf[cur],
-                       vbuf[cur]);
-    kin = kbuf[cur];
-    vin = vbuf[cur];
+  *kout = kin;
+  *vout = vin;
+  *flag_out = flag;
+  *idle_out = (vin == vbuf[0]) ? vbuf[1] : vbuf[0];      // (the idle half of the payload ping-pong)
+  *scan_out = scan_ws;
+  return CCN_OK;
+}
+
+// rank[i] = dense rank of key[i] (non-negative int64) among the distinct keys; count[0] = number of distinct keys.
+// digit_mask: bit b set = sort on the 8-bit digit b (0 = least significant); pass the digits in which the keys differ
+// (ccn_key_spread), or 0xff for all eight.
+int ccn_rank_keys(const int64_t* key, int64_t n, int digit_mask, int64_t* rank, int64_t* count, void* workspace,
+                  size_t workspace_bytes, void* stream) {
+  CCN_REQUIRE(key && rank && count && n >= 0 && n < ((int64_t)1 << 31), "rank_keys: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    CCN_HIP(hipMemsetAsync(count, 0, 8, s), "rank_keys");
+    return CCN_OK;
   }
+  const uint64_t* kin;
+  const int32_t* vin;
+  int32_t *flag, *incl;
+  void* scan_ws;
+  int rc = rs_sort(key, n, digit_mask, workspace, workspace_bytes, s, &kin, &vin, &flag, &incl, &scan_ws);
+  if (rc) return rc;
   hipLaunchKernelGGL(key_flags_kernel, dim3(ccn_blocks(n, 256)), dim3(256), 0, s, kin, n, flag);
-  int32_t* incl = (vin == vbuf[0]) ? vbuf[1] : vbuf[0];      // (the idle half of the payload ping-pong)
-  int rc = ccn_scan_i32(flag, incl, n, true, nullptr, scan_ws, s);
+  rc = ccn_scan_i32(flag, incl, n, true, nullptr, scan_ws, s);
   if (rc) return rc;
   hipLaunchKernelGGL(rank_scatter_kernel, dim3(ccn_blocks(n, 256)), dim3(256), 0, s, incl, vin, n, rank, count);
   CCN_LAUNCH_OK("rank_keys");
+  return CCN_OK;
+}
+
+// sorted[] = the keys in ascending order (the final torch.sort of the reference's farthest-point indices, point_ops.py:57-70;
+// same workspace as ccn_rank_keys)
+int ccn_sort_keys(const int64_t* key, int64_t n, int digit_mask, int64_t* sorted, void* workspace, size_t workspace_bytes,
+                  void* stream) {
+  CCN_REQUIRE(key && sorted && n >= 0 && n < ((int64_t)1 << 31), "sort_keys: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) return CCN_OK;
+  const uint64_t* kin;
+  const int32_t* vin;
+  int32_t *flag, *incl;
+  void* scan_ws;
+  int rc = rs_sort(key, n, digit_mask, workspace, workspace_bytes, s, &kin, &vin, &flag, &incl, &scan_ws);
+  if (rc) return rc;
+  CCN_HIP(hipMemcpyAsync(sorted, kin, (size_t)n * 8, hipMemcpyDeviceToDevice, s), "sort_keys");
   return CCN_OK;
 }
 

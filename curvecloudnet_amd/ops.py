@@ -1615,7 +1615,13 @@ def fps(pos, topo, ratio, start=None):
     start_d, out_ptr_d = start.to(dev), out_ptr.to(dev)     # named: must outlive the asynchronous launch
     call("fps", ptr(pos), ptr(topo.cloud_ptr), ptr(start_d), ptr(out_ptr_d), topo.num_clouds, topo.max_cloud, ptr(mind),
          ptr(out))
-    return torch.sort(out)[0]
+    # ascending packed indices (the reference sorts them too): ccn_sort_keys on the digits an index < n can differ in
+    digits = (1 << max(1, (max(int(topo.n) - 1, 1).bit_length() + 7) // 8)) - 1
+    nb = lib().ccn_rank_keys_workspace_bytes(total)
+    ws = workspace(nb, dev)
+    srt = torch.empty_like(out)
+    call("sort_keys", ptr(out), total, digits, ptr(srt), ptr(ws), nb)
+    return srt
 
 
 class SGEdgeLayer(torch.autograd.Function):

@@ -489,6 +489,9 @@ int ccn_key_spread(const int64_t* key, int64_t n, int64_t* spread, void* stream)
 size_t ccn_rank_keys_workspace_bytes(int64_t n);
 int ccn_rank_keys(const int64_t* key, int64_t n, int digit_mask, int64_t* rank, int64_t* count, void* workspace,
                   size_t workspace_bytes, void* stream);
+/* sorted[] = the keys in ascending order (the final sort of the reference's farthest-point indices, point_ops.py:57-70) */
+int ccn_sort_keys(const int64_t* key, int64_t n, int digit_mask, int64_t* sorted, void* workspace, size_t workspace_bytes,
+                  void* stream);
 /* sample_farthest_points (point_ops.py:57-70): per cloud out_ptr[b+1]-out_ptr[b] samples starting at start[b];
  * out = packed point indices in selection order; mind: float scratch (n); max_cloud: largest cloud size (clouds of up
  * to 16384 points are processed register-resident, 0 = unknown). */
