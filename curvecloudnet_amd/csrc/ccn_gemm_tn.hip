@@ -23,6 +23,8 @@
 //     back), so the chunk's rows are fetched from HBM once and re-read from that XCD's L2 by the other tiles.
 // Rows beyond M in the last slice: source rows are clamped (in bounds) and the dY fragment is zeroed for them.
 // Columns beyond N / K: source columns are clamped into the row; they only feed accumulator elements that are never stored.
+#include <type_traits>
+
 #include "ccn_common.h"
 
 namespace {
@@ -175,57 +177,65 @@ __global__ __launch_bounds__(TN_TPB, 2) void gemm_tn_glds_kernel(const float* __
         const uint32_t sb = lds_base + (uint32_t)(stage * STAGE * 4);
         const int64_t rl64 = M - s * TN_SLICE;              // >= 32 except in the last slice of all
         const int rows_left = rl64 < TN_SLICE ? (int)rl64 : TN_SLICE;
-        f32x2 fa[2], fb[2];
-        // fragment reads are inline asm (hipcc would otherwise wait for every pending LDS-DMA before a visible ds_read);
-        // step t+1 is read before the MFMAs of step t and waited for with a counted lgkmcnt
-        asm volatile("ds_read_b64 %0, %1" : "=v"(fa[0]) : "v"(sb + a_off) : "memory");
-        asm volatile("ds_read_b64 %0, %1" : "=v"(fb[0]) : "v"(sb + b_off) : "memory");
-        if (XF) {
-          // (the waits name the fragment registers as operands: a plain VALU use of an inline-asm ds_read's result is otherwise
-          // free to be scheduled in front of the wait)
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0]) : : "memory");
-          xform(fb[0]);
+        // The slice's MFMA steps, in two instantiations: only the LAST slice of the matrix can hold rows beyond M, and the test
+        // "is this lane's row beyond M" if-converts into a compare and four selects PER STEP -- five vector instructions per four
+        // MFMAs on every slice of every launch when written inline (round 2).  Full slices take the form without it.
+        auto compute = [&](auto partial_tag) {
+          constexpr bool partial = decltype(partial_tag)::value;
+          f32x2 fa[2], fb[2];
+          // fragment reads are inline asm (hipcc would otherwise wait for every pending LDS-DMA before a visible ds_read);
+          // step t+1 is read before the MFMAs of step t and waited for with a counted lgkmcnt
+          asm volatile("ds_read_b64 %0, %1" : "=v"(fa[0]) : "v"(sb + a_off) : "memory");
+          asm volatile("ds_read_b64 %0, %1" : "=v"(fb[0]) : "v"(sb + b_off) : "memory");
+          if (XF) {
+            // (the waits name the fragment registers as operands: a plain VALU use of an inline-asm ds_read's result is otherwise
+            // free to be scheduled in front of the wait)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0]) : : "memory");
+            xform(fb[0]);
+#pragma unroll
+            for (int t = 0; t < STEPS; ++t) {
+              if (t + 1 < STEPS) {
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[(t + 1) & 1]) : "v"(sb + a_off), "n"((t + 1) * 2 * TN * 4) : "memory");
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb[(t + 1) & 1]) : "v"(sb + b_off), "n"((t + 1) * 2 * TK * 4) : "memory");
+              }
+              __builtin_amdgcn_sched_barrier(0);
+              f32x2 a = fa[t & 1];
+              const f32x2 b = fb[t & 1];
+              if (partial && wc * 2 * STEPS + 2 * t + h >= rows_left) a = f32x2{0.f, 0.f};   // rows beyond M (last slice only)
+              acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
+              acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
+              acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
+              acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
+              __builtin_amdgcn_sched_barrier(0);
+              if (t + 1 < STEPS) {     // the next step's transform behind this step's four MFMAs: the wave gets here when the
+                // fourth has ISSUED (in-order issue, one MFMA per 64 cycles), i.e. with 64 cycles of matrix work still ahead
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[(t + 1) & 1]), "+v"(fa[(t + 1) & 1]) : : "memory");
+                xform(fb[(t + 1) & 1]);
+              }
+            }
+            return;
+          }
 #pragma unroll
           for (int t = 0; t < STEPS; ++t) {
             if (t + 1 < STEPS) {
               asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[(t + 1) & 1]) : "v"(sb + a_off), "n"((t + 1) * 2 * TN * 4) : "memory");
               asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb[(t + 1) & 1]) : "v"(sb + b_off), "n"((t + 1) * 2 * TK * 4) : "memory");
+              asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
             f32x2 a = fa[t & 1];
             const f32x2 b = fb[t & 1];
-            if (rows_left < TN_SLICE && wc * 2 * STEPS + 2 * t + h >= rows_left) a = f32x2{0.f, 0.f};   // rows beyond M
+            if (partial && wc * 2 * STEPS + 2 * t + h >= rows_left) a = f32x2{0.f, 0.f};   // rows beyond M (last slice only)
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < STEPS) {       // the next step's transform behind this step's four MFMAs: the wave gets here when the
-              // fourth has ISSUED (in-order issue, one MFMA per 64 cycles), i.e. with 64 cycles of matrix work still ahead
-              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[(t + 1) & 1]), "+v"(fa[(t + 1) & 1]) : : "memory");
-              xform(fb[(t + 1) & 1]);
-            }
           }
-          continue;
-        }
-#pragma unroll
-        for (int t = 0; t < STEPS; ++t) {
-          if (t + 1 < STEPS) {
-            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[(t + 1) & 1]) : "v"(sb + a_off), "n"((t + 1) * 2 * TN * 4) : "memory");
-            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb[(t + 1) & 1]) : "v"(sb + b_off), "n"((t + 1) * 2 * TK * 4) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-          } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          f32x2 a = fa[t & 1];
-          const f32x2 b = fb[t & 1];
-          if (rows_left < TN_SLICE && wc * 2 * STEPS + 2 * t + h >= rows_left) a = f32x2{0.f, 0.f};   // rows beyond M
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[1][1], 0, 0, 0);
-        }
+        };
+        if (rows_left < TN_SLICE) compute(std::true_type{});
+        else compute(std::false_type{});
       }
     }
 
