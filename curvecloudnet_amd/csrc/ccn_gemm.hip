@@ -635,6 +635,7 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
 }
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 // one K group (q) of fragments for lane (i, h): A band row and NT B rows, 16 bytes each, swizzled chunk
 template <int NT>
@@ -1424,11 +1425,21 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
           const uint32_t lane_off = (uint32_t)((4 * h * ldc + i) * 4);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float v = acc[ab][t][r];
             float* const rowp = cbase + (int64_t)((r & 3) + 8 * (r >> 2)) * ldc;
-            asm volatile("global_store_dword %0, %1, %2" : : "v"(lane_off), "v"(v), "s"(rowp) : "memory");
-            s1 += v;
-            s2 += v * v;
+            asm volatile("global_store_dword %0, %1, %2" : : "v"(lane_off), "v"(acc[ab][t][r]), "s"(rowp) : "memory");
+          }
+          if (colstats != nullptr) {
+            // column statistics only where a BatchNorm follows (a data-gradient launch skips 128 vector instructions per tile
+            // and wave), two accumulator registers per packed instruction (v_pk_add_f32 / v_pk_fma_f32)
+            f32x2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const f32x2 vv = {acc[ab][t][r], acc[ab][t][r + 1]};
+              p1 += vv;
+              p2 = __builtin_elementwise_fma(vv, vv, p2);
+            }
+            s1 += p1.x + p1.y;
+            s2 += p2.x + p2.y;
           }
         } else {
 #pragma unroll
