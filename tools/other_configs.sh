@@ -4,7 +4,7 @@ out=$1; shift
 : > $out
 while read -r flags; do
   echo "== $flags $*" >> $out
-  timeout -k 10 300 python bench.py --no-cpu-baseline --no-kernel-timing --steps 8 --warmup 3 $flags $* 2>/dev/null | tail -1 >> $out || echo "FAILED" >> $out
+  timeout -k 10 300 python bench.py --no-cpu-baseline --steps 8 --warmup 3 $flags $* 2>/dev/null | tail -1 >> $out || echo "FAILED" >> $out
   echo "done: $flags $*"
 done <<'CFG'
 --baseline-config 0 --clouds-per-gpu 64
