@@ -476,7 +476,9 @@ def main():
     for st in pools:
         with torch.cuda.stream(st):
             held = [torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                    for nbytes in (1 << 30, 1 << 30, 256 << 20, 256 << 20, 64 << 20, 64 << 20, 16 << 20, 16 << 20)]
+                    for nbytes in (2 << 30, 1 << 30, 1 << 30, 512 << 20, 512 << 20, 256 << 20, 256 << 20, 128 << 20, 128 << 20,
+                                   64 << 20, 64 << 20, 32 << 20, 32 << 20, 16 << 20, 16 << 20, 8 << 20, 8 << 20, 4 << 20, 4 << 20)]
+            held += [torch.empty((1 << 20) - 512, dtype=torch.uint8, device=dev) for _ in range(128)]   # (the small-block pool)
             del held
     barrier()
     if os.environ.get("CCN_BENCH_LAZY_LOG") == "1":             # diagnostics: which layers hand over deferred activations
@@ -523,12 +525,17 @@ def main():
     ref_event = torch.cuda.Event(enable_timing=True)
     ref_event.record()
     mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+    seg0 = {k: torch.cuda.memory_stats(dev).get("segment.%s_pool.allocated" % k, 0) for k in ("large", "small")}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
     device_mallocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - mallocs0
+    if os.environ.get("CCN_BENCH_DEBUG") == "1":
+        print("segments allocated in the timed region:",
+              {k: torch.cuda.memory_stats(dev).get("segment.%s_pool.allocated" % k, 0) - v for k, v in seg0.items()},
+              "reserved GB", torch.cuda.memory_reserved(dev) / 2 ** 30, flush=True)
     records, _lib.PROFILE, _lib.PROFILE_ONLY, _lib.PROFILE_FILTER = _lib.PROFILE, None, None, None
     full_records = None
     if records is not None and world == 1:

@@ -25,7 +25,7 @@ print("`--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE` passes of
 print("MI355X_MICROARCH.md prescribes for gfx950).  GB/s = (read + written bytes per launch) / average launch duration; HBM3E")
 print("spec peak 8000 GB/s.  MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); clock = GRBM_GUI_ACTIVE")
 print("/ 8 / duration in the (serialised) counter pass.  Durations come from the un-instrumented stats run, where kernels of")
-print("three streams overlap (position-only work, weight-gradient products, everything else): a kernel's GB/s here is what it")
+print("two streams overlap (position-only work of the next step, everything else): a kernel's GB/s here is what it")
 print("gets while sharing the chip, not its stand-alone rate (BN backward apply: 5.6 TB/s alone, 2.8 TB/s next to a GEMM).\n")
 print("| % GPU time | kernel | launches | avg us | read MB | written MB | GB/s | % of 8 TB/s | MFMA util | clock GHz |")
 print("|---|---|---|---|---|---|---|---|---|---|")
