@@ -991,7 +991,7 @@ class LinearBNActH(torch.autograd.Function):
 # (tools/bench_xf.py: 1.34 M x 128 -> 192: 1.20 -> 0.98 ms).  Above K = 256 the pass saved is worth less than the transform
 # costs the two products, and the layer is written out as before.  CCN_LAZY_ACT=0 disables.
 LAZY_ACT = os.environ.get("CCN_LAZY_ACT", "1") != "0"
-LAZY_ACT_MAX_K = 256
+LAZY_ACT_MAX_K = int(os.environ.get("CCN_LAZY_ACT_MAX_K", "256"))       # (A/B: 512 and 1024 measured in round 3)
 LAZY_ACT_COUNT = {"fused": 0, "written": 0}      # deferred inputs consumed by the fused kernel / written out after all (tests)
 LAZY_ACT_LOG = None                               # diagnostics: a list collects (rows, N, K, fused) per deferred input
 
