@@ -93,13 +93,15 @@ def gemm_bytes(name, ints):
     return 0.0
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc*.json, written by
+def pmc_traffic(kernel, tag):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of the SAME workload (profiles/*_<tag>_pmc*.json, written by
     tools/collect_profiles.sh + tools/pmc_summary.py: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc
     runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; a third pass holds
     SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE).  None when the kernel is not in the newest profile that has it."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc*.json")), reverse=True):
+    if tag is None:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s_pmc*.json" % tag)), reverse=True):
         table = json.load(open(path))
         hits = [(name, t) for name, t in table.items() if kernel + "(" in name or kernel + "<" in name]
         for name, t in sorted(hits, key=lambda kv: -kv[1]["launches"])[:1]:      # (template variants: the most launched)
@@ -630,7 +632,10 @@ def main():
                            sites=len(per_site))
             else:
                 achieved = top["flops"] / (top["ms"] * 1e-3) / 1e12
-            tr = pmc_traffic(name)
+            label = workload_label(args)
+            tr = pmc_traffic(name, "kitti" if label.startswith("BASELINE metric shape") else
+                             "c2" if label.startswith("BASELINE configs[2]") else
+                             "c4" if label.startswith("BASELINE configs[4]") and args.mlp_dtype == "fp16" else None)
             # the split product spends six bf16 MFMAs per algorithmic multiply-add
             peak = (PEAK_BF16_MFMA_TFLOPS / 6.0 if "x3" in name else
                     PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_F32_MFMA_TFLOPS)

@@ -42,3 +42,26 @@ for m, n, k in SHAPES:
           % (m, n, k, fl / t_old, fl / t_new, m * (2 * k + 4 * n) / t_new / 1e6, fl / t_16, m * (2 * k + 2 * n) / t_16 / 1e6,
              fl / t_told, fl / t_tnew, m * (n + k) * 2 / t_tnew / 1e6))
     del x32, w32, x16, w16, y, y16, dy32, dy16
+
+print("\nelementwise 16-bit kernels, GB/s (algorithmic bytes / time)")
+print("%-16s | cast    bn_fwd_h  reduce_h  apply_h(dz16)  apply_h(dz32)" % "rows x C")
+for m, c in [(1870000, 256), (3227000, 64), (818000, 128), (198000, 512), (59000, 1024), (290000, 259)]:
+    x = torch.randn(m, c, device=dev)
+    ld16 = (c + 7) // 8 * 8
+    o16 = torch.empty(m, ld16, dtype=torch.bfloat16, device=dev)
+    g16 = torch.randn(m, ld16, device=dev).to(torch.bfloat16)
+    par = torch.rand(4, c, device=dev) + 0.5
+    sums = torch.zeros((lib().ccn_stats_rows(m) + 1) * 2 * c, dtype=torch.float64, device=dev)
+    dgb = torch.zeros(2, c, device=dev)
+    t_c = timeit(lambda: call("cast_rows_h", ptr(x), c, m, c, ptr(o16), ld16, 0))
+    t_f = timeit(lambda: call("bn_act_fwd_h", ptr(x), c, m, c, ptr(par[0]), ptr(par[1]), 1, 0.2, ptr(o16), ld16, 0))
+    t_r = timeit(lambda: call("bn_act_bwd_reduce_h", ptr(g16), ld16, ptr(x), c, m, c, ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                              ptr(par[3]), 1, 0.2, ptr(sums)))
+    t_a = timeit(lambda: call("bn_act_bwd_apply_h", ptr(g16), 1, ld16, ptr(x), c, m, c, ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                              ptr(par[3]), 1, 0.2, ptr(sums), float(m), 1, 0, ptr(o16), ld16, ptr(dgb[0]), ptr(dgb[1]), 0))
+    g32 = torch.randn(m, c, device=dev)
+    t_a32 = timeit(lambda: call("bn_act_bwd_apply_h", ptr(g32), 0, c, ptr(x), c, m, c, ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                                ptr(par[3]), 1, 0.2, ptr(sums), float(m), 1, 0, ptr(o16), ld16, ptr(dgb[0]), ptr(dgb[1]), 0))
+    e = m * c / 1e6
+    print("%8d x %4d | %6.0f  %6.0f   %6.0f   %6.0f   %6.0f" % (m, c, 6 * e / t_c, 6 * e / t_f, 6 * e / t_r, 8 * e / t_a, 10 * e / t_a32))
+    del x, o16, g16, g32

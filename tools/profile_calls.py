@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--baseline-config", type=int, default=1)
 ap.add_argument("--filter", default="")
 ap.add_argument("--top", type=int, default=40)
+ap.add_argument("--cast-callers", action="store_true", help="who asks for fp32 -> 16-bit casts (16-bit storage modes)")
 a = ap.parse_args()
 preset = bench.BASELINE_PRESETS[a.baseline_config]
 bench.torch = torch
@@ -39,6 +40,24 @@ def step():
 
 for _ in range(3):
     step()
+if a.cast_callers:
+    import traceback
+    casts = {}
+    inner = ops._cast16
+
+    def logged(x, dtype=torch.bfloat16):
+        if not ops._is_rows16(x, dtype):
+            frames = [f for f in traceback.extract_stack(limit=12)[:-1] if "autograd" not in f.filename]
+            where = " < ".join("%s:%d %s" % (os.path.basename(f.filename), f.lineno, f.name) for f in frames[-4:][::-1])
+            key = (tuple(x.shape), where)
+            casts[key] = casts.get(key, 0) + 1
+        return inner(x, dtype)
+
+    ops._cast16 = logged
+    step()
+    ops._cast16 = inner
+    for (shape, where), cnt in sorted(casts.items(), key=lambda kv: -kv[0][0][0] * kv[0][0][1] * kv[1]):
+        print("%3d x %-18s %7.1f MB  %s" % (cnt, shape, cnt * shape[0] * shape[1] * 6e-6, where))
 torch.cuda.synchronize()
 _lib.PROFILE = []
 step()
