@@ -638,7 +638,7 @@ def main():
                              "c4" if label.startswith("BASELINE configs[4]") and args.mlp_dtype == "fp16" else None)
             # the split product spends six bf16 MFMAs per algorithmic multiply-add
             peak = (PEAK_BF16_MFMA_TFLOPS / 6.0 if "x3" in name else
-                    PEAK_BF16_MFMA_TFLOPS if "bf16" in name else PEAK_F32_MFMA_TFLOPS)
+                    PEAK_BF16_MFMA_TFLOPS if ("bf16" in name or "gemm_h_" in name) else PEAK_F32_MFMA_TFLOPS)
             result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": peak,
                                   "unit": "TFLOP/s", "frac": achieved / peak,
                                   "traffic": tr["bytes_per_launch"] if tr else None, "traffic_source": tr,

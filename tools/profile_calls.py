@@ -47,8 +47,8 @@ if a.cast_callers:
 
     def logged(x, dtype=torch.bfloat16):
         if not ops._is_rows16(x, dtype):
-            frames = [f for f in traceback.extract_stack(limit=12)[:-1] if "autograd" not in f.filename]
-            where = " < ".join("%s:%d %s" % (os.path.basename(f.filename), f.lineno, f.name) for f in frames[-4:][::-1])
+            frames = [f for f in traceback.extract_stack(limit=30)[:-1] if "autograd" not in f.filename]
+            where = " < ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in frames[-12:][::-1] if "module.py" not in f.filename)
             key = (tuple(x.shape), where)
             casts[key] = casts.get(key, 0) + 1
         return inner(x, dtype)
