@@ -388,16 +388,39 @@ __global__ void cg_fill_kernel(const int64_t* __restrict__ idx, const int64_t* _
   }
 }
 
+// ---- 16-bit rows at the MLP boundary of the 16-bit storage modes (ccn_gemm_h.hip): the first-layer kernels below can write
+// their activation as bf16 / fp16 rows (ZT) and read the gradient of such an activation as bf16 rows (DZ16) -- the fp32 round
+// trip through ccn_cast_rows_h is 8 bytes per element of an E x C tensor.  T: 0 = fp32, 1 = bf16, 2 = fp16.
+template <int T>
+__device__ __forceinline__ float ld_el(const void* __restrict__ p, int64_t i) {
+  if (T == 0) return reinterpret_cast<const float*>(p)[i];
+  const uint16_t v = reinterpret_cast<const uint16_t*>(p)[i];
+  if (T == 2) return (float)__builtin_bit_cast(_Float16, v);
+  return __builtin_bit_cast(float, (uint32_t)v << 16);
+}
+template <int T>
+__device__ __forceinline__ void st_el(void* __restrict__ p, int64_t i, float v) {
+  if (T == 0) {
+    reinterpret_cast<float*>(p)[i] = v;
+  } else if (T == 2) {
+    const _Float16 x = (_Float16)v;
+    reinterpret_cast<uint16_t*>(p)[i] = __builtin_bit_cast(uint16_t, x);
+  } else {
+    const __bf16 x = (__bf16)v;        // round to nearest even (the rounding of ccn_cast_rows_h)
+    reinterpret_cast<uint16_t*>(p)[i] = __builtin_bit_cast(uint16_t, x);
+  }
+}
+
 // the sources of one point's real rows across the wave (lane s = row s of the group, groups have <= 64 rows)
 __device__ __forceinline__ int cg_src(int v, int s) { return __builtin_amdgcn_readlane(v, s); }
 
 // MODE 0: weighted column sums of y and y^2;  MODE 1: of g and g*xhat (g = dZ * act'(y*scale+shift)).
 // "Point" N is the padding pseudo-point: no real rows, representative row E+Ne with y = 0.
-template <int MODE>
+template <int MODE, int DT = 0>
 __global__ __launch_bounds__(TPB) void cg_edge_stats_kernel(
     const float* __restrict__ ps, int64_t ldps, const int32_t* __restrict__ grp_ptr, const int32_t* __restrict__ row_src,
     const int32_t* __restrict__ rep_row, const float* __restrict__ row_w, int64_t N, int64_t E, int64_t Ne, int Co,
-    const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
+    const void* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope, int pts,
     double* __restrict__ partial) {
   __shared__ double red[4][64][2];
@@ -428,7 +451,10 @@ __global__ __launch_bounds__(TPB) void cg_edge_stats_kernel(
         const bool ok = sidx < cnt;
         const int j = cg_src(mysrc, sidx & 63);
         pv[u] = ok ? ps[(int64_t)j * ldps + cc] : 0.f;
-        if (MODE == 1) dz[u] = ok ? dZ[(int64_t)(g0 + sidx) * lddz + cc] : 0.f;
+        if (MODE == 1) {   // (row clamped, load unconditional, then select: a predicated 16-bit load became a branch + full wait each)
+          const float v = ld_el<DT>(dZ, (int64_t)(g0 + (ok ? sidx : 0)) * lddz + cc);
+          dz[u] = ok ? v : 0.f;
+        }
       }
 #pragma unroll
       for (int u = 0; u < SG_UNROLL; ++u) {
@@ -451,7 +477,7 @@ __global__ __launch_bounds__(TPB) void cg_edge_stats_kernel(
         s1 += w * (double)y;
         s2 += w * (double)y * (double)y;
       } else {
-        const float g = dZ[(int64_t)rrow * lddz + cc] * edge_act_grad(y * sc + sh, act, slope);
+        const float g = ld_el<DT>(dZ, (int64_t)rrow * lddz + cc) * edge_act_grad(y * sc + sh, act, slope);
         s1 += w * (double)g;
         s2 += w * (double)(g * ((y - mu) * rs));
       }
@@ -472,10 +498,11 @@ __global__ __launch_bounds__(TPB) void cg_edge_stats_kernel(
   }
 }
 
+template <int ZT>
 __global__ __launch_bounds__(TPB) void cg_edge_apply_kernel(
     const float* __restrict__ ps, int64_t ldps, const int32_t* __restrict__ grp_ptr, const int32_t* __restrict__ row_src,
     const int32_t* __restrict__ rep_row, int64_t N, int64_t E, int64_t Ne, int Co, const float* __restrict__ scale,
-    const float* __restrict__ shift, int act, float slope, float* __restrict__ Z, int64_t ldz) {
+    const float* __restrict__ shift, int act, float slope, void* __restrict__ Z, int64_t ldz) {
   CCN_LANES;
   const int64_t p = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
   if (p > N) return;
@@ -496,17 +523,18 @@ __global__ __launch_bounds__(TPB) void cg_edge_apply_kernel(
       }
 #pragma unroll
       for (int u = 0; u < SG_UNROLL; ++u)
-        if (s0 + u < cnt && c < Co) Z[(int64_t)(g0 + s0 + u) * ldz + c] = edge_act((pv[u] + si) * sc + sh, act, slope);
+        if (s0 + u < cnt && c < Co) st_el<ZT>(Z, (int64_t)(g0 + s0 + u) * ldz + c, edge_act((pv[u] + si) * sc + sh, act, slope));
     }
-    if (rrow >= 0 && c < Co) Z[(int64_t)rrow * ldz + c] = edge_act(si * sc + sh, act, slope);
+    if (rrow >= 0 && c < Co) st_el<ZT>(Z, (int64_t)rrow * ldz + c, edge_act(si * sc + sh, act, slope));
   }
 }
 
 // dS[p] is owned by point p (plain store), dP[src] is accumulated atomically (the entry point zeroes that half).
+template <int DT>
 __global__ __launch_bounds__(TPB) void cg_edge_bwd_kernel(
     const float* __restrict__ ps, int64_t ldps, const int32_t* __restrict__ grp_ptr, const int32_t* __restrict__ row_src,
     const int32_t* __restrict__ rep_row, const float* __restrict__ row_w, int64_t N, int64_t E, int Co,
-    const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
+    const void* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope,
     const double* __restrict__ sums, double count, int training, float* __restrict__ dps, int64_t lddps) {
   CCN_LANES;
@@ -532,7 +560,8 @@ __global__ __launch_bounds__(TPB) void cg_edge_bwd_kernel(
         const bool ok = s0 + u < cnt;
         jj[u] = cg_src(mysrc, (s0 + u) & 63);
         pv[u] = ok ? ps[(int64_t)jj[u] * ldps + cc] : 0.f;
-        dz[u] = ok ? dZ[(int64_t)(g0 + s0 + u) * lddz + cc] : 0.f;
+        const float dzv = ld_el<DT>(dZ, (int64_t)(g0 + (ok ? s0 + u : 0)) * lddz + cc);
+        dz[u] = ok ? dzv : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < SG_UNROLL; ++u) {
@@ -546,7 +575,7 @@ __global__ __launch_bounds__(TPB) void cg_edge_bwd_kernel(
     }
     if (rrow >= 0) {
       const float y = si;
-      const float g = dZ[(int64_t)rrow * lddz + cc] * edge_act_grad(y * sc + sh, act, slope);
+      const float g = ld_el<DT>(dZ, (int64_t)rrow * lddz + cc) * edge_act_grad(y * sc + sh, act, slope);
       const float dy = (training && sums) ? sc * (g - m1 - (y - mu) * rs * m2) : sc * g;
       ds += row_w[rrow - E] * dy;
     }
@@ -657,12 +686,12 @@ __device__ __forceinline__ PnEdge pn_edge_bcast(const PnEdge& g, int t) {
 }
 
 // MODE 0: column sums of y and y^2;  MODE 1: column sums of g and g*xhat, g = dZ * act'(y*scale+shift)
-template <int MODE>
+template <int MODE, int DT = 0>
 __global__ __launch_bounds__(TPB) void pn_edge_stats_kernel(
     const float* __restrict__ px, int64_t ldpx, const float* __restrict__ wp, int64_t ldwp,
     const float* __restrict__ bias, const float* __restrict__ pos_src, const float* __restrict__ pos_dst,
     const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, int Co, float radius,
-    const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
+    const void* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope, int per_wave,
     double* __restrict__ partial) {
   __shared__ double red[4][64][2];
@@ -690,7 +719,10 @@ __global__ __launch_bounds__(TPB) void pn_edge_stats_kernel(
       ed[u] = pn_edge_bcast(mine, (t0 + u) & 63);
       const bool ok = t0 + u < cnt;
       pv[u] = ok ? px[ed[u].j * ldpx + cc] : 0.f;
-      if (MODE == 1) dz[u] = ok ? dZ[(first + t0 + u) * lddz + cc] : 0.f;
+      if (MODE == 1) {
+        const float v = ld_el<DT>(dZ, (first + (ok ? t0 + u : 0)) * lddz + cc);
+        dz[u] = ok ? v : 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -722,11 +754,12 @@ __global__ __launch_bounds__(TPB) void pn_edge_stats_kernel(
 }
 
 constexpr int PN_APPLY_EDGES = 16;  // edges per wave in the apply kernel
+template <int ZT>
 __global__ __launch_bounds__(TPB) void pn_edge_apply_kernel(
     const float* __restrict__ px, int64_t ldpx, const float* __restrict__ wp, int64_t ldwp,
     const float* __restrict__ bias, const float* __restrict__ pos_src, const float* __restrict__ pos_dst,
     const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, int Co, float radius,
-    const float* __restrict__ scale, const float* __restrict__ shift, int act, float slope, float* __restrict__ Z,
+    const float* __restrict__ scale, const float* __restrict__ shift, int act, float slope, void* __restrict__ Z,
     int64_t ldz) {
   CCN_LANES;
   const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * PN_APPLY_EDGES;
@@ -751,7 +784,7 @@ __global__ __launch_bounds__(TPB) void pn_edge_apply_kernel(
       for (int u = 0; u < 4; ++u) {
         if (t0 + u >= cnt || c >= Co) continue;
         const float y = pv[u] + (w0 * ed[u].r0 + w1 * ed[u].r1 + w2 * ed[u].r2) + bv;
-        Z[(first + t0 + u) * ldz + c] = edge_act(y * sc + sh, act, slope);
+        st_el<ZT>(Z, (first + t0 + u) * ldz + c, edge_act(y * sc + sh, act, slope));
       }
     }
   }
@@ -760,11 +793,12 @@ __global__ __launch_bounds__(TPB) void pn_edge_apply_kernel(
 // dPX must be zero on entry (atomic accumulation per source point).  Each wave walks `per_wave` consecutive edges
 // and keeps the sums dWp[c][0..2] = sum dy*rel, dbias[c] = sum dy in registers; wpart: [gridDim.x*4][4][Co] doubles,
 // every row written (no initialisation needed).
+template <int DT>
 __global__ __launch_bounds__(TPB) void pn_edge_bwd_kernel(
     const float* __restrict__ px, int64_t ldpx, const float* __restrict__ wp, int64_t ldwp,
     const float* __restrict__ bias, const float* __restrict__ pos_src, const float* __restrict__ pos_dst,
     const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, int Co, float radius,
-    const float* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
+    const void* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope,
     const double* __restrict__ sums, int training, int per_wave, float* __restrict__ dpx, int64_t lddpx,
     double* __restrict__ wpart) {
@@ -798,7 +832,8 @@ __global__ __launch_bounds__(TPB) void pn_edge_bwd_kernel(
           ed[u] = pn_edge_bcast(mine, (t0 + u) & 63);
           const bool ok = t0 + u < cnt;
           pv[u] = ok ? px[ed[u].j * ldpx + cc] : 0.f;
-          dz[u] = ok ? dZ[(e0 + t0 + u) * lddz + cc] : 0.f;
+          const float dzv = ld_el<DT>(dZ, (e0 + (ok ? t0 + u : 0)) * lddz + cc);
+          dz[u] = ok ? dzv : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -1412,7 +1447,7 @@ int ccn_cg_edge_stats(const float* ps, int64_t ldps, const int32_t* grp_ptr, con
                       double* partial, void* stream) {
   CCN_REQUIRE(ps && grp_ptr && row_src && rep_row && row_w && partial && N > 0 && CCN_SMALL_INT(Co) && ldps >= 2 * Co,
               "cg_edge_stats: bad arguments");
-  hipLaunchKernelGGL(cg_edge_stats_kernel<0>, dim3((unsigned)ccn_cg_edge_stats_rows(N, Co), (unsigned)((Co + 63) / 64)),
+  hipLaunchKernelGGL((cg_edge_stats_kernel<0, 0>), dim3((unsigned)ccn_cg_edge_stats_rows(N, Co), (unsigned)((Co + 63) / 64)),
                      dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr, row_src, rep_row, row_w, N, E, Ne, (int)Co,
                      (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, 0, 0.f, cg_pts(N, Co), partial);
@@ -1420,14 +1455,54 @@ int ccn_cg_edge_stats(const float* ps, int64_t ldps, const int32_t* grp_ptr, con
   return CCN_OK;
 }
 
+static int cg_edge_apply_impl(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
+                              const int32_t* rep_row, int64_t N, int64_t E, int64_t Ne, int64_t Co, const float* scale,
+                              const float* shift, int act, float slope, void* Z, int64_t ldz, int zt, void* stream) {
+  CCN_REQUIRE(ps && grp_ptr && row_src && rep_row && Z && N > 0 && CCN_SMALL_INT(Co) && ldps >= 2 * Co && ldz >= Co,
+              "cg_edge_apply: bad arguments");
+#define CCN_CG_APPLY(ZT_)                                                                                                  \
+  hipLaunchKernelGGL(cg_edge_apply_kernel<ZT_>, dim3(row_blocks(N + 1)), dim3(TPB), 0, (hipStream_t)stream, ps, ldps,      \
+                     grp_ptr, row_src, rep_row, N, E, Ne, (int)Co, scale, shift, act, slope, Z, ldz)
+  if (zt == 0) CCN_CG_APPLY(0);
+  else if (zt == 1) CCN_CG_APPLY(1);
+  else CCN_CG_APPLY(2);
+#undef CCN_CG_APPLY
+  CCN_LAUNCH_OK("cg_edge_apply");
+  return CCN_OK;
+}
+
 int ccn_cg_edge_apply(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
                       const int32_t* rep_row, int64_t N, int64_t E, int64_t Ne, int64_t Co, const float* scale,
                       const float* shift, int act, float slope, float* Z, int64_t ldz, void* stream) {
-  CCN_REQUIRE(ps && grp_ptr && row_src && rep_row && Z && N > 0 && CCN_SMALL_INT(Co) && ldps >= 2 * Co && ldz >= Co,
-              "cg_edge_apply: bad arguments");
-  hipLaunchKernelGGL(cg_edge_apply_kernel, dim3(row_blocks(N + 1)), dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr,
-                     row_src, rep_row, N, E, Ne, (int)Co, scale, shift, act, slope, Z, ldz);
-  CCN_LAUNCH_OK("cg_edge_apply");
+  return cg_edge_apply_impl(ps, ldps, grp_ptr, row_src, rep_row, N, E, Ne, Co, scale, shift, act, slope, Z, ldz, 0, stream);
+}
+
+// ... the activation written as 16-bit rows (bf16, or fp16 when f16 != 0): every row's columns [0, Co) are written, Co % 8 == 0
+// (no padding columns to clear), ldz in 16-bit elements
+int ccn_cg_edge_apply_h(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
+                        const int32_t* rep_row, int64_t N, int64_t E, int64_t Ne, int64_t Co, const float* scale,
+                        const float* shift, int act, float slope, void* Z, int64_t ldz, int f16, void* stream) {
+  CCN_REQUIRE(Co % 8 == 0 && ldz % 8 == 0 && ((uintptr_t)Z & 15) == 0, "cg_edge_apply_h: rows of Co % 8 == 0 elements, 16-byte aligned");
+  return cg_edge_apply_impl(ps, ldps, grp_ptr, row_src, rep_row, N, E, Ne, Co, scale, shift, act, slope, Z, ldz, f16 ? 2 : 1,
+                            stream);
+}
+
+static int cg_edge_bwd_stats_impl(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
+                                  const int32_t* rep_row, const float* row_w, int64_t N, int64_t E, int64_t Ne, int64_t Co,
+                                  const void* dZ, int dz16, int64_t lddz, const float* scale, const float* shift,
+                                  const float* mean, const float* rstd, int act, float slope, double* partial,
+                                  void* stream) {
+  CCN_REQUIRE(ps && grp_ptr && row_src && rep_row && row_w && dZ && scale && shift && mean && rstd && partial && N > 0 &&
+                  CCN_SMALL_INT(Co) && ldps >= 2 * Co && lddz >= Co,
+              "cg_edge_bwd_stats: bad arguments");
+  const dim3 grid((unsigned)ccn_cg_edge_stats_rows(N, Co), (unsigned)((Co + 63) / 64));
+  if (dz16)
+    hipLaunchKernelGGL((cg_edge_stats_kernel<1, 1>), grid, dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr, row_src,
+                       rep_row, row_w, N, E, Ne, (int)Co, dZ, lddz, scale, shift, mean, rstd, act, slope, cg_pts(N, Co), partial);
+  else
+    hipLaunchKernelGGL((cg_edge_stats_kernel<1, 0>), grid, dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr, row_src,
+                       rep_row, row_w, N, E, Ne, (int)Co, dZ, lddz, scale, shift, mean, rstd, act, slope, cg_pts(N, Co), partial);
+  CCN_LAUNCH_OK("cg_edge_bwd_stats");
   return CCN_OK;
 }
 
@@ -1435,20 +1510,24 @@ int ccn_cg_edge_bwd_stats(const float* ps, int64_t ldps, const int32_t* grp_ptr,
                           const int32_t* rep_row, const float* row_w, int64_t N, int64_t E, int64_t Ne, int64_t Co,
                           const float* dZ, int64_t lddz, const float* scale, const float* shift, const float* mean,
                           const float* rstd, int act, float slope, double* partial, void* stream) {
-  CCN_REQUIRE(ps && grp_ptr && row_src && rep_row && row_w && dZ && scale && shift && mean && rstd && partial && N > 0 &&
-                  CCN_SMALL_INT(Co) && ldps >= 2 * Co && lddz >= Co,
-              "cg_edge_bwd_stats: bad arguments");
-  hipLaunchKernelGGL(cg_edge_stats_kernel<1>, dim3((unsigned)ccn_cg_edge_stats_rows(N, Co), (unsigned)((Co + 63) / 64)),
-                     dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr, row_src, rep_row, row_w, N, E, Ne, (int)Co, dZ,
-                     lddz, scale, shift, mean, rstd, act, slope, cg_pts(N, Co), partial);
-  CCN_LAUNCH_OK("cg_edge_bwd_stats");
-  return CCN_OK;
+  return cg_edge_bwd_stats_impl(ps, ldps, grp_ptr, row_src, rep_row, row_w, N, E, Ne, Co, dZ, 0, lddz, scale, shift, mean, rstd,
+                                act, slope, partial, stream);
 }
 
-int ccn_cg_edge_bwd(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src, const int32_t* rep_row,
-                    const float* row_w, int64_t N, int64_t E, int64_t Co, const float* dZ, int64_t lddz,
-                    const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
-                    const double* sums, double count, int training, float* dps, int64_t lddps, void* stream) {
+// ... with dZ as bf16 rows (the gradient of a 16-bit activation; lddz in 16-bit elements)
+int ccn_cg_edge_bwd_stats_h(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
+                            const int32_t* rep_row, const float* row_w, int64_t N, int64_t E, int64_t Ne, int64_t Co,
+                            const void* dZ, int64_t lddz, const float* scale, const float* shift, const float* mean,
+                            const float* rstd, int act, float slope, double* partial, void* stream) {
+  return cg_edge_bwd_stats_impl(ps, ldps, grp_ptr, row_src, rep_row, row_w, N, E, Ne, Co, dZ, 1, lddz, scale, shift, mean, rstd,
+                                act, slope, partial, stream);
+}
+
+static int cg_edge_bwd_impl(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
+                            const int32_t* rep_row, const float* row_w, int64_t N, int64_t E, int64_t Co, const void* dZ,
+                            int dz16, int64_t lddz, const float* scale, const float* shift, const float* mean,
+                            const float* rstd, int act, float slope, const double* sums, double count, int training,
+                            float* dps, int64_t lddps, void* stream) {
   CCN_REQUIRE(ps && grp_ptr && row_src && rep_row && row_w && dZ && dps && N > 0 && CCN_SMALL_INT(Co) && ldps >= 2 * Co &&
                   lddz >= Co && lddps >= 2 * Co && count > 0,
               "cg_edge_bwd: bad arguments");
@@ -1456,11 +1535,32 @@ int ccn_cg_edge_bwd(const float* ps, int64_t ldps, const int32_t* grp_ptr, const
   // owner.  One linear memset of the whole table: the 2-D fill of the left half alone (hipMemset2DAsync) measured 73 us
   // against ~45 us for twice the bytes in one run.
   CCN_HIP(hipMemsetAsync(dps, 0, (size_t)N * (size_t)lddps * sizeof(float), (hipStream_t)stream), "cg_edge_bwd");
-  hipLaunchKernelGGL(cg_edge_bwd_kernel, dim3(row_blocks(N)), dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr,
-                     row_src, rep_row, row_w, N, E, (int)Co, dZ, lddz, scale, shift, mean, rstd, act, slope, sums, count,
-                     training, dps, lddps);
+  if (dz16)
+    hipLaunchKernelGGL(cg_edge_bwd_kernel<1>, dim3(row_blocks(N)), dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr,
+                       row_src, rep_row, row_w, N, E, (int)Co, dZ, lddz, scale, shift, mean, rstd, act, slope, sums, count,
+                       training, dps, lddps);
+  else
+    hipLaunchKernelGGL(cg_edge_bwd_kernel<0>, dim3(row_blocks(N)), dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr,
+                       row_src, rep_row, row_w, N, E, (int)Co, dZ, lddz, scale, shift, mean, rstd, act, slope, sums, count,
+                       training, dps, lddps);
   CCN_LAUNCH_OK("cg_edge_bwd");
   return CCN_OK;
+}
+
+int ccn_cg_edge_bwd(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src, const int32_t* rep_row,
+                    const float* row_w, int64_t N, int64_t E, int64_t Co, const float* dZ, int64_t lddz,
+                    const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                    const double* sums, double count, int training, float* dps, int64_t lddps, void* stream) {
+  return cg_edge_bwd_impl(ps, ldps, grp_ptr, row_src, rep_row, row_w, N, E, Co, dZ, 0, lddz, scale, shift, mean, rstd, act, slope,
+                          sums, count, training, dps, lddps, stream);
+}
+
+int ccn_cg_edge_bwd_h(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src, const int32_t* rep_row,
+                      const float* row_w, int64_t N, int64_t E, int64_t Co, const void* dZ, int64_t lddz,
+                      const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                      const double* sums, double count, int training, float* dps, int64_t lddps, void* stream) {
+  return cg_edge_bwd_impl(ps, ldps, grp_ptr, row_src, rep_row, row_w, N, E, Co, dZ, 1, lddz, scale, shift, mean, rstd, act, slope,
+                          sums, count, training, dps, lddps, stream);
 }
 
 int ccn_cg_max_fwd(const float* f, int64_t ldf, const int32_t* grp_ptr, const int32_t* rep_row, int64_t N, int64_t C,
@@ -1510,7 +1610,7 @@ int ccn_pn_edge_stats(const float* px, int64_t ldpx, const float* wp, int64_t ld
   CCN_REQUIRE(px && wp && pos_src && pos_dst && src && dst && partial && E > 0 && CCN_SMALL_INT(Co) && ldpx >= Co &&
                   ldwp >= 3,
               "pn_edge_stats: bad arguments");
-  hipLaunchKernelGGL(pn_edge_stats_kernel<0>, dim3((unsigned)ccn_pn_edge_stats_rows(E, Co), (unsigned)((Co + 63) / 64)),
+  hipLaunchKernelGGL((pn_edge_stats_kernel<0, 0>), dim3((unsigned)ccn_pn_edge_stats_rows(E, Co), (unsigned)((Co + 63) / 64)),
                      dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp, bias, pos_src, pos_dst, src, dst, E, (int)Co,
                      radius, (const float*)nullptr, (int64_t)0, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, 0, 0.f, pn_per_wave(E, Co), partial);
@@ -1518,17 +1618,61 @@ int ccn_pn_edge_stats(const float* px, int64_t ldpx, const float* wp, int64_t ld
   return CCN_OK;
 }
 
+static int pn_edge_apply_impl(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                              const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                              int64_t Co, float radius, const float* scale, const float* shift, int act, float slope,
+                              void* Z, int64_t ldz, int zt, void* stream) {
+  CCN_REQUIRE(px && wp && pos_src && pos_dst && src && dst && Z && E > 0 && CCN_SMALL_INT(Co) && ldpx >= Co &&
+                  ldwp >= 3 && ldz >= Co,
+              "pn_edge_apply: bad arguments");
+  const dim3 grid((unsigned)((E + 4 * PN_APPLY_EDGES - 1) / (4 * PN_APPLY_EDGES)));
+#define CCN_PN_APPLY(ZT_)                                                                                                 \
+  hipLaunchKernelGGL(pn_edge_apply_kernel<ZT_>, grid, dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp, bias, pos_src, \
+                     pos_dst, src, dst, E, (int)Co, radius, scale, shift, act, slope, Z, ldz)
+  if (zt == 0) CCN_PN_APPLY(0);
+  else if (zt == 1) CCN_PN_APPLY(1);
+  else CCN_PN_APPLY(2);
+#undef CCN_PN_APPLY
+  CCN_LAUNCH_OK("pn_edge_apply");
+  return CCN_OK;
+}
+
 int ccn_pn_edge_apply(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
                       const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
                       int64_t Co, float radius, const float* scale, const float* shift, int act, float slope, float* Z,
                       int64_t ldz, void* stream) {
-  CCN_REQUIRE(px && wp && pos_src && pos_dst && src && dst && Z && E > 0 && CCN_SMALL_INT(Co) && ldpx >= Co &&
-                  ldwp >= 3 && ldz >= Co,
-              "pn_edge_apply: bad arguments");
-  hipLaunchKernelGGL(pn_edge_apply_kernel, dim3((unsigned)((E + 4 * PN_APPLY_EDGES - 1) / (4 * PN_APPLY_EDGES))),
-                     dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp,
-                     bias, pos_src, pos_dst, src, dst, E, (int)Co, radius, scale, shift, act, slope, Z, ldz);
-  CCN_LAUNCH_OK("pn_edge_apply");
+  return pn_edge_apply_impl(px, ldpx, wp, ldwp, bias, pos_src, pos_dst, src, dst, E, Co, radius, scale, shift, act, slope, Z, ldz,
+                            0, stream);
+}
+
+// ... the activation written as 16-bit rows (as ccn_cg_edge_apply_h)
+int ccn_pn_edge_apply_h(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                        const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                        int64_t Co, float radius, const float* scale, const float* shift, int act, float slope, void* Z,
+                        int64_t ldz, int f16, void* stream) {
+  CCN_REQUIRE(Co % 8 == 0 && ldz % 8 == 0 && ((uintptr_t)Z & 15) == 0, "pn_edge_apply_h: rows of Co % 8 == 0 elements, 16-byte aligned");
+  return pn_edge_apply_impl(px, ldpx, wp, ldwp, bias, pos_src, pos_dst, src, dst, E, Co, radius, scale, shift, act, slope, Z, ldz,
+                            f16 ? 2 : 1, stream);
+}
+
+static int pn_edge_bwd_stats_impl(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                                  const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst,
+                                  int64_t E, int64_t Co, float radius, const void* dZ, int dz16, int64_t lddz,
+                                  const float* scale, const float* shift, const float* mean, const float* rstd, int act,
+                                  float slope, double* partial, void* stream) {
+  CCN_REQUIRE(px && wp && pos_src && pos_dst && src && dst && dZ && scale && shift && mean && rstd && partial && E > 0 &&
+                  CCN_SMALL_INT(Co) && ldpx >= Co && ldwp >= 3 && lddz >= Co,
+              "pn_edge_bwd_stats: bad arguments");
+  const dim3 grid((unsigned)ccn_pn_edge_stats_rows(E, Co), (unsigned)((Co + 63) / 64));
+  if (dz16)
+    hipLaunchKernelGGL((pn_edge_stats_kernel<1, 1>), grid, dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp, bias, pos_src,
+                       pos_dst, src, dst, E, (int)Co, radius, dZ, lddz, scale, shift, mean, rstd, act, slope, pn_per_wave(E, Co),
+                       partial);
+  else
+    hipLaunchKernelGGL((pn_edge_stats_kernel<1, 0>), grid, dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp, bias, pos_src,
+                       pos_dst, src, dst, E, (int)Co, radius, dZ, lddz, scale, shift, mean, rstd, act, slope, pn_per_wave(E, Co),
+                       partial);
+  CCN_LAUNCH_OK("pn_edge_bwd_stats");
   return CCN_OK;
 }
 
@@ -1537,13 +1681,39 @@ int ccn_pn_edge_bwd_stats(const float* px, int64_t ldpx, const float* wp, int64_
                           int64_t Co, float radius, const float* dZ, int64_t lddz, const float* scale,
                           const float* shift, const float* mean, const float* rstd, int act, float slope,
                           double* partial, void* stream) {
-  CCN_REQUIRE(px && wp && pos_src && pos_dst && src && dst && dZ && scale && shift && mean && rstd && partial && E > 0 &&
-                  CCN_SMALL_INT(Co) && ldpx >= Co && ldwp >= 3 && lddz >= Co,
-              "pn_edge_bwd_stats: bad arguments");
-  hipLaunchKernelGGL(pn_edge_stats_kernel<1>, dim3((unsigned)ccn_pn_edge_stats_rows(E, Co), (unsigned)((Co + 63) / 64)),
-                     dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp, bias, pos_src, pos_dst, src, dst, E, (int)Co,
-                     radius, dZ, lddz, scale, shift, mean, rstd, act, slope, pn_per_wave(E, Co), partial);
-  CCN_LAUNCH_OK("pn_edge_bwd_stats");
+  return pn_edge_bwd_stats_impl(px, ldpx, wp, ldwp, bias, pos_src, pos_dst, src, dst, E, Co, radius, dZ, 0, lddz, scale, shift,
+                                mean, rstd, act, slope, partial, stream);
+}
+
+int ccn_pn_edge_bwd_stats_h(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                            const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                            int64_t Co, float radius, const void* dZ, int64_t lddz, const float* scale,
+                            const float* shift, const float* mean, const float* rstd, int act, float slope,
+                            double* partial, void* stream) {
+  return pn_edge_bwd_stats_impl(px, ldpx, wp, ldwp, bias, pos_src, pos_dst, src, dst, E, Co, radius, dZ, 1, lddz, scale, shift,
+                                mean, rstd, act, slope, partial, stream);
+}
+
+static int pn_edge_bwd_impl(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                            const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                            int64_t Co, float radius, const void* dZ, int dz16, int64_t lddz, const float* scale,
+                            const float* shift, const float* mean, const float* rstd, int act, float slope,
+                            const double* sums, int training, float* dpx, int64_t lddpx, double* wpart, void* stream) {
+  CCN_REQUIRE(px && wp && pos_src && pos_dst && src && dst && dZ && dpx && wpart && E > 0 && CCN_SMALL_INT(Co) &&
+                  ldpx >= Co && ldwp >= 3 && lddz >= Co && lddpx >= Co,
+              "pn_edge_bwd: bad arguments");
+  const int64_t waves = ccn_pn_edge_bwd_rows(E);
+  int64_t per = (E + 8191) / 8192;
+  if (per < 1) per = 1;
+  if (dz16)
+    hipLaunchKernelGGL(pn_edge_bwd_kernel<1>, dim3((unsigned)(waves / 4)), dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp,
+                       ldwp, bias, pos_src, pos_dst, src, dst, E, (int)Co, radius, dZ, lddz, scale, shift, mean, rstd, act,
+                       slope, sums, training, (int)per, dpx, lddpx, wpart);
+  else
+    hipLaunchKernelGGL(pn_edge_bwd_kernel<0>, dim3((unsigned)(waves / 4)), dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp,
+                       ldwp, bias, pos_src, pos_dst, src, dst, E, (int)Co, radius, dZ, lddz, scale, shift, mean, rstd, act,
+                       slope, sums, training, (int)per, dpx, lddpx, wpart);
+  CCN_LAUNCH_OK("pn_edge_bwd");
   return CCN_OK;
 }
 
@@ -1552,17 +1722,17 @@ int ccn_pn_edge_bwd(const float* px, int64_t ldpx, const float* wp, int64_t ldwp
                     int64_t Co, float radius, const float* dZ, int64_t lddz, const float* scale, const float* shift,
                     const float* mean, const float* rstd, int act, float slope, const double* sums, int training,
                     float* dpx, int64_t lddpx, double* wpart, void* stream) {
-  CCN_REQUIRE(px && wp && pos_src && pos_dst && src && dst && dZ && dpx && wpart && E > 0 && CCN_SMALL_INT(Co) &&
-                  ldpx >= Co && ldwp >= 3 && lddz >= Co && lddpx >= Co,
-              "pn_edge_bwd: bad arguments");
-  const int64_t waves = ccn_pn_edge_bwd_rows(E);
-  int64_t per = (E + 8191) / 8192;
-  if (per < 1) per = 1;
-  hipLaunchKernelGGL(pn_edge_bwd_kernel, dim3((unsigned)(waves / 4)), dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp,
-                     ldwp, bias, pos_src, pos_dst, src, dst, E, (int)Co, radius, dZ, lddz, scale, shift, mean, rstd, act,
-                     slope, sums, training, (int)per, dpx, lddpx, wpart);
-  CCN_LAUNCH_OK("pn_edge_bwd");
-  return CCN_OK;
+  return pn_edge_bwd_impl(px, ldpx, wp, ldwp, bias, pos_src, pos_dst, src, dst, E, Co, radius, dZ, 0, lddz, scale, shift, mean,
+                          rstd, act, slope, sums, training, dpx, lddpx, wpart, stream);
+}
+
+int ccn_pn_edge_bwd_h(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                      const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                      int64_t Co, float radius, const void* dZ, int64_t lddz, const float* scale, const float* shift,
+                      const float* mean, const float* rstd, int act, float slope, const double* sums, int training,
+                      float* dpx, int64_t lddpx, double* wpart, void* stream) {
+  return pn_edge_bwd_impl(px, ldpx, wp, ldwp, bias, pos_src, pos_dst, src, dst, E, Co, radius, dZ, 1, lddz, scale, shift, mean,
+                          rstd, act, slope, sums, training, dpx, lddpx, wpart, stream);
 }
 
 int ccn_msg_build_fwd(const float* x_src, int64_t ldx, const float* pos_src, const float* pos_dst, const int64_t* src,

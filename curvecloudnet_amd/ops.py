@@ -1704,7 +1704,7 @@ class PNEdgeLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, px, wp, bias, pos_src, pos_dst, src, dst, radius, gamma, beta, running_mean, running_var, training,
-                act, eps, momentum):
+                act, eps, momentum, out16=False):
         px, wp = _mat(px), _mat(wp.contiguous())
         e, co, dev = src.numel(), px.size(1), px.device
         has_bn = gamma is not None
@@ -1723,18 +1723,25 @@ class PNEdgeLayer(torch.autograd.Function):
             else:
                 call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), co,
                      ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        ctx.save_for_backward(px, wp, bias if bias is not None else px.new_empty(0), pos_src, pos_dst, src, dst,
+                              par if has_bn else px.new_empty(0))
+        if out16:       # 16-bit storage modes: the next Linear of the MLP reads 16-bit rows (edge_out16)
+            fdt = _fwd16()
+            z = _rows16(e, co, dev, fdt)
+            call("pn_edge_apply_h", ptr(px), _ld(px), ptr(wp), _ld(wp), ptr(bias), *geo, ptr(par[0]) if has_bn else None,
+                 ptr(par[1]) if has_bn else None, ctx.act, LEAKY_SLOPE, ptr(z), _ld(z), 1 if fdt == torch.float16 else 0)
+            return z.view(torch.bfloat16) if fdt == torch.float16 else z
         z = _rows(e, co, dev)
         call("pn_edge_apply", ptr(px), _ld(px), ptr(wp), _ld(wp), ptr(bias), *geo, ptr(par[0]) if has_bn else None,
              ptr(par[1]) if has_bn else None, ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
-        ctx.save_for_backward(px, wp, bias if bias is not None else px.new_empty(0), pos_src, pos_dst, src, dst,
-                              par if has_bn else px.new_empty(0))
         _trace_act(z, ctx.act)
         return z
 
     @staticmethod
     def backward(ctx, g):
         px, wp, bias, pos_src, pos_dst, src, dst, par = ctx.saved_tensors
-        g = _mat(g)
+        h = "_h" if _is_rows16(g) else ""          # the gradient of a 16-bit activation arrives as bf16 rows
+        g = g if h else _mat(g.float() if g.dtype != torch.float32 else g)
         e, co, dev = src.numel(), px.size(1), g.device
         bias_p = ptr(bias) if ctx.has_bias else None
         geo = (ptr(pos_src), ptr(pos_dst), ptr(src), ptr(dst), e, co, ctx.radius)
@@ -1744,7 +1751,7 @@ class PNEdgeLayer(torch.autograd.Function):
             pp = [ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3])]
             nparts = lib().ccn_pn_edge_stats_rows(e, co)
             partial = torch.empty((nparts + 1) * 2 * co, dtype=torch.float64, device=dev)
-            call("pn_edge_bwd_stats", ptr(px), _ld(px), ptr(wp), _ld(wp), bias_p, *geo, ptr(g), _ld(g), *pp, ctx.act,
+            call("pn_edge_bwd_stats" + h, ptr(px), _ld(px), ptr(wp), _ld(wp), bias_p, *geo, ptr(g), _ld(g), *pp, ctx.act,
                  LEAKY_SLOPE, ptr(partial))
             sums = partial[nparts * 2 * co:]
             call("reduce_partials", ptr(partial), nparts, 2 * co, ptr(sums))
@@ -1753,7 +1760,7 @@ class PNEdgeLayer(torch.autograd.Function):
         dpx = _rows(px.size(0), co, dev, zero=True)
         nw = lib().ccn_pn_edge_bwd_rows(e)
         wpart = torch.empty((nw + 1) * 4 * co, dtype=torch.float64, device=dev)       # every partial row is written
-        call("pn_edge_bwd", ptr(px), _ld(px), ptr(wp), _ld(wp), bias_p, *geo, ptr(g), _ld(g), *pp, ctx.act, LEAKY_SLOPE,
+        call("pn_edge_bwd" + h, ptr(px), _ld(px), ptr(wp), _ld(wp), bias_p, *geo, ptr(g), _ld(g), *pp, ctx.act, LEAKY_SLOPE,
              ptr(sums) if sums is not None else None, 1 if (ctx.training and ctx.has_bn) else 0, ptr(dpx), _ld(dpx),
              ptr(wpart))
         tot = wpart[nw * 4 * co:]
@@ -1761,10 +1768,29 @@ class PNEdgeLayer(torch.autograd.Function):
         tot = tot.view(4, co).float()
         dwp = tot[:3].t().contiguous()
         dbias = tot[3].contiguous() if ctx.has_bias else None
-        return dpx, dwp, dbias, None, None, None, None, None, dgamma, dbeta, None, None, None, None, None, None
+        return dpx, dwp, dbias, None, None, None, None, None, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def pn_edge_layer(px, wp, bias, pos_src, pos_dst, edges, radius, bn, training, act):
+EDGE_OUT16 = os.environ.get("CCN_EDGE_OUT16", "1") != "0"      # (A/B and tests: 0 = fp32 rows + ccn_cast_rows_h as before)
+
+
+def edge_out16(mlp, channels):
+    """May the algebraic first layer of ``mlp`` (an nn.MLP) write its activation as 16-bit rows?  Yes in the 16-bit storage
+    modes when that activation is a hidden one whose only consumer is the next Linear of the same MLP -- the rows the
+    consumer would otherwise get through ccn_cast_rows_h, with the same rounding (and a bf16 gradient back, as for every
+    other hidden activation of those modes)."""
+    return bool(EDGE_OUT16 and _MLP_DTYPE in ("bf16", "fp16") and STORE16 and ACT_TRACE is None and len(mlp.norms) > 0
+                and (len(mlp.norms) > 1 or mlp.plain_last) and mlp.dropout == 0.0 and ACT[mlp.act] != 0
+                and channels % 8 == 0)
+
+
+def _mark16(z, out16):
+    if out16 and _MLP_DTYPE == "fp16":
+        z._ccn_f16_bits = True         # fp16 bit patterns in a bfloat16-typed tensor (see LinearBNActH)
+    return z
+
+
+def pn_edge_layer(px, wp, bias, pos_src, pos_dst, edges, radius, bn, training, act, out16=False):
     pos_src, pos_dst = _pos(pos_src), _pos(pos_dst)
     if bn is None:
         return PNEdgeLayer.apply(px, wp, bias, pos_src, pos_dst, edges.col, edges.row, radius, None, None, None, None,
@@ -1772,9 +1798,10 @@ def pn_edge_layer(px, wp, bias, pos_src, pos_dst, edges, radius, bn, training, a
     if training and bn.track_running_stats:
         bn.num_batches_tracked += 1
     use_batch_stats = training or not bn.track_running_stats
-    return PNEdgeLayer.apply(px, wp, bias, pos_src, pos_dst, edges.col, edges.row, radius, bn.weight, bn.bias,
-                             bn.running_mean, bn.running_var, use_batch_stats, act, bn.eps,
-                             bn.momentum if bn.momentum is not None else 0.1)
+    out16 = bool(out16 and edges.num_edges > 0)
+    return _mark16(PNEdgeLayer.apply(px, wp, bias, pos_src, pos_dst, edges.col, edges.row, radius, bn.weight, bn.bias,
+                                     bn.running_mean, bn.running_var, use_batch_stats, act, bn.eps,
+                                     bn.momentum if bn.momentum is not None else 0.1, out16), out16)
 
 
 # --------------------------------------------------------------------------------------
@@ -1833,7 +1860,7 @@ class CGEdgeLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ps, grp_ptr, row_src, rep_row, row_w, dims, gamma, beta, running_mean, running_var, training, act,
-                eps, momentum):
+                eps, momentum, out16=False):
         ps = _mat(ps)
         n, e, ne, count = dims
         co = ps.size(1) // 2
@@ -1854,17 +1881,24 @@ class CGEdgeLayer(torch.autograd.Function):
             else:
                 call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), co,
                      ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        ctx.save_for_backward(ps, grp_ptr, row_src, rep_row, row_w, par if has_bn else ps.new_empty(0))
+        if out16:       # 16-bit storage modes: the plain last Linear of the MLP reads 16-bit rows (edge_out16)
+            fdt = _fwd16()
+            z = _rows16(e + ne + 1, co, dev, fdt)
+            call("cg_edge_apply_h", ptr(ps), _ld(ps), *idx, n, e, ne, co, ptr(par[0]) if has_bn else None,
+                 ptr(par[1]) if has_bn else None, ctx.act, LEAKY_SLOPE, ptr(z), _ld(z), 1 if fdt == torch.float16 else 0)
+            return z.view(torch.bfloat16) if fdt == torch.float16 else z
         z = _rows(e + ne + 1, co, dev)
         call("cg_edge_apply", ptr(ps), _ld(ps), *idx, n, e, ne, co, ptr(par[0]) if has_bn else None,
              ptr(par[1]) if has_bn else None, ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
-        ctx.save_for_backward(ps, grp_ptr, row_src, rep_row, row_w, par if has_bn else ps.new_empty(0))
         _trace_act(z, ctx.act)
         return z
 
     @staticmethod
     def backward(ctx, g):
         ps, grp_ptr, row_src, rep_row, row_w, par = ctx.saved_tensors
-        g = _mat(g)
+        h = "_h" if _is_rows16(g) else ""          # the gradient of a 16-bit activation arrives as bf16 rows
+        g = g if h else _mat(g.float() if g.dtype != torch.float32 else g)
         n, e, ne, count = ctx.dims
         co = ps.size(1) // 2
         dev = g.device
@@ -1875,7 +1909,7 @@ class CGEdgeLayer(torch.autograd.Function):
             pp = [ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3])]
             nparts = lib().ccn_cg_edge_stats_rows(n, co)
             partial = torch.empty((nparts + 1) * 2 * co, dtype=torch.float64, device=dev)
-            call("cg_edge_bwd_stats", ptr(ps), _ld(ps), *idx, ptr(row_w), n, e, ne, co, ptr(g), _ld(g), *pp, ctx.act,
+            call("cg_edge_bwd_stats" + h, ptr(ps), _ld(ps), *idx, ptr(row_w), n, e, ne, co, ptr(g), _ld(g), *pp, ctx.act,
                  LEAKY_SLOPE, ptr(partial))
             sums = partial[nparts * 2 * co:]
             call("reduce_partials", ptr(partial), nparts, 2 * co, ptr(sums))
@@ -1884,21 +1918,22 @@ class CGEdgeLayer(torch.autograd.Function):
         dps = _rows(ps.size(0), 2 * co, dev)        # (the entry point zeroes the table it accumulates into)
         if ps.size(0) > n:
             dps[n:].zero_()
-        call("cg_edge_bwd", ptr(ps), _ld(ps), *idx, ptr(row_w), n, e, co, ptr(g), _ld(g), *pp, ctx.act, LEAKY_SLOPE,
+        call("cg_edge_bwd" + h, ptr(ps), _ld(ps), *idx, ptr(row_w), n, e, co, ptr(g), _ld(g), *pp, ctx.act, LEAKY_SLOPE,
              ptr(sums) if sums is not None else None, float(count), 1 if (ctx.training and ctx.has_bn) else 0, ptr(dps),
              _ld(dps))
-        return dps, None, None, None, None, None, dgamma, dbeta, None, None, None, None, None, None
+        return dps, None, None, None, None, None, dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def cg_edge_layer(ps, comp, bn, training, act):
+def cg_edge_layer(ps, comp, bn, training, act, out16=False):
     dims = (comp.n, comp.e, comp.ne, comp.count)
     if bn is None:
         return CGEdgeLayer.apply(ps, *comp.tensors(), dims, None, None, None, None, False, None, 0.0, 0.0)
     if training and bn.track_running_stats:
         bn.num_batches_tracked += 1
     use_batch_stats = training or not bn.track_running_stats
-    return CGEdgeLayer.apply(ps, *comp.tensors(), dims, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                             use_batch_stats, act, bn.eps, bn.momentum if bn.momentum is not None else 0.1)
+    return _mark16(CGEdgeLayer.apply(ps, *comp.tensors(), dims, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                     use_batch_stats, act, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
+                                     bool(out16)), out16)
 
 
 class LinearBNActTail(torch.autograd.Function):

@@ -347,7 +347,8 @@ class PointNetConv2(nn.Module):
             px = ops.linear_bn_act(x_src, lin0.weight[:, :c], None, None, False, None)
             hidden0 = len(nn0.norms) > 0
             msg = ops.pn_edge_layer(px, lin0.weight[:, c:], lin0.bias, pos_src, pos_dst, edges, self.normalize_radius,
-                                    nn0.norms[0].module if hidden0 else None, self.training, nn0.act if hidden0 else None)
+                                    nn0.norms[0].module if hidden0 else None, self.training, nn0.act if hidden0 else None,
+                                    out16=ops.edge_out16(nn0, lin0.weight.size(0)))
             msg = nn0(msg, start=1)
         else:
             msg = ops.MessageBuild.apply(x_src, pos_src, pos_dst, edges.col, edges.row, self.normalize_radius)
@@ -565,8 +566,10 @@ class SGCNNLayer(nn.Module):
             if ops.ACT_TRACE is not None:       # test hook: sign tables in the reference's dense row layout
                 ops.ACT_ROW_MAP = comp.dense_row_map(nbr, topo)
             try:
+                # (16-bit rows only when the plain last layer follows directly: the weighted-tail layers take fp32 rows)
                 feat = ops.cg_edge_layer(ps, comp, self.nn.norms[0].module if hidden0 else None, self.training,
-                                         self.nn.act if hidden0 else None)
+                                         self.nn.act if hidden0 else None,
+                                         out16=len(self.nn.norms) == 1 and ops.edge_out16(self.nn, lin0.weight.size(0)))
                 feat = self.nn(feat, start=1, tail=(comp.e, comp.row_w, comp.count))
             finally:
                 ops.ACT_ROW_MAP = None

@@ -462,6 +462,35 @@ int ccn_pn_edge_bwd(const float* px, int64_t ldpx, const float* wp, int64_t ldwp
                     int64_t Co, float radius, const float* dZ, int64_t lddz, const float* scale, const float* shift,
                     const float* mean, const float* rstd, int act, float slope, const double* sums, int training,
                     float* dpx, int64_t lddpx, double* wpart, void* stream);
+/* The same first layers at the boundary of the 16-bit storage modes (round 3; ccn_gemm_nt_h and friends): `_apply_h` writes the
+ * activation as bf16 rows (fp16 when f16 != 0; Co % 8 == 0, ldz in 16-bit elements, rows 16-byte aligned) for the next
+ * Linear of the MLP (PyG MLP inside dgcnn.py:172-177 / point_conv.py:60-69), `_bwd_stats_h` / `_bwd_h` read the gradient of
+ * that activation as bf16 rows.  Same arithmetic as the fp32 entries; one rounding on the way out / in. */
+int ccn_cg_edge_apply_h(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
+                        const int32_t* rep_row, int64_t N, int64_t E, int64_t Ne, int64_t Co, const float* scale,
+                        const float* shift, int act, float slope, void* Z, int64_t ldz, int f16, void* stream);
+int ccn_cg_edge_bwd_stats_h(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src,
+                            const int32_t* rep_row, const float* row_w, int64_t N, int64_t E, int64_t Ne, int64_t Co,
+                            const void* dZ, int64_t lddz, const float* scale, const float* shift, const float* mean,
+                            const float* rstd, int act, float slope, double* partial, void* stream);
+int ccn_cg_edge_bwd_h(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src, const int32_t* rep_row,
+                      const float* row_w, int64_t N, int64_t E, int64_t Co, const void* dZ, int64_t lddz,
+                      const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                      const double* sums, double count, int training, float* dps, int64_t lddps, void* stream);
+int ccn_pn_edge_apply_h(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                        const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                        int64_t Co, float radius, const float* scale, const float* shift, int act, float slope, void* Z,
+                        int64_t ldz, int f16, void* stream);
+int ccn_pn_edge_bwd_stats_h(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                            const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                            int64_t Co, float radius, const void* dZ, int64_t lddz, const float* scale,
+                            const float* shift, const float* mean, const float* rstd, int act, float slope,
+                            double* partial, void* stream);
+int ccn_pn_edge_bwd_h(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
+                      const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
+                      int64_t Co, float radius, const void* dZ, int64_t lddz, const float* scale, const float* shift,
+                      const float* mean, const float* rstd, int act, float slope, const double* sums, int training,
+                      float* dpx, int64_t lddpx, double* wpart, void* stream);
 /* ball query between D-dimensional feature vectors (dgcnn.py:114-127 DGCNNLayerRadius: the ball-group search of
  * point_ops.py:81 on features): padded (B,P,ld) rows of D floats, same first-K-in-index-order rule, d2 summed over
  * the D components in order. */

@@ -732,6 +732,58 @@ def test_bf16_model_tracks_emulation_and_fp32(bf16_mode, which):
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in mine.parameters())
 
 
+@pytest.mark.parametrize("which", ["sgcnn", "sa-max", "sa-attend"])
+def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
+    """16-bit storage modes: the algebraic first layer of an edge MLP writes its activation as 16-bit rows for the next Linear
+    (ccn_cg_edge_apply_h / ccn_pn_edge_apply_h) instead of fp32 rows + ccn_cast_rows_h: the same rounding of the same fp32
+    value, so the module's output is bit-identical; backward then reads the activation's gradient as bf16 rows (one more
+    rounding, as for every other hidden activation of these modes: gradients agree to bf16 resolution)."""
+    from curvecloudnet_amd import steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    ops = _ops()
+    d = make_batch([2, 3], n_curves=50)
+    c = 21
+    torch.manual_seed(0)
+    if which == "sgcnn":
+        mod = steps.SGCNNLayer(MLP([2 * (c + 3), 40, 24], bias=False), 12, r=0.05, with_xyz=True)
+    else:
+        att = MLP([24, 16, 24], act="leaky_relu", bias=False) if which == "sa-attend" else None
+        mod = steps.SAModule(0.5, 0.06, MLP([c + 3, 40, 32, 24], bias=False), 16, downsample_type="curve-fps",
+                             curve_fps_arclen=0.01, attend_nn=att, aggr_type="attend" if att is not None else "max")
+    mod = mod.to(DEV).train()
+    x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4)).to(DEV)
+    res, calls = [], []
+    for direct in (True, False):
+        ops.EDGE_OUT16 = direct
+        log = []
+        inner = ops.call
+
+        def spy(name, *a):
+            log.append(name)
+            return inner(name, *a)
+
+        ops.call = spy
+        try:
+            xi = x.clone().requires_grad_(True)
+            torch.manual_seed(9)
+            out = mod(xi, d.pos.to(DEV), d.batch.to(DEV), d.curve_idxs.to(DEV))[0]
+            cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+            res.append([out.detach()] + list(torch.autograd.grad((out * cot).sum(), [xi] + list(mod.parameters()))))
+        finally:
+            ops.call = inner
+            ops.EDGE_OUT16 = True
+        calls.append(log)
+    kind = "cg" if which == "sgcnn" else "pn"
+    assert kind + "_edge_apply_h" in calls[0] and kind + "_edge_bwd_h" in calls[0] and kind + "_edge_bwd_stats_h" in calls[0]
+    assert kind + "_edge_apply" in calls[1] and kind + "_edge_bwd" in calls[1]
+    assert calls[0].count("cast_rows_h") < calls[1].count("cast_rows_h")
+    assert torch.equal(res[0][0], res[1][0]), "forward must not change: same fp32 value, same rounding"
+    for a, b in zip(res[0][1:], res[1][1:]):
+        err = float((a - b).norm() / b.norm().clamp_min(1e-20))
+        assert err < 1e-2, err
+
+
 @pytest.mark.parametrize("ids,k,r", [([2, 3], 12, 0.05), ([0], 20, 0.02), ([4, 5, 6], 8, 0.5)])
 def test_sgcnn_compact_rows_match_dense_rows(ids, k, r):
     """The compact-row SGCNN path (real rows + weighted representatives of the empty slots / padding rows) against the
