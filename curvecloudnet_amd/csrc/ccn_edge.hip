@@ -621,16 +621,17 @@ __global__ __launch_bounds__(TPB) void cg_max_fwd_kernel(const float* __restrict
 
 // df rows of the point: the argmax row gets the gradient, the others (and the representative) zero; wave N clears
 // the padding row
+template <int T>     // T = 1: df as bf16 rows (the 16-bit storage modes: dY of the plain Linear in front of the max)
 __global__ __launch_bounds__(TPB) void cg_max_bwd_kernel(const float* __restrict__ dout, int64_t lddo,
                                                          const int32_t* __restrict__ arg,
                                                          const int32_t* __restrict__ grp_ptr,
                                                          const int32_t* __restrict__ rep_row, int64_t N, int64_t R, int C,
-                                                         float* __restrict__ df, int64_t lddf) {
+                                                         void* __restrict__ df, int64_t lddf) {
   CCN_LANES;
   const int64_t p = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
   if (p > N) return;
   if (p == N) {
-    for (int c = cx; c < C; c += 64) df[(R - 1) * lddf + c] = 0.f;
+    for (int c = cx; c < C; c += 64) st_el<T>(df, (R - 1) * lddf + c, 0.f);
     return;
   }
   const int32_t g0 = grp_ptr[p], cnt = grp_ptr[p + 1] - g0;
@@ -638,8 +639,8 @@ __global__ __launch_bounds__(TPB) void cg_max_bwd_kernel(const float* __restrict
   for (int c = cx; c < C; c += 64) {
     const int at = arg[p * C + c];
     const float g = dout[p * lddo + c];
-    for (int s = 0; s < cnt; ++s) df[(int64_t)(g0 + s) * lddf + c] = s == at ? g : 0.f;
-    if (rrow >= 0) df[(int64_t)rrow * lddf + c] = 0.f;
+    for (int s = 0; s < cnt; ++s) st_el<T>(df, (int64_t)(g0 + s) * lddf + c, s == at ? g : 0.f);
+    if (rrow >= 0) st_el<T>(df, (int64_t)rrow * lddf + c, 0.f);
   }
 }
 
@@ -1577,9 +1578,22 @@ int ccn_cg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const in
                    int64_t N, int64_t R, int64_t C, float* df, int64_t lddf, void* stream) {
   CCN_REQUIRE(dout && arg && grp_ptr && rep_row && df && N > 0 && R > N && CCN_SMALL_INT(C) && lddo >= C && lddf >= C,
               "cg_max_bwd: bad arguments");
-  hipLaunchKernelGGL(cg_max_bwd_kernel, dim3(row_blocks(N + 1)), dim3(TPB), 0, (hipStream_t)stream, dout, lddo, arg,
+  hipLaunchKernelGGL(cg_max_bwd_kernel<0>, dim3(row_blocks(N + 1)), dim3(TPB), 0, (hipStream_t)stream, dout, lddo, arg,
                      grp_ptr, rep_row, N, R, (int)C, df, lddf);
   CCN_LAUNCH_OK("cg_max_bwd");
+  return CCN_OK;
+}
+
+// ... df as bf16 rows (C % 8 == 0, lddf in 16-bit elements): the dY operand of the data- / weight-gradient products of the
+// plain Linear in front of the max (ccn_gemm_nt_h / ccn_gemm_tn_h)
+int ccn_cg_max_bwd_h(const float* dout, int64_t lddo, const int32_t* arg, const int32_t* grp_ptr, const int32_t* rep_row,
+                     int64_t N, int64_t R, int64_t C, void* df, int64_t lddf, void* stream) {
+  CCN_REQUIRE(dout && arg && grp_ptr && rep_row && df && N > 0 && R > N && CCN_SMALL_INT(C) && lddo >= C && lddf >= C &&
+                  C % 8 == 0 && lddf % 8 == 0 && ((uintptr_t)df & 15) == 0,
+              "cg_max_bwd_h: bad arguments");
+  hipLaunchKernelGGL(cg_max_bwd_kernel<1>, dim3(row_blocks(N + 1)), dim3(TPB), 0, (hipStream_t)stream, dout, lddo, arg,
+                     grp_ptr, rep_row, N, R, (int)C, df, lddf);
+  CCN_LAUNCH_OK("cg_max_bwd_h");
   return CCN_OK;
 }
 

@@ -57,10 +57,12 @@ class MLP(nn.Module):
     def out_channels(self):
         return self.channel_list[-1]
 
-    def forward(self, x, start=0, tail=None):
+    def forward(self, x, start=0, tail=None, post=None):
         """``start`` > 0 resumes after the first ``start`` layers (a caller computed them in fused form).
         ``tail`` = (first weighted row, weights, total count): the rows from that index on stand for several identical
-        rows each (compact SGCNN rows, ops.LinearBNActTail); the final plain layer needs no weights."""
+        rows each (compact SGCNN rows, ops.LinearBNActTail); the final plain layer needs no weights.
+        ``post`` = (grp_ptr, rep_row, n, row_src): return ops.CGMax of the MLP's output (handed to the plain last layer, which
+        can produce the max's gradient in the form its own backward products read: ops.linear_bn_act)."""
         n_hidden = len(self.norms)
         for idx, (lin, norm) in enumerate(zip(self.lins, self.norms)):
             if idx < start:
@@ -77,10 +79,13 @@ class MLP(nn.Module):
                 x = F.dropout(x, p=self.dropouts[idx], training=self.training)
         if self.plain_last and start <= n_hidden:
             last = self.lins[-1]
-            x = ops.linear_bn_act(x, last.weight, last.bias, None, self.training, None)
+            fuse = post is not None and self.dropouts[-1] == 0.0
+            x = ops.linear_bn_act(x, last.weight, last.bias, None, self.training, None, post=post if fuse else None)
+            if fuse:
+                return x
             if self.dropouts[-1] > 0.0:
                 x = F.dropout(x, p=self.dropouts[-1], training=self.training)
-        return x
+        return x if post is None else ops.CGMax.apply(x, *post)
 
     def __repr__(self):
         return "MLP(%s)" % ", ".join(str(c) for c in self.channel_list)

@@ -848,7 +848,10 @@ class LinearBNActH(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum, grad_on, out16,
-                x_f16_bits=False):
+                x_f16_bits=False, post=None):
+        # post = (grp_ptr, rep_row, n points): the compact-row SGCNN max (CGMax) applied to the product inside this function --
+        # the (rows, N) product never reaches autograd, so its gradient can be written as bf16 rows straight by the max's
+        # backward (ccn_cg_max_bwd_h) instead of fp32 rows + ccn_cast_rows_h.  Plain (no BatchNorm) layers only.
         # x_f16_bits: ``x`` is a 16-bit activation of the fp16 mode -- fp16 bit patterns in a tensor TYPED bfloat16, so that
         # autograd hands its gradient over as bf16 (an fp16-typed tensor would get an fp16 gradient: out of range)
         require_gpu(x, weight)
@@ -879,10 +882,21 @@ class LinearBNActH(torch.autograd.Function):
             if m:
                 call("gemm_nt_h", ptr(x16), _ld(x16), ptr(w16), _ld(w16), ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats), f16, 0)
 
+        ctx.post = None
         if not has_bn:
             product(None)
+            if post is not None:
+                grp_ptr, rep_row, n_pts = post
+                out = _rows(n_pts, n, dev)
+                arg = torch.empty((n_pts, n), dtype=torch.int32, device=dev)
+                call("cg_max_fwd", ptr(y), _ld(y), ptr(grp_ptr), ptr(rep_row), n_pts, n, ptr(out), _ld(out), ptr(arg))
+                ctx.post = n_pts
+                ctx.save_for_backward(x16, weight, arg, grp_ptr, rep_row)
+                return out
             ctx.save_for_backward(x16, weight)
             return y
+        if post is not None:
+            raise ValueError("LinearBNActH: a fused max follows plain layers only")
         par = torch.empty((4, n), dtype=torch.float32, device=dev)      # scale, shift, mean, rstd
         if training:
             if m < 2:
@@ -941,6 +955,12 @@ class LinearBNActH(torch.autograd.Function):
                 dgamma, dbeta = _main_grad_done(refs[0]), _main_grad_done(refs[1])
             else:
                 dgamma, dbeta = gview, bview
+        elif ctx.post is not None:
+            x16, weight, arg, grp_ptr, rep_row = ctx.saved_tensors
+            sums = par = None
+            g = _mat(g.float() if g.dtype != torch.float32 else g)
+            dy16 = _rows16(m, n, dev)
+            call("cg_max_bwd_h", ptr(g), _ld(g), ptr(arg), ptr(grp_ptr), ptr(rep_row), ctx.post, m, n, ptr(dy16), _ld(dy16))
         else:
             x16, weight = ctx.saved_tensors
             sums = par = None
@@ -978,11 +998,12 @@ class LinearBNActH(torch.autograd.Function):
                 # running statistics it is scale * sum(g act'): both from the column sums of the first pass
                 db = torch.zeros(n, dtype=torch.float32, device=dev) if ctx.training else par[0] * sums[:n].float()
             else:
+                # (behind a fused max every (point, channel) gradient lands on exactly one row: same column sums)
                 gf = _mat(g.float()) if g.dtype != torch.float32 else _mat(g)
-                acc = _stats_buffer(m, n, dev)
+                acc = _stats_buffer(gf.size(0), n, dev)
                 db = torch.empty(n, dtype=torch.float32, device=dev)
-                call("colsum", ptr(gf), _ld(gf), m, n, ptr(acc), ptr(db))
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+                call("colsum", ptr(gf), _ld(gf), gf.size(0), n, ptr(acc), ptr(db))
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 # A hidden MLP layer whose only consumer is the next Linear of the same MLP hands over its PRE-normalisation product; the
@@ -996,14 +1017,23 @@ LAZY_ACT_COUNT = {"fused": 0, "written": 0}      # deferred inputs consumed by t
 LAZY_ACT_LOG = None                               # diagnostics: a list collects (rows, N, K, fused) per deferred input
 
 
-def linear_bn_act(x, weight, bias, bn, training, act, defer=False):
+def linear_bn_act(x, weight, bias, bn, training, act, defer=False, post=None):
     """bn: a torch.nn.BatchNorm1d used as parameter/buffer container, or None.  ``defer``: the caller feeds the result to
-    another linear_bn_act and nothing else (nn.MLP); the result may then be a deferred activation (see LAZY_ACT)."""
+    another linear_bn_act and nothing else (nn.MLP); the result may then be a deferred activation (see LAZY_ACT).
+    ``post`` = (grp_ptr, rep_row, n, row_src): the result is CGMax of the layer's output (plain layers; fused into the
+    layer's autograd function in the 16-bit storage modes, see LinearBNActH)."""
     grad_on = torch.is_grad_enabled()
+    if post is not None:
+        if bn is not None:
+            raise ValueError("linear_bn_act: a max follows plain layers only")
+        if not (EDGE_OUT16 and _MLP_DTYPE in ("bf16", "fp16") and STORE16 and x.dim() == 2 and x.size(0) > 0
+                and MAX_TRACE is None and weight.size(0) % 8 == 0):
+            return CGMax.apply(linear_bn_act(x, weight, bias, None, training, act), *post)
     if _MLP_DTYPE in ("bf16", "fp16") and STORE16 and x.dim() == 2 and x.size(0) > 0:
         xbits = bool(getattr(x, "_ccn_f16_bits", False))
         if bn is None:
-            return LinearBNActH.apply(x, weight, bias, None, None, None, None, False, None, 0.0, 0.0, grad_on, False, xbits)
+            return LinearBNActH.apply(x, weight, bias, None, None, None, None, False, None, 0.0, 0.0, grad_on, False, xbits,
+                                      post[:3] if post is not None else None)
         if training and bn.track_running_stats:
             bn.num_batches_tracked += 1
         use_batch_stats = training or not bn.track_running_stats

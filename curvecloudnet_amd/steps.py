@@ -570,10 +570,11 @@ class SGCNNLayer(nn.Module):
                 feat = ops.cg_edge_layer(ps, comp, self.nn.norms[0].module if hidden0 else None, self.training,
                                          self.nn.act if hidden0 else None,
                                          out16=len(self.nn.norms) == 1 and ops.edge_out16(self.nn, lin0.weight.size(0)))
-                feat = self.nn(feat, start=1, tail=(comp.e, comp.row_w, comp.count))
+                # (the max over a point's rows is handed to the MLP: its plain last layer fuses it in the 16-bit storage modes)
+                return self.nn(feat, start=1, tail=(comp.e, comp.row_w, comp.count),
+                               post=(comp.grp_ptr, comp.rep_row, topo.n, comp.row_src))
             finally:
                 ops.ACT_ROW_MAP = None
-            return ops.CGMax.apply(feat, comp.grp_ptr, comp.rep_row, topo.n, comp.row_src)
         if algebraic:
             # first layer in algebraic form: two per-point products + a gather-add instead of a GEMM over
             # 21x the rows (ops.SGEdgeLayer); exact up to fp32 re-association

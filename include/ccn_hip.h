@@ -421,6 +421,9 @@ int ccn_cg_max_fwd(const float* f, int64_t ldf, const int32_t* grp_ptr, const in
                    float* out, int64_t ldo, int32_t* arg, void* stream);
 int ccn_cg_max_bwd(const float* dout, int64_t lddo, const int32_t* arg, const int32_t* grp_ptr, const int32_t* rep_row,
                    int64_t N, int64_t R, int64_t C, float* df, int64_t lddf, void* stream);
+/* ... df written as bf16 rows (round 3, 16-bit storage modes): dY of the plain Linear in front of the max (dgcnn.py:172-181). */
+int ccn_cg_max_bwd_h(const float* dout, int64_t lddo, const int32_t* arg, const int32_t* grp_ptr, const int32_t* rep_row,
+                     int64_t N, int64_t R, int64_t C, void* df, int64_t lddf, void* stream);
 /* w == NULL: all weights 1 (plain column sums of x and x^2) */
 int ccn_colstats_weighted(const float* X, int64_t ldx, const float* w, int64_t rows, int64_t C, double* acc,
                           void* stream);

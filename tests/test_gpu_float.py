@@ -747,6 +747,8 @@ def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
     torch.manual_seed(0)
     if which == "sgcnn":
         mod = steps.SGCNNLayer(MLP([2 * (c + 3), 40, 24], bias=False), 12, r=0.05, with_xyz=True)
+        # (a bias on the plain last layer: its gradient behind the fused max = column sums of the max's own gradient)
+        mod.nn.lins[-1].bias = torch.nn.Parameter(torch.randn(24, generator=torch.Generator().manual_seed(3)) * 0.1)
     else:
         att = MLP([24, 16, 24], act="leaky_relu", bias=False) if which == "sa-attend" else None
         mod = steps.SAModule(0.5, 0.06, MLP([c + 3, 40, 32, 24], bias=False), 16, downsample_type="curve-fps",
@@ -778,6 +780,9 @@ def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
     assert kind + "_edge_apply_h" in calls[0] and kind + "_edge_bwd_h" in calls[0] and kind + "_edge_bwd_stats_h" in calls[0]
     assert kind + "_edge_apply" in calls[1] and kind + "_edge_bwd" in calls[1]
     assert calls[0].count("cast_rows_h") < calls[1].count("cast_rows_h")
+    if which == "sgcnn":      # ... and the max over a point's rows hands its gradient to the plain last layer as bf16 rows
+        assert "cg_max_bwd_h" in calls[0] and "cg_max_bwd" not in calls[0] and "cg_max_bwd" in calls[1]
+        assert calls[0].count("cast_rows_h") <= calls[1].count("cast_rows_h") - 2
     assert torch.equal(res[0][0], res[1][0]), "forward must not change: same fp32 value, same rounding"
     for a, b in zip(res[0][1:], res[1][1:]):
         err = float((a - b).norm() / b.norm().clamp_min(1e-20))
