@@ -973,12 +973,13 @@ __global__ __launch_bounds__(TPB) void seg_softmax_agg_fwd_kernel(const float* _
   }
 }
 
+template <int T>     // T = 1: datt as bf16 rows (16-bit storage modes: dY of the plain Linear that produced att)
 __global__ __launch_bounds__(TPB) void seg_softmax_agg_bwd_kernel(const float* __restrict__ msg, int64_t ldm,
                                                                   const float* __restrict__ att, int64_t lda,
                                                                   const int32_t* __restrict__ offsets, int64_t M,
                                                                   int C, const float* __restrict__ dout,
                                                                   int64_t lddo, float* __restrict__ dmsg,
-                                                                  int64_t lddm, float* __restrict__ datt,
+                                                                  int64_t lddm, void* __restrict__ datt,
                                                                   int64_t ldda) {
   CCN_LANES;
   const int64_t i = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
@@ -1013,13 +1014,13 @@ __global__ __launch_bounds__(TPB) void seg_softmax_agg_bwd_kernel(const float* _
       for (int u = 0; u < 4; ++u) {
         const float w = __expf(a[u] - s.top) * inv;
         dmsg[(int64_t)(e + u) * lddm + c] = w * g;
-        datt[(int64_t)(e + u) * ldda + c] = w * (v[u] * g - dot);
+        st_el<T>(datt, (int64_t)(e + u) * ldda + c, w * (v[u] * g - dot));
       }
     }
     for (; e < hi; ++e) {
       const float w = __expf(att[(int64_t)e * lda + c] - s.top) * inv;
       dmsg[(int64_t)e * lddm + c] = w * g;
-      datt[(int64_t)e * ldda + c] = w * (msg[(int64_t)e * ldm + c] * g - dot);
+      st_el<T>(datt, (int64_t)e * ldda + c, w * (msg[(int64_t)e * ldm + c] * g - dot));
     }
   }
 }
@@ -1810,9 +1811,24 @@ int ccn_seg_softmax_agg_bwd(const float* msg, int64_t ldm, const float* att, int
                   lda >= C && lddm >= C && ldda >= C,
               "seg_softmax_agg_bwd: bad arguments");
   if (M == 0) return CCN_OK;
-  hipLaunchKernelGGL(seg_softmax_agg_bwd_kernel, dim3(row_blocks(M)), dim3(TPB), 0, (hipStream_t)stream, msg, ldm, att,
+  hipLaunchKernelGGL(seg_softmax_agg_bwd_kernel<0>, dim3(row_blocks(M)), dim3(TPB), 0, (hipStream_t)stream, msg, ldm, att,
                      lda, offsets, M, (int)C, dout, lddo, dmsg, lddm, datt, ldda);
   CCN_LAUNCH_OK("seg_softmax_agg_bwd");
+  return CCN_OK;
+}
+
+// ... datt as bf16 rows (C % 8 == 0, ldda in 16-bit elements): the dY operand of the backward products of the plain Linear
+// that produced att (attend_nn's last layer)
+int ccn_seg_softmax_agg_bwd_h(const float* msg, int64_t ldm, const float* att, int64_t lda, const int32_t* offsets,
+                              int64_t M, int64_t C, const float* dout, int64_t lddo, float* dmsg, int64_t lddm,
+                              void* datt, int64_t ldda, void* stream) {
+  CCN_REQUIRE(msg && att && offsets && dout && dmsg && datt && CCN_SMALL_INT(C) && lddo >= C && ldm >= C &&
+                  lda >= C && lddm >= C && ldda >= C && C % 8 == 0 && ldda % 8 == 0 && ((uintptr_t)datt & 15) == 0,
+              "seg_softmax_agg_bwd_h: bad arguments");
+  if (M == 0) return CCN_OK;
+  hipLaunchKernelGGL(seg_softmax_agg_bwd_kernel<1>, dim3(row_blocks(M)), dim3(TPB), 0, (hipStream_t)stream, msg, ldm, att,
+                     lda, offsets, M, (int)C, dout, lddo, dmsg, lddm, datt, ldda);
+  CCN_LAUNCH_OK("seg_softmax_agg_bwd_h");
   return CCN_OK;
 }
 

@@ -381,6 +381,29 @@ __global__ __launch_bounds__(EW_TPB) void cast_rows_h_kernel(const float* __rest
   }
 }
 
+// bf16(A + B): the gradient of a product that left as fp32 rows AND as a 16-bit copy (LinearBNActH, dual output) -- the fp32
+// gradient of the one and the bf16 gradient of the other become the dY rows of the backward products in one pass
+__global__ __launch_bounds__(EW_TPB) void add_cast_rows_h_kernel(const float* __restrict__ A, int64_t lda,
+                                                                 const u16* __restrict__ B, int64_t ldb, int64_t rows, int64_t C,
+                                                                 u16* __restrict__ Y, int64_t ldy, int cpb, int rpp) {
+  const int ch = threadIdx.x % cpb, rr = threadIdx.x / cpb;
+  const int64_t c0 = ((int64_t)blockIdx.y * cpb + ch) * 8;
+  if (rr >= rpp || c0 >= ldy) return;
+  const bool full = c0 + 8 <= C;
+  const bool avec = full && (lda & 3) == 0 && ((uintptr_t)A & 15) == 0;
+  const bool bvec = full && (ldb & 7) == 0 && ((uintptr_t)B & 15) == 0;
+  const int64_t r0 = (int64_t)blockIdx.x * EW_ROWS;
+  const int64_t r1 = r0 + EW_ROWS < rows ? r0 + EW_ROWS : rows;
+  for (int64_t r = r0 + rr; r < r1; r += rpp) {
+    float a[8], b[8];
+    load8(A + r * lda + c0, avec, c0, C, a);
+    load8h(B + r * ldb + c0, bvec, c0, C, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = c0 + e < C ? a[e] + b[e] : 0.f;
+    store8h<false>(Y + r * ldy + c0, a);
+  }
+}
+
 // fp16 rows -> bf16 rows (the fp16 mode keeps its activations as fp16 rows for the forward products; the weight-gradient
 // product, a bf16 product, takes bf16(fp16(x))): 8 elements per thread and row, same walk as the casts above
 __global__ __launch_bounds__(EW_TPB) void f16_to_bf16_rows_kernel(const u16* __restrict__ X, int64_t ldx, int64_t rows, int64_t C,
@@ -938,6 +961,18 @@ int ccn_cast_rows_h(const float* X, int64_t ldx, int64_t rows, int64_t C, void* 
   if (f16) hipLaunchKernelGGL(cast_rows_h_kernel<true>, grid, dim3(EW_TPB), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy, g.cpb, g.rpp);
   else hipLaunchKernelGGL(cast_rows_h_kernel<false>, grid, dim3(EW_TPB), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy, g.cpb, g.rpp);
   CCN_LAUNCH_OK("cast_rows_h");
+  return CCN_OK;
+}
+
+int ccn_add_cast_rows_h(const float* A, int64_t lda, const void* B, int64_t ldb, int64_t rows, int64_t C, void* Y, int64_t ldy,
+                        void* stream) {
+  CCN_REQUIRE(A && B && Y && rows >= 0 && C > 0 && lda >= C && ldb >= C && ldy >= C && ldy % 8 == 0 && aligned16(Y),
+              "add_cast_rows_h: bad arguments");
+  if (rows == 0) return CCN_OK;
+  const EwGeom g = ew_geom(ldy);
+  hipLaunchKernelGGL(add_cast_rows_h_kernel, dim3((unsigned)ccn_blocks(rows, EW_ROWS), g.gy), dim3(EW_TPB), 0, (hipStream_t)stream,
+                     A, lda, (const u16*)B, ldb, rows, C, (u16*)Y, ldy, g.cpb, g.rpp);
+  CCN_LAUNCH_OK("add_cast_rows_h");
   return CCN_OK;
 }
 

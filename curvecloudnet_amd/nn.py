@@ -57,12 +57,13 @@ class MLP(nn.Module):
     def out_channels(self):
         return self.channel_list[-1]
 
-    def forward(self, x, start=0, tail=None, post=None):
+    def forward(self, x, start=0, tail=None, post=None, post_x=None, dual=False):
         """``start`` > 0 resumes after the first ``start`` layers (a caller computed them in fused form).
         ``tail`` = (first weighted row, weights, total count): the rows from that index on stand for several identical
         rows each (compact SGCNN rows, ops.LinearBNActTail); the final plain layer needs no weights.
-        ``post`` = (grp_ptr, rep_row, n, row_src): return ops.CGMax of the MLP's output (handed to the plain last layer, which
-        can produce the max's gradient in the form its own backward products read: ops.linear_bn_act)."""
+        ``post`` (+ ``post_x``): return that reduction of the MLP's output (ops.apply_post; handed to the plain last layer, which
+        can produce the reduction's gradient in the form its own backward products read: ops.linear_bn_act).
+        ``dual``: return (output, its 16-bit copy or None) -- see ops.linear_bn_act."""
         n_hidden = len(self.norms)
         for idx, (lin, norm) in enumerate(zip(self.lins, self.norms)):
             if idx < start:
@@ -79,13 +80,14 @@ class MLP(nn.Module):
                 x = F.dropout(x, p=self.dropouts[idx], training=self.training)
         if self.plain_last and start <= n_hidden:
             last = self.lins[-1]
-            fuse = post is not None and self.dropouts[-1] == 0.0
-            x = ops.linear_bn_act(x, last.weight, last.bias, None, self.training, None, post=post if fuse else None)
-            if fuse:
-                return x
+            if (post is not None or dual) and self.dropouts[-1] == 0.0:
+                return ops.linear_bn_act(x, last.weight, last.bias, None, self.training, None, post=post, post_x=post_x, dual=dual)
+            x = ops.linear_bn_act(x, last.weight, last.bias, None, self.training, None)
             if self.dropouts[-1] > 0.0:
                 x = F.dropout(x, p=self.dropouts[-1], training=self.training)
-        return x if post is None else ops.CGMax.apply(x, *post)
+        if dual:
+            return x, None
+        return x if post is None else ops.apply_post(x, post, post_x)
 
     def __repr__(self):
         return "MLP(%s)" % ", ".join(str(c) for c in self.channel_list)

@@ -848,10 +848,15 @@ class LinearBNActH(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum, grad_on, out16,
-                x_f16_bits=False, post=None):
-        # post = (grp_ptr, rep_row, n points): the compact-row SGCNN max (CGMax) applied to the product inside this function --
-        # the (rows, N) product never reaches autograd, so its gradient can be written as bf16 rows straight by the max's
-        # backward (ccn_cg_max_bwd_h) instead of fp32 rows + ccn_cast_rows_h.  Plain (no BatchNorm) layers only.
+                x_f16_bits=False, post=None, post_x=None, dual=False):
+        # Plain (no BatchNorm) layers only:
+        # post = ("max", grp_ptr, rep_row, n points) / ("attend", offsets, n destinations) with post_x = the messages: the
+        #   reduction that follows the layer (CGMax / SegSoftmaxAgg) applied inside this function -- the (rows, N) product never
+        #   reaches autograd, so its gradient is written as bf16 rows straight by the reduction's backward (ccn_cg_max_bwd_h,
+        #   ccn_seg_softmax_agg_bwd_h) instead of fp32 rows + ccn_cast_rows_h.
+        # dual: the product leaves as fp32 rows AND as a 16-bit copy (PointNetConv2's messages: the aggregation reads the
+        #   former, attend_nn the latter); backward turns the two gradients into dY rows in one pass (ccn_add_cast_rows_h)
+        #   where autograd would add two fp32 tensors and this function would cast the sum.
         # x_f16_bits: ``x`` is a 16-bit activation of the fp16 mode -- fp16 bit patterns in a tensor TYPED bfloat16, so that
         # autograd hands its gradient over as bf16 (an fp16-typed tensor would get an fp16 gradient: out of range)
         require_gpu(x, weight)
@@ -882,21 +887,35 @@ class LinearBNActH(torch.autograd.Function):
             if m:
                 call("gemm_nt_h", ptr(x16), _ld(x16), ptr(w16), _ld(w16), ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats), f16, 0)
 
-        ctx.post = None
+        ctx.post, ctx.dual = None, False
         if not has_bn:
             product(None)
-            if post is not None:
-                grp_ptr, rep_row, n_pts = post
+            if post is not None and post[0] == "max":
+                _, grp_ptr, rep_row, n_pts = post
                 out = _rows(n_pts, n, dev)
                 arg = torch.empty((n_pts, n), dtype=torch.int32, device=dev)
                 call("cg_max_fwd", ptr(y), _ld(y), ptr(grp_ptr), ptr(rep_row), n_pts, n, ptr(out), _ld(out), ptr(arg))
-                ctx.post = n_pts
+                ctx.post = ("max", n_pts)
                 ctx.save_for_backward(x16, weight, arg, grp_ptr, rep_row)
                 return out
+            if post is not None:
+                _, offsets, n_dst = post
+                msg = _mat(post_x)
+                if tuple(msg.shape) != (m, n):
+                    raise ValueError("attend: messages %s against scores (%d, %d)" % (tuple(msg.shape), m, n))
+                out = _rows(n_dst, n, dev)
+                call("seg_softmax_agg_fwd", ptr(msg), _ld(msg), ptr(y), _ld(y), ptr(offsets), n_dst, n, ptr(out), _ld(out))
+                ctx.post = ("attend", n_dst)
+                ctx.save_for_backward(x16, weight, msg, y, offsets)
+                return out
             ctx.save_for_backward(x16, weight)
+            if dual:
+                ctx.dual = True
+                y16 = _cast16(y, fdt)
+                return y, (y16.view(torch.bfloat16) if f16 else y16)
             return y
-        if post is not None:
-            raise ValueError("LinearBNActH: a fused max follows plain layers only")
+        if post is not None or dual:
+            raise ValueError("LinearBNActH: a fused reduction / a dual output follows plain layers only")
         par = torch.empty((4, n), dtype=torch.float32, device=dev)      # scale, shift, mean, rstd
         if training:
             if m < 2:
@@ -920,10 +939,10 @@ class LinearBNActH(torch.autograd.Function):
         return z
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_copy=None):
         m, n, k = ctx.shape
-        dev = g.device
-        dgamma = dbeta = None
+        dev = ctx.saved_tensors[1].device
+        dgamma = dbeta = dpost = None
         if ctx.has_bn:
             x16, weight, y, par = ctx.saved_tensors
             g16 = g.dtype == torch.bfloat16
@@ -955,16 +974,33 @@ class LinearBNActH(torch.autograd.Function):
                 dgamma, dbeta = _main_grad_done(refs[0]), _main_grad_done(refs[1])
             else:
                 dgamma, dbeta = gview, bview
-        elif ctx.post is not None:
+        elif ctx.post is not None and ctx.post[0] == "max":
             x16, weight, arg, grp_ptr, rep_row = ctx.saved_tensors
             sums = par = None
             g = _mat(g.float() if g.dtype != torch.float32 else g)
             dy16 = _rows16(m, n, dev)
-            call("cg_max_bwd_h", ptr(g), _ld(g), ptr(arg), ptr(grp_ptr), ptr(rep_row), ctx.post, m, n, ptr(dy16), _ld(dy16))
+            call("cg_max_bwd_h", ptr(g), _ld(g), ptr(arg), ptr(grp_ptr), ptr(rep_row), ctx.post[1], m, n, ptr(dy16), _ld(dy16))
+        elif ctx.post is not None:
+            x16, weight, msg, att, offsets = ctx.saved_tensors
+            sums = par = None
+            g = _mat(g.float() if g.dtype != torch.float32 else g)
+            dy16, dpost = _rows16(m, n, dev), _rows(m, n, dev)
+            call("seg_softmax_agg_bwd_h", ptr(msg), _ld(msg), ptr(att), _ld(att), ptr(offsets), ctx.post[1], n, ptr(g), _ld(g),
+                 ptr(dpost), _ld(dpost), ptr(dy16), _ld(dy16))
         else:
             x16, weight = ctx.saved_tensors
             sums = par = None
-            dy16 = _cast16(g)
+            if ctx.dual and g is not None and g_copy is not None:
+                # gradient of the fp32 rows + gradient of their 16-bit copy -> dY rows, one pass
+                ga = _mat(g.float() if g.dtype != torch.float32 else g)
+                gb = g_copy if _is_rows16(g_copy) else _cast16(g_copy.float())
+                dy16 = _rows16(m, n, dev)
+                call("add_cast_rows_h", ptr(ga), _ld(ga), ptr(gb), _ld(gb), m, n, ptr(dy16), _ld(dy16))
+                g = None            # (a bias gradient below takes its column sums from dY)
+            else:
+                if g is None:
+                    g = g_copy
+                dy16 = _cast16(g)
         dx = None
         if ctx.needs_input_grad[0]:
             wt16 = _rows16(k, n, dev)
@@ -998,12 +1034,19 @@ class LinearBNActH(torch.autograd.Function):
                 # running statistics it is scale * sum(g act'): both from the column sums of the first pass
                 db = torch.zeros(n, dtype=torch.float32, device=dev) if ctx.training else par[0] * sums[:n].float()
             else:
-                # (behind a fused max every (point, channel) gradient lands on exactly one row: same column sums)
-                gf = _mat(g.float()) if g.dtype != torch.float32 else _mat(g)
-                acc = _stats_buffer(gf.size(0), n, dev)
-                db = torch.empty(n, dtype=torch.float32, device=dev)
-                call("colsum", ptr(gf), _ld(gf), gf.size(0), n, ptr(acc), ptr(db))
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+                if ctx.post is not None and ctx.post[0] == "attend":
+                    # a per-channel shift of the scores leaves every group's softmax unchanged: this gradient is identically
+                    # zero (the column sums of datt are rounding noise, 1e-5 of the weight gradient's size in fp32)
+                    db = torch.zeros(n, dtype=torch.float32, device=dev)
+                else:
+                    # (behind a fused max every (point, channel) gradient lands on exactly one row: same column sums; for the
+                    # sum of two gradients they are taken from dY itself)
+                    src = g if g is not None else dy16[:, :n]
+                    gf = _mat(src.float()) if src.dtype != torch.float32 else _mat(src)
+                    acc = _stats_buffer(gf.size(0), n, dev)
+                    db = torch.empty(n, dtype=torch.float32, device=dev)
+                    call("colsum", ptr(gf), _ld(gf), gf.size(0), n, ptr(acc), ptr(db))
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, dpost, None
 
 
 # A hidden MLP layer whose only consumer is the next Linear of the same MLP hands over its PRE-normalisation product; the
@@ -1017,23 +1060,36 @@ LAZY_ACT_COUNT = {"fused": 0, "written": 0}      # deferred inputs consumed by t
 LAZY_ACT_LOG = None                               # diagnostics: a list collects (rows, N, K, fused) per deferred input
 
 
-def linear_bn_act(x, weight, bias, bn, training, act, defer=False, post=None):
+def apply_post(y, post, post_x=None):
+    """The reduction a ``post`` tuple names, as its own autograd function: ("max", grp_ptr, rep_row, n, row_src) = CGMax of
+    ``y``; ("attend", offsets, n destinations) = SegSoftmaxAgg of the messages ``post_x`` with scores ``y``."""
+    if post[0] == "max":
+        return CGMax.apply(y, *post[1:])
+    return SegSoftmaxAgg.apply(post_x, y, post[1], post[2], True)
+
+
+def linear_bn_act(x, weight, bias, bn, training, act, defer=False, post=None, post_x=None, dual=False):
     """bn: a torch.nn.BatchNorm1d used as parameter/buffer container, or None.  ``defer``: the caller feeds the result to
     another linear_bn_act and nothing else (nn.MLP); the result may then be a deferred activation (see LAZY_ACT).
-    ``post`` = (grp_ptr, rep_row, n, row_src): the result is CGMax of the layer's output (plain layers; fused into the
-    layer's autograd function in the 16-bit storage modes, see LinearBNActH)."""
+    ``post`` (see apply_post): the result is that reduction of the layer's output; ``dual``: the result is the pair
+    (output, its 16-bit copy or None).  Plain layers only; both are fused into the layer's autograd function in the 16-bit
+    storage modes (LinearBNActH) and are separate functions / absent otherwise."""
     grad_on = torch.is_grad_enabled()
-    if post is not None:
+    if post is not None or dual:
         if bn is not None:
-            raise ValueError("linear_bn_act: a max follows plain layers only")
+            raise ValueError("linear_bn_act: a reduction / a 16-bit copy follows plain layers only")
         if not (EDGE_OUT16 and _MLP_DTYPE in ("bf16", "fp16") and STORE16 and x.dim() == 2 and x.size(0) > 0
-                and MAX_TRACE is None and weight.size(0) % 8 == 0):
-            return CGMax.apply(linear_bn_act(x, weight, bias, None, training, act), *post)
+                and MAX_TRACE is None and ACT_TRACE is None and weight.size(0) % 8 == 0):
+            y = linear_bn_act(x, weight, bias, None, training, act)
+            return (y, None) if dual else apply_post(y, post, post_x)
     if _MLP_DTYPE in ("bf16", "fp16") and STORE16 and x.dim() == 2 and x.size(0) > 0:
         xbits = bool(getattr(x, "_ccn_f16_bits", False))
         if bn is None:
-            return LinearBNActH.apply(x, weight, bias, None, None, None, None, False, None, 0.0, 0.0, grad_on, False, xbits,
-                                      post[:3] if post is not None else None)
+            out = LinearBNActH.apply(x, weight, bias, None, None, None, None, False, None, 0.0, 0.0, grad_on, False, xbits,
+                                     post[:4] if post is not None and post[0] == "max" else post, post_x, bool(dual))
+            if dual and _MLP_DTYPE == "fp16":
+                out[1]._ccn_f16_bits = True
+            return out
         if training and bn.track_running_stats:
             bn.num_batches_tracked += 1
         use_batch_stats = training or not bn.track_running_stats

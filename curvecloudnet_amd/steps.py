@@ -338,6 +338,10 @@ class PointNetConv2(nn.Module):
         x_src = x[0] if isinstance(x, tuple) else x
         pos_src, pos_dst = pos if isinstance(pos, tuple) else (pos, pos)
         nn0 = self.local_nn
+        # softmax attention: the messages go to attend_nn AND to the aggregation -- in the 16-bit storage modes the plain last
+        # layer of local_nn hands out fp32 rows for the one and a 16-bit copy for the other (ops.linear_bn_act, dual)
+        attend = self.aggr_type not in ("max", "mean", "weighted-sum")
+        msg16 = None
         if (nn0 is not None and x_src is not None and not self.force_edge_gemm and nn0.dropout == 0.0
                 and edges.num_edges > 0):
             # first layer in algebraic form: one product per SOURCE POINT + a gather pass per edge (ops.PNEdgeLayer)
@@ -349,11 +353,13 @@ class PointNetConv2(nn.Module):
             msg = ops.pn_edge_layer(px, lin0.weight[:, c:], lin0.bias, pos_src, pos_dst, edges, self.normalize_radius,
                                     nn0.norms[0].module if hidden0 else None, self.training, nn0.act if hidden0 else None,
                                     out16=ops.edge_out16(nn0, lin0.weight.size(0)))
-            msg = nn0(msg, start=1)
+            msg = nn0(msg, start=1, dual=attend)
         else:
             msg = ops.MessageBuild.apply(x_src, pos_src, pos_dst, edges.col, edges.row, self.normalize_radius)
             if nn0 is not None:
-                msg = nn0(msg)
+                msg = nn0(msg, dual=attend)
+        if isinstance(msg, tuple):
+            msg, msg16 = msg
         if self.aggr_type == "max":
             out = ops.SegMax.apply(msg, edges.offsets, edges.num_dst, edges.col)
         elif self.aggr_type == "mean":
@@ -361,7 +367,8 @@ class PointNetConv2(nn.Module):
         elif self.aggr_type == "weighted-sum":
             out = ops.SegWSum.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst, 1)
         else:
-            out = ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst, True)
+            # (the aggregation is handed to attend_nn: its plain last layer fuses it in the 16-bit storage modes)
+            out = self.attend_nn(msg16 if msg16 is not None else msg, post=("attend", edges.offsets, edges.num_dst), post_x=msg)
         if self.global_nn is not None:
             out = self.global_nn(out)
         return out
@@ -548,11 +555,14 @@ class SGCNNLayer(nn.Module):
             # message nn([x_i, x_j - x_i]), per-query max or softmax-attention over the CSR groups (BatchNorm sees the
             # real edges only)
             edges = g.edges
-            msg = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row))
             if self.aggr_type == "max":
+                msg = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row))
                 return ops.SegMax.apply(msg, edges.offsets, edges.num_dst, edges.col)
-            # ref dgcnn.py:239-244: every other aggr_type takes the softmax-attention branch
-            return ops.SegSoftmaxAgg.apply(msg, self.attend_nn(msg), edges.offsets, edges.num_dst, True)
+            # ref dgcnn.py:239-244: every other aggr_type takes the softmax-attention branch (messages as fp32 rows for the
+            # aggregation + a 16-bit copy for attend_nn, aggregation fused into attend_nn's last layer: see PointNetConv2)
+            msg, msg16 = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row), dual=True)
+            return self.attend_nn(msg16 if msg16 is not None else msg, post=("attend", edges.offsets, edges.num_dst),
+                                  post_x=msg)
         topo, nbr, comp = g.topo, g.nbr, g.comp
         algebraic, _ = self._mode()
         lin0 = self.nn.lins[0]
@@ -572,7 +582,7 @@ class SGCNNLayer(nn.Module):
                                          out16=len(self.nn.norms) == 1 and ops.edge_out16(self.nn, lin0.weight.size(0)))
                 # (the max over a point's rows is handed to the MLP: its plain last layer fuses it in the 16-bit storage modes)
                 return self.nn(feat, start=1, tail=(comp.e, comp.row_w, comp.count),
-                               post=(comp.grp_ptr, comp.rep_row, topo.n, comp.row_src))
+                               post=("max", comp.grp_ptr, comp.rep_row, topo.n, comp.row_src))
             finally:
                 ops.ACT_ROW_MAP = None
         if algebraic:

@@ -260,6 +260,9 @@ int ccn_gemm_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, floa
 /* fp32 rows -> 16-bit rows (round to nearest even), padding columns [C, ldy) zeroed; W (N x K fp32) -> W^T (K x N 16-bit) */
 int ccn_cast_rows_h(const float* X, int64_t ldx, int64_t rows, int64_t C, void* Y, int64_t ldy, int f16, void* stream);
 int ccn_transpose_cast_h(const float* W, int64_t ldw, int64_t N, int64_t K, void* Wt, int64_t ldt, int f16, void* stream);
+/* Y = bf16(A + B), A fp32 rows, B bf16 rows: the two gradients of a product that left as fp32 rows and as a 16-bit copy */
+int ccn_add_cast_rows_h(const float* A, int64_t lda, const void* B, int64_t ldb, int64_t rows, int64_t C, void* Y, int64_t ldy,
+                        void* stream);
 /* fp16 rows -> bf16 rows (the fp16 mode's weight-gradient operand: bf16(fp16(x))) */
 int ccn_f16_to_bf16_rows(const void* X, int64_t ldx, int64_t rows, int64_t C, void* Y, int64_t ldy, void* stream);
 /* ccn_bn_act_fwd writing z as 16-bit rows; ccn_bn_act_bwd_reduce reading a bf16 dZ; ccn_bn_act_bwd_apply_ex reading an fp32
@@ -361,6 +364,10 @@ int ccn_seg_softmax_agg_fwd(const float* msg, int64_t ldm, const float* att, int
 int ccn_seg_softmax_agg_bwd(const float* msg, int64_t ldm, const float* att, int64_t lda, const int32_t* offsets,
                             int64_t M, int64_t C, const float* dout, int64_t lddo, float* dmsg, int64_t lddm,
                             float* datt, int64_t ldda, void* stream);
+/* ... datt written as bf16 rows (round 3, 16-bit storage modes): dY of attend_nn's plain last Linear (point_conv.py:89-92). */
+int ccn_seg_softmax_agg_bwd_h(const float* msg, int64_t ldm, const float* att, int64_t lda, const int32_t* offsets,
+                              int64_t M, int64_t C, const float* dout, int64_t lddo, float* dmsg, int64_t lddm,
+                              void* datt, int64_t ldda, void* stream);
 /* scatter_max (point_conv.py:81-82): empty groups give 0. */
 int ccn_seg_max_fwd(const float* msg, int64_t ldm, const int32_t* offsets, int64_t M, int64_t C, float* out,
                     int64_t ldo, int32_t* arg, void* stream);
