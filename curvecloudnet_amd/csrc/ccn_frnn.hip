@@ -94,7 +94,9 @@ __global__ __launch_bounds__(BUILD_TPB) void grid_insert_kernel(const float* __r
   if (!SCATTER) {
     atomicAdd(&cell_fill[slot], 1);
   } else {
-    const int32_t at = cell_start[slot] + atomicAdd(&cell_fill[slot], 1);
+    // (the counters of the first pass are counted DOWN: every point of a bucket gets a distinct slot cnt-1 .. 0 without a
+    // second clearing of the table between the passes; the order inside a bucket is arbitrary either way)
+    const int32_t at = cell_start[slot] + atomicSub(&cell_fill[slot], 1) - 1;
     sorted_pts[at] = make_float4(x, y, z, __int_as_float((int)j));
   }
 }
@@ -403,7 +405,6 @@ int ccn_frnn_grid_build(const float* points2, const int64_t* lengths2, const flo
                      (const int32_t*)nullptr, g.cell_fill, (float4*)nullptr);
   int rc = ccn_scan_i32(g.cell_fill, g.cell_start, cells, false, g.cell_start + cells, g.scan_scratch, s);
   if (rc) return rc;
-  CCN_HIP(hipMemsetAsync(g.cell_fill, 0, (size_t)cells * 4, s), "frnn_grid_build");
   hipLaunchKernelGGL(grid_insert_kernel<true>, gridDim_, dim3(BUILD_TPB), 0, s, points2, lengths2, r, P2, g.T,
                      g.cell_start, g.cell_fill, g.sorted_pts);
   CCN_LAUNCH_OK("frnn_grid_build");
