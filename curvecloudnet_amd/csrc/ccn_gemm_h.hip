@@ -65,7 +65,9 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
                                                                 const u16* __restrict__ B, int64_t ldb,
                                                                 const float* __restrict__ bias, void* __restrict__ Cv,
                                                                 int64_t ldc, int64_t M, int64_t N, int64_t K, int64_t tiles,
-                                                                int64_t gn, int xcd_order, double* __restrict__ colstats) {
+                                                                int64_t gn, int xcd_order, double* __restrict__ colstats,
+                                                                int opt) {
+  // opt (diagnostics, ccn_gemm_h_opt; results WRONG when set): bit 0 = no epilogue stores, bit 1 = no wait for the LDS-DMA
   constexpr int AF = HB_BM * HB_BK, BF = HB_BN * HB_BK, STAGE = AF + BF;   // 16-bit elements
   constexpr int NC = 4;   // LDS-DMA copies (8 rows x 128 B) per wave, slice and operand
   __shared__ __attribute__((aligned(16))) u16 lds[2 * STAGE];
@@ -165,6 +167,8 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
       it_tile = tile_of(++it_j);
     }
   };
+  if ((opt & 4) && blockIdx.x >= 256)          // (experiment: the second workgroup of a CU starts (opt >> 8) x 3.4 us late)
+    for (int r = 0; r < (opt >> 8); ++r) __builtin_amdgcn_s_sleep(127);
   issue_next();
 
   int64_t stat_tile = -1;
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
     }
 
     for (int u = 0; u < TT; ++u, ++g) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice g has landed (and the previous tile's stores retired)
+      if (!(opt & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice g has landed (and the previous tile's stores retired)
       __builtin_amdgcn_s_barrier();
       issue_next();
       if (u == 0 && stat_tile >= 0) stats_readout();
@@ -233,6 +237,46 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
     }
 
     // ---- tile epilogue
+    if (opt & 1) {
+      if (acc[0][0][0] == 1.2345e30f) reinterpret_cast<float*>(Cv)[0] = acc[1][1][3] + acc[0][1][5] + acc[1][0][7];   // (keeps the MFMAs alive)
+      continue;
+    }
+    if (OUT16 && (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)Cv & 15) == 0) {
+      // Through LDS, so that the tile leaves in whole 256-byte rows (the direct form below writes 8 bytes into each of 32
+      // rows per instruction: the store phase ran at 3.3 TB/s against 5.7 for full lines, tools/bench_gemm_h_opt.py).  The
+      // stage the last slice was read from is free until the next iteration's copies (issued behind that iteration's
+      // barrier): [128 rows][256 bytes], 16-byte chunk c of row r at chunk c ^ (r & 15).
+      u16* const C = reinterpret_cast<u16*>(Cv);
+      const uint32_t tbase = lds_base + (uint32_t)(((g - 1) & 1) * STAGE * 2);
+      __builtin_amdgcn_s_barrier();            // every wave has read its last fragments of that stage
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab) {
+        const int r = wm * 64 + ab * 32 + i;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int col = wn * 64 + t * 32 + 8 * q4 + 4 * h;         // 4 consecutive columns = 8 bytes
+            const uint32_t w0 = (uint32_t)to_h<F16>(acc[ab][t][4 * q4 + 0]) | ((uint32_t)to_h<F16>(acc[ab][t][4 * q4 + 1]) << 16);
+            const uint32_t w1 = (uint32_t)to_h<F16>(acc[ab][t][4 * q4 + 2]) | ((uint32_t)to_h<F16>(acc[ab][t][4 * q4 + 3]) << 16);
+            const uint32_t at = tbase + (uint32_t)(r * 256 + (((col >> 3) ^ (r & 15)) << 4) + ((col & 7) << 1));
+            asm volatile("ds_write_b64 %0, %1" : : "v"(at), "v"(make_uint2(w0, w1)) : "memory");
+          }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // 16 lanes x 16 bytes = one row; a wave instruction stores 4 rows, the workgroup 16: 8 passes
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) {
+        const int r = ps * 16 + (int)(threadIdx.x >> 4), c = (int)(threadIdx.x & 15);
+        uint4 v;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(tbase + (uint32_t)(r * 256 + ((c ^ (r & 15)) << 4))) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t m = m0 + r, n = n0 + 8 * c;
+        if (m < M && n < N) *reinterpret_cast<uint4*>(C + m * ldc + n) = v;
+      }
+      continue;      // (the next iteration's barrier sits between these reads and the copies that reuse the stage)
+    }
     if (OUT16) {
       // D[p][q] of mfma(B-fragment, A-fragment): p = column n (registers: (r&3) + 8*(r>>2) + 4*h), q = row m (lane i)
       u16* const C = reinterpret_cast<u16*>(Cv);
@@ -876,6 +920,7 @@ inline HtPlan ht_plan(int64_t M, int64_t N, int64_t K) {
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+static int g_h_opt = 0;      // diagnostics (ccn_gemm_h_opt)
 
 template <bool F16, bool OUT16>
 int launch_nt_h(const u16* A, int64_t lda, const u16* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
@@ -888,13 +933,18 @@ int launch_nt_h(const u16* A, int64_t lda, const u16* W, int64_t ldw, const floa
   }
   const int64_t grid = tiles < 512 ? tiles : 512;  // two workgroups per CU
   hipLaunchKernelGGL((gemm_h_pair_kernel<F16, OUT16>), dim3((unsigned)grid), dim3(HB_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy, M,
-                     N, K, tiles, gn, 1, colstats);
+                     N, K, tiles, gn, 1, colstats, g_h_opt);
   return CCN_OK;
 }
 
 }  // namespace
 
 extern "C" {
+
+int ccn_gemm_h_opt(int opt) {
+  g_h_opt = opt;
+  return CCN_OK;
+}
 
 int ccn_gemm_nt_h(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
                   int64_t N, int64_t K, double* colstats, int f16, int out16, void* stream) {

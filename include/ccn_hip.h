@@ -254,6 +254,8 @@ int ccn_gemm_tn_bf16(const float* dY, int64_t lddy, const float* X, int64_t ldx,
  *                  (ccn_gemm_tn_h_workspace_bytes), summed in chunk order (deterministic). */
 int ccn_gemm_nt_h(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
                   int64_t N, int64_t K, double* colstats, int f16, int out16, void* stream);
+/* diagnostics of ccn_gemm_nt_h (timing only, results wrong when set): bit 0 = no epilogue stores, bit 1 = no wait for the copies */
+int ccn_gemm_h_opt(int opt);
 size_t ccn_gemm_tn_h_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int ccn_gemm_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
                   int64_t K, void* workspace, size_t workspace_bytes, void* stream);
