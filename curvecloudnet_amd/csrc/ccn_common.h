@@ -69,3 +69,26 @@ int ccn_scan_f64(const double* in, double* out, int64_t n, bool inclusive, void*
 __device__ __forceinline__ float ccn_sqdist3(float dx, float dy, float dz) {
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
+
+// ---- 16-bit rows at the MLP boundary of the 16-bit storage modes (ccn_gemm_h.hip): the first-layer edge kernels (ccn_edge.hip) and the shifted-row matrix (ccn_curve.hip) can write
+// their activation as bf16 / fp16 rows (ZT) and read the gradient of such an activation as bf16 rows (DZ16) -- the fp32 round
+// trip through ccn_cast_rows_h is 8 bytes per element of an E x C tensor.  T: 0 = fp32, 1 = bf16, 2 = fp16.
+template <int T>
+__device__ __forceinline__ float ld_el(const void* __restrict__ p, int64_t i) {
+  if (T == 0) return reinterpret_cast<const float*>(p)[i];
+  const uint16_t v = reinterpret_cast<const uint16_t*>(p)[i];
+  if (T == 2) return (float)__builtin_bit_cast(_Float16, v);
+  return __builtin_bit_cast(float, (uint32_t)v << 16);
+}
+template <int T>
+__device__ __forceinline__ void st_el(void* __restrict__ p, int64_t i, float v) {
+  if (T == 0) {
+    reinterpret_cast<float*>(p)[i] = v;
+  } else if (T == 2) {
+    const _Float16 x = (_Float16)v;
+    reinterpret_cast<uint16_t*>(p)[i] = __builtin_bit_cast(uint16_t, x);
+  } else {
+    const __bf16 x = (__bf16)v;        // round to nearest even (the rounding of ccn_cast_rows_h)
+    reinterpret_cast<uint16_t*>(p)[i] = __builtin_bit_cast(uint16_t, x);
+  }
+}

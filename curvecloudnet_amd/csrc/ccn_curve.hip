@@ -170,9 +170,10 @@ __global__ void diff_concat_bwd_kernel(const float* __restrict__ x, int64_t ldx,
 // Element-parallel: thread -> (row i, q = tap*C + c).  Row i of the shifted-row matrix is the contiguous span
 // x[(i - taps/2)*C ...] with the taps that leave the curve zeroed, so reads and writes are both coalesced whatever C
 // is (the narrow first layers, C = 8 / 32, would leave most of a wave idle with one row per wave).
+template <int ZT>     // ZT: the shifted-row matrix as fp32 (0), bf16 (1) or fp16 (2) rows (ccn_common.h: st_el)
 __global__ __launch_bounds__(256) void im2col_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                          const int32_t* __restrict__ seg, int64_t rows, int C,
-                                                         int taps, float* __restrict__ col, int64_t ldcol) {
+                                                         int taps, void* __restrict__ col, int64_t ldcol) {
   const int W = taps * C;
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= rows * W) return;
@@ -182,13 +183,14 @@ __global__ __launch_bounds__(256) void im2col_fwd_kernel(const float* __restrict
   const int tap = (int)((uint32_t)q / (uint32_t)C), c = q - tap * C;
   const int64_t j = i + tap - taps / 2;
   const bool ok = j >= 0 && j < rows && (seg == nullptr || seg[j] == seg[i]);
-  col[i * ldcol + q] = ok ? x[j * ldx + c] : 0.0f;
+  st_el<ZT>(col, i * ldcol + q, ok ? x[j * ldx + c] : 0.0f);
 }
 
 // wide rows: one wave per output row, lanes stride over the channels of each tap (256 contiguous bytes per access)
+template <int ZT>
 __global__ __launch_bounds__(256) void im2col_fwd_rows_kernel(const float* __restrict__ x, int64_t ldx,
                                                               const int32_t* __restrict__ seg, int64_t rows, int C,
-                                                              int taps, float* __restrict__ col, int64_t ldcol) {
+                                                              int taps, void* __restrict__ col, int64_t ldcol) {
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 4 + ry;
   if (i >= rows) return;
@@ -196,11 +198,12 @@ __global__ __launch_bounds__(256) void im2col_fwd_rows_kernel(const float* __res
   for (int tap = 0; tap < taps; ++tap) {
     const int64_t j = i + tap - taps / 2;
     const bool ok = j >= 0 && j < rows && (seg == nullptr || seg[j] == me);
-    for (int c = cx; c < C; c += 64) col[i * ldcol + tap * C + c] = ok ? x[j * ldx + c] : 0.0f;
+    for (int c = cx; c < C; c += 64) st_el<ZT>(col, i * ldcol + tap * C + c, ok ? x[j * ldx + c] : 0.0f);
   }
 }
 
-__global__ __launch_bounds__(256) void im2col_bwd_kernel(const float* __restrict__ dcol, int64_t ldcol,
+template <int DT>     // DT = 1: dcol as bf16 rows (the gradient of a 16-bit shifted-row matrix)
+__global__ __launch_bounds__(256) void im2col_bwd_kernel(const void* __restrict__ dcol, int64_t ldcol,
                                                          const int32_t* __restrict__ seg, int64_t rows, int C,
                                                          int taps, float* __restrict__ dx, int64_t lddx) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void im2col_bwd_kernel(const float* __restrict
   float acc = 0.0f;
   for (int tap = 0; tap < taps; ++tap) {
     const int64_t i = j - tap + taps / 2;  // output row whose tap `tap` read x[j]
-    if (i >= 0 && i < rows && (seg == nullptr || seg[i] == me)) acc += dcol[i * ldcol + tap * C + c];
+    if (i >= 0 && i < rows && (seg == nullptr || seg[i] == me)) acc += ld_el<DT>(dcol, i * ldcol + tap * C + c);
   }
   dx[j * lddx + c] = acc;
 }
@@ -774,20 +777,40 @@ int ccn_diff_concat_bwd(const float* x, int64_t ldx, const int32_t* cid, int64_t
   return CCN_OK;
 }
 
-int ccn_im2col_fwd(const float* x, int64_t ldx, const int32_t* seg, int64_t rows, int64_t C, int64_t taps, float* col,
-                   int64_t ldcol, void* stream) {
+static int im2col_fwd_impl(const float* x, int64_t ldx, const int32_t* seg, int64_t rows, int64_t C, int64_t taps, void* col,
+                           int64_t ldcol, int zt, void* stream) {
   CCN_REQUIRE(x && col && ldx >= C && taps >= 1 && (taps & 1) && taps < 64 && C > 0 && C < (1 << 24) &&
                   ldcol >= taps * C,
               "im2col_fwd: bad arguments");
   if (rows == 0) return CCN_OK;
-  if (C >= 64)
-    hipLaunchKernelGGL(im2col_fwd_rows_kernel, dim3(ccn_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, seg,
-                       rows, (int)C, (int)taps, col, ldcol);
-  else
-    hipLaunchKernelGGL(im2col_fwd_kernel, dim3(ccn_blocks(rows * taps * C, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                       ldx, seg, rows, (int)C, (int)taps, col, ldcol);
+#define CCN_IM2COL(ZT_)                                                                                                   \
+  do {                                                                                                                    \
+    if (C >= 64)                                                                                                          \
+      hipLaunchKernelGGL(im2col_fwd_rows_kernel<ZT_>, dim3(ccn_blocks(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, \
+                         seg, rows, (int)C, (int)taps, col, ldcol);                                                       \
+    else                                                                                                                  \
+      hipLaunchKernelGGL(im2col_fwd_kernel<ZT_>, dim3(ccn_blocks(rows * taps * C, 256)), dim3(256), 0, (hipStream_t)stream, \
+                         x, ldx, seg, rows, (int)C, (int)taps, col, ldcol);                                               \
+  } while (0)
+  if (zt == 0) CCN_IM2COL(0);
+  else if (zt == 1) CCN_IM2COL(1);
+  else CCN_IM2COL(2);
+#undef CCN_IM2COL
   CCN_LAUNCH_OK("im2col_fwd");
   return CCN_OK;
+}
+
+int ccn_im2col_fwd(const float* x, int64_t ldx, const int32_t* seg, int64_t rows, int64_t C, int64_t taps, float* col,
+                   int64_t ldcol, void* stream) {
+  return im2col_fwd_impl(x, ldx, seg, rows, C, taps, col, ldcol, 0, stream);
+}
+
+// ... the shifted-row matrix as 16-bit rows (bf16, fp16 when f16 != 0; (taps * C) % 8 == 0, ldcol in 16-bit elements)
+int ccn_im2col_fwd_h(const float* x, int64_t ldx, const int32_t* seg, int64_t rows, int64_t C, int64_t taps, void* col,
+                     int64_t ldcol, int f16, void* stream) {
+  CCN_REQUIRE((taps * C) % 8 == 0 && ldcol % 8 == 0 && ((uintptr_t)col & 15) == 0,
+              "im2col_fwd_h: rows of (taps * C) % 8 == 0 elements, 16-byte aligned");
+  return im2col_fwd_impl(x, ldx, seg, rows, C, taps, col, ldcol, f16 ? 2 : 1, stream);
 }
 
 int ccn_im2col_bwd(const float* dcol, int64_t ldcol, const int32_t* seg, int64_t rows, int64_t C, int64_t taps,
@@ -796,9 +819,22 @@ int ccn_im2col_bwd(const float* dcol, int64_t ldcol, const int32_t* seg, int64_t
                   ldcol >= taps * C,
               "im2col_bwd: bad arguments");
   if (rows == 0) return CCN_OK;
-  hipLaunchKernelGGL(im2col_bwd_kernel, dim3(ccn_blocks(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, dcol, ldcol, seg,
+  hipLaunchKernelGGL(im2col_bwd_kernel<0>, dim3(ccn_blocks(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, dcol, ldcol, seg,
                      rows, (int)C, (int)taps, dx, lddx);
   CCN_LAUNCH_OK("im2col_bwd");
+  return CCN_OK;
+}
+
+// ... dcol as bf16 rows (ldcol in 16-bit elements)
+int ccn_im2col_bwd_h(const void* dcol, int64_t ldcol, const int32_t* seg, int64_t rows, int64_t C, int64_t taps, float* dx,
+                     int64_t lddx, void* stream) {
+  CCN_REQUIRE(dcol && dx && lddx >= C && taps >= 1 && (taps & 1) && taps < 64 && C > 0 && C < (1 << 24) &&
+                  ldcol >= taps * C,
+              "im2col_bwd_h: bad arguments");
+  if (rows == 0) return CCN_OK;
+  hipLaunchKernelGGL(im2col_bwd_kernel<1>, dim3(ccn_blocks(rows * C, 256)), dim3(256), 0, (hipStream_t)stream, dcol, ldcol, seg,
+                     rows, (int)C, (int)taps, dx, lddx);
+  CCN_LAUNCH_OK("im2col_bwd_h");
   return CCN_OK;
 }
 

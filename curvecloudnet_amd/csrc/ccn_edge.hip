@@ -388,29 +388,6 @@ __global__ void cg_fill_kernel(const int64_t* __restrict__ idx, const int64_t* _
   }
 }
 
-// ---- 16-bit rows at the MLP boundary of the 16-bit storage modes (ccn_gemm_h.hip): the first-layer kernels below can write
-// their activation as bf16 / fp16 rows (ZT) and read the gradient of such an activation as bf16 rows (DZ16) -- the fp32 round
-// trip through ccn_cast_rows_h is 8 bytes per element of an E x C tensor.  T: 0 = fp32, 1 = bf16, 2 = fp16.
-template <int T>
-__device__ __forceinline__ float ld_el(const void* __restrict__ p, int64_t i) {
-  if (T == 0) return reinterpret_cast<const float*>(p)[i];
-  const uint16_t v = reinterpret_cast<const uint16_t*>(p)[i];
-  if (T == 2) return (float)__builtin_bit_cast(_Float16, v);
-  return __builtin_bit_cast(float, (uint32_t)v << 16);
-}
-template <int T>
-__device__ __forceinline__ void st_el(void* __restrict__ p, int64_t i, float v) {
-  if (T == 0) {
-    reinterpret_cast<float*>(p)[i] = v;
-  } else if (T == 2) {
-    const _Float16 x = (_Float16)v;
-    reinterpret_cast<uint16_t*>(p)[i] = __builtin_bit_cast(uint16_t, x);
-  } else {
-    const __bf16 x = (__bf16)v;        // round to nearest even (the rounding of ccn_cast_rows_h)
-    reinterpret_cast<uint16_t*>(p)[i] = __builtin_bit_cast(uint16_t, x);
-  }
-}
-
 // the sources of one point's real rows across the wave (lane s = row s of the group, groups have <= 64 rows)
 __device__ __forceinline__ int cg_src(int v, int s) { return __builtin_amdgcn_readlane(v, s); }
 

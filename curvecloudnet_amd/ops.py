@@ -303,21 +303,38 @@ def compute_feature_diffs(x, topo):
 
 class Im2Col(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, seg, taps):
+    def forward(ctx, x, seg, taps, out16=False):
+        # out16 (16-bit storage modes, im2col()): the matrix is written as 16-bit rows for the layer's product and its gradient
+        # comes back as bf16 rows -- no fp32 round trip through ccn_cast_rows_h
         x = _mat(x)
         rows, c = x.shape
+        ctx.seg, ctx.taps, ctx.c = seg, taps, c
+        if out16:
+            fdt = _fwd16()
+            col = _rows16(rows, taps * c, x.device, fdt)
+            call("im2col_fwd_h", ptr(x), _ld(x), ptr(seg), rows, c, taps, ptr(col), _ld(col), 1 if fdt == torch.float16 else 0)
+            return col.view(torch.bfloat16) if fdt == torch.float16 else col
         col = _rows(rows, taps * c, x.device)
         call("im2col_fwd", ptr(x), _ld(x), ptr(seg), rows, c, taps, ptr(col), _ld(col))
-        ctx.seg, ctx.taps, ctx.c = seg, taps, c
         return col
 
     @staticmethod
     def backward(ctx, g):
-        g = _mat(g)
         rows = g.size(0)
         dx = _rows(rows, ctx.c, g.device)
-        call("im2col_bwd", ptr(g), _ld(g), ptr(ctx.seg), rows, ctx.c, ctx.taps, ptr(dx), _ld(dx))
-        return dx, None, None
+        if _is_rows16(g):
+            call("im2col_bwd_h", ptr(g), _ld(g), ptr(ctx.seg), rows, ctx.c, ctx.taps, ptr(dx), _ld(dx))
+        else:
+            g = _mat(g.float() if g.dtype != torch.float32 else g)
+            call("im2col_bwd", ptr(g), _ld(g), ptr(ctx.seg), rows, ctx.c, ctx.taps, ptr(dx), _ld(dx))
+        return dx, None, None, None
+
+
+def im2col(x, seg, taps):
+    """The shifted-row matrix of a curve convolution for ``linear_bn_act``: 16-bit rows in the 16-bit storage modes."""
+    out16 = bool(EDGE_OUT16 and _MLP_DTYPE in ("bf16", "fp16") and STORE16 and ACT_TRACE is None and x.size(0) > 0
+                 and (taps * x.size(1)) % 8 == 0)
+    return _mark16(Im2Col.apply(x, seg, taps, out16), out16)
 
 
 # --------------------------------------------------------------------------------------

@@ -178,8 +178,7 @@ def _conv_bn_act(x, seg, taps, conv, norm, training):
         # many more input than output channels on the unsegmented V2 sequence: product first (taps*C_out columns per row),
         # shift-add second, instead of materialising the taps*C_in-column shifted-row matrix
         return ops.conv_rows_bn_act(x, conv.gemm_weight(), conv.bias, norm, training, "leaky_relu", taps)
-    col = ops.Im2Col.apply(x, seg, taps)
-    return ops.linear_bn_act(col, conv.gemm_weight(), conv.bias, norm, training, "leaky_relu")
+    return ops.linear_bn_act(ops.im2col(x, seg, taps), conv.gemm_weight(), conv.bias, norm, training, "leaky_relu")
 
 
 CONV_SHIFT_ADD = os.environ.get("CCN_CONV_SHIFT_ADD", "1") != "0"

@@ -78,6 +78,12 @@ int ccn_im2col_fwd(const float* x, int64_t ldx, const int32_t* seg, int64_t rows
                    float* col, int64_t ldcol, void* stream);
 int ccn_im2col_bwd(const float* dcol, int64_t ldcol, const int32_t* seg, int64_t rows, int64_t C, int64_t taps,
                    float* dx, int64_t lddx, void* stream);
+/* ... at the boundary of the 16-bit storage modes (round 3): the shifted-row matrix written as bf16 / fp16 rows for the layer's
+ * product (ccn_gemm_nt_h), its gradient read as bf16 rows ((taps * C) % 8 == 0; leading dimensions in 16-bit elements). */
+int ccn_im2col_fwd_h(const float* x, int64_t ldx, const int32_t* seg, int64_t rows, int64_t C, int64_t taps, void* col,
+                     int64_t ldcol, int f16, void* stream);
+int ccn_im2col_bwd_h(const void* dcol, int64_t ldcol, const int32_t* seg, int64_t rows, int64_t C, int64_t taps, float* dx,
+                     int64_t lddx, void* stream);
 
 /* row gather / scatter (fast_conv1d.py:136-141 x_padded[valid] = x ; x = x_padded[valid]; x[idx]) */
 int ccn_gather_rows(const float* src, int64_t lds, const int64_t* index, int64_t m, int64_t C, float* dst,

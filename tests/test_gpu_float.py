@@ -732,7 +732,7 @@ def test_bf16_model_tracks_emulation_and_fp32(bf16_mode, which):
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in mine.parameters())
 
 
-@pytest.mark.parametrize("which", ["sgcnn", "sa-max", "sa-attend", "sgcnn-sparse-attend"])
+@pytest.mark.parametrize("which", ["sgcnn", "sa-max", "sa-attend", "sgcnn-sparse-attend", "conv-v1"])
 def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
     """16-bit storage modes: the algebraic first layer of an edge MLP writes its activation as 16-bit rows for the next Linear
     (ccn_cg_edge_apply_h / ccn_pn_edge_apply_h) instead of fp32 rows + ccn_cast_rows_h: the same rounding of the same fp32
@@ -749,6 +749,9 @@ def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
         mod = steps.SGCNNLayer(MLP([2 * (c + 3), 40, 24], bias=False), 12, r=0.05, with_xyz=True)
         # (a bias on the plain last layer: its gradient behind the fused max = column sums of the max's own gradient)
         mod.nn.lins[-1].bias = torch.nn.Parameter(torch.randn(24, generator=torch.Generator().manual_seed(3)) * 0.1)
+    elif which == "conv-v1":      # the shifted-row matrix of the curve convolutions (ccn_im2col_fwd_h / _bwd_h)
+        c = 16
+        mod = steps.SymmetricCurve1DConvFastV1([c + 3, 16, 8, 16], 5, with_xyz=True)
     elif which == "sgcnn-sparse-attend":
         mod = steps.SGCNNLayer(MLP([2 * (c + 3), 40, 24], bias=False), 12, r=0.05, with_xyz=True, aggr_type="attend",
                                use_sparse_feat_agg=True, attend_nn=MLP([24, 16, 24], act="leaky_relu", bias=True))
@@ -779,7 +782,9 @@ def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
             ops.call = inner
             ops.EDGE_OUT16 = True
         calls.append(log)
-    if which != "sgcnn-sparse-attend":
+    if which == "conv-v1":
+        assert "im2col_fwd_h" in calls[0] and "im2col_bwd_h" in calls[0] and "im2col_fwd_h" not in calls[1]
+    elif which != "sgcnn-sparse-attend":
         kind = "cg" if which == "sgcnn" else "pn"
         assert kind + "_edge_apply_h" in calls[0] and kind + "_edge_bwd_h" in calls[0] and kind + "_edge_bwd_stats_h" in calls[0]
         assert kind + "_edge_apply" in calls[1] and kind + "_edge_bwd" in calls[1]
