@@ -1,5 +1,5 @@
 """Per-kernel HBM GB/s (and MFMA pipe utilisation) table from a rocprofv3 kernel-stats CSV and a pmc_summary JSON.
-    python tools/hbm_table.py profiles/r01f_kitti_kernel_stats.csv profiles/r01f_kitti_pmc.json > profiles/r01f_kitti_hbm_table.md"""
+    python tools/hbm_table.py profiles/r01f_kitti_kernel_stats.csv profiles/r01f_kitti_pmc.json ["bench.py flags"] > profiles/r01f_kitti_hbm_table.md"""
 import csv
 import json
 import re
@@ -18,9 +18,10 @@ for name, t in pmc.items():
     rows.append((float(st["Percentage"]), short[:58], int(st["Calls"]), avg_us, rd / 1e6, wr / 1e6,
                  (rd + wr) / (avg_us * 1e-6) / 1e9, t.get("mfma_pipe_utilisation", 0.0), t.get("effective_clock_ghz", 0.0)))
 rows.sort(reverse=True)
-print("# HBM traffic and MFMA utilisation per kernel, full KITTI bench (rocprofv3)\n")
-print("Sources: `%s` (--kernel-trace --stats of `python bench.py`) and `%s` (separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and"
-      % (sys.argv[1], sys.argv[2]))
+flags = sys.argv[3] if len(sys.argv) > 3 else ""
+print("# HBM traffic and MFMA utilisation per kernel, %s (rocprofv3)\n" % ("bench.py " + flags if flags else "full KITTI bench"))
+print("Sources: `%s` (--kernel-trace --stats of `python bench.py%s`) and `%s` (separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and"
+      % (sys.argv[1], " " + flags if flags else "", sys.argv[2]))
 print("`--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE` passes of the same command; FETCH_SIZE doubled as")
 print("MI355X_MICROARCH.md prescribes for gfx950).  GB/s = (read + written bytes per launch) / average launch duration; HBM3E")
 print("spec peak 8000 GB/s.  MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); clock = GRBM_GUI_ACTIVE")
