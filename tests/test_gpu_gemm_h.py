@@ -203,3 +203,94 @@ def test_batchnorm_passes_with_16bit_rows(rows, C, act):
         assert float((diff > 0).float().mean()) < 1e-3
         assert torch.equal(dgb2, dgb)
         assert bool((dy16[:, C:] == 0).all())
+
+
+# ---------------------------------------------------------------- the MLP boundaries of the 16-bit storage modes (round 3)
+@pytest.mark.parametrize("rows,C", [(1000, 64), (4099, 72), (33, 8), (70001, 128)])
+def test_add_cast_rows(rows, C):
+    """ccn_add_cast_rows_h: bf16(fp32 gradient + bf16 gradient), one rounding of the fp32 sum."""
+    call, lib, ptr, _ = _api()
+    gen = torch.Generator().manual_seed(rows)
+    a = torch.randn(rows, C, generator=gen).to(DEV)
+    b16, ldb = _to16(torch.randn(rows, C, generator=gen))
+    out, ldo = _rows16(rows, C)
+    out.fill_(3.0)
+    call("add_cast_rows_h", ptr(a), C, ptr(b16), ldb, rows, C, ptr(out), ldo)
+    assert torch.equal(out[:, :C], (a + b16[:, :C].float()).to(torch.bfloat16))
+    assert bool((out[:, C:] == 0).all())
+
+
+@pytest.mark.parametrize("rows,C,taps", [(500, 16, 5), (3000, 64, 5), (257, 8, 7)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_im2col_16bit_rows(rows, C, taps, dtype):
+    """ccn_im2col_fwd_h = ccn_im2col_fwd rounded once; ccn_im2col_bwd_h = ccn_im2col_bwd on the widened bf16 gradient."""
+    call, lib, ptr, _ = _api()
+    gen = torch.Generator().manual_seed(rows + taps)
+    x = torch.randn(rows, C, generator=gen).to(DEV)
+    seg = torch.sort(torch.randint(0, 9, (rows,), generator=gen)).values.to(torch.int32).to(DEV)
+    W = taps * C
+    col32 = torch.empty(rows, W, device=DEV)
+    call("im2col_fwd", ptr(x), C, ptr(seg), rows, C, taps, ptr(col32), W)
+    col16, ld = _rows16(rows, W, dtype)
+    call("im2col_fwd_h", ptr(x), C, ptr(seg), rows, C, taps, ptr(col16), ld, 1 if dtype == torch.float16 else 0)
+    assert torch.equal(col16[:, :W], col32.to(dtype))
+    g16, ldg = _to16(torch.randn(rows, W, generator=gen))
+    g32 = g16[:, :W].float().contiguous()
+    dx_a, dx_b = torch.empty(rows, C, device=DEV), torch.empty(rows, C, device=DEV)
+    call("im2col_bwd", ptr(g32), W, ptr(seg), rows, C, taps, ptr(dx_a), C)
+    call("im2col_bwd_h", ptr(g16), ldg, ptr(seg), rows, C, taps, ptr(dx_b), C)
+    assert torch.equal(dx_a, dx_b)
+
+
+def _random_groups(n_groups, max_len, gen):
+    lens = torch.randint(0, max_len + 1, (n_groups,), generator=gen)
+    offsets = torch.zeros(n_groups + 1, dtype=torch.int64)
+    offsets[1:] = torch.cumsum(lens, 0)
+    return offsets.to(torch.int32), int(offsets[-1])
+
+
+@pytest.mark.parametrize("n_dst,C", [(700, 64), (90, 136), (3000, 8)])
+def test_softmax_aggregation_backward_writes_bf16_scores_gradient(n_dst, C):
+    """ccn_seg_softmax_agg_bwd_h: the messages' gradient bit-identical to the fp32 entry, the scores' gradient = its fp32
+    value rounded once (empty groups included)."""
+    call, lib, ptr, _ = _api()
+    gen = torch.Generator().manual_seed(n_dst)
+    offsets, e = _random_groups(n_dst, 12, gen)
+    offsets = offsets.to(DEV)
+    msg, att = torch.randn(e, C, generator=gen).to(DEV), torch.randn(e, C, generator=gen).to(DEV)
+    g = torch.randn(n_dst, C, generator=gen).to(DEV)
+    dm_a, da_a = torch.empty(e, C, device=DEV), torch.empty(e, C, device=DEV)
+    call("seg_softmax_agg_bwd", ptr(msg), C, ptr(att), C, ptr(offsets), n_dst, C, ptr(g), C, ptr(dm_a), C, ptr(da_a), C)
+    dm_b = torch.empty(e, C, device=DEV)
+    da_b, ld = _rows16(e, C)
+    call("seg_softmax_agg_bwd_h", ptr(msg), C, ptr(att), C, ptr(offsets), n_dst, C, ptr(g), C, ptr(dm_b), C, ptr(da_b), ld)
+    assert torch.equal(dm_a, dm_b)
+    assert torch.equal(da_b[:, :C], da_a.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("n,C", [(500, 64), (77, 72), (2000, 8)])
+def test_compact_row_max_backward_writes_bf16_rows(n, C):
+    """ccn_cg_max_bwd_h against ccn_cg_max_bwd on a random compact-row structure (real rows grouped by point, optional
+    representative row per point, one padding row): every row of the table written, same values rounded once."""
+    call, lib, ptr, _ = _api()
+    gen = torch.Generator().manual_seed(n + C)
+    lens = torch.randint(1, 9, (n,), generator=gen)                      # the self row always exists
+    grp = torch.zeros(n + 1, dtype=torch.int64)
+    grp[1:] = torch.cumsum(lens, 0)
+    e = int(grp[-1])
+    has_rep = torch.rand(n, generator=gen) < 0.4
+    rep = torch.full((n,), -1, dtype=torch.int64)
+    rep[has_rep] = e + torch.arange(int(has_rep.sum()))
+    ne = int(has_rep.sum())
+    rows = e + ne + 1
+    arg = (torch.rand(n, C, generator=gen) * lens[:, None].float()).long().clamp(max=8).to(torch.int32)
+    arg = torch.minimum(arg, (lens[:, None] - 1).to(torch.int32))
+    g = torch.randn(n, C, generator=gen).to(DEV)
+    grp_d, rep_d, arg_d = grp.to(torch.int32).to(DEV), rep.to(torch.int32).to(DEV), arg.contiguous().to(DEV)
+    df32 = torch.full((rows, C), 5.0, device=DEV)
+    call("cg_max_bwd", ptr(g), C, ptr(arg_d), ptr(grp_d), ptr(rep_d), n, rows, C, ptr(df32), C)
+    df16, ld = _rows16(rows, C)
+    df16.fill_(5.0)
+    call("cg_max_bwd_h", ptr(g), C, ptr(arg_d), ptr(grp_d), ptr(rep_d), n, rows, C, ptr(df16), ld)
+    assert torch.equal(df16[:, :C], df32.to(torch.bfloat16))
+    assert float(df32.abs().sum()) > 0 and bool((df32[e:] == 0).all())
