@@ -848,23 +848,27 @@ int launch_glds(const float* A, int64_t lda, const float* W, int64_t ldw, const 
 // vmcnt retires loads, stores and LDS-DMA in issue order, so the counted waits are arranged as follows: before
 // the stores every DMA issued so far is waited for (it is at least one compute phase old) and remembered as
 // landed; the next two slices then need no wait, and later counted waits see the stores as the oldest entries.
-template <int BN, int STAGES>
-__global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const float* __restrict__ A, int64_t lda,
+// WAVES = 8: one workgroup per CU on 256-row tiles (above).  WAVES = 4 (round 3, widths <= 64): 128-row tiles, 74 KB of LDS, TWO
+// independent workgroups per CU -- at N = K = 64 the 8-wave form is bound neither by its stores (+9 % without them) nor by
+// the copies (+1 % without waiting for them) nor by HBM (48 %) or the matrix pipe (43 %), but by eight waves marching in step.
+template <int BN, int STAGES, int WAVES = 8>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void gemm_glds_persistent_kernel(const float* __restrict__ A, int64_t lda,
                                                                       const float* __restrict__ B, int64_t ldb,
                                                                       const float* __restrict__ bias,
                                                                       float* __restrict__ C, int64_t ldc, int64_t M,
                                                                       int64_t N, int64_t K, int64_t tiles, int64_t gn,
                                                                       int xcd_order, double* __restrict__ colstats) {
   constexpr int NT = BN / 32;
-  constexpr int AF = GL_BM * BK, BF = BN * BK, STAGE = AF + BF;
-  constexpr int NA = GL_BM / 8 / 8;
-  constexpr int NB = BN >= 64 ? BN / 64 : 1;
+  constexpr int BM = WAVES * 32, TPB_ = WAVES * 64;
+  constexpr int AF = BM * BK, BF = BN * BK, STAGE = AF + BF;
+  constexpr int NA = BM / 8 / WAVES;                                   // copies per wave and slice: A (4)
+  constexpr int NB = BN / 8 >= WAVES ? BN / 8 / WAVES : 1;             // ... B (fewer copies than waves: some waves duplicate)
   __shared__ __attribute__((aligned(16))) float lds[STAGES * STAGE];
   // per-wave BatchNorm partial sums of the finished tile ([8 waves][BN][2] fp32, sums over the wave's 32 rows).  A
   // table of its own instead of a recycled stage: no barrier is then needed before it is written, and it is read out
   // (fp64 across the 4 waves of each 128-row half) after the FIRST slice barrier of the next tile, so the statistics
   // add no workgroup barrier at all to the tile loop (two extra barriers per tile cost 13 % at K = 256).
-  __shared__ float stat_part[8 * BN * 2];
+  __shared__ float stat_part[WAVES * BN * 2];
 
   // (wave index as a scalar, copies addressed as scalar tile base + 32-bit lane offset: see the paired kernel below)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -885,11 +889,12 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
   // that XCD's L2 by the other column tiles (measured on the split-bf16 twin of this kernel: 707 -> 379 MB read per
   // launch at K = N = 256).  Otherwise tiles are dealt round-robin.
   const int64_t gm_tiles = tiles / gn;
-  const bool xcd_map = xcd_order && gridDim.x == 256 && gn <= 32 && 32 % gn == 0;
+  constexpr int GRID = WAVES == 8 ? 256 : 512;       // workgroups of a full launch (GRID / 8 slots per XCD)
+  const bool xcd_map = xcd_order && gridDim.x == GRID && gn <= GRID / 8 && (GRID / 8) % gn == 0;
   auto tile_of = [&](int64_t j) -> int64_t {   // (>= tiles: this workgroup has no tile in step j)
     if (xcd_map) {
       const int64_t slot = blockIdx.x >> 3;
-      const int64_t m = j * (256 / gn) + (slot / gn) * 8 + (blockIdx.x & 7);
+      const int64_t m = j * (GRID / gn) + (slot / gn) * 8 + (blockIdx.x & 7);
       return m < gm_tiles ? m * gn + slot % gn : tiles;
     }
     return j * gridDim.x + blockIdx.x;
@@ -901,7 +906,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
   auto issue_next = [&]() {
     if (it_tile >= tiles) return;
     if (it_u == 0) {
-      const int64_t im0 = (it_tile / gn) * GL_BM, in0 = (it_tile % gn) * BN;
+      const int64_t im0 = (it_tile / gn) * BM, in0 = (it_tile % gn) * BN;
       a_tile = reinterpret_cast<const char*>(A + im0 * lda);
       b_tile = reinterpret_cast<const char*>(B + in0 * ldb);
       const int64_t a_rows = M - im0, b_rows = N - in0;
@@ -913,7 +918,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
       }
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
-        const int g = BN >= 64 ? wave * NB + j : (wave & 3);
+        const int g = BN / 8 >= WAVES ? wave * NB + j : (wave % (BN / 8));
         const int r = 8 * g + lr;
         const int64_t rb = r < b_rows ? r : b_rows - 1;
         b_off32[j] = (uint32_t)((rb * ldb + 4 * (lc ^ ((r >> 1) & 7))) * 4);
@@ -927,7 +932,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
     for (int j = 0; j < NA; ++j) glds16(reinterpret_cast<const float*>(a_sl + a_off32[j]), st + (8 * (wave * NA + j)) * BK);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int g = BN >= 64 ? wave * NB + j : (wave & 3);
+      const int g = BN / 8 >= WAVES ? wave * NB + j : (wave % (BN / 8));
       glds16(reinterpret_cast<const float*>(b_sl + b_off32[j]), st + AF + (8 * g) * BK);
     }
     ++gi;
@@ -940,11 +945,12 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
 
   int64_t stat_tile = -1;  // tile whose statistics wait in stat_part
   auto stats_readout = [&]() {
+    constexpr int HALVES = WAVES / 4;      // 128-row partial rows per tile (ccn_stats_rows): four waves each
     const int64_t pm = stat_tile / gn, pn0 = (stat_tile % gn) * BN;
-    for (int e = threadIdx.x; e < 2 * BN; e += GL_TPB) {
+    for (int e = threadIdx.x; e < HALVES * BN; e += TPB_) {
       const int half = e / BN, c = e - half * BN;
       const int64_t n = pn0 + c;
-      const int64_t prow = pm * 2 + half;
+      const int64_t prow = pm * HALVES + half;
       if (n < N && prow * 128 < M) {
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -963,7 +969,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
   int64_t g = 0;       // slices computed so far
   int64_t landed = 0;  // slices [0, landed) are known to be in LDS for this wave
   for (int64_t j = 0, tile; (tile = tile_of(j)) < tiles; ++j) {
-    const int64_t m0 = (tile / gn) * GL_BM, n0 = (tile % gn) * BN;
+    const int64_t m0 = (tile / gn) * BM, n0 = (tile % gn) * BN;
     f32x16 acc[NT];
     acc_init<NT>(acc, bias, n0, N, i);  // bias (or 0) as the initial accumulator value
 
@@ -1007,7 +1013,7 @@ __global__ __launch_bounds__(GL_TPB) void gemm_glds_persistent_kernel(const floa
     // Interior tiles (all but the last tile row / column) store without per-element bounds tests: 16*NT stores per lane
     // with a compare, a branch and a 64-bit multiply-add each made the epilogue ~8.5k cycles per tile (measured 4.2 us
     // per tile whatever K), a quarter of a K = 128 tile.
-    const bool interior = m0 + GL_BM <= M && n0 + BN <= N;
+    const bool interior = m0 + BM <= M && n0 + BN <= N;
     float* const crow = C + (m0 + wave * 32 + 4 * h) * ldc + n0 + i;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -1530,6 +1536,18 @@ int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, c
 template <int BN>
 int launch_glds_persistent(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y,
                            int64_t ldy, int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s) {
+  if constexpr (BN <= 64) {
+    // two 4-wave workgroups per CU on 128-row tiles (measured stand-alone, 2.1 M x 64 x 64: 67.4 -> 73.2 TFLOP/s, 618 k x 64 x 64:
+    // 61.8 -> 68.1; A/B hook: ccn_gemm_pair_opt bit 8 = the 8-wave form)
+    if (!(g_pair_opt & 256)) {
+      const int64_t gm4 = (M + 127) / 128, gn4 = (N + BN - 1) / BN;
+      const int64_t tiles4 = gm4 * gn4;
+      const int64_t grid4 = tiles4 < 512 ? tiles4 : 512;
+      hipLaunchKernelGGL((gemm_glds_persistent_kernel<BN, 3, 4>), dim3((unsigned)grid4), dim3(256), 0, s, A, lda, W, ldw, bias,
+                         Y, ldy, M, N, K, tiles4, gn4, g_xcd_map ? 1 : 0, colstats);
+      return CCN_OK;
+    }
+  }
   const int64_t gm = (M + GL_BM - 1) / GL_BM, gn = (N + BN - 1) / BN;
   const int64_t tiles = gm * gn;
   const int64_t grid = tiles < 256 ? tiles : 256;  // one workgroup per CU (147 KB of LDS each)

@@ -11,6 +11,8 @@ from curvecloudnet_amd.ops import _ld, _rows  # noqa: E402
 SHAPES = [(1342781, 256, 256), (656150, 256, 256), (197729, 512, 512), (58660, 1024, 1024), (208234, 128, 128),
           (1342781, 192, 256), (10550, 1024, 1024), (208234, 256, 259), (1342781, 192, 128), (498380, 262, 160),
           (208234, 259, 256), (498380, 160, 262)]
+if os.environ.get("SHAPES") == "narrow":      # (the 8-wave persistent kernel's shapes: N <= 64)
+    SHAPES = [(2341754, 64, 64), (2134741, 64, 64), (688586, 64, 128), (617950, 64, 64)]
 if os.environ.get("SHAPES") == "odd":
     SHAPES = [sh for sh in SHAPES if sh[1] % 128]
 dev = "cuda"
