@@ -1278,14 +1278,27 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
         const int64_t n = n0 + wn * 64 + t * 32 + i;
 #pragma unroll
         for (int ab = 0; ab < 2; ++ab) {
+          if (inside) {
+            // as the epilogue's stores: scalar row base + one 32-bit lane offset, straight into the accumulator registers
+            // (the 64-bit vector address per element of the generic form below cost this variant 256 VGPRs + 296 B of scratch)
+            const float* const cbase = C + (m0 + wm * 64 + ab * 32) * ldc + n0 + wn * 64 + t * 32;
+            const uint32_t lane_off = (uint32_t)((4 * h * ldc + i) * 4);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float* const rowp = cbase + (int64_t)((r & 3) + 8 * (r >> 2)) * ldc;
+              asm volatile("global_load_dword %0, %1, %2" : "=v"(acc[ab][t][r]) : "v"(lane_off), "s"(rowp) : "memory");
+            }
+            continue;
+          }
           const float* const crow = C + (m0 + wm * 64 + ab * 32 + 4 * h) * ldc + n;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int64_t m = m0 + wm * 64 + ab * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            acc[ab][t][r] = (inside || (m < M && n < N)) ? crow[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] : 0.f;
+            acc[ab][t][r] = (m < M && n < N) ? crow[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] : 0.f;
           }
         }
       }
+      // (the loads above are waited for by the first slice's s_waitcnt vmcnt(0), long before the first MFMA reads them)
     } else {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
