@@ -409,9 +409,17 @@ __device__ __forceinline__ void store8h(u16* __restrict__ p, const float (&v)[8]
 }
 
 // fp32 rows -> 16-bit rows; columns [C, ld16) are zeroed
-template <bool F16>
+// TWIN (fp16 mode): the bf16 rounding of the fp16 value is written alongside -- the operand the layer's weight-gradient
+// product (a bf16 product: gradients leave fp16's range) needs, which ccn_f16_to_bf16_rows otherwise makes in a pass of its own
+__device__ __forceinline__ void twin8(const float (&v)[8], float (&o)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = from_h<true>(to_h<true>(v[e]));
+}
+
+template <bool F16, bool TWIN = false>
 __global__ __launch_bounds__(EW_TPB) void cast_rows_h_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int64_t C,
-                                                             u16* __restrict__ Y, int64_t ldy, int cpb, int rpp) {
+                                                             u16* __restrict__ Y, int64_t ldy, int cpb, int rpp,
+                                                             u16* __restrict__ Yb = nullptr) {
   const int ch = threadIdx.x % cpb, rr = threadIdx.x / cpb;
   const int64_t c0 = ((int64_t)blockIdx.y * cpb + ch) * 8;
   if (rr >= rpp || c0 >= ldy) return;
@@ -422,6 +430,11 @@ __global__ __launch_bounds__(EW_TPB) void cast_rows_h_kernel(const float* __rest
     float v[8];
     load8(X + r * ldx + c0, vec, c0, C, v);
     store8h<F16>(Y + r * ldy + c0, v);
+    if (TWIN) {
+      float o[8];
+      twin8(v, o);
+      store8h<false>(Yb + r * ldy + c0, o);
+    }
   }
 }
 
@@ -512,11 +525,11 @@ __device__ __forceinline__ float act_grad_h(float z, int act, float slope) {
 
 // z = act(y * scale + shift) written as 16-bit rows (the expression of ccn_bn_act_fwd, then ONE rounding); padding columns
 // [C, ldz) zeroed
-template <bool F16>
+template <bool F16, bool TWIN = false>
 __global__ __launch_bounds__(EW_TPB) void bn_act_fwd_h_kernel(const float* __restrict__ Y, int64_t ldy, int64_t rows, int64_t C,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               int act, float slope, u16* __restrict__ Z, int64_t ldz, int cpb,
-                                                              int rpp) {
+                                                              int rpp, u16* __restrict__ Zb = nullptr) {
   const int ch = threadIdx.x % cpb, rr = threadIdx.x / cpb;
   const int64_t c0 = ((int64_t)blockIdx.y * cpb + ch) * 8;
   if (rr >= rpp || c0 >= ldz) return;
@@ -535,6 +548,11 @@ __global__ __launch_bounds__(EW_TPB) void bn_act_fwd_h_kernel(const float* __res
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? act_fwd_h(v[e] * sc[e] + sh[e], act, slope) : 0.f;
     store8h<F16>(Z + r * ldz + c0, v);
+    if (TWIN) {
+      float o[8];
+      twin8(v, o);
+      store8h<false>(Zb + r * ldz + c0, o);
+    }
   }
 }
 
@@ -1011,6 +1029,30 @@ int ccn_cast_rows_h(const float* X, int64_t ldx, int64_t rows, int64_t C, void* 
   if (f16) hipLaunchKernelGGL(cast_rows_h_kernel<true>, grid, dim3(EW_TPB), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy, g.cpb, g.rpp);
   else hipLaunchKernelGGL(cast_rows_h_kernel<false>, grid, dim3(EW_TPB), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy, g.cpb, g.rpp);
   CCN_LAUNCH_OK("cast_rows_h");
+  return CCN_OK;
+}
+
+int ccn_cast_rows_f16_twin(const float* X, int64_t ldx, int64_t rows, int64_t C, void* Y, void* Yb, int64_t ldy, void* stream) {
+  CCN_REQUIRE(X && Y && Yb && rows >= 0 && C > 0 && ldx >= C && ldy >= C && ldy % 8 == 0 && aligned16(Y) && aligned16(Yb),
+              "cast_rows_f16_twin: bad arguments");
+  if (rows == 0) return CCN_OK;
+  const EwGeom g = ew_geom(ldy);
+  hipLaunchKernelGGL((cast_rows_h_kernel<true, true>), dim3((unsigned)ccn_blocks(rows, EW_ROWS), g.gy), dim3(EW_TPB), 0,
+                     (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy, g.cpb, g.rpp, (u16*)Yb);
+  CCN_LAUNCH_OK("cast_rows_f16_twin");
+  return CCN_OK;
+}
+
+int ccn_bn_act_fwd_f16_twin(const float* Y, int64_t ldy, int64_t rows, int64_t C, const float* scale, const float* shift, int act,
+                            float slope, void* Z, void* Zb, int64_t ldz, void* stream) {
+  CCN_REQUIRE(Y && Z && Zb && scale && shift && rows >= 0 && C > 0 && ldy >= C && ldz >= C && ldz % 8 == 0 && aligned16(Z) &&
+                  aligned16(Zb),
+              "bn_act_fwd_f16_twin: bad arguments");
+  if (rows == 0) return CCN_OK;
+  const EwGeom g = ew_geom(ldz);
+  hipLaunchKernelGGL((bn_act_fwd_h_kernel<true, true>), dim3((unsigned)ccn_blocks(rows, EW_ROWS), g.gy), dim3(EW_TPB), 0,
+                     (hipStream_t)stream, Y, ldy, rows, C, scale, shift, act, slope, (u16*)Z, ldz, g.cpb, g.rpp, (u16*)Zb);
+  CCN_LAUNCH_OK("bn_act_fwd_f16_twin");
   return CCN_OK;
 }
 

@@ -732,6 +732,47 @@ def test_bf16_model_tracks_emulation_and_fp32(bf16_mode, which):
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in mine.parameters())
 
 
+def test_fp16_mode_bf16_twins_replace_the_conversion_pass():
+    """fp16 mode: the weight-gradient product (a bf16 product) takes bf16(fp16(x)).  The producer of a 16-bit activation
+    (BatchNorm + activation pass, cast of an fp32 input) writes that twin in the same pass; without it backward converts the
+    fp16 rows (ccn_f16_to_bf16_rows).  Same operand either way: outputs and every gradient bit-identical."""
+    from oracle import torch_ref as R
+    from curvecloudnet_amd.nn import MLP
+    ops = _ops()
+    ops.set_mlp_dtype("fp16")
+    try:
+        torch.manual_seed(3)
+        mlp = MLP([40, 64, 128, 64], bias=False).to(DEV).train()
+        x = torch.randn(3000, 40, generator=torch.Generator().manual_seed(1)).to(DEV)
+        cot = torch.randn(3000, 64, generator=torch.Generator().manual_seed(2)).to(DEV)
+        res, logs = [], []
+        for twin in (True, False):
+            ops.F16_TWIN = twin
+            log = []
+            inner = ops.call
+
+            def spy(name, *a):
+                log.append(name)
+                return inner(name, *a)
+
+            ops.call = spy
+            try:
+                xi = x.clone().requires_grad_(True)
+                out = mlp(xi)
+                res.append([out.detach()] + list(torch.autograd.grad((out * cot).sum(), [xi] + list(mlp.parameters()))))
+            finally:
+                ops.call = inner
+                ops.F16_TWIN = True
+            logs.append(log)
+        assert "f16_to_bf16_rows" not in logs[0] and "bn_act_fwd_f16_twin" in logs[0] and "cast_rows_f16_twin" in logs[0]
+        assert logs[1].count("f16_to_bf16_rows") == 3 and "bn_act_fwd_f16_twin" not in logs[1]
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+    finally:
+        ops.set_mlp_dtype("fp32")
+        R.set_mlp_dtype("fp32")
+
+
 @pytest.mark.parametrize("which", ["sgcnn", "sa-max", "sa-attend", "sgcnn-sparse-attend", "conv-v1"])
 def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
     """16-bit storage modes: the algebraic first layer of an edge MLP writes its activation as 16-bit rows for the next Linear
@@ -788,14 +829,17 @@ def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
         kind = "cg" if which == "sgcnn" else "pn"
         assert kind + "_edge_apply_h" in calls[0] and kind + "_edge_bwd_h" in calls[0] and kind + "_edge_bwd_stats_h" in calls[0]
         assert kind + "_edge_apply" in calls[1] and kind + "_edge_bwd" in calls[1]
-    assert calls[0].count("cast_rows_h") < calls[1].count("cast_rows_h")
+    def casts(log):       # (fp16 mode: a cast that also writes the bf16 twin of its fp16 rows has its own entry point)
+        return log.count("cast_rows_h") + log.count("cast_rows_f16_twin")
+
+    assert casts(calls[0]) < casts(calls[1])
     if "attend" in which:     # messages: fp32 rows + 16-bit copy, their two gradients merged in one pass; the softmax
         # aggregation fused into attend_nn's last layer hands over the scores' gradient as bf16 rows
         assert "add_cast_rows_h" in calls[0] and "seg_softmax_agg_bwd_h" in calls[0] and "seg_softmax_agg_bwd" not in calls[0]
         assert "seg_softmax_agg_bwd" in calls[1] and "add_cast_rows_h" not in calls[1]
     if which == "sgcnn":      # ... and the max over a point's rows hands its gradient to the plain last layer as bf16 rows
         assert "cg_max_bwd_h" in calls[0] and "cg_max_bwd" not in calls[0] and "cg_max_bwd" in calls[1]
-        assert calls[0].count("cast_rows_h") <= calls[1].count("cast_rows_h") - 2
+        assert casts(calls[0]) <= casts(calls[1]) - 2
     assert torch.equal(res[0][0], res[1][0]), "forward must not change: same fp32 value, same rounding"
     gmax = max(float(b.norm()) for b in res[1][1:])
     for a, b in zip(res[0][1:], res[1][1:]):
