@@ -643,7 +643,10 @@ def bf16_mode(request):
     ops = _ops()
     ops.set_mlp_dtype(request.param)
     R.set_mlp_dtype(request.param)
+    store16 = R.STORE16
+    R.STORE16 = ops.STORE16          # (CCN_STORE16=0 runs: the emulation follows the product's storage form)
     yield request.param
+    R.STORE16 = store16
     ops.set_mlp_dtype("fp32")
     R.set_mlp_dtype("fp32")
 
