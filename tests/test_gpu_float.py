@@ -845,11 +845,14 @@ def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
         assert casts(calls[0]) <= casts(calls[1]) - 2
     assert torch.equal(res[0][0], res[1][0]), "forward must not change: same fp32 value, same rounding"
     gmax = max(float(b.norm()) for b in res[1][1:])
+    worst = 0.0
     for a, b in zip(res[0][1:], res[1][1:]):
         # (gradients that are identically zero in exact arithmetic -- a bias in front of BatchNorm or of a softmax -- are
         # rounding noise on one side and exact zeros on the other: measured on the scale of the real gradients)
         err = float((a - b).norm()) / max(float(b.norm()), 1e-3 * gmax)
+        worst = max(worst, err)
         assert err < 1e-2, err
+    print("%s %s: largest relative l2 gradient difference %.2e (bound 1e-2)" % (bf16_mode, which, worst))
 
 
 @pytest.mark.parametrize("ids,k,r", [([2, 3], 12, 0.05), ([0], 20, 0.02), ([4, 5, 6], 8, 0.5)])
