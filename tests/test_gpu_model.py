@@ -234,7 +234,9 @@ def test_deferred_activations_give_the_same_bits():
         scale = float(g0[n].abs().max())
         same_mode = float((g0[n] - ga[n]).abs().max())
         across = float((g0[n] - g1[n]).abs().max())
-        assert across <= 3.0 * same_mode + 1e-5 * scale + 1e-12, (n, across, same_mode, scale)
+        # (same_mode is ONE sample of the atomic-order noise and can come out as zero for a tensor: the floor is five times the
+        # typical noise, 1e-5 of the tensor's scale; a wrong transform moves gradients by 1e-2 and more)
+        assert across <= 3.0 * same_mode + 5e-5 * scale + 1e-12, (n, across, same_mode, scale)
 
 
 def test_full_kitti_config_matches_oracle():
