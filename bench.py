@@ -478,7 +478,8 @@ def main():
     for st in pools:
         with torch.cuda.stream(st):
             held = [torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                    for nbytes in (2 << 30, 1 << 30, 1 << 30, 512 << 20, 512 << 20, 256 << 20, 256 << 20, 128 << 20, 128 << 20,
+                    for nbytes in (4 << 30, 2 << 30, 2 << 30, 1 << 30, 1 << 30, 1 << 30, 512 << 20, 512 << 20, 512 << 20,
+                                   256 << 20, 256 << 20, 128 << 20, 128 << 20,
                                    64 << 20, 64 << 20, 32 << 20, 32 << 20, 16 << 20, 16 << 20, 8 << 20, 8 << 20, 4 << 20, 4 << 20)]
             held += [torch.empty((1 << 20) - 512, dtype=torch.uint8, device=dev) for _ in range(128)]   # (the small-block pool)
             del held

@@ -837,7 +837,10 @@ def _is_rows16(t, dtype=torch.bfloat16):
             and t.stride(0) >= t.size(1) and t.data_ptr() % 16 == 0)
 
 
-F16_TWIN = os.environ.get("CCN_F16_TWIN", "1") != "0"      # (A/B and tests: 0 = backward converts with ccn_f16_to_bf16_rows)
+# Opt-in (CCN_F16_TWIN=1): the twins save 78 conversion passes per step of BASELINE configs[4] (5 ms of kernel time) but
+# keep one more 16-bit copy of every MLP input alive from forward to backward (29.6 -> 49.3 GB peak there), and that
+# configuration's step is not bound by the feature stream's kernel time (103.9 / 107.6 ms without, 102.7 / 104.1 with, same box).
+F16_TWIN = os.environ.get("CCN_F16_TWIN", "0") != "0"
 
 
 def _cast16_twin(x):

@@ -749,6 +749,7 @@ def test_fp16_mode_bf16_twins_replace_the_conversion_pass():
         x = torch.randn(3000, 40, generator=torch.Generator().manual_seed(1)).to(DEV)
         cot = torch.randn(3000, 64, generator=torch.Generator().manual_seed(2)).to(DEV)
         res, logs = [], []
+        default_twin = ops.F16_TWIN
         for twin in (True, False):
             ops.F16_TWIN = twin
             log = []
@@ -765,7 +766,7 @@ def test_fp16_mode_bf16_twins_replace_the_conversion_pass():
                 res.append([out.detach()] + list(torch.autograd.grad((out * cot).sum(), [xi] + list(mlp.parameters()))))
             finally:
                 ops.call = inner
-                ops.F16_TWIN = True
+                ops.F16_TWIN = default_twin
             logs.append(log)
         assert "f16_to_bf16_rows" not in logs[0] and "bn_act_fwd_f16_twin" in logs[0] and "cast_rows_f16_twin" in logs[0]
         assert logs[1].count("f16_to_bf16_rows") == 3 and "bn_act_fwd_f16_twin" not in logs[1]
