@@ -494,6 +494,104 @@ __global__ __launch_bounds__(FPS_TPB) void fps_reg_kernel(const float* __restric
   }
 }
 
+// Clouds beyond the register-resident form's 16 k points (round 3: the exact FPS over A2D2's ~49 k-point clouds was 37.8 ms per
+// step in fps_kernel, the critical path of BASELINE configs[4] -- one CU streams 20 bytes per point and round through its L1).
+// Hybrid: the first PR points of every thread live in registers as above; for the rest only the coordinates are re-read
+// from global memory (12 bytes per point and round), their running minima live in LDS (up to FPS_HYB_LDS floats), and the
+// winner's coordinates travel with the reduction: one barrier per sample, no dependent global load.  Same arithmetic, same
+// visiting order per thread (indices increase), same tie rule as fps_kernel.
+constexpr int FPS_HYB_LDS = 36864;      // 144 KB of running minima
+template <int PR>
+__global__ __launch_bounds__(FPS_TPB) void fps_hybrid_kernel(const float* __restrict__ pos,
+                                                             const int64_t* __restrict__ cloud_ptr,
+                                                             const int64_t* __restrict__ start,
+                                                             const int64_t* __restrict__ out_ptr,
+                                                             int64_t* __restrict__ out) {
+  extern __shared__ float md_l[];                       // [n - PR * FPS_TPB] running minima of the points beyond the registers
+  __shared__ FpsBest red[2][FPS_TPB / 64];
+  const int64_t b = blockIdx.x;
+  const int64_t p0 = cloud_ptr[b];
+  const int n = (int)(cloud_ptr[b + 1] - p0);
+  const int64_t o0 = out_ptr[b];
+  const int keep = (int)(out_ptr[b + 1] - o0);
+  if (n <= 0 || keep <= 0) return;
+  const float* p = pos + 3 * p0;
+  float px[PR], py[PR], pz[PR], md[PR];
+#pragma unroll
+  for (int k = 0; k < PR; ++k) {
+    const int i = threadIdx.x + k * FPS_TPB;
+    const bool in = i < n;
+    px[k] = in ? p[3 * i] : 0.f;
+    py[k] = in ? p[3 * i + 1] : 0.f;
+    pz[k] = in ? p[3 * i + 2] : 0.f;
+    md[k] = in ? __builtin_inff() : -2.f;  // never the maximum
+  }
+  const int rest0 = PR * FPS_TPB;
+  for (int i = rest0 + threadIdx.x; i < n; i += FPS_TPB) md_l[i - rest0] = __builtin_inff();
+  int cur = (int)start[b];
+  cur = cur < 0 ? 0 : (cur >= n ? n - 1 : cur);
+  float cx = p[3 * cur], cy = p[3 * cur + 1], cz = p[3 * cur + 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int it = 0; it < keep; ++it) {
+    if (threadIdx.x == 0) out[o0 + it] = p0 + cur;
+    FpsBest best = {-1.f, 0x7fffffff, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < PR; ++k) {
+      const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      const float m = md[k] < 0.f ? md[k] : fminf(md[k], d2);
+      md[k] = m;
+      if (m > best.v) {  // k (hence the point index) increases: strict > keeps the smallest index
+        best.v = m;
+        best.i = threadIdx.x + k * FPS_TPB;
+        best.x = px[k];
+        best.y = py[k];
+        best.z = pz[k];
+      }
+    }
+    for (int i0 = rest0 + threadIdx.x; i0 < n; i0 += 4 * FPS_TPB) {
+      float x[4], y[4], z[4], m0[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {      // (four points' loads in flight together)
+        const int i = i0 + u * FPS_TPB;
+        const int ic = i < n ? i : i0;
+        x[u] = p[3 * ic];
+        y[u] = p[3 * ic + 1];
+        z[u] = p[3 * ic + 2];
+        m0[u] = md_l[ic - rest0];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * FPS_TPB;
+        if (i >= n) break;
+        const float dx = x[u] - cx, dy = y[u] - cy, dz = z[u] - cz;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        const float m = fminf(m0[u], d2);
+        md_l[i - rest0] = m;
+        if (m > best.v) {
+          best.v = m;
+          best.i = i;
+          best.x = x[u];
+          best.y = y[u];
+          best.z = z[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) fps_take(best, fps_shfl(best, off));
+    FpsBest* tab = red[it & 1];
+    if (lane == 0) tab[wave] = best;
+    __syncthreads();
+    FpsBest all = tab[lane & (FPS_TPB / 64 - 1)];
+#pragma unroll
+    for (int off = FPS_TPB / 128; off > 0; off >>= 1) fps_take(all, fps_shfl(all, off));
+    cur = all.i;
+    cx = all.x;
+    cy = all.y;
+    cz = all.z;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -617,6 +715,8 @@ int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, co
     ok = ok && hipFuncSetAttribute((const void*)fps_reg_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void*)fps_reg_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void*)fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)fps_hybrid_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   FPS_HYB_LDS * 4) == hipSuccess;
     CCN_REQUIRE(ok, "fps: cannot raise the dynamic LDS limit");
     claimed = true;
   }
@@ -626,6 +726,9 @@ int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, co
     hipLaunchKernelGGL(fps_reg_kernel<8>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, out);
   else if (max_cloud > 0 && max_cloud <= 16 * FPS_TPB)
     hipLaunchKernelGGL(fps_reg_kernel<16>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, out);
+  else if (max_cloud > 0 && max_cloud <= 16 * FPS_TPB + FPS_HYB_LDS && g_fps_claim > 0)      // (claim 0 = A/B: the streaming form)
+    hipLaunchKernelGGL(fps_hybrid_kernel<16>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)FPS_HYB_LDS * 4, s, pos, cloud_ptr, start,
+                       out_ptr, out);
   else
     hipLaunchKernelGGL(fps_kernel, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, mind, out);
   CCN_LAUNCH_OK("fps");
