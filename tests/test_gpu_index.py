@@ -269,10 +269,12 @@ def test_fps_matches_oracle(ids, ratio):
 
 def test_fps_lds_claim_does_not_change_the_samples():
     """The sampling workgroups claim 96 KB of dynamic LDS they never touch (so that no GEMM workgroup shares their CU);
-    with and without the claim the sample indices are the same, on the register and on the global-memory variant."""
+    with and without the claim the sample indices are the same.  Clouds of 16 k .. 53 k points take the hybrid kernel
+    (registers + running minima in LDS) when the claim is on and the streaming kernel when it is 0: same samples."""
     ops = _ops()
     from curvecloudnet_amd import _lib
-    for n_curves, ratio in ((40, 0.25), (1500, 0.05)):        # ~1 k points (registers) and ~36 k points per cloud (global)
+    # ~1 k points (registers), ~36 k and ~50 k points per cloud (hybrid / streaming; the second near the hybrid form's capacity)
+    for n_curves, ratio in ((40, 0.25), (1500, 0.05), (2150, 0.02)):
         d = _synth([1, 2], n_curves=n_curves)
         topo = ops.CurveTopology(d.batch.to(DEV), d.curve_idxs.to(DEV))
         outs = []
