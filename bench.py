@@ -31,13 +31,13 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 def gemm_label(name, ints, nulls=()):
     """(kernel symbol as rocprofv3 prints it, flops) of a GEMM launch; mirrors the dispatch in csrc/ccn_gemm.hip."""
     if name not in ("gemm_nt", "gemm_nn", "gemm_tn", "gemm_tn_ws", "gemm_nt_bf16", "gemm_nt_f16", "gemm_tn_bf16", "gemm_nt_x3",
-                    "gemm_nt_h", "gemm_tn_h"):
+                    "gemm_nt_h", "gemm_tn_h", "gemm_tn_h_xf16"):
         return None, 0.0
     ld_a, ld_b, _, m, n, k = ints[:6]
     flops = 2.0 * m * n * k
     if name == "gemm_nt_h":       # (16-bit rows: the LDS-DMA kernels of csrc/ccn_gemm_h.hip)
         return "gemm_h_pair_kernel<%s, %s>" % ("true" if ints[6] else "false", "true" if ints[7] else "false"), flops
-    if name == "gemm_tn_h":
+    if name in ("gemm_tn_h", "gemm_tn_h_xf16"):
         return "gemm_h_tn_kernel", flops
     if name == "gemm_tn_ws":
         def tile(d):        # (a small remainder over 128 goes to a second, 64-wide launch: the label is the main one's)
@@ -87,7 +87,7 @@ def gemm_bytes(name, ints):
     if name == "gemm_nt_h":
         _, _, _, m, n, k, _, out16 = ints[:8]
         return m * (2.0 * k + (2.0 if out16 else 4.0) * n) + 2.0 * n * k
-    if name == "gemm_tn_h":
+    if name in ("gemm_tn_h", "gemm_tn_h_xf16"):
         _, _, _, m, n, k = ints[:6]
         return 2.0 * m * (n + k) + 8.0 * n * k
     return 0.0

@@ -409,17 +409,9 @@ __device__ __forceinline__ void store8h(u16* __restrict__ p, const float (&v)[8]
 }
 
 // fp32 rows -> 16-bit rows; columns [C, ld16) are zeroed
-// TWIN (fp16 mode): the bf16 rounding of the fp16 value is written alongside -- the operand the layer's weight-gradient
-// product (a bf16 product: gradients leave fp16's range) needs, which ccn_f16_to_bf16_rows otherwise makes in a pass of its own
-__device__ __forceinline__ void twin8(const float (&v)[8], float (&o)[8]) {
-#pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = from_h<true>(to_h<true>(v[e]));
-}
-
-template <bool F16, bool TWIN = false>
+template <bool F16>
 __global__ __launch_bounds__(EW_TPB) void cast_rows_h_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int64_t C,
-                                                             u16* __restrict__ Y, int64_t ldy, int cpb, int rpp,
-                                                             u16* __restrict__ Yb = nullptr) {
+                                                             u16* __restrict__ Y, int64_t ldy, int cpb, int rpp) {
   const int ch = threadIdx.x % cpb, rr = threadIdx.x / cpb;
   const int64_t c0 = ((int64_t)blockIdx.y * cpb + ch) * 8;
   if (rr >= rpp || c0 >= ldy) return;
@@ -430,11 +422,6 @@ __global__ __launch_bounds__(EW_TPB) void cast_rows_h_kernel(const float* __rest
     float v[8];
     load8(X + r * ldx + c0, vec, c0, C, v);
     store8h<F16>(Y + r * ldy + c0, v);
-    if (TWIN) {
-      float o[8];
-      twin8(v, o);
-      store8h<false>(Yb + r * ldy + c0, o);
-    }
   }
 }
 
@@ -525,11 +512,11 @@ __device__ __forceinline__ float act_grad_h(float z, int act, float slope) {
 
 // z = act(y * scale + shift) written as 16-bit rows (the expression of ccn_bn_act_fwd, then ONE rounding); padding columns
 // [C, ldz) zeroed
-template <bool F16, bool TWIN = false>
+template <bool F16>
 __global__ __launch_bounds__(EW_TPB) void bn_act_fwd_h_kernel(const float* __restrict__ Y, int64_t ldy, int64_t rows, int64_t C,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               int act, float slope, u16* __restrict__ Z, int64_t ldz, int cpb,
-                                                              int rpp, u16* __restrict__ Zb = nullptr) {
+                                                              int rpp) {
   const int ch = threadIdx.x % cpb, rr = threadIdx.x / cpb;
   const int64_t c0 = ((int64_t)blockIdx.y * cpb + ch) * 8;
   if (rr >= rpp || c0 >= ldz) return;
@@ -548,11 +535,6 @@ __global__ __launch_bounds__(EW_TPB) void bn_act_fwd_h_kernel(const float* __res
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? act_fwd_h(v[e] * sc[e] + sh[e], act, slope) : 0.f;
     store8h<F16>(Z + r * ldz + c0, v);
-    if (TWIN) {
-      float o[8];
-      twin8(v, o);
-      store8h<false>(Zb + r * ldz + c0, o);
-    }
   }
 }
 
@@ -679,7 +661,16 @@ constexpr int HT_SL = 64;     // contraction rows per slice (4 MFMA k-steps)
 // treated as a copy of the first by hipcc 7.2 -- v_mov v89, v88 in front of the MFMAs)
 using u64 = unsigned long long;
 
-template <int EPI>   // 0: slab store, 2: plain add into dW (one chunk)
+// two fp16 values -> their bf16 roundings (the conversion of f16_to_bf16_rows_kernel, on an MFMA operand dword)
+__device__ __forceinline__ uint32_t f16x2_to_bf16x2(uint32_t w) {
+  const float lo = from_h<true>((u16)(w & 0xffffu)), hi = from_h<true>((u16)(w >> 16));
+  return (uint32_t)to_h<false>(lo) | ((uint32_t)to_h<false>(hi) << 16);
+}
+
+// XF16 (fp16 mode): X holds fp16 rows and is converted to bf16 on the way into the MFMA -- the product of bf16(fp16(x)) that
+// ccn_f16_to_bf16_rows + this kernel give, without the conversion pass (78 per step of BASELINE configs[4], 5 ms) and without
+// keeping a bf16 copy alive; the matrix pipe is 17 % busy here, the 24 extra VALU per k-step are free
+template <int EPI, bool XF16>   // EPI 0: slab store, 2: plain add into dW (one chunk)
 __global__ __launch_bounds__(HT_TPB, 2) void gemm_h_tn_kernel(const u16* __restrict__ A, int64_t lda,
                                                               const u16* __restrict__ B, int64_t ldb, float* __restrict__ C,
                                                               int64_t ldc, int64_t M, int64_t N, int64_t K, int tiles_k,
@@ -806,8 +797,13 @@ __global__ __launch_bounds__(HT_TPB, 2) void gemm_h_tn_kernel(const u16* __restr
       }                                                                                                                  \
       oa[t] = f32x4{__builtin_bit_cast(float, l0), __builtin_bit_cast(float, l1), __builtin_bit_cast(float, h0),        \
                     __builtin_bit_cast(float, h1)};                                                                      \
-      ob[t] = f32x4{__builtin_bit_cast(float, (uint32_t)fb[PAR][t][0]), __builtin_bit_cast(float, (uint32_t)(fb[PAR][t][0] >> 32)), \
-                    __builtin_bit_cast(float, (uint32_t)fb[PAR][t][1]), __builtin_bit_cast(float, (uint32_t)(fb[PAR][t][1] >> 32))}; \
+      uint32_t x0 = (uint32_t)fb[PAR][t][0], x1 = (uint32_t)(fb[PAR][t][0] >> 32);                                      \
+      uint32_t x2 = (uint32_t)fb[PAR][t][1], x3 = (uint32_t)(fb[PAR][t][1] >> 32);                                      \
+      if (XF16) {                                                                                                        \
+        x0 = f16x2_to_bf16x2(x0); x1 = f16x2_to_bf16x2(x1); x2 = f16x2_to_bf16x2(x2); x3 = f16x2_to_bf16x2(x3);          \
+      }                                                                                                                  \
+      ob[t] = f32x4{__builtin_bit_cast(float, x0), __builtin_bit_cast(float, x1), __builtin_bit_cast(float, x2),        \
+                    __builtin_bit_cast(float, x3)};                                                                      \
     }                                                                                                                    \
     _Pragma("unroll") for (int ta = 0; ta < 2; ++ta) _Pragma("unroll") for (int tb = 0; tb < 2; ++tb)                    \
         acc[ta][tb] = mfma_h<false>(oa[ta], ob[tb], acc[ta][tb]);                                                        \
@@ -991,8 +987,8 @@ size_t ccn_gemm_tn_h_workspace_bytes(int64_t M, int64_t N, int64_t K) {
   return (size_t)ht_plan(M, N, K).slab_floats * sizeof(float);
 }
 
-int ccn_gemm_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
-                  int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+static int gemm_tn_h_impl(const void* dY, int64_t lddy, const void* X, int x_f16, int64_t ldx, float* dW, int64_t lddw, int64_t M,
+                          int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
   CCN_REQUIRE(dY && X && dW, "gemm_tn_h: null pointer");
   CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "gemm_tn_h: bad sizes");
   CCN_REQUIRE(aligned16(dY) && aligned16(X) && lddy % 8 == 0 && ldx % 8 == 0 && lddy >= 8 && ldx >= 8,
@@ -1003,22 +999,41 @@ int ccn_gemm_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, floa
   const int64_t grid = p.n_ids < 512 ? p.n_ids : 512;
   const u16* a = (const u16*)dY;
   const u16* b = (const u16*)X;
+#define CCN_TN_H(EPI_, SLABS_)                                                                                                \
+  do {                                                                                                                        \
+    if (x_f16)                                                                                                                \
+      hipLaunchKernelGGL((gemm_h_tn_kernel<EPI_, true>), dim3((unsigned)grid), dim3(HT_TPB), 0, s, a, lddy, b, ldx, dW, lddw,  \
+                         M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, SLABS_);           \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((gemm_h_tn_kernel<EPI_, false>), dim3((unsigned)grid), dim3(HT_TPB), 0, s, a, lddy, b, ldx, dW, lddw, \
+                         M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, SLABS_);           \
+  } while (0)
   if (p.split == 1) {
-    hipLaunchKernelGGL(gemm_h_tn_kernel<2>, dim3((unsigned)grid), dim3(HT_TPB), 0, s, a, lddy, b, ldx, dW, lddw, M, N, K, p.tiles_k,
-                       p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, (float*)nullptr);
+    CCN_TN_H(2, (float*)nullptr);
   } else {
     CCN_REQUIRE(workspace != nullptr && workspace_bytes >= (size_t)p.slab_floats * sizeof(float) && aligned16(workspace),
                 "gemm_tn_h: workspace too small (%zu < %zu bytes) or unaligned", workspace_bytes,
                 (size_t)p.slab_floats * sizeof(float));
     float* slabs = (float*)workspace;
-    hipLaunchKernelGGL(gemm_h_tn_kernel<0>, dim3((unsigned)grid), dim3(HT_TPB), 0, s, a, lddy, b, ldx, dW, lddw, M, N, K, p.tiles_k,
-                       p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, slabs);
+    CCN_TN_H(0, slabs);
     const int64_t work = (int64_t)p.tiles * (HT_T * HT_T / 4);
     hipLaunchKernelGGL(tn_h_reduce_kernel, dim3((unsigned)((work + 63) / 64)), dim3(64 * HRED_WAVES), 0, s, slabs, p.split,
                        p.tiles_k, p.tiles, N, K, dW, lddw);
   }
+#undef CCN_TN_H
   CCN_LAUNCH_OK("gemm_tn_h");
   return CCN_OK;
+}
+
+int ccn_gemm_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
+                  int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  return gemm_tn_h_impl(dY, lddy, X, 0, ldx, dW, lddw, M, N, K, workspace, workspace_bytes, stream);
+}
+
+// ... with X as fp16 rows (the fp16 mode's forward operand): dW += dY^T bf16(X), converted inside the kernel
+int ccn_gemm_tn_h_xf16(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
+                       int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  return gemm_tn_h_impl(dY, lddy, X, 1, ldx, dW, lddw, M, N, K, workspace, workspace_bytes, stream);
 }
 
 int ccn_cast_rows_h(const float* X, int64_t ldx, int64_t rows, int64_t C, void* Y, int64_t ldy, int f16, void* stream) {
@@ -1029,30 +1044,6 @@ int ccn_cast_rows_h(const float* X, int64_t ldx, int64_t rows, int64_t C, void* 
   if (f16) hipLaunchKernelGGL(cast_rows_h_kernel<true>, grid, dim3(EW_TPB), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy, g.cpb, g.rpp);
   else hipLaunchKernelGGL(cast_rows_h_kernel<false>, grid, dim3(EW_TPB), 0, (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy, g.cpb, g.rpp);
   CCN_LAUNCH_OK("cast_rows_h");
-  return CCN_OK;
-}
-
-int ccn_cast_rows_f16_twin(const float* X, int64_t ldx, int64_t rows, int64_t C, void* Y, void* Yb, int64_t ldy, void* stream) {
-  CCN_REQUIRE(X && Y && Yb && rows >= 0 && C > 0 && ldx >= C && ldy >= C && ldy % 8 == 0 && aligned16(Y) && aligned16(Yb),
-              "cast_rows_f16_twin: bad arguments");
-  if (rows == 0) return CCN_OK;
-  const EwGeom g = ew_geom(ldy);
-  hipLaunchKernelGGL((cast_rows_h_kernel<true, true>), dim3((unsigned)ccn_blocks(rows, EW_ROWS), g.gy), dim3(EW_TPB), 0,
-                     (hipStream_t)stream, X, ldx, rows, C, (u16*)Y, ldy, g.cpb, g.rpp, (u16*)Yb);
-  CCN_LAUNCH_OK("cast_rows_f16_twin");
-  return CCN_OK;
-}
-
-int ccn_bn_act_fwd_f16_twin(const float* Y, int64_t ldy, int64_t rows, int64_t C, const float* scale, const float* shift, int act,
-                            float slope, void* Z, void* Zb, int64_t ldz, void* stream) {
-  CCN_REQUIRE(Y && Z && Zb && scale && shift && rows >= 0 && C > 0 && ldy >= C && ldz >= C && ldz % 8 == 0 && aligned16(Z) &&
-                  aligned16(Zb),
-              "bn_act_fwd_f16_twin: bad arguments");
-  if (rows == 0) return CCN_OK;
-  const EwGeom g = ew_geom(ldz);
-  hipLaunchKernelGGL((bn_act_fwd_h_kernel<true, true>), dim3((unsigned)ccn_blocks(rows, EW_ROWS), g.gy), dim3(EW_TPB), 0,
-                     (hipStream_t)stream, Y, ldy, rows, C, scale, shift, act, slope, (u16*)Z, ldz, g.cpb, g.rpp, (u16*)Zb);
-  CCN_LAUNCH_OK("bn_act_fwd_f16_twin");
   return CCN_OK;
 }
 

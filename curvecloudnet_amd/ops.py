@@ -837,22 +837,7 @@ def _is_rows16(t, dtype=torch.bfloat16):
             and t.stride(0) >= t.size(1) and t.data_ptr() % 16 == 0)
 
 
-# Opt-in (CCN_F16_TWIN=1): the twins save 78 conversion passes per step of BASELINE configs[4] (5 ms of kernel time) but
-# keep one more 16-bit copy of every MLP input alive from forward to backward (29.6 -> 49.3 GB peak there), and that
-# configuration's step is not bound by the feature stream's kernel time (103.9 / 107.6 ms without, 102.7 / 104.1 with, same box).
-F16_TWIN = os.environ.get("CCN_F16_TWIN", "0") != "0"
-
-
-def _cast16_twin(x):
-    """fp32 rows -> (fp16 rows, their bf16 rounding) in one pass (fp16 mode: forward operand + weight-gradient operand)."""
-    if x.dtype != torch.float32:
-        x = x.float()
-    x = _mat(x)
-    out = _rows16(x.size(0), x.size(1), x.device, torch.float16)
-    twin = _rows16(x.size(0), x.size(1), x.device)          # (same leading dimension by construction)
-    if x.size(0):
-        call("cast_rows_f16_twin", ptr(x), _ld(x), x.size(0), x.size(1), ptr(out), ptr(twin), _ld(out))
-    return out, twin
+F16_XCONV = os.environ.get("CCN_F16_XCONV", "1") != "0"     # (A/B and tests: see LinearBNActH.backward)
 
 
 def _cast16(x, dtype=torch.bfloat16):
@@ -881,11 +866,9 @@ def _bf16_of(x16):
 class LinearBNActH(torch.autograd.Function):
     """LinearBNAct on 16-bit rows (see STORE16 above): y = act(BN(bf16(x) bf16(W)^T + b)), fp32 accumulation and statistics."""
 
-    last_twin = None      # fp16 mode: the bf16 twin of the 16-bit tensor the last forward() returned (picked up by linear_bn_act)
-
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum, grad_on, out16,
-                x_f16_bits=False, post=None, post_x=None, dual=False, x_twin=None):
+                x_f16_bits=False, post=None, post_x=None, dual=False):
         # Plain (no BatchNorm) layers only:
         # post = ("max", grp_ptr, rep_row, n points) / ("attend", offsets, n destinations) with post_x = the messages: the
         #   reduction that follows the layer (CGMax / SegSoftmaxAgg) applied inside this function -- the (rows, N) product never
@@ -907,20 +890,8 @@ class LinearBNActH(torch.autograd.Function):
         fdt = _fwd16()                                   # forward operand dtype (bf16 / fp16)
         f16 = 1 if fdt == torch.float16 else 0
         ctx.x16_in = bool(x_f16_bits) or (x.dtype == torch.bfloat16 and fdt == torch.bfloat16)
-        # fp16 mode: the weight-gradient product is a bf16 product and takes bf16(fp16(x)) -- the "twin" of a 16-bit activation,
-        # written by its producer in the same pass (x_twin) or by the cast below; without one backward converts (ccn_f16_to_bf16_rows)
-        want_twin = bool(F16_TWIN and f16 and grad_on and ctx.needs_input_grad[1] and m > 0)
-        ctx.xb = None
-        if _is_rows16(x, fdt):
-            x16 = x
-            if want_twin and x_twin is not None and _is_rows16(x_twin) and tuple(x_twin.shape) == (m, k):
-                ctx.xb = x_twin
-        elif want_twin:
-            x16, ctx.xb = _cast16_twin(x)
-        else:
-            x16 = _cast16(x, fdt)
+        x16 = _cast16(x, fdt)
         w16 = _cast16(weight.detach(), fdt)
-        LinearBNActH.last_twin = None
         y = _rows(m, n, dev)
         has_bn = gamma is not None
         ctx.has_bn, ctx.act, ctx.training, ctx.has_bias = has_bn, ACT[act], bool(training), bias is not None
@@ -960,10 +931,7 @@ class LinearBNActH(torch.autograd.Function):
             ctx.save_for_backward(x16, weight)
             if dual:
                 ctx.dual = True
-                if F16_TWIN and f16 and grad_on:
-                    y16, LinearBNActH.last_twin = _cast16_twin(y)
-                else:
-                    y16 = _cast16(y, fdt)
+                y16 = _cast16(y, fdt)
                 return y, (y16.view(torch.bfloat16) if f16 else y16)
             return y
         if post is not None or dual:
@@ -983,13 +951,7 @@ class LinearBNActH(torch.autograd.Function):
         ctx.save_for_backward(x16, weight, y, par)
         if ctx.out16:
             z = _rows16(m, n, dev, fdt)
-            if F16_TWIN and f16 and grad_on and m:
-                zb = _rows16(m, n, dev)
-                call("bn_act_fwd_f16_twin", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), ptr(zb),
-                     _ld(z))
-                LinearBNActH.last_twin = zb
-            else:
-                call("bn_act_fwd_h", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z), f16)
+            call("bn_act_fwd_h", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z), f16)
             return z.view(torch.bfloat16) if f16 else z
         z = _rows(m, n, dev)
         call("bn_act_fwd", ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
@@ -1078,11 +1040,15 @@ class LinearBNActH(torch.autograd.Function):
                 _main_grad_cancel(ctx.main_grad_of)
             dw = into if into is not None else _rows(n, k, dev, zero=True)
             if m:
-                xb = ctx.xb if ctx.xb is not None else _bf16_of(x16)
+                # fp16 mode: the product takes bf16(fp16(x)); the kernel converts the fp16 rows on its MFMA operand
+                # (CCN_F16_XCONV=0: a ccn_f16_to_bf16_rows pass first, as before)
+                inline = F16_XCONV and x16.dtype == torch.float16
+                xb = x16 if inline else _bf16_of(x16)
                 with _WgradScope(into, dy16, xb):
                     nb = lib().ccn_gemm_tn_h_workspace_bytes(m, n, k)
                     ws = _tn_scratch(nb, dev)
-                    call("gemm_tn_h", ptr(dy16), _ld(dy16), ptr(xb), _ld(xb), ptr(dw), _ld(dw), m, n, k, ptr(ws), nb)
+                    call("gemm_tn_h_xf16" if inline else "gemm_tn_h", ptr(dy16), _ld(dy16), ptr(xb), _ld(xb), ptr(dw), _ld(dw),
+                         m, n, k, ptr(ws), nb)
             if into is not None:
                 dw = _main_grad_done(ctx.main_grad_of)
         db = None
@@ -1104,7 +1070,7 @@ class LinearBNActH(torch.autograd.Function):
                     acc = _stats_buffer(gf.size(0), n, dev)
                     db = torch.empty(n, dtype=torch.float32, device=dev)
                     call("colsum", ptr(gf), _ld(gf), gf.size(0), n, ptr(acc), ptr(db))
-        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, dpost, None, None
+        return dx, dw, db, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, dpost, None
 
 
 # A hidden MLP layer whose only consumer is the next Linear of the same MLP hands over its PRE-normalisation product; the
@@ -1142,13 +1108,11 @@ def linear_bn_act(x, weight, bias, bn, training, act, defer=False, post=None, po
             return (y, None) if dual else apply_post(y, post, post_x)
     if _MLP_DTYPE in ("bf16", "fp16") and STORE16 and x.dim() == 2 and x.size(0) > 0:
         xbits = bool(getattr(x, "_ccn_f16_bits", False))
-        xtwin = getattr(x, "_ccn_bf16_twin", None) if xbits else None
         if bn is None:
             out = LinearBNActH.apply(x, weight, bias, None, None, None, None, False, None, 0.0, 0.0, grad_on, False, xbits,
-                                     post[:4] if post is not None and post[0] == "max" else post, post_x, bool(dual), xtwin)
+                                     post[:4] if post is not None and post[0] == "max" else post, post_x, bool(dual))
             if dual and _MLP_DTYPE == "fp16":
                 out[1]._ccn_f16_bits = True
-                out[1]._ccn_bf16_twin, LinearBNActH.last_twin = LinearBNActH.last_twin, None
             return out
         if training and bn.track_running_stats:
             bn.num_batches_tracked += 1
@@ -1156,11 +1120,9 @@ def linear_bn_act(x, weight, bias, bn, training, act, defer=False, post=None, po
         # (the parity tests read sign tables off the fp32 activation: no 16-bit activation while they are recorded)
         out16 = bool(defer and ACT_TRACE is None and ACT[act] != 0)
         out = LinearBNActH.apply(x, weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats, act,
-                                 bn.eps, bn.momentum if bn.momentum is not None else 0.1, grad_on, out16, xbits, None, None, False,
-                                 xtwin)
+                                 bn.eps, bn.momentum if bn.momentum is not None else 0.1, grad_on, out16, xbits)
         if out16 and _MLP_DTYPE == "fp16":
             out._ccn_f16_bits = True
-            out._ccn_bf16_twin, LinearBNActH.last_twin = LinearBNActH.last_twin, None     # (see LinearBNActH: x_twin)
         return out
     if x.dtype in (torch.bfloat16, torch.float16):
         x = x.float()

@@ -265,17 +265,15 @@ int ccn_gemm_h_opt(int opt);
 size_t ccn_gemm_tn_h_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int ccn_gemm_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
                   int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+/* ... with X as fp16 rows (fp16 mode): dW += dY^T bf16(fp16 X), the conversion done on the MFMA operand (no ccn_f16_to_bf16_rows pass) */
+int ccn_gemm_tn_h_xf16(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
+                       int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 /* fp32 rows -> 16-bit rows (round to nearest even), padding columns [C, ldy) zeroed; W (N x K fp32) -> W^T (K x N 16-bit) */
 int ccn_cast_rows_h(const float* X, int64_t ldx, int64_t rows, int64_t C, void* Y, int64_t ldy, int f16, void* stream);
 int ccn_transpose_cast_h(const float* W, int64_t ldw, int64_t N, int64_t K, void* Wt, int64_t ldt, int f16, void* stream);
 /* Y = bf16(A + B), A fp32 rows, B bf16 rows: the two gradients of a product that left as fp32 rows and as a 16-bit copy */
 int ccn_add_cast_rows_h(const float* A, int64_t lda, const void* B, int64_t ldb, int64_t rows, int64_t C, void* Y, int64_t ldy,
                         void* stream);
-/* fp16 mode: the fp16 rows AND their bf16 rounding (bf16(fp16(v)), the weight-gradient operand) in one pass -- same leading
- * dimension for both; what ccn_f16_to_bf16_rows otherwise makes from the fp16 rows in a pass of its own */
-int ccn_cast_rows_f16_twin(const float* X, int64_t ldx, int64_t rows, int64_t C, void* Y, void* Yb, int64_t ldy, void* stream);
-int ccn_bn_act_fwd_f16_twin(const float* Y, int64_t ldy, int64_t rows, int64_t C, const float* scale, const float* shift, int act,
-                            float slope, void* Z, void* Zb, int64_t ldz, void* stream);
 /* fp16 rows -> bf16 rows (the fp16 mode's weight-gradient operand: bf16(fp16(x))) */
 int ccn_f16_to_bf16_rows(const void* X, int64_t ldx, int64_t rows, int64_t C, void* Y, int64_t ldy, void* stream);
 /* ccn_bn_act_fwd writing z as 16-bit rows; ccn_bn_act_bwd_reduce reading a bf16 dZ; ccn_bn_act_bwd_apply_ex reading an fp32

@@ -735,10 +735,10 @@ def test_bf16_model_tracks_emulation_and_fp32(bf16_mode, which):
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in mine.parameters())
 
 
-def test_fp16_mode_bf16_twins_replace_the_conversion_pass():
-    """fp16 mode: the weight-gradient product (a bf16 product) takes bf16(fp16(x)).  The producer of a 16-bit activation
-    (BatchNorm + activation pass, cast of an fp32 input) writes that twin in the same pass; without it backward converts the
-    fp16 rows (ccn_f16_to_bf16_rows).  Same operand either way: outputs and every gradient bit-identical."""
+def test_fp16_mode_weight_gradient_converts_its_operand_in_the_kernel():
+    """fp16 mode: the weight-gradient product (a bf16 product) takes bf16(fp16(x)).  ccn_gemm_tn_h_xf16 converts the fp16 rows
+    on its MFMA operand; the form before made the bf16 rows in a pass of its own (ccn_f16_to_bf16_rows).  Same operand either
+    way: outputs and every gradient bit-identical."""
     from oracle import torch_ref as R
     from curvecloudnet_amd.nn import MLP
     ops = _ops()
@@ -749,9 +749,8 @@ def test_fp16_mode_bf16_twins_replace_the_conversion_pass():
         x = torch.randn(3000, 40, generator=torch.Generator().manual_seed(1)).to(DEV)
         cot = torch.randn(3000, 64, generator=torch.Generator().manual_seed(2)).to(DEV)
         res, logs = [], []
-        default_twin = ops.F16_TWIN
-        for twin in (True, False):
-            ops.F16_TWIN = twin
+        for inline in (True, False):
+            ops.F16_XCONV = inline
             log = []
             inner = ops.call
 
@@ -766,10 +765,10 @@ def test_fp16_mode_bf16_twins_replace_the_conversion_pass():
                 res.append([out.detach()] + list(torch.autograd.grad((out * cot).sum(), [xi] + list(mlp.parameters()))))
             finally:
                 ops.call = inner
-                ops.F16_TWIN = default_twin
+                ops.F16_XCONV = True
             logs.append(log)
-        assert "f16_to_bf16_rows" not in logs[0] and "bn_act_fwd_f16_twin" in logs[0] and "cast_rows_f16_twin" in logs[0]
-        assert logs[1].count("f16_to_bf16_rows") == 3 and "bn_act_fwd_f16_twin" not in logs[1]
+        assert "f16_to_bf16_rows" not in logs[0] and logs[0].count("gemm_tn_h_xf16") == 3
+        assert logs[1].count("f16_to_bf16_rows") == 3 and "gemm_tn_h_xf16" not in logs[1]
         for a, b in zip(*res):
             assert torch.equal(a, b)
     finally:
@@ -833,8 +832,8 @@ def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
         kind = "cg" if which == "sgcnn" else "pn"
         assert kind + "_edge_apply_h" in calls[0] and kind + "_edge_bwd_h" in calls[0] and kind + "_edge_bwd_stats_h" in calls[0]
         assert kind + "_edge_apply" in calls[1] and kind + "_edge_bwd" in calls[1]
-    def casts(log):       # (fp16 mode: a cast that also writes the bf16 twin of its fp16 rows has its own entry point)
-        return log.count("cast_rows_h") + log.count("cast_rows_f16_twin")
+    def casts(log):
+        return log.count("cast_rows_h")
 
     assert casts(calls[0]) < casts(calls[1])
     if "attend" in which:     # messages: fp32 rows + 16-bit copy, their two gradients merged in one pass; the softmax
