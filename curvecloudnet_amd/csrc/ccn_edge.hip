@@ -876,18 +876,60 @@ __global__ __launch_bounds__(TPB) void msg_build_bwd_kernel(const float* __restr
 
 // ------------------------------------------------------------------ sparse edge conv message (dgcnn.py:227-228)
 // msg[e] = [x_i, x_j - x_i], i = dst[e] (the query), j = src[e] (its neighbour)
+template <int ZT>     // ZT: the message rows as fp32 (0), bf16 (1) or fp16 (2) (ccn_common.h: st_el)
 __global__ __launch_bounds__(TPB) void edge_feat_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                             const int64_t* __restrict__ src,
                                                             const int64_t* __restrict__ dst, int64_t E, int C,
-                                                            float* __restrict__ msg, int64_t ldm) {
+                                                            void* __restrict__ msg, int64_t ldm) {
   CCN_LANES;
   const int64_t e = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
   if (e >= E) return;
   const int64_t j = src[e], i = dst[e];
   for (int c = cx; c < C; c += 64) {
     const float xi = x[i * ldx + c];
-    msg[e * ldm + c] = xi;
-    msg[e * ldm + C + c] = x[j * ldx + c] - xi;
+    st_el<ZT>(msg, e * ldm + c, xi);
+    st_el<ZT>(msg, e * ldm + C + c, x[j * ldx + c] - xi);
+  }
+}
+
+// Backward over edges GROUPED by destination (CSR offsets: the layout the sparse path builds anyway): a wave owns one
+// destination i, sums (a - b) over its edges in registers and adds it to dx[i] once; only the neighbour side keeps one atomic
+// per edge and channel (round 3: half of the per-edge form's atomics, 2.5 ms per step of BASELINE configs[4]).  DT = 1: dmsg as
+// bf16 rows (the gradient of 16-bit message rows).
+template <int DT>
+__global__ __launch_bounds__(TPB) void edge_feat_bwd_csr_kernel(const void* __restrict__ dmsg, int64_t lddm,
+                                                                const int64_t* __restrict__ src,
+                                                                const int32_t* __restrict__ offsets, int64_t num_dst, int C,
+                                                                float* __restrict__ dx, int64_t lddx) {
+  CCN_LANES;
+  const int64_t i = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (i >= num_dst) return;
+  const int32_t lo = offsets[i], hi = offsets[i + 1];
+  if (lo >= hi) return;
+  for (int c = cx; c < C; c += 64) {
+    float own = 0.f;
+    int32_t e = lo;
+    for (; e + 4 <= hi; e += 4) {
+      float a[4], b[4];
+      int64_t j[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        j[u] = src[e + u];
+        a[u] = ld_el<DT>(dmsg, (int64_t)(e + u) * lddm + c);
+        b[u] = ld_el<DT>(dmsg, (int64_t)(e + u) * lddm + C + c);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        own += a[u] - b[u];
+        atomicAdd(&dx[j[u] * lddx + c], b[u]);
+      }
+    }
+    for (; e < hi; ++e) {
+      const float a = ld_el<DT>(dmsg, (int64_t)e * lddm + c), b = ld_el<DT>(dmsg, (int64_t)e * lddm + C + c);
+      own += a - b;
+      atomicAdd(&dx[src[e] * lddx + c], b);
+    }
+    atomicAdd(&dx[i * lddx + c], own);
   }
 }
 
@@ -1753,9 +1795,43 @@ int ccn_edge_feat_fwd(const float* x, int64_t ldx, const int64_t* src, const int
                       float* msg, int64_t ldm, void* stream) {
   CCN_REQUIRE(x && src && dst && msg && CCN_SMALL_INT(C) && ldx >= C && ldm >= 2 * C, "edge_feat_fwd: bad arguments");
   if (E == 0) return CCN_OK;
-  hipLaunchKernelGGL(edge_feat_fwd_kernel, dim3(row_blocks(E)), dim3(TPB), 0, (hipStream_t)stream, x, ldx, src, dst, E,
+  hipLaunchKernelGGL(edge_feat_fwd_kernel<0>, dim3(row_blocks(E)), dim3(TPB), 0, (hipStream_t)stream, x, ldx, src, dst, E,
                      (int)C, msg, ldm);
   CCN_LAUNCH_OK("edge_feat_fwd");
+  return CCN_OK;
+}
+
+// ... the message rows written as 16-bit rows (bf16, fp16 when f16 != 0; (2 C) % 8 == 0, ldm in 16-bit elements)
+int ccn_edge_feat_fwd_h(const float* x, int64_t ldx, const int64_t* src, const int64_t* dst, int64_t E, int64_t C, void* msg,
+                        int64_t ldm, int f16, void* stream) {
+  CCN_REQUIRE(x && src && dst && msg && CCN_SMALL_INT(C) && ldx >= C && ldm >= 2 * C && (2 * C) % 8 == 0 && ldm % 8 == 0 &&
+                  ((uintptr_t)msg & 15) == 0,
+              "edge_feat_fwd_h: bad arguments");
+  if (E == 0) return CCN_OK;
+  if (f16)
+    hipLaunchKernelGGL(edge_feat_fwd_kernel<2>, dim3(row_blocks(E)), dim3(TPB), 0, (hipStream_t)stream, x, ldx, src, dst, E,
+                       (int)C, msg, ldm);
+  else
+    hipLaunchKernelGGL(edge_feat_fwd_kernel<1>, dim3(row_blocks(E)), dim3(TPB), 0, (hipStream_t)stream, x, ldx, src, dst, E,
+                       (int)C, msg, ldm);
+  CCN_LAUNCH_OK("edge_feat_fwd_h");
+  return CCN_OK;
+}
+
+// backward over edges grouped by destination (offsets: num_dst + 1 int32, edge e of destination i in [offsets[i], offsets[i+1]));
+// dmsg fp32 rows (dm16 = 0) or bf16 rows (dm16 = 1, lddm in 16-bit elements); accumulates into dx (zero on entry)
+int ccn_edge_feat_bwd_csr(const void* dmsg, int dm16, int64_t lddm, const int64_t* src, const int32_t* offsets, int64_t num_dst,
+                          int64_t E, int64_t C, float* dx, int64_t lddx, void* stream) {
+  CCN_REQUIRE(dmsg && src && offsets && dx && num_dst >= 0 && CCN_SMALL_INT(C) && lddx >= C && lddm >= 2 * C,
+              "edge_feat_bwd_csr: bad arguments");
+  if (E == 0 || num_dst == 0) return CCN_OK;
+  if (dm16)
+    hipLaunchKernelGGL(edge_feat_bwd_csr_kernel<1>, dim3(row_blocks(num_dst)), dim3(TPB), 0, (hipStream_t)stream, dmsg, lddm, src,
+                       offsets, num_dst, (int)C, dx, lddx);
+  else
+    hipLaunchKernelGGL(edge_feat_bwd_csr_kernel<0>, dim3(row_blocks(num_dst)), dim3(TPB), 0, (hipStream_t)stream, dmsg, lddm, src,
+                       offsets, num_dst, (int)C, dx, lddx);
+  CCN_LAUNCH_OK("edge_feat_bwd_csr");
   return CCN_OK;
 }
 

@@ -1438,22 +1438,46 @@ class EdgeFeat(torch.autograd.Function):
     """cat([x_i, x_j - x_i]) per edge (ref dgcnn.py:227-228, the sparse path's message input)."""
 
     @staticmethod
-    def forward(ctx, x, src, dst):
+    def forward(ctx, x, src, dst, offsets=None, out16=False):
+        # offsets (CSR of the edges grouped by destination): backward then adds once per destination and channel on that side
+        # (ccn_edge_feat_bwd_csr); out16 (16-bit storage modes, edge_feat()): 16-bit message rows, bf16 gradient back
         x = _mat(x)
         e, c = src.numel(), x.size(1)
+        ctx.n, ctx.c = x.size(0), c
+        ctx.csr = offsets is not None
+        ctx.save_for_backward(src, dst, offsets if offsets is not None else src.new_empty(0))
+        if out16:
+            fdt = _fwd16()
+            msg = _rows16(e, 2 * c, x.device, fdt)
+            call("edge_feat_fwd_h", ptr(x), _ld(x), ptr(src), ptr(dst), e, c, ptr(msg), _ld(msg), 1 if fdt == torch.float16 else 0)
+            return msg.view(torch.bfloat16) if fdt == torch.float16 else msg
         msg = _rows(e, 2 * c, x.device)
         call("edge_feat_fwd", ptr(x), _ld(x), ptr(src), ptr(dst), e, c, ptr(msg), _ld(msg))
-        ctx.save_for_backward(src, dst)
-        ctx.n, ctx.c = x.size(0), c
         return msg
 
     @staticmethod
     def backward(ctx, g):
-        src, dst = ctx.saved_tensors
-        g = _mat(g)
+        src, dst, offsets = ctx.saved_tensors
+        g16 = _is_rows16(g)
+        if not g16:
+            g = _mat(g.float() if g.dtype != torch.float32 else g)
         dx = _rows(ctx.n, ctx.c, g.device, zero=True)
-        call("edge_feat_bwd", ptr(g), _ld(g), ptr(src), ptr(dst), src.numel(), ctx.c, ptr(dx), _ld(dx))
-        return dx, None, None
+        if ctx.csr:
+            call("edge_feat_bwd_csr", ptr(g), 1 if g16 else 0, _ld(g), ptr(src), ptr(offsets), offsets.numel() - 1, src.numel(),
+                 ctx.c, ptr(dx), _ld(dx))
+        else:
+            if g16:
+                g = _mat(g.float())
+            call("edge_feat_bwd", ptr(g), _ld(g), ptr(src), ptr(dst), src.numel(), ctx.c, ptr(dx), _ld(dx))
+        return dx, None, None, None, None
+
+
+def edge_feat(x, edges):
+    """cat([x_i, x_j - x_i]) per edge of a CSR edge list (``edges``: row = destination, col = source, offsets) for the message
+    MLP: 16-bit rows in the 16-bit storage modes."""
+    out16 = bool(EDGE_OUT16 and _MLP_DTYPE in ("bf16", "fp16") and STORE16 and ACT_TRACE is None and edges.num_edges > 0
+                 and (2 * x.size(1)) % 8 == 0)
+    return _mark16(EdgeFeat.apply(x, edges.col, edges.row, edges.offsets, out16), out16)
 
 
 class SegSoftmaxAgg(torch.autograd.Function):

@@ -555,11 +555,11 @@ class SGCNNLayer(nn.Module):
             # real edges only)
             edges = g.edges
             if self.aggr_type == "max":
-                msg = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row))
+                msg = self.nn(ops.edge_feat(x, edges))
                 return ops.SegMax.apply(msg, edges.offsets, edges.num_dst, edges.col)
             # ref dgcnn.py:239-244: every other aggr_type takes the softmax-attention branch (messages as fp32 rows for the
             # aggregation + a 16-bit copy for attend_nn, aggregation fused into attend_nn's last layer: see PointNetConv2)
-            msg, msg16 = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row), dual=True)
+            msg, msg16 = self.nn(ops.edge_feat(x, edges), dual=True)
             return self.attend_nn(msg16 if msg16 is not None else msg, post=("attend", edges.offsets, edges.num_dst),
                                   post_x=msg)
         topo, nbr, comp = g.topo, g.nbr, g.comp
@@ -626,7 +626,7 @@ class _DynamicEdgeConv(nn.Module):
         with _geometry(kwargs) as geo:
             topo = _topology(batch, point2curveidx, kwargs, curves=False)
             edges = geo.publish(self._search(x.detach(), topo))
-        msg = self.nn(ops.EdgeFeat.apply(x, edges.col, edges.row))
+        msg = self.nn(ops.edge_feat(x, edges))
         return ops.SegMax.apply(msg, edges.offsets, edges.num_dst, edges.col), pos, batch, point2curveidx
 
 

@@ -524,6 +524,13 @@ int ccn_edge_feat_fwd(const float* x, int64_t ldx, const int64_t* src, const int
                       float* msg, int64_t ldm, void* stream);
 int ccn_edge_feat_bwd(const float* dmsg, int64_t lddm, const int64_t* src, const int64_t* dst, int64_t E, int64_t C,
                       float* dx, int64_t lddx, void* stream);
+/* round 3: the message rows as 16-bit rows for the 16-bit storage modes ((2 C) % 8 == 0); backward over edges GROUPED by
+ * destination (CSR offsets, num_dst + 1 int32): one add per destination and channel instead of one per edge on that side;
+ * dmsg as fp32 (dm16 = 0) or bf16 rows (dm16 = 1). */
+int ccn_edge_feat_fwd_h(const float* x, int64_t ldx, const int64_t* src, const int64_t* dst, int64_t E, int64_t C, void* msg,
+                        int64_t ldm, int f16, void* stream);
+int ccn_edge_feat_bwd_csr(const void* dmsg, int dm16, int64_t lddm, const int64_t* src, const int32_t* offsets, int64_t num_dst,
+                          int64_t E, int64_t C, float* dx, int64_t lddx, void* stream);
 /* VoxelFPS (fps_ops.py:42-60): key = (cloud, floor(p/v)) packed in lexicographic order, score = distance to the
  * voxel corner + rnd*v/4; argmin: per voxel the point with the smallest score.  bad: device int64 = #points whose
  * voxel coordinates do not fit 18 bits. */

@@ -836,6 +836,8 @@ def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
         return log.count("cast_rows_h")
 
     assert casts(calls[0]) < casts(calls[1])
+    if which == "sgcnn-sparse-attend":     # [x_i, x_j - x_i] written as 16-bit rows, its bf16 gradient summed per destination
+        assert "edge_feat_fwd_h" in calls[0] and "edge_feat_fwd" in calls[1] and "edge_feat_bwd_csr" in calls[0]
     if "attend" in which:     # messages: fp32 rows + 16-bit copy, their two gradients merged in one pass; the softmax
         # aggregation fused into attend_nn's last layer hands over the scores' gradient as bf16 rows
         assert "add_cast_rows_h" in calls[0] and "seg_softmax_agg_bwd_h" in calls[0] and "seg_softmax_agg_bwd" not in calls[0]
