@@ -991,7 +991,8 @@ def test_conv_shift_add_short_sequences():
     _run_pair(ref, mine, [x, d.pos, d.batch, d.curve_idxs], seed=0)
 
 
-@pytest.mark.parametrize("rows,C,ignore", [(1, 5, -100), (1000, 20, -100), (400070, 20, -100), (70001, 17, 0), (513, 55, 3)])
+@pytest.mark.parametrize("rows,C,ignore", [(1, 5, -100), (1000, 20, -100), (400070, 20, -100), (70001, 17, 0), (513, 55, 3),
+                                           (300, 70, -100)])      # (C > 63: rows are not staged through LDS)
 def test_nll_loss_matches_torch(rows, C, ignore):
     """segmentation_loss = F.nll_loss(F.log_softmax(logits), target) (ref kitti_seg.py:184-192): value, gradient, ignore_index."""
     from curvecloudnet_amd.model import segmentation_loss
