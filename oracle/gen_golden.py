@@ -4,7 +4,8 @@ Run in the build container only (the reference tree is not on the GPU box):
 
     cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
 
-For every curve function on the hot path the reference
+For every curve function on the hot path and -- round 4 -- for the step modules
+and the whole ``ModelBase`` above them (rows A10, A13-A18, H: ``gen_modules`` / ``gen_models``) the reference
 implementation is imported in place (``oracle/ref_import.py``), run on small seeded inputs and
 its inputs/outputs are stored as arrays.  While generating, the CPU restatement in
 ``oracle/torch_ref.py`` is checked against the same outputs (bit-exact for integer results), so a
@@ -64,6 +65,10 @@ def close(a, b, what, tol=1e-5):
 
 
 def main():
+    # Bit-identical regeneration: summation order depends on the thread count (MKL / OpenMP blocking), and index_add_ --
+    # the backward of every gather -- accumulates with atomics unless the deterministic algorithms are requested.
+    torch.set_num_threads(8)
+    torch.use_deterministic_algorithms(True)
     fc, po, fo = load_reference()
     os.makedirs(OUT, exist_ok=True)
 
@@ -268,9 +273,166 @@ def main():
         blob[key + ".probas"], blob[key + ".labels"] = np_(probas), np_(labels)
         blob[key + ".loss"], blob[key + ".grad"] = np_(loss), np_(grad)
     np.savez_compressed(os.path.join(OUT, "harness.npz"), **blob)
+    gen_modules()
+    gen_models()
     print("golden vectors written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print("  %-24s %7.1f KB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))
+
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 4: the assembled path from the REFERENCE's own ModelBase / step modules
+# ---------------------------------------------------------------------------------------------------------------
+
+
+def _state_blob(prefix, module):
+    return {"%s.%s" % (prefix, n): np_(v).copy() for n, v in module.state_dict().items()}   # (copy: buffers are updated in place)
+
+
+def _grad_gap(a, b):
+    scale = max(float(torch.as_tensor(b).abs().max()), 1e-12)
+    return float((torch.as_tensor(a) - torch.as_tensor(b)).abs().max()) / scale
+
+
+def gen_modules():
+    """tests/golden/modules.npz: every case of oracle/module_cases.CASES run through the reference's classes."""
+    from oracle import module_cases as M
+    from oracle.draws import Draws
+    ns_ref, ns_or = M.namespace("reference"), M.namespace("oracle")
+    blob = {}
+    for name, make in M.CASES.items():
+        torch.manual_seed(1000 + len(name))
+        mod, args, diff = make(ns_ref)
+        M.randomise_norms(mod)
+        blob.update(_state_blob(name + ".state0", mod))
+        rec = Draws()
+        torch.manual_seed(7)
+        res = M.run_case(mod, args, diff, rec, backward=name not in M.FORWARD_ONLY)
+        flat = []
+        for a in args:
+            flat.extend(a if isinstance(a, list) else [a])
+        for i, a in enumerate(flat):
+            blob["%s.in.%d" % (name, i)] = np_(a)
+        blob.update(rec.to_blob(name))
+        blob[name + ".y"] = np_(res["y"])
+        for i, o in enumerate(res["outs"]):
+            if o is not None:
+                blob["%s.out.%d" % (name, i + 1)] = np_(o)
+        for i, gval in enumerate(res["grad_in"]):
+            blob["%s.grad_in.%d" % (name, i)] = np_(gval)
+        for n, gval in res["grad"].items():
+            blob["%s.grad.%s" % (name, n)] = np_(gval)
+        for n, v in mod.named_buffers():
+            blob["%s.state1.%s" % (name, n)] = np_(v)
+        # the oracle must already agree (a fixture is only written then)
+        mine, args2, diff2 = make(ns_or)
+        mine.load_state_dict({k[len(name) + 8:]: torch.from_numpy(v) for k, v in blob.items()
+                              if k.startswith(name + ".state0.")}, strict=True)
+        got = M.run_case(mine, args2, diff2, Draws(replay=rec.log), backward=name not in M.FORWARD_ONLY)
+        close(got["y"], res["y"], "module %s forward" % name, 1e-5 * max(1.0, float(res["y"].abs().max())))
+        for a, b in zip(got["outs"], res["outs"]):
+            if b is not None:
+                eq(a, b, "module %s secondary output" % name)
+        for a, b in zip(got["grad_in"], res["grad_in"]):
+            assert _grad_gap(a, b) < 2e-4, ("module %s input gradient" % name, _grad_gap(a, b))
+        gmax = max([float(v.abs().max()) for v in res["grad"].values()] + [0.0])
+        for n, b in res["grad"].items():          # (a bias in front of a BatchNorm has a mathematically zero gradient: floor)
+            gap = float((got["grad"][n] - b).abs().max()) / max(float(b.abs().max()), 1e-3 * gmax, 1e-12)
+            assert gap < 2e-4, ("module %s grad %s" % (name, n), gap)
+        print("  module %-28s y %s  oracle |diff| %.1e" % (name, tuple(res["y"].shape), float((got["y"] - res["y"]).abs().max())))
+    np.savez_compressed(os.path.join(OUT, "modules.npz"), **blob)
+
+
+def reference_loss(kind, runners):
+    """The loss of the reference's own runner for a model case (oracle/module_cases.LOSS_FORMS)."""
+    kitti_seg, nuscenes_seg, audi_seg = runners
+    if kind == "kitti":
+        return lambda out, y: kitti_seg.seg_loss_kitti(out, y)[0]                               # kitti_seg.py:184-200, ignore=0
+    if kind == "nuscenes":
+        return lambda out, y: nuscenes_seg.seg_loss(out, y, ignore=0)[0]                        # nuscenes_seg.py:36,229-231
+    if kind == "a2d2":
+        return lambda out, y: audi_seg.seg_loss_audi(out, y, ignore=12)[0]                      # audi_seg.py:29,178-180
+    return lambda out, y: torch.nn.functional.nll_loss(torch.log_softmax(out, dim=-1), y)      # shapenet_seg.py:182-186
+
+
+def gen_models():
+    """tests/golden/model_<case>.npz: the reference's ModelBase (base.py:16-215) built from the shipped model sections at
+    reduced width: inputs, the random draws it took, state_dict, logits, the runner's loss, gradients, the BatchNorm
+    running statistics after the step and the eval-mode logits."""
+    import copy
+    import yaml
+    from curvecloudnet_amd import configs
+    from oracle import module_cases as M
+    from oracle.draws import Draws
+    from oracle.ref_import import REFERENCE_ROOT, load_reference_model, load_reference_runners
+    ref = load_reference_model()
+    runners = load_reference_runners()
+    # the programmatic sections ARE the reference's YAML sections (full width)
+    base = os.path.join(REFERENCE_ROOT, "configs", "curvecloudnet-eval", "%s-curvecloudnet.yaml")
+    for yml, cfg in (("kitti", configs.kitti_config()), ("nuscenes", configs.nuscenes_config()), ("audi", configs.a2d2_config()),
+                     ("shapenet-seg", configs.shapenet_seg_config()), ("kortx-testsplit", configs.shapenet_seg_config(kortx=True)),
+                     ("shapenet-class", configs.shapenet_cls_config())):
+        assert yaml.safe_load(open(base % yml))["model"] == cfg, yml
+    for name in M.MODEL_CASES:
+        kw, in_dim, n_out, data, fwd, labels, loss_kind = M.model_case(name)
+        torch.manual_seed(2000 + len(name))
+        model = ref.base.ModelBase(in_dim, n_out, **copy.deepcopy(kw))
+        M.randomise_norms(model)
+        blob = _state_blob("state0", model)
+        blob["pos"], blob["batch"], blob["curve_idxs"], blob["labels"] = np_(data.pos), np_(data.batch), np_(data.curve_idxs), np_(labels)
+        if data.x is not None:
+            blob["x"] = np_(data.x)
+        for k, v in fwd.items():
+            blob["fwd." + k] = np_(v)
+        model.train()
+        rec = Draws()
+        torch.manual_seed(5)
+        with rec:
+            logits = model(data, **fwd)
+        loss = reference_loss(loss_kind, runners)(logits, labels)
+        params = dict(model.named_parameters())
+        grads = dict(zip(params, torch.autograd.grad(loss, list(params.values()))))
+        blob.update(rec.to_blob("train"))
+        blob["logits"], blob["loss"] = np_(logits), np_(loss)
+        blob["grad_names"] = np.array(list(params))
+        blob["grad_summary"] = np.array([[float(g.double().sum()), float(g.double().norm())] for g in grads.values()])
+        for n in M.selected_gradients(params):
+            blob["grad." + n] = np_(grads[n])
+        for n, v in model.named_buffers():
+            blob["state1." + n] = np_(v)
+        model.eval()
+        rec_eval = Draws()
+        with rec_eval, torch.no_grad():
+            blob["logits_eval"] = np_(model(data, **fwd))
+        blob.update(rec_eval.to_blob("eval"))
+        # the oracle must already agree
+        mine = R.ModelBase(in_dim, n_out, **copy.deepcopy(kw))
+        mine.load_state_dict({k[7:]: torch.from_numpy(v) for k, v in blob.items() if k.startswith("state0.")}, strict=True)
+        mine.train()
+        with Draws(replay=rec.log):
+            out2 = mine(data, **fwd)
+        scale = max(1.0, float(logits.abs().max()))
+        close(out2, logits, "model %s logits" % name, 1e-6 * scale)
+        ign, red = M.LOSS_FORMS[loss_kind]
+        per = torch.nn.functional.nll_loss(torch.log_softmax(out2, -1), labels, ignore_index=ign, reduction="none")
+        loss2 = per.mean() if red == "mean_all" else per.sum() / (labels != ign).sum()
+        close(loss2, loss, "model %s loss" % name, 1e-6)
+        g2 = torch.autograd.grad(loss2, list(mine.parameters()))
+        gmax = max(float(g.abs().max()) for g in grads.values())
+        worst = 0.0
+        for (n, b), a in zip(grads.items(), g2):
+            # per tensor, relative to its own largest entry but not below 1e-3 of the model's largest (a bias in front of a
+            # BatchNorm has a mathematically zero gradient: what is left is summation noise, floored at 2e-6 of the largest)
+            err = float((a - b).abs().max())
+            gap = 0.0 if err <= 2e-6 * gmax else err / max(float(b.abs().max()), 1e-3 * gmax)
+            worst = max(worst, gap)
+            assert gap <= 2e-4, ("model %s grad %s" % (name, n), gap)
+        path = os.path.join(OUT, "model_%s.npz" % name)
+        np.savez_compressed(path, **blob)
+        print("  model %-13s %7d points, %7d parameters, %2d draws, loss %.6f, oracle logits |diff| %.1e, worst relative gradient gap %.1e"
+              % (name, data.pos.size(0), sum(p.numel() for p in params.values()), len(rec.log), float(loss),
+                 float((out2 - logits).abs().max()), worst))
 
 
 if __name__ == "__main__":

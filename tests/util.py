@@ -162,3 +162,37 @@ def adjudicate(res, rms=False):
 
 
 GRAD_TOL = 3e-4          # routed gradients, per tensor (see routed_parity)
+
+
+# ---------------------------------------------------------------- round 4: fixtures generated from the reference's ModelBase
+def module_fixture(name, kind, device="cpu"):
+    """A case of tests/golden/modules.npz (oracle/module_cases.CASES) rebuilt from the ``kind`` side ("oracle" | "product"),
+    the fixture's state_dict loaded strict, its stored inputs substituted: (module, args, diff, recorded draws, blob)."""
+    from oracle import module_cases as M
+    from oracle.draws import Draws
+    g = golden("modules")
+    mod, args, diff = M.CASES[name](M.namespace(kind))
+    mod.load_state_dict({k[len(name) + 8:]: t(g[k]) for k in g.files if k.startswith(name + ".state0.")}, strict=True)
+    it = iter(range(10 ** 6))
+    stored = [[t(g["%s.in.%d" % (name, next(it))]) for _ in a] if isinstance(a, list) else t(g["%s.in.%d" % (name, next(it))])
+              for a in args]
+    return mod.to(device), stored, diff, Draws.from_blob(g, name), g
+
+
+def model_fixture(name):
+    """tests/golden/model_<name>.npz as (blob, model kwargs, in_dim, n_out, data, forward kwargs, labels, loss form)."""
+    from oracle import module_cases as M
+    g = golden("model_" + name)
+    kw, in_dim, n_out, data, fwd, labels, loss_kind = M.model_case(name)
+    data = SimpleNamespace(x=t(g["x"]) if "x" in g.files else None, pos=t(g["pos"]), batch=t(g["batch"]),
+                           curve_idxs=t(g["curve_idxs"]), num_clouds=int(g["batch"].max()) + 1)
+    fwd = {k[4:]: t(g[k]) for k in g.files if k.startswith("fwd.")}
+    return g, kw, in_dim, n_out, data, fwd, t(g["labels"]), M.LOSS_FORMS[loss_kind]
+
+
+def tensor_gap(got, want, floor=0.0):
+    """max |got - want| relative to max(|want|_max, floor)."""
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    if want.numel() == 0:
+        return 0.0
+    return float((got - want).abs().max()) / max(float(want.abs().max()), floor, 1e-30)
