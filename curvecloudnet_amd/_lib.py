@@ -15,6 +15,7 @@ _ROOT = os.path.dirname(_PKG)
 # (CCN_LIB_PATH: another build of the SAME library for one-box A/B runs of a kernel change -- tools/ only)
 LIB_PATH = os.environ.get("CCN_LIB_PATH") or os.path.join(_PKG, "libccn_hip.so")
 HEADER_PATH = os.path.join(_ROOT, "include", "ccn_hip.h")
+DEBUG_HEADER_PATH = os.path.join(_ROOT, "include", "ccn_hip_debug.h")   # diagnostics / A-B / test hooks: not the boundary
 
 _CTYPES = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
@@ -22,8 +23,13 @@ _CTYPES = {
 }
 
 
-def parse_header(path=HEADER_PATH):
-    """-> {name: (restype, [argtypes])} for every function the header declares."""
+def parse_header(path=None):
+    """-> {name: (restype, [argtypes])} for every function the header declares (default: the boundary header and the
+    diagnostics header together)."""
+    if path is None:
+        protos = parse_header(HEADER_PATH)
+        protos.update(parse_header(DEBUG_HEADER_PATH))
+        return protos
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
     text = re.sub(r"^\s*#.*$", " ", text, flags=re.M)

@@ -1819,11 +1819,14 @@ int ccn_edge_feat_fwd_h(const float* x, int64_t ldx, const int64_t* src, const i
 }
 
 // backward over edges grouped by destination (offsets: num_dst + 1 int32, edge e of destination i in [offsets[i], offsets[i+1]));
-// dmsg fp32 rows (dm16 = 0) or bf16 rows (dm16 = 1, lddm in 16-bit elements); accumulates into dx (zero on entry)
+// dmsg fp32 rows (dm16 = 0) or bf16 rows (dm16 = 1, lddm in 16-bit elements); accumulates into dx (N rows, zero on entry).
+// Group i of the CSR list is POINT i of x (the destination side of the message is x[i]): num_dst must equal N.
 int ccn_edge_feat_bwd_csr(const void* dmsg, int dm16, int64_t lddm, const int64_t* src, const int32_t* offsets, int64_t num_dst,
-                          int64_t E, int64_t C, float* dx, int64_t lddx, void* stream) {
+                          int64_t N, int64_t E, int64_t C, float* dx, int64_t lddx, void* stream) {
   CCN_REQUIRE(dmsg && src && offsets && dx && num_dst >= 0 && CCN_SMALL_INT(C) && lddx >= C && lddm >= 2 * C,
               "edge_feat_bwd_csr: bad arguments");
+  CCN_REQUIRE(num_dst == N, "edge_feat_bwd_csr: %lld destination groups for %lld points (the grouped form needs group i = point i; "
+              "use ccn_edge_feat_bwd for an edge list over a subset)", (long long)num_dst, (long long)N);
   if (E == 0 || num_dst == 0) return CCN_OK;
   if (dm16)
     hipLaunchKernelGGL(edge_feat_bwd_csr_kernel<1>, dim3(row_blocks(num_dst)), dim3(TPB), 0, (hipStream_t)stream, dmsg, lddm, src,

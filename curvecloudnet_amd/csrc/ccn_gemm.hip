@@ -1117,12 +1117,11 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
                                                                    const float* __restrict__ bias, float* __restrict__ C,
                                                                    int64_t ldc, int64_t M, int64_t N, int64_t K,
                                                                    int64_t tiles, int64_t gn, int xcd_order,
-                                                                   double* __restrict__ colstats, int64_t a_extent, int opt,
+                                                                   double* __restrict__ colstats, int64_t a_extent,
                                                                    const float* __restrict__ xf_scale,
                                                                    const float* __restrict__ xf_shift, int xf_act,
                                                                    float xf_slope) {
   // a_extent: floats readable from the start of an A row (= lda, or K when rows overlap: ccn_conv_rows_nt)
-  // opt (A/B hook ccn_gemm_pair_opt): bit 0 = counted wait behind an interior tile's stores, bit 1 = s_setprio around MFMAs
   constexpr int AF = PR_BM * BK, BF = PR_BN * BK, STAGE = AF + BF;
   constexpr int NC = 4;  // LDS-DMA copies (8 rows x 128 B) per wave, slice and operand
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
@@ -1236,14 +1235,9 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       it_tile = tile_of(++it_j);
     }
   };
-  // experiments (A/B hook; profiles/r02_pair_kernel_experiments.txt: none of them pays): bit 3 = the second workgroup of a CU
-  // starts (opt >> 8) x 3.6 us late, bit 4 = ... and runs at low instruction priority; bit 2 (host side) = one workgroup per CU
-  if ((opt & 8) && blockIdx.x >= 256)
-    for (int r = 0; r < (opt >> 8); ++r) __builtin_amdgcn_s_sleep(127);
-  if (opt & 16) {
-    if (blockIdx.x >= 256) __builtin_amdgcn_s_setprio(0);
-    else __builtin_amdgcn_s_setprio(3);
-  }
+  // (in-kernel experiments of rounds 2-3 -- a start stagger / instruction priorities for the second workgroup of a CU, a
+  // counted wait behind the stores, s_setprio around the MFMAs -- are measured in profiles/r02_pair_kernel_experiments.txt and
+  // r03_pair_kernel_anatomy.txt; none paid, none is compiled any more)
   issue_next();
 
   int64_t stat_tile = -1;
@@ -1267,7 +1261,6 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_r0) : : "memory");
   }
   int64_t g = 0;
-  bool stores_behind = false;   // the previous tile was interior: exactly 64 stores per lane were issued after the last copy
   for (int64_t j = 0, tile; (tile = tile_of(j)) < tiles; ++j) {
     const int64_t m0 = tile_row(tile) * PR_BM, n0 = tile_col(tile) * PR_BN;
     f32x16 acc[2][2];
@@ -1298,7 +1291,10 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
           }
         }
       }
-      // (the loads above are waited for by the first slice's s_waitcnt vmcnt(0), long before the first MFMA reads them)
+      // The inline-asm loads above are invisible to the compiler's own wait insertion: this wait names the accumulators as
+      // operands, so no copy, spill or AGPR move of them can be scheduled in front of it.  It is the wait the first slice
+      // would take anyway (vmcnt(0): nothing is issued in between), moved up by a few scalar instructions.
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) : : "memory");
     } else {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -1312,15 +1308,9 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     }
 
     for (int u = 0; u < TT; ++u, ++g) {
-      if (u == 0 && stores_behind && (opt & 1))
-        // the copy of this slice was issued BEFORE the previous tile's 64 stores (vmcnt retires in issue order): wait for it
-        // and the first store only, not for the whole store burst to drain
-        asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-      else {
-        if (STAMP) PR_STAMP(st_a);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice g has landed (and the previous tile's stores retired)
-        if (STAMP) { PR_STAMP(st_b); sum_w += (uint32_t)(st_b - st_a); }
-      }
+      if (STAMP) PR_STAMP(st_a);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice g has landed (and the previous tile's stores retired)
+      if (STAMP) { PR_STAMP(st_b); sum_w += (uint32_t)(st_b - st_a); }
       __builtin_amdgcn_s_barrier();
       if (STAMP) { PR_STAMP(st_a); sum_b += (uint32_t)(st_a - st_b); }
       issue_next();
@@ -1337,7 +1327,6 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       };
       auto mfma_group = [&](int par) {
         __builtin_amdgcn_sched_barrier(0);
-        if (opt & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ab = 0; ab < 2; ++ab)
 #pragma unroll
@@ -1347,7 +1336,6 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
             acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][ab].z, fb[par][t].z, acc[ab][t], 0, 0, 0);
             acc[ab][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[par][ab].w, fb[par][t].w, acc[ab][t], 0, 0, 0);
           }
-        if (opt & 2) __builtin_amdgcn_s_setprio(0);
       };
       if (XF) {
         f32x4 xs[2], xh[2];   // scale / shift of the four channels of a K group, [parity]
@@ -1428,7 +1416,6 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
 
     // ---- tile epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
     const bool interior = m0 + PR_BM <= M && n0 + PR_BN <= N;
-    stores_behind = interior && has_tail == 0;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int ncol = wn * 64 + t * 32 + i;
@@ -1529,19 +1516,19 @@ int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, c
   const int64_t grid = tiles < slots ? tiles : slots;  // two workgroups per CU
   if (g_pair_dbg_host != nullptr && xf_scale == nullptr && !accumulate && !split_part)
     hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 0, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y,
-                       ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, nullptr, nullptr, 0, 0.f);
+                       ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, nullptr, nullptr, 0, 0.f);
   else if (xf_scale != nullptr)
     hipLaunchKernelGGL((gemm_glds_pair_kernel<false, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
-                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, xf_scale, xf_shift, xf_act, xf_slope);
+                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, xf_scale, xf_shift, xf_act, xf_slope);
   else if (accumulate)
     hipLaunchKernelGGL((gemm_glds_pair_kernel<true, false>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
-                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, nullptr, nullptr, 0, 0.f);
+                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, nullptr, nullptr, 0, 0.f);
   else if (split_part)
     hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 1>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y,
-                       ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, nullptr, nullptr, 0, 0.f);
+                       ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, nullptr, nullptr, 0, 0.f);
   else
     hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
-                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, g_pair_opt, nullptr, nullptr, 0, 0.f);
+                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, nullptr, nullptr, 0, 0.f);
   return CCN_OK;
 }
 

@@ -60,14 +60,17 @@ __device__ __forceinline__ float from_h(u16 v) {
 // OUT16: the result is written as 16-bit (a data gradient): the MFMA operands are SWAPPED, so that a lane holds one output
 // ROW and four consecutive COLUMNS per register quad -- 16 eight-byte stores per lane and tile instead of 64 two-byte ones
 // (the sums per output element are the same fma chains in the same k order: a*b commutes).  No statistics in that form.
-template <bool F16, bool OUT16>
+// DIAG: the timing-only ablation build behind ccn_gemm_h_opt (include/ccn_hip_debug.h); in the shipping instantiations
+// (DIAG = false) ``opt`` is the constant 0 and every branch on it is compiled out.
+template <bool F16, bool OUT16, bool DIAG = false>
 __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __restrict__ A, int64_t lda,
                                                                 const u16* __restrict__ B, int64_t ldb,
                                                                 const float* __restrict__ bias, void* __restrict__ Cv,
                                                                 int64_t ldc, int64_t M, int64_t N, int64_t K, int64_t tiles,
                                                                 int64_t gn, int xcd_order, double* __restrict__ colstats,
-                                                                int opt) {
+                                                                int opt_rt) {
   // opt (diagnostics, ccn_gemm_h_opt; results WRONG when set): bit 0 = no epilogue stores, bit 1 = no wait for the LDS-DMA
+  const int opt = DIAG ? opt_rt : 0;
   constexpr int AF = HB_BM * HB_BK, BF = HB_BN * HB_BK, STAGE = AF + BF;   // 16-bit elements
   constexpr int NC = 4;   // LDS-DMA copies (8 rows x 128 B) per wave, slice and operand
   __shared__ __attribute__((aligned(16))) u16 lds[2 * STAGE];
@@ -946,8 +949,12 @@ int launch_nt_h(const u16* A, int64_t lda, const u16* W, int64_t ldw, const floa
     return CCN_ERR_ARG;
   }
   const int64_t grid = tiles < 512 ? tiles : 512;  // two workgroups per CU
-  hipLaunchKernelGGL((gemm_h_pair_kernel<F16, OUT16>), dim3((unsigned)grid), dim3(HB_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy, M,
-                     N, K, tiles, gn, 1, colstats, g_h_opt);
+  if (g_h_opt != 0)
+    hipLaunchKernelGGL((gemm_h_pair_kernel<F16, OUT16, true>), dim3((unsigned)grid), dim3(HB_TPB), 0, s, A, lda, W, ldw, bias, Y,
+                       ldy, M, N, K, tiles, gn, 1, colstats, g_h_opt);
+  else
+    hipLaunchKernelGGL((gemm_h_pair_kernel<F16, OUT16>), dim3((unsigned)grid), dim3(HB_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
+                       M, N, K, tiles, gn, 1, colstats, 0);
   return CCN_OK;
 }
 

@@ -159,10 +159,20 @@ extern "C" int ccn_nll_loss_fwd(const float* logits, int64_t ld, const int64_t* 
   CCN_REQUIRE(logits && target && lse && scratch && loss && rows > 0 && C > 0 && C < (1 << 20) && ld >= C,
               "nll_loss_fwd: bad arguments");
   const int64_t nb = ccn_nll_loss_blocks(rows);
-  if (C <= 63)       // (256 rows x (C + 1) floats of LDS: <= 64 KB)
+  if (C <= 63) {     // 256 rows x (C + 1) floats of dynamic LDS: 64 KB at C = 63, plus the static reduction scratch
+    const size_t dyn = (size_t)NLL_TPB * (C + 1) * sizeof(float);
+    if (dyn > 48 * 1024) {   // above the default dynamic-LDS limit: opt in explicitly (as ccn_fps does), not by runtime leniency
+      static bool raised = false;
+      if (!raised) {
+        CCN_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(nll_fwd_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, NLL_TPB * 64 * (int)sizeof(float)) == hipSuccess,
+                    "nll_loss_fwd: cannot raise the dynamic LDS limit");
+        raised = true;
+      }
+    }
     hipLaunchKernelGGL(nll_fwd_kernel<true>, dim3((unsigned)nb), dim3(NLL_TPB), (size_t)NLL_TPB * (C + 1) * sizeof(float),
                        (hipStream_t)stream, logits, ld, target, rows, (int)C, ignore_index, lse, per_point, scratch);
-  else
+  } else
     hipLaunchKernelGGL(nll_fwd_kernel<false>, dim3((unsigned)nb), dim3(NLL_TPB), 0, (hipStream_t)stream, logits, ld, target, rows,
                        (int)C, ignore_index, lse, per_point, scratch);
   hipLaunchKernelGGL(nll_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, nb, scratch + 2 * nb, loss);

@@ -263,8 +263,4 @@ def segmentation_loss(logits, target, ignore_index=-100, reduction="mean", check
         bad = (target != ignore_index) & ((target < 0) | (target >= c))
         if bool(bad.any()):
             raise IndexError("Target %d is out of bounds." % int(target[bad][0]))
-    loss = ops.NLLLoss.apply(logits, target, ignore_index)
-    if reduction == "mean_all":
-        counted = (target != ignore_index).sum().to(loss.dtype)
-        loss = loss * (counted / max(target.numel(), 1))
-    return loss
+    return ops.NLLLoss.apply(logits, target, ignore_index, reduction == "mean_all")

@@ -825,11 +825,17 @@ def _fwd16():
     return torch.float16 if _MLP_DTYPE == "fp16" else torch.bfloat16
 
 
+ROWS16_WATCH = None     # tests: a list collects every 16-bit row matrix allocated (range check of the stored fp16 activations)
+
+
 def _rows16(rows, cols, device, dtype=torch.bfloat16):
     """(rows, cols) 16-bit matrix whose rows start 16-byte aligned: leading dimension a multiple of 8 elements."""
     ld = (cols + 7) // 8 * 8
     buf = torch.empty((rows, ld), dtype=dtype, device=device)
-    return buf if ld == cols else buf[:, :cols]
+    out = buf if ld == cols else buf[:, :cols]
+    if ROWS16_WATCH is not None:
+        ROWS16_WATCH.append(out)
+    return out
 
 
 def _is_rows16(t, dtype=torch.bfloat16):
@@ -1146,10 +1152,12 @@ def linear_bn_act(x, weight, bias, bn, training, act, defer=False, post=None, po
 
 class NLLLoss(torch.autograd.Function):
     """mean over the rows with target != ignore_index of -log_softmax(logits)[target] (harness row H; ref
-    src/run/kitti_seg.py:184-192): ccn_nll_loss_fwd / _bwd."""
+    src/run/kitti_seg.py:184-192): ccn_nll_loss_fwd / _bwd.  ``mean_all``: the KITTI runner's form -- the ignored rows
+    contribute zero but stay in the denominator (sum / rows: 0 with a zero gradient for an all-ignored batch, where the
+    mean over the counted rows is 0 / 0)."""
 
     @staticmethod
-    def forward(ctx, logits, target, ignore_index=-100):
+    def forward(ctx, logits, target, ignore_index=-100, mean_all=False):
         logits, target = _mat(logits), _i64(target)
         rows, c = logits.shape
         if target.numel() != rows:
@@ -1161,20 +1169,23 @@ class NLLLoss(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         call("nll_loss_fwd", ptr(logits), _ld(logits), ptr(target), rows, c, int(ignore_index), ptr(lse), None, ptr(scratch),
              ptr(loss))
-        ctx.save_for_backward(logits, target, lse, scratch)
+        totals = scratch[2 * nb:]                     # (sum of the per-row losses, counted rows)
+        if mean_all:
+            totals = torch.stack([totals[0], torch.full((), float(rows), dtype=torch.float64, device=dev)])
+            loss = (totals[0] / rows).to(torch.float32)
+        ctx.save_for_backward(logits, target, lse, totals)
         ctx.ignore = int(ignore_index)
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        logits, target, lse, scratch = ctx.saved_tensors
+        logits, target, lse, totals = ctx.saved_tensors
         rows, c = logits.shape
-        nb = lib().ccn_nll_loss_blocks(rows)
         d = _rows(rows, c, logits.device)
         g = g.to(torch.float32).contiguous()
         call("nll_loss_bwd", ptr(logits), _ld(logits), ptr(target), ptr(lse), rows, c, ctx.ignore, ptr(g),
-             ptr(scratch[2 * nb:]), ptr(d), _ld(d))
-        return d, None, None
+             ptr(totals), ptr(d), _ld(d))
+        return d, None, None, None
 
 
 # --------------------------------------------------------------------------------------
@@ -1444,6 +1455,10 @@ class EdgeFeat(torch.autograd.Function):
         x = _mat(x)
         e, c = src.numel(), x.size(1)
         ctx.n, ctx.c = x.size(0), c
+        # the CSR backward writes dx[i] for group i = 0 .. num_dst - 1 and assumes group i IS point i of x (x_i = x[dst], dst =
+        # the group's index): an edge list over a subset of the points takes the per-edge atomics form instead
+        if offsets is not None and offsets.numel() - 1 != x.size(0):
+            offsets = None
         ctx.csr = offsets is not None
         ctx.save_for_backward(src, dst, offsets if offsets is not None else src.new_empty(0))
         if out16:
@@ -1463,8 +1478,8 @@ class EdgeFeat(torch.autograd.Function):
             g = _mat(g.float() if g.dtype != torch.float32 else g)
         dx = _rows(ctx.n, ctx.c, g.device, zero=True)
         if ctx.csr:
-            call("edge_feat_bwd_csr", ptr(g), 1 if g16 else 0, _ld(g), ptr(src), ptr(offsets), offsets.numel() - 1, src.numel(),
-                 ctx.c, ptr(dx), _ld(dx))
+            call("edge_feat_bwd_csr", ptr(g), 1 if g16 else 0, _ld(g), ptr(src), ptr(offsets), offsets.numel() - 1, ctx.n,
+                 src.numel(), ctx.c, ptr(dx), _ld(dx))
         else:
             if g16:
                 g = _mat(g.float())

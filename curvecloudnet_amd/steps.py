@@ -661,13 +661,14 @@ class DGCNNLayerRadius(_DynamicEdgeConv):
 
 
 class GlobalSAModule(nn.Module):
-    """ref pointnet2.py:81-116: nn([x, pos]) then per-cloud max pooling (ShapeNet classification head)."""
+    """ref pointnet2.py:81-116: nn([x, pos]) then per-cloud max pooling (ShapeNet classification head) or, with
+    ``pooling="mean"`` (:97-99), the per-cloud mean (scatter_mean over the clouds = ops.SegWSum mode 0)."""
 
     def __init__(self, nn, **kwargs):
         super().__init__()
         self.nn = nn
         self.pooling = kwargs.get("pooling", "max")
-        if self.pooling != "max":
+        if self.pooling not in ("max", "mean"):
             raise NotImplementedError("Pooling strategy %s not implemented!" % self.pooling)
 
     def geometry(self, pos, batch, point2curveidx, kwargs):
@@ -678,6 +679,8 @@ class GlobalSAModule(nn.Module):
 
     def features(self, x, pos, g):
         f = self.nn(ops.cat_cols([x, pos]))
+        if self.pooling == "mean":
+            return ops.SegWSum.apply(f, None, g.offsets, g.num_clouds, 0)
         return ops.SegMax.apply(f, g.offsets, g.num_clouds)
 
     def forward(self, x, pos, batch, point2curveidx=None, **kwargs):

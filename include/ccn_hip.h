@@ -153,7 +153,6 @@ int ccn_frnn_grid_build(const float* points2, const int64_t* lengths2, const flo
                         void* grid, size_t grid_bytes, void* stream);
 int ccn_frnn_query(const float* points1, const int64_t* lengths1, const float* r, int64_t B, int64_t P1, int64_t K,
                    const void* grid, int64_t P2, int64_t* idx, float* dist2, int32_t* count, void* stream);
-int ccn_frnn_query_mode(int mode); /* A/B hook: 0 = automatic, 1 = one thread per query, 2 / 3 = a team of 32 / 64 lanes per query */
 
 /* ---- A12: point_ops.py:98-111 / :287-290 dense (B,P1,K) idx -> flat (row, col) edge list ----------
  * counts: int32 per packed query (cloud_ptr1[b] + i).  fill writes row = packed query, col = packed point. */
@@ -168,10 +167,6 @@ int ccn_dense_to_csr_fill(const int64_t* idx, const int64_t* cloud_ptr1, const i
  * (deterministic, no atomics); ccn_bn_finalize reduces them (using the last 2*N doubles as scratch)
  * into the BatchNorm batch statistics (torch.nn.BatchNorm1d inside PyG MLP; fast_conv1d.py:30,73). */
 int64_t ccn_stats_rows(int64_t rows); /* partial-statistics rows a reduction over `rows` rows produces (= ceil(rows/128)) */
-int ccn_gemm_use_dma(int on);       /* A/B hook: 0 = register-staged kernels only, 2 = LDS-DMA without the persistent tile loop, 3 = persistent with round-robin tiles, 4 = the 8-wave persistent kernel for every N (no paired 4-wave workgroups), 1 = default */
-int ccn_gemm_pair_debug(void* buf);  /* diagnostic: a device buffer of 512 x 4 x 16 uint64 words switches ccn_gemm_nt's paired kernel to a build that stamps (s_memtime) where every wave's cycles go; NULL = off (tools/pair_stamps.py) */
-int ccn_gemm_pair_opt(int bits);    /* A/B hook of the paired kernel: bit 0 = counted wait behind a tile's stores, bit 1 = s_setprio around the MFMA groups */
-int ccn_gemm_force_generic(int on); /* test hook: route every GEMM through the unaligned-operand kernel */
 int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                 int64_t M, int64_t N, int64_t K, double* colstats, void* stream);
 /* bf16 MFMA form of ccn_gemm_nt (BASELINE configs 3 / 5, "bf16 MLP MFMA path"): same arguments and outputs; A and W are
@@ -184,7 +179,6 @@ int ccn_gemm_nt_bf16(const float* A, int64_t lda, const float* W, int64_t ldw, c
  * < 2^-23 |a b|).  Same arguments and outputs as ccn_gemm_nt plus caller-owned scratch for the split weight
  * (ccn_gemm_x3_workspace_bytes(N, K) bytes, 16-byte aligned).  Requires 16-byte aligned A and lda % 4 == 0. */
 int64_t ccn_gemm_x3_workspace_bytes(int64_t N, int64_t K);
-int ccn_gemm_x3_use_persistent(int on); /* A/B hook: 0 = the register-staged kernel for every shape, 2 = no paired 4-wave workgroups (8-wave persistent kernel for every N), 1 = default */
 int ccn_gemm_nt_x3(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                    int64_t M, int64_t N, int64_t K, double* colstats, void* wsplit, int64_t wsplit_bytes, void* stream);
 int ccn_gemm_nn(const float* dY, int64_t lddy, const float* W, int64_t ldw, float* dX, int64_t lddx, int64_t M,
@@ -198,7 +192,6 @@ int ccn_gemm_tn(const float* dY, int64_t lddy, const float* X, int64_t ldx, floa
  * tile once and a second launch adds the tiles of each output block to dW in chunk order.  Operands that do not
  * qualify (unaligned, leading dimension not a multiple of 4, N or K <= 32, M < 1024) take ccn_gemm_tn. */
 size_t ccn_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t K);
-int ccn_gemm_tn_use_dma(int on);    /* A/B hook: 0 = always the register-staged split-K kernel of ccn_gemm_tn */
 int ccn_gemm_tn_ws(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw, int64_t M,
                    int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 /* Y += A W^T (the accumulators start from Y): lets a data-gradient product ADD into a gradient that another consumer of the
@@ -260,8 +253,6 @@ int ccn_gemm_tn_bf16(const float* dY, int64_t lddy, const float* X, int64_t ldx,
  *                  (ccn_gemm_tn_h_workspace_bytes), summed in chunk order (deterministic). */
 int ccn_gemm_nt_h(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
                   int64_t N, int64_t K, double* colstats, int f16, int out16, void* stream);
-/* diagnostics of ccn_gemm_nt_h (timing only, results wrong when set): bit 0 = no epilogue stores, bit 1 = no wait for the copies */
-int ccn_gemm_h_opt(int opt);
 size_t ccn_gemm_tn_h_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int ccn_gemm_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
                   int64_t K, void* workspace, size_t workspace_bytes, void* stream);
@@ -530,7 +521,7 @@ int ccn_edge_feat_bwd(const float* dmsg, int64_t lddm, const int64_t* src, const
 int ccn_edge_feat_fwd_h(const float* x, int64_t ldx, const int64_t* src, const int64_t* dst, int64_t E, int64_t C, void* msg,
                         int64_t ldm, int f16, void* stream);
 int ccn_edge_feat_bwd_csr(const void* dmsg, int dm16, int64_t lddm, const int64_t* src, const int32_t* offsets, int64_t num_dst,
-                          int64_t E, int64_t C, float* dx, int64_t lddx, void* stream);
+                          int64_t N, int64_t E, int64_t C, float* dx, int64_t lddx, void* stream); /* group i = point i of x: num_dst == N (rows of dx) is required */
 /* VoxelFPS (fps_ops.py:42-60): key = (cloud, floor(p/v)) packed in lexicographic order, score = distance to the
  * voxel corner + rnd*v/4; argmin: per voxel the point with the smallest score.  bad: device int64 = #points whose
  * voxel coordinates do not fit 18 bits. */
@@ -552,7 +543,6 @@ int ccn_sort_keys(const int64_t* key, int64_t n, int digit_mask, int64_t* sorted
 /* sample_farthest_points (point_ops.py:57-70): per cloud out_ptr[b+1]-out_ptr[b] samples starting at start[b];
  * out = packed point indices in selection order; mind: float scratch (n); max_cloud: largest cloud size (clouds of up
  * to 16384 points are processed register-resident, 0 = unknown). */
-int ccn_fps_set_lds_claim(int bytes); /* A/B hook: dynamic LDS a sampling workgroup claims to keep its CU free of GEMM workgroups (default and maximum 98304, 0 = none) */
 int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, const int64_t* out_ptr, int64_t B,
             int64_t max_cloud, float* mind, int64_t* out, void* stream);
 

@@ -1012,6 +1012,54 @@ def test_nll_loss_matches_torch(rows, C, ignore):
 
 
 
+def test_edge_feat_backward_with_groups_over_a_subset_of_the_points():
+    """EdgeFeat with CSR offsets whose groups do not cover every point of x: the grouped backward assumes group
+    i = point i, so the op must fall back to the per-edge form -- and the C entry point refuses the mismatch."""
+    from curvecloudnet_amd import ops
+    from curvecloudnet_amd._lib import lib, ptr
+    gen = torch.Generator().manual_seed(0)
+    n, groups, c = 50, 20, 6
+    counts = torch.randint(1, 5, (groups,), generator=gen)
+    dst = torch.repeat_interleave(torch.arange(groups), counts)
+    src = torch.randint(0, n, (dst.numel(),), generator=gen)
+    offsets = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)]).to(torch.int32)
+    x = torch.randn(n, c, generator=gen)
+    cot = torch.randn(dst.numel(), 2 * c, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad((torch.cat([xr[dst], xr[src] - xr[dst]], 1) * cot).sum(), xr)
+    xd = x.to(DEV).requires_grad_(True)
+    msg = ops.EdgeFeat.apply(xd, src.to(DEV), dst.to(DEV), offsets.to(DEV), False)
+    (gd,) = torch.autograd.grad((msg * cot.to(DEV)).sum(), xd)
+    _close(gd, gr, 1e-5, "dx over a subset edge list")
+    dx = torch.zeros(n, 8, device=DEV)
+    g = cot.to(DEV).contiguous()
+    rc = lib().ccn_edge_feat_bwd_csr(ptr(g), 0, g.stride(0), ptr(src.to(DEV)), ptr(offsets.to(DEV)), groups, n, dst.numel(), c,
+                                     ptr(dx), 8, None)
+    assert rc != 0 and b"group i = point i" in lib().ccn_last_error()
+
+
+@pytest.mark.parametrize("C", [55, 56, 62, 63, 64])
+def test_nll_loss_staged_rows_with_padded_leading_dimension(C):
+    """The LDS-staged forward (C <= 63: 256 rows x (C + 1) floats, 64 KB + the reduction scratch at C = 63 -- the kernel raises
+    its dynamic-LDS limit) against the unstaged form's neighbours, on logits whose leading dimension is padded (ld > C) and
+    with a ragged last block."""
+    from curvecloudnet_amd.model import segmentation_loss
+    rows = 256 * 3 + 77
+    gen = torch.Generator().manual_seed(C)
+    wide = torch.randn(rows, C + 5, generator=gen) * 3
+    t = torch.randint(0, C, (rows,), generator=gen)
+    xr = wide[:, :C].clone().requires_grad_(True)
+    lr = F.nll_loss(F.log_softmax(xr, dim=-1), t, ignore_index=2)
+    (gr,) = torch.autograd.grad(lr, xr)
+    base = wide.to(DEV)
+    xd = base[:, :C].detach().requires_grad_(True)          # a view with stride C + 5 > C
+    assert xd.stride(0) == C + 5
+    ld = segmentation_loss(xd, t.to(DEV), ignore_index=2)
+    (gd,) = torch.autograd.grad(ld, xd)
+    assert abs(float(ld) - float(lr)) <= 2e-6 * max(1.0, abs(float(lr)))
+    _close(gd, gr, 1e-6, "dlogits")
+
+
 def test_nll_loss_kitti_runner_form_and_target_check():
     """reduction="mean_all": the KITTI runner's literal form (ref kitti_seg.py:184-192: nll_loss(reduction='none',
     ignore_index=0) then torch.mean over ALL points -- ignored rows stay in the denominator); check_targets raises on a
@@ -1028,6 +1076,13 @@ def test_nll_loss_kitti_runner_form_and_target_check():
     (gd,) = torch.autograd.grad(ld, xd)
     assert abs(float(ld) - float(lr)) <= 2e-6 * max(1.0, abs(float(lr)))
     _close(gd, gr, 1e-6, "dlogits")
+    # one all-unlabelled crop: the reference gives 0 with a zero gradient, not 0 / 0
+    zeros = torch.zeros(5000, dtype=torch.long, device=DEV)
+    xz = x.to(DEV).requires_grad_(True)
+    lz = segmentation_loss(xz, zeros, ignore_index=0, reduction="mean_all")
+    (gz,) = torch.autograd.grad(lz, xz)
+    assert float(lz) == 0.0 and float(gz.abs().max()) == 0.0
+    assert bool(torch.isnan(segmentation_loss(xz, zeros, ignore_index=0)))         # torch's 'mean' is nan there, as torch
     bad = t.clone()
     bad[17] = 20
     with pytest.raises(IndexError):

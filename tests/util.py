@@ -62,7 +62,34 @@ def _data_as(data, dtype):
     return out
 
 
-def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backward=True, fp64=False):
+def _ref_loss(logits, labels, loss_form):
+    """The runner's loss on the oracle side: ``loss_form`` = (ignore_index, "mean" | "mean_all"), oracle/module_cases.LOSS_FORMS."""
+    import torch.nn.functional as F
+    ignore, reduction = loss_form
+    per = F.nll_loss(F.log_softmax(logits, dim=-1), labels, ignore_index=ignore, reduction="none")
+    return per.mean() if reduction == "mean_all" else per.sum() / (labels != ignore).sum()
+
+
+class _Seeded:
+    """The random draws of one forward: torch.manual_seed(seed), or a recorded log replayed (oracle.draws.Draws)."""
+
+    def __init__(self, seed, draws):
+        self.seed, self.draws, self.ctx = seed, draws, None
+
+    def __enter__(self):
+        if self.draws is None:
+            torch.manual_seed(self.seed)
+        else:
+            from oracle.draws import Draws
+            self.ctx = Draws(replay=list(self.draws))
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc) if self.ctx is not None else False
+
+
+def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backward=True, fp64=False, draws=None,
+                  loss_form=(-100, "mean")):
     """Product forward (+ backward) with its routing tables recorded -- which source point won every max aggregation,
     which slope every ReLU / LeakyReLU took -- then the CPU oracle with those tables FORCED (oracle.torch_ref.MAX_TRACE,
     ACT_TRACE): both sides then differentiate along identical routes, so gradients can be held to a tight tolerance, and
@@ -75,6 +102,9 @@ def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backwar
     defines on this input, and the fp32 CPU oracle and the GPU are two fp32 evaluations of it whose distances to it can
     be compared (``adjudicate``).
 
+    ``draws``: a recorded draw log (a fixture's) replayed in every forward instead of seeding torch.  ``loss_form``:
+    (ignore_index, reduction) of the runner's loss on both sides.
+
     Returns dict(out_d, out_r, loss_d, loss_r, flips, entries, grad_err=[(err, name)], grad_scale[, out_64, grad_64])."""
     from oracle import torch_ref as R
     from curvecloudnet_amd import ops
@@ -84,19 +114,19 @@ def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backwar
     ref64 = copy.deepcopy(ref).double() if fp64 else None     # (before the passes below update the running statistics)
     ops.MAX_TRACE, ops.ACT_TRACE = [], []
     try:
-        torch.manual_seed(seed)
-        out_d = mine(batch_to(data, dev), **kw_d)
+        with _Seeded(seed, draws):
+            out_d = mine(batch_to(data, dev), **kw_d)
     finally:
         tables, ops.MAX_TRACE = ops.MAX_TRACE, None
         signs, ops.ACT_TRACE = ops.ACT_TRACE, None
-    loss_d = segmentation_loss(out_d, labels.to(dev))
+    loss_d = segmentation_loss(out_d, labels.to(dev), ignore_index=loss_form[0], reduction=loss_form[1])
     if backward:
         loss_d.backward()
     R.MAX_TRACE = {"record": [], "force": [t.clone() for t in tables]}
     R.ACT_TRACE = {"force": list(signs), "mismatch": 0, "entries": 0, "max_abs": 0.0}
     try:
-        torch.manual_seed(seed)
-        out_r = ref(data, **kw)
+        with _Seeded(seed, draws):
+            out_r = ref(data, **kw)
         natural = R.MAX_TRACE["record"]
         max_gap = R.MAX_TRACE.get("max_gap", 0.0)
         act = R.ACT_TRACE
@@ -105,7 +135,7 @@ def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backwar
     finally:
         R.MAX_TRACE = R.ACT_TRACE = None
     assert len(natural) == len(tables)
-    loss_r = R.segmentation_loss(out_r, labels)
+    loss_r = _ref_loss(out_r, labels, loss_form)
     if backward:
         loss_r.backward()
     flips = sum(int((a != b).sum()) for a, b in zip(natural, tables))
@@ -118,12 +148,12 @@ def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backwar
         R.ACT_TRACE = {"force": list(signs), "mismatch": 0, "entries": 0, "max_abs": 0.0}
         R.FEATURE_DTYPE = torch.float64
         try:
-            torch.manual_seed(seed)
-            out_64 = ref64(_data_as(data, torch.float64), **kw)
+            with _Seeded(seed, draws):
+                out_64 = ref64(_data_as(data, torch.float64), **kw)
             assert out_64.dtype == torch.float64
             assert not R.MAX_TRACE["force"] and not R.ACT_TRACE["force"]
             if backward:
-                R.segmentation_loss(out_64, labels).backward()
+                _ref_loss(out_64, labels, loss_form).backward()
         finally:
             R.MAX_TRACE = R.ACT_TRACE = None
             R.FEATURE_DTYPE = None
