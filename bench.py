@@ -29,12 +29,19 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
 def gemm_label(name, ints, nulls=()):
-    """(kernel symbol as rocprofv3 prints it, flops) of a GEMM launch; mirrors the dispatch in csrc/ccn_gemm.hip."""
-    if name not in ("gemm_nt", "gemm_nn", "gemm_tn", "gemm_tn_ws", "gemm_nt_bf16", "gemm_nt_f16", "gemm_tn_bf16", "gemm_nt_x3",
-                    "gemm_nt_h", "gemm_tn_h", "gemm_tn_h_xf16"):
+    """(kernel symbol as rocprofv3 prints it, flops) of a GEMM launch; mirrors the dispatch in csrc/ccn_gemm.hip.  The
+    product's shape comes from curvecloudnet_amd.costs (ONE table of the entries' argument orders).  The transforming /
+    accumulating / implicit-convolution entries (gemm_nt_xf, gemm_tn_ws_xf, gemm_nt_acc, conv_rows_*) are listed under
+    their entry names: they are other instantiations than the plain product the `roofline` object samples."""
+    from curvecloudnet_amd import costs
+    shape = costs.gemm_shape(name, ints)
+    if shape is None:
         return None, 0.0
-    ld_a, ld_b, _, m, n, k = ints[:6]
+    m, n, k = shape
     flops = 2.0 * m * n * k
+    if name in ("gemm_nt_xf", "gemm_tn_ws_xf", "gemm_nt_acc", "conv_rows_nt", "conv_rows_tn"):
+        return name, flops
+    ld_a, ld_b = ints[0], ints[1]
     if name == "gemm_nt_h":       # (16-bit rows: the LDS-DMA kernels of csrc/ccn_gemm_h.hip)
         return "gemm_h_pair_kernel<%s, %s>" % ("true" if ints[6] else "false", "true" if ints[7] else "false"), flops
     if name in ("gemm_tn_h", "gemm_tn_h_xf16"):
@@ -128,10 +135,63 @@ def empty_bracket_ms(n=64):
     return sorted(b.elapsed_time(e) for b, e in pairs)[n // 2]
 
 
+def _union_ms(spans):
+    spans = sorted(spans)
+    if not spans:
+        return 0.0
+    busy, cur_s, cur_e = 0.0, spans[0][0], spans[0][1]
+    for s_, e_ in spans[1:]:
+        if s_ > cur_e:
+            busy += cur_e - cur_s
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    return busy + cur_e - cur_s
+
+
+def step_roofline(records, steps, ms_per_step, ref_event, mfma_peak_tflops, bracket_ms=0.0):
+    """What the STEP could be (SURVEY.md section 8d "whole model"): every library launch of `steps` fully instrumented steps
+    priced by curvecloudnet_amd.costs -- a launch's floor = max(flops / MFMA peak, algorithmic bytes / HBM peak) -- and
+    summed per family next to the measured launch durations.  Launches without a byte model count their MEASURED time
+    (the floor is then an upper bound of the true floor, never an understatement); position-only work runs on the side
+    stream behind the previous backward pass and is listed but not on the critical path.  `unattributed_ms` = step time
+    minus the union of the feature-stream launches = torch's own kernels (gradient sums, cat, memsets) + idle gaps."""
+    from curvecloudnet_amd import costs
+    fams, crit_spans = {}, []
+    for name, ints, beg, end, nulls, *rest in records:
+        rows = rest[0] if rest else None
+        fam, flops, nbytes, modelled = costs.entry_cost(name, ints, rows)
+        ms = max(beg.elapsed_time(end) - bracket_ms, 0.0)
+        floor = max(flops / (mfma_peak_tflops * 1e12), nbytes / (PEAK_HBM_GBS * 1e9)) * 1e3 if modelled else ms
+        f = fams.setdefault(fam, {"measured_ms": 0.0, "floor_ms": 0.0, "tflop": 0.0, "gbytes": 0.0, "launches": 0,
+                                  "unmodelled_ms": 0.0})
+        f["measured_ms"] += ms / steps
+        f["floor_ms"] += floor / steps
+        f["tflop"] += flops / 1e12 / steps
+        f["gbytes"] += nbytes / 1e9 / steps
+        f["launches"] += 1.0 / steps
+        if not modelled:
+            f["unmodelled_ms"] += ms / steps
+        if fam != "geometry":
+            crit_spans.append((ref_event.elapsed_time(beg), ref_event.elapsed_time(end)))
+    crit = {k: v for k, v in fams.items() if k != "geometry"}
+    floor_ms = sum(v["floor_ms"] for v in crit.values())
+    busy = _union_ms(crit_spans) / steps
+    out = {"floor_ms": floor_ms, "ms_per_step": ms_per_step, "frac_of_floor": floor_ms / ms_per_step,
+           "feature_stream_busy_ms": busy, "unattributed_ms": ms_per_step - busy,
+           "peaks": {"mfma_tflops": mfma_peak_tflops, "hbm_gbs": PEAK_HBM_GBS},
+           "families": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in sorted(fams.items())},
+           "note": "floor = sum over the launches of one step of max(flops / MFMA peak, algorithmic bytes / HBM peak), families "
+                   "on the feature stream only (geometry runs on the side stream during the previous backward); launches "
+                   "without a byte model are counted at their measured time; from %d fully instrumented steps after the timed "
+                   "region" % steps}
+    return out
+
+
 def summarise_profile(records, steps, write_shapes=True, bracket_ms=0.0):
     torch.cuda.synchronize()
     table = {}
-    for name, ints, beg, end, nulls in records:
+    for name, ints, beg, end, nulls, *_ in records:
         label, flops = gemm_label(name, ints, nulls)
         key = label or name
         t = table.setdefault(key, {"ms": 0.0, "launches": 0, "flops": 0.0})
@@ -142,9 +202,11 @@ def summarise_profile(records, steps, write_shapes=True, bracket_ms=0.0):
     rows = sorted(table.items(), key=lambda kv: -kv[1]["ms"])
     # per-shape view of the GEMMs (which layers carry the time)
     shapes = {}
-    for name, ints, beg, end, _ in records:
-        if name.startswith("gemm_"):
-            key = (name, ints[3], ints[4], ints[5])
+    from curvecloudnet_amd import costs
+    for name, ints, beg, end, *_ in records:
+        shape = costs.gemm_shape(name, ints)
+        if shape is not None:
+            key = (name,) + shape
             t = shapes.setdefault(key, [0.0, 0])
             t[0] += beg.elapsed_time(end)
             t[1] += 1
@@ -468,21 +530,11 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # Allocator headroom, still outside the timed region: the caching allocator keeps one pool per stream, and in the timed
-    # region the host runs further ahead of the GPU than during warm-up (nothing synchronises there), so a pool can need a
-    # little more than its warm-up peak -- a hipMalloc in mid-run (3-4 per 20 steps in round 2).  A block of headroom is
-    # allocated and freed once on every stream the step allocates on: it stays cached in that stream's pool and is split
-    # on demand.
-    from curvecloudnet_amd import steps as _steps
-    pools = [torch.cuda.current_stream(dev)] + list(_steps._GEOMETRY_STREAMS.values()) + list(ops._WGRAD_STREAMS.values())
-    for st in pools:
-        with torch.cuda.stream(st):
-            held = [torch.empty(nbytes, dtype=torch.uint8, device=dev)
-                    for nbytes in (4 << 30, 2 << 30, 2 << 30, 1 << 30, 1 << 30, 1 << 30, 512 << 20, 512 << 20, 512 << 20,
-                                   256 << 20, 256 << 20, 128 << 20, 128 << 20,
-                                   64 << 20, 64 << 20, 32 << 20, 32 << 20, 16 << 20, 16 << 20, 8 << 20, 8 << 20, 4 << 20, 4 << 20)]
-            held += [torch.empty((1 << 20) - 512, dtype=torch.uint8, device=dev) for _ in range(128)]   # (the small-block pool)
-            del held
+    # Allocator headroom, still outside the timed region (curvecloudnet_amd.memory.reserve_headroom, the call a training
+    # loop makes after its own warm-up): a ladder of free blocks sized from the warm-up peak in the
+    # pool of every stream the step allocates on, so that no hipMalloc lands in mid-run.  CCN_BENCH_HEADROOM=0 skips it.
+    from curvecloudnet_amd import memory as _memory
+    headroom = ({} if os.environ.get("CCN_BENCH_HEADROOM", "1") == "0" else _memory.reserve_headroom(dev))
     barrier()
     if os.environ.get("CCN_BENCH_LAZY_LOG") == "1":             # diagnostics: which layers hand over deferred activations
         from curvecloudnet_amd import ops as _ops
@@ -601,6 +653,7 @@ def main():
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                    "reserved_hbm_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 1),
                    "device_mallocs_in_timed_region": device_mallocs,
+                   "allocator_headroom_gb": round(sum(headroom.values()) / 2 ** 30, 1),
                    "clouds_per_gpu": b, "points_per_cloud": n_points // b, "parallelism": "dp%d" % world,
                    "loss": float(loss.detach())},
         "multi_gpu": multi_gpu,
@@ -619,7 +672,7 @@ def main():
             # sampled it how often: mean duration per site first, then flops and time summed over the sites seen
             per_site = {}
             if len(sampled_sites) == len(records):
-                for st, (rname, ints, beg, end, nulls) in zip(sampled_sites, records):
+                for st, (rname, ints, beg, end, nulls, *_) in zip(sampled_sites, records):
                     e = per_site.setdefault(st, [0.0, 0, gemm_label(rname, ints, nulls)[1], gemm_bytes(rname, ints)])
                     e[0] += max(beg.elapsed_time(end) - bracket, 0.0)
                     e[1] += 1
@@ -664,21 +717,20 @@ def main():
             # launch's own duration includes the time it shares the chip.  All GEMM launches together: flops over the
             # UNION of their execution intervals = the MFMA throughput the step actually gets out of the chip.
             fam_records, fam_steps = (full_records, 2) if full_records else (records, args.steps)
+            from curvecloudnet_amd import costs
             spans = sorted((ref_event.elapsed_time(r[2]), ref_event.elapsed_time(r[3])) for r in fam_records
-                           if r[0].startswith("gemm_"))
-            busy, cur_s, cur_e = 0.0, spans[0][0], spans[0][1]
-            for s_, e_ in spans[1:]:
-                if s_ > cur_e:
-                    busy += cur_e - cur_s
-                    cur_s, cur_e = s_, e_
-                else:
-                    cur_e = max(cur_e, e_)
-            busy += cur_e - cur_s
+                           if costs.gemm_shape(r[0], r[1]) is not None)
+            busy = _union_ms(spans)
             fam_flops = sum(gemm_label(r[0], r[1], r[4])[1] for r in fam_records)
             fam = fam_flops / (busy * 1e-3) / 1e12
             if world == 1 and os.environ.get("CCN_WGRAD_STREAM", "0") != "0":
                 result["roofline"]["note"] = ("CCN_WGRAD_STREAM is on: launch durations include the time this kernel shares the "
                                               "chip with the weight-gradient stream (ops._WgradScope)")
+            if full_records:
+                result["roofline"]["step"] = step_roofline(full_records, 2, 1e3 * elapsed / args.steps, ref_event,
+                                                           PEAK_BF16_MFMA_TFLOPS if args.mlp_dtype in ("bf16", "fp16") else
+                                                           PEAK_BF16_MFMA_TFLOPS / 6.0 if args.mlp_dtype == "bf16x3" else
+                                                           PEAK_F32_MFMA_TFLOPS, bracket)
             result["roofline"]["all_gemm_launches"] = {
                 "achieved": fam, "frac": fam / peak, "busy_ms_per_step": busy / fam_steps,
                 "note": "flops of every GEMM launch / union of their execution intervals"

@@ -99,8 +99,10 @@ PROFILE_FILTER = None   # optional predicate(name, args): only the launches it a
 EXTRA_LAUNCH = None     # experiment (tools/launch_cost.py): a callable launching one trivial kernel after every call
 
 
-def call(name, *args):
-    """Invoke ``ccn_<name>`` on the current torch stream (appended as the last argument)."""
+def call(name, *args, work_rows=None):
+    """Invoke ``ccn_<name>`` on the current torch stream (appended as the last argument).  ``work_rows``: the row count of
+    the edge-sized operand where the prototype does not carry it (CSR aggregations) -- recorded for bench.py's step
+    roofline (curvecloudnet_amd.costs), never passed to the library."""
     fn = getattr(lib(), "ccn_" + name)
     if EXTRA_LAUNCH is not None:
         EXTRA_LAUNCH()
@@ -115,7 +117,7 @@ def call(name, *args):
     end.record()
     # integer arguments (sizes / leading dimensions) and the positions of NULL pointers identify the kernel variant
     PROFILE.append((name, tuple(a for a in args if isinstance(a, int)), beg, end,
-                    tuple(i for i, a in enumerate(args) if a is None)))
+                    tuple(i for i, a in enumerate(args) if a is None), work_rows))
 
 
 def require_gpu(*tensors):

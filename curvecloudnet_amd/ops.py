@@ -920,7 +920,7 @@ class LinearBNActH(torch.autograd.Function):
                 _, grp_ptr, rep_row, n_pts = post
                 out = _rows(n_pts, n, dev)
                 arg = torch.empty((n_pts, n), dtype=torch.int32, device=dev)
-                call("cg_max_fwd", ptr(y), _ld(y), ptr(grp_ptr), ptr(rep_row), n_pts, n, ptr(out), _ld(out), ptr(arg))
+                call("cg_max_fwd", ptr(y), _ld(y), ptr(grp_ptr), ptr(rep_row), n_pts, n, ptr(out), _ld(out), ptr(arg), work_rows=y.size(0))
                 ctx.post = ("max", n_pts)
                 ctx.save_for_backward(x16, weight, arg, grp_ptr, rep_row)
                 return out
@@ -930,7 +930,7 @@ class LinearBNActH(torch.autograd.Function):
                 if tuple(msg.shape) != (m, n):
                     raise ValueError("attend: messages %s against scores (%d, %d)" % (tuple(msg.shape), m, n))
                 out = _rows(n_dst, n, dev)
-                call("seg_softmax_agg_fwd", ptr(msg), _ld(msg), ptr(y), _ld(y), ptr(offsets), n_dst, n, ptr(out), _ld(out))
+                call("seg_softmax_agg_fwd", ptr(msg), _ld(msg), ptr(y), _ld(y), ptr(offsets), n_dst, n, ptr(out), _ld(out), work_rows=msg.size(0))
                 ctx.post = ("attend", n_dst)
                 ctx.save_for_backward(x16, weight, msg, y, offsets)
                 return out
@@ -1012,7 +1012,7 @@ class LinearBNActH(torch.autograd.Function):
             g = _mat(g.float() if g.dtype != torch.float32 else g)
             dy16, dpost = _rows16(m, n, dev), _rows(m, n, dev)
             call("seg_softmax_agg_bwd_h", ptr(msg), _ld(msg), ptr(att), _ld(att), ptr(offsets), ctx.post[1], n, ptr(g), _ld(g),
-                 ptr(dpost), _ld(dpost), ptr(dy16), _ld(dy16))
+                 ptr(dpost), _ld(dpost), ptr(dy16), _ld(dy16), work_rows=msg.size(0))
         else:
             x16, weight = ctx.saved_tensors
             sums = par = None
@@ -1506,7 +1506,7 @@ class SegSoftmaxAgg(torch.autograd.Function):
         msg, att = _mat(msg), _mat(att)
         c = msg.size(1)
         out = _rows(num_dst, c, msg.device)
-        call("seg_softmax_agg_fwd", ptr(msg), _ld(msg), ptr(att), _ld(att), ptr(offsets), num_dst, c, ptr(out), _ld(out))
+        call("seg_softmax_agg_fwd", ptr(msg), _ld(msg), ptr(att), _ld(att), ptr(offsets), num_dst, c, ptr(out), _ld(out), work_rows=msg.size(0))
         _GRAD_SINK.clear()                   # (nothing of an earlier backward pass may survive into this one)
         ctx.save_for_backward(msg, att, offsets)
         ctx.owns_msg = bool(owns_msg)
@@ -1519,7 +1519,7 @@ class SegSoftmaxAgg(torch.autograd.Function):
         m, c = g.shape
         dmsg, datt = _rows(msg.size(0), c, g.device), _rows(att.size(0), c, g.device)
         call("seg_softmax_agg_bwd", ptr(msg), _ld(msg), ptr(att), _ld(att), ptr(offsets), m, c, ptr(g), _ld(g),
-             ptr(dmsg), _ld(dmsg), ptr(datt), _ld(datt))
+             ptr(dmsg), _ld(dmsg), ptr(datt), _ld(datt), work_rows=msg.size(0))
         if ctx.owns_msg:
             _grad_sink_offer(msg, dmsg)      # attend_nn's first layer adds its data gradient into dmsg (see _GRAD_SINK)
         return dmsg, datt, None, None, None
@@ -1535,7 +1535,7 @@ class SegWSum(torch.autograd.Function):
         c = msg.size(1)
         out = _rows(num_dst, c, msg.device)
         call("seg_wsum_fwd", ptr(msg), _ld(msg), ptr(att), _ld(att) if att is not None else 0, ptr(offsets), num_dst, c, mode,
-             ptr(out), _ld(out))
+             ptr(out), _ld(out), work_rows=msg.size(0))
         ctx.save_for_backward(msg, att if att is not None else msg.new_empty(0), offsets)
         ctx.mode = mode
         return out
@@ -1549,7 +1549,7 @@ class SegWSum(torch.autograd.Function):
         dmsg = _rows(msg.size(0), c, g.device)
         datt = _rows(msg.size(0), c, g.device) if has_att else None
         call("seg_wsum_bwd", ptr(msg), _ld(msg), ptr(att) if has_att else None, _ld(att) if has_att else 0, ptr(offsets), m, c,
-             ctx.mode, ptr(g), _ld(g), ptr(dmsg), _ld(dmsg), ptr(datt), _ld(datt) if has_att else 0)
+             ctx.mode, ptr(g), _ld(g), ptr(dmsg), _ld(dmsg), ptr(datt), _ld(datt) if has_att else 0, work_rows=msg.size(0))
         return dmsg, datt, None, None, None
 
 
@@ -1562,7 +1562,7 @@ class SegMax(torch.autograd.Function):
         c = msg.size(1)
         out = _rows(num_dst, c, msg.device)
         arg = torch.empty((num_dst, c), dtype=torch.int32, device=msg.device)
-        call("seg_max_fwd", ptr(msg), _ld(msg), ptr(offsets), num_dst, c, ptr(out), _ld(out), ptr(arg))
+        call("seg_max_fwd", ptr(msg), _ld(msg), ptr(offsets), num_dst, c, ptr(out), _ld(out), ptr(arg), work_rows=msg.size(0))
         ctx.save_for_backward(arg, offsets)
         ctx.e = msg.size(0)
         if MAX_TRACE is not None:
@@ -1575,7 +1575,7 @@ class SegMax(torch.autograd.Function):
         g = _mat(g)
         m, c = g.shape
         dmsg = _rows(ctx.e, c, g.device)
-        call("seg_max_bwd", ptr(g), _ld(g), ptr(arg), ptr(offsets), m, c, ptr(dmsg), _ld(dmsg))
+        call("seg_max_bwd", ptr(g), _ld(g), ptr(arg), ptr(offsets), m, c, ptr(dmsg), _ld(dmsg), work_rows=ctx.e)
         return dmsg, None, None, None
 
 
@@ -2186,7 +2186,7 @@ class CGMax(torch.autograd.Function):
         c = f.size(1)
         out = _rows(n, c, f.device)
         arg = torch.empty((n, c), dtype=torch.int32, device=f.device)
-        call("cg_max_fwd", ptr(f), _ld(f), ptr(grp_ptr), ptr(rep_row), n, c, ptr(out), _ld(out), ptr(arg))
+        call("cg_max_fwd", ptr(f), _ld(f), ptr(grp_ptr), ptr(rep_row), n, c, ptr(out), _ld(out), ptr(arg), work_rows=f.size(0))
         ctx.save_for_backward(arg, grp_ptr, rep_row)
         ctx.shape = (n, f.size(0), c)
         if MAX_TRACE is not None and row_src is not None:

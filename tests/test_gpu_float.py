@@ -754,9 +754,9 @@ def test_fp16_mode_weight_gradient_converts_its_operand_in_the_kernel():
             log = []
             inner = ops.call
 
-            def spy(name, *a):
+            def spy(name, *a, **kw):
                 log.append(name)
-                return inner(name, *a)
+                return inner(name, *a, **kw)
 
             ops.call = spy
             try:
@@ -811,9 +811,9 @@ def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
         log = []
         inner = ops.call
 
-        def spy(name, *a):
+        def spy(name, *a, **kw):
             log.append(name)
-            return inner(name, *a)
+            return inner(name, *a, **kw)
 
         ops.call = spy
         try:

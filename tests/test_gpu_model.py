@@ -39,7 +39,7 @@ def _check_routed(res, what):
     run carries an fp64 evaluation of the oracle along the same routes (``fp64=True``), ADJUDICATED by it: two correct
     fp32 evaluations of a deep network differ from each other by the sum of their rounding errors, so the GPU is held
     to  |gpu - fp64| <= max(1e-4 scale, 1.5 |cpu_fp32 - fp64|)  and  |gpu - fp64| <= 1e-4 scale + |cpu_fp32 - fp64|
-    (or, where the max-norm ratio lands between 1.5 and 2: rms(gpu - fp64) <= 1.5 rms(cpu_fp32 - fp64)):
+    (or, where the max-norm ratio lands between 1.5 and 1.75: rms(gpu - fp64) <= 1.5 rms(cpu_fp32 - fp64)):
     as close to the value the network defines as the reference's own arithmetic is.  Gradients likewise: every tensor
     within GRAD_TOL of the fp32 oracle, or no farther from the fp64 gradient than 1.5 x the fp32 oracle is (+ GRAD_TOL/3)."""
     out_d, out_r = res["out_d"], res["out_r"]
@@ -58,9 +58,10 @@ def _check_routed(res, what):
         _log("%s: fp64 adjudication: |gpu - fp64| %.2e, |cpu_fp32 - fp64| %.2e (ratio %.2f; rms %.2e vs %.2e, ratio %.2f), "
              "1e-4 x scale = %.2e" % (what, d_gpu, d_cpu, d_gpu / max(d_cpu, 1e-30), r_gpu, r_cpu, r_gpu / max(r_cpu, 1e-30), band))
         # (the maximum over ~1e6 logits of each side's error is an extreme-value statistic and the CPU side's depends on the
-        # host's thread count: where the max-norm ratio lands between 1.5 and 2, the rms ratio -- stable -- must be within 1.5)
+        # host's thread count: where the max-norm ratio lands between 1.5 and 1.75, the rms ratio -- stable -- must be within 1.5;
+        # measured r4: 1.13 / 1.19 (max / rms) at 49 652 points with backward, 1.36 / 1.31 at 12 051: the hatch has not been needed)
         ok_max = d_gpu <= max(band, ADJ_RATIO * d_cpu) and d_gpu <= band + d_cpu
-        ok_rms = d_gpu <= 2.0 * d_cpu and r_gpu <= ADJ_RATIO * r_cpu
+        ok_rms = d_gpu <= 1.75 * d_cpu and r_gpu <= ADJ_RATIO * r_cpu
         assert ok_max or ok_rms, (d_gpu, d_cpu, r_gpu, r_cpu, band)
         band = max(band, d_gpu + d_cpu)               # what the two fp32 evaluations may then differ by
     assert err <= band, (err, band)

@@ -47,7 +47,7 @@ def run(name, pq, tq, ps, ts, K, r, reps=20):
         ops.fast_knn(qp, sp, tq.lengths, ts.lengths, K, r)
     torch.cuda.synchronize()
     per = {}
-    for name, _, b_, e_, _ in _lib.PROFILE:
+    for name, _, b_, e_, *_ in _lib.PROFILE:
         per[name] = per.get(name, 0.0) + b_.elapsed_time(e_) / reps
     _lib.PROFILE = None
     p1, p2 = pq.size(0), ps.size(0)

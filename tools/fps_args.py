@@ -27,5 +27,5 @@ torch.manual_seed(7)
 model.prepare(data)
 torch.cuda.synchronize()
 print("points", data.pos.size(0))
-for name, ints, beg, end, _ in _lib.PROFILE:
+for name, ints, beg, end, *_ in _lib.PROFILE:
     print(name, "B=%d max_cloud=%d" % (ints[0], ints[1]), "%.2f ms" % beg.elapsed_time(end))

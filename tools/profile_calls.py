@@ -64,7 +64,7 @@ step()
 torch.cuda.synchronize()
 rec, _lib.PROFILE = _lib.PROFILE, None
 groups = {}
-for name, ints, beg, end, nulls in rec:
+for name, ints, beg, end, nulls, *_ in rec:
     if a.filter and a.filter not in name:
         continue
     g = groups.setdefault((name, ints), [0.0, 0])
