@@ -420,7 +420,7 @@ int ccn_frnn_query(const float* points1, const int64_t* lengths1, const float* r
   CCN_REQUIRE(carve(const_cast<void*>(grid), grid_bytes(B, P2), B, P2, &g), "frnn_query: carve failed");
   // teams need K <= TEAM_CAP - 64 list slots free for a round of candidates
   int mode = g_query_mode;
-  // measured (tools/bench_frnn.py, profiles/r02_frnn_microbench.txt): 32-lane teams win at every level of the KITTI
+  // measured (tools/bench_frnn.py, profiles/archive/r02_frnn_microbench.txt): 32-lane teams win at every level of the KITTI
   // model -- 2.5x on the full 8 x 50 k cloud, 4-10x on the coarse levels -- over both the thread form and 64-lane teams
   if (mode == 0) mode = 2;
   if (K > TEAM_CAP - 64) mode = 1;

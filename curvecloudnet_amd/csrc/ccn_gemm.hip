@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     }
   };
   // (in-kernel experiments of rounds 2-3 -- a start stagger / instruction priorities for the second workgroup of a CU, a
-  // counted wait behind the stores, s_setprio around the MFMAs -- are measured in profiles/r02_pair_kernel_experiments.txt and
+  // counted wait behind the stores, s_setprio around the MFMAs -- are measured in profiles/archive/r02_pair_kernel_experiments.txt and
   // r03_pair_kernel_anatomy.txt; none paid, none is compiled any more)
   issue_next();
 

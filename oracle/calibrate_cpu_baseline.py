@@ -4,7 +4,7 @@ bench.py's `cpu_baseline` is `kind: "port"`: the oracle (oracle/torch_ref.py), b
 the GPU box.  This script times the oracle's restatement NEXT TO the imported reference on the survey's three
 curve-convolution shapes (the only part of the hot path the reference can run here), same inputs, same thread count,
 so that the port's speed relative to the reference is on record:  python oracle/calibrate_cpu_baseline.py
-Output committed as profiles/r02_cpu_baseline_calibration.txt.
+Output committed as profiles/archive/r02_cpu_baseline_calibration.txt.
 """
 import os
 import statistics

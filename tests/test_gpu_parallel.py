@@ -191,6 +191,9 @@ def test_bench_two_ranks_describes_itself(tmp_path):
     assert 1.0 <= mg["load_imbalance_max_over_mean"] < 1.5
     assert mg["gradient_bytes"] > 0 and abs(mg["allreduce_bytes_per_step"] - mg["gradient_bytes"]) < 1e-6 * mg["gradient_bytes"]
     assert mg["finish_wait_ms_per_step"] >= 0.0
+    # overlap really happens: a bucket's all-reduce is issued from backward when its last gradient reports; at most the one
+    # bucket that closes with the very last gradient of the pass may be left for finish()
+    assert mg["buckets_reduced_in_finish_per_step"] <= 1.0, mg
     # a rank that fails takes the launcher's exit code with it
     bad = subprocess.run(cmd, env=dict(env, CCN_BENCH_FAIL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          timeout=600)

@@ -84,6 +84,74 @@ def test_gradient_allreduce_world2_matches_single_process():
     assert float((a - want).abs().max()) < 1e-6
 
 
+def _worker_uneven(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from curvecloudnet_amd.parallel import GradientAllReduce, init_process_group_from_env, shard_clouds
+    init_process_group_from_env(backend="gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    sync = GradientAllReduce(model, bucket_bytes=300)
+    clouds = shard_clouds(range(6), rank, world)              # 6 clouds over 4 ranks: two ranks take 2, two take 1
+    sync.zero_grad()
+    points = 0
+    loss = 0
+    for c in clouds:
+        g = torch.Generator().manual_seed(200 + c)
+        n = 5 + 7 * c                                         # clouds of very different sizes
+        x, y = torch.randn(n, 6, generator=g), torch.randn(n, 3, generator=g)
+        points += n
+        loss = loss + ((model(x) - y) ** 2).mean() / len(clouds)
+    loss.backward()
+    sync.finish()
+    flat = torch.cat([p.grad.flatten() for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    counts = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([points]))
+    if rank == 0:
+        out.put(([t.tolist() for t in gathered], [int(c) for c in counts], dict(sync.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world4_uneven_clouds_per_rank():
+    """Four gloo ranks, six clouds of very different sizes: shard_clouds gives the ranks 2 / 2 / 1 / 1 whole clouds, the
+    load-imbalance figure of a run (max / mean points per rank, SURVEY section 8e "Caveat") is far from 1, the replicas stay
+    identical, and the reduced gradient is the mean over the ranks of each rank's own mean-over-its-clouds gradient --
+    what one process per GPU with per-rank batches computes (no cross-rank weighting by points)."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    world = 4
+    procs = [ctx.Process(target=_worker_uneven, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    grads, points, stats = out.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    grads = [torch.tensor(g) for g in grads]
+    for g in grads[1:]:
+        assert torch.equal(g, grads[0])
+    assert points == [5 + 7 * 0 + 5 + 7 * 4, 5 + 7 * 1 + 5 + 7 * 5, 5 + 7 * 2, 5 + 7 * 3]
+    imbalance = max(points) / (sum(points) / len(points))
+    assert imbalance > 1.5
+    assert stats["bytes_reduced"] > 0 and stats["steps"] == 1
+    want = 0
+    for rank in range(world):
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+        clouds = list(range(6))[rank::world]
+        for c in clouds:
+            g = torch.Generator().manual_seed(200 + c)
+            n = 5 + 7 * c
+            x, y = torch.randn(n, 6, generator=g), torch.randn(n, 3, generator=g)
+            (((m(x) - y) ** 2).mean() / len(clouds)).backward()
+        want = want + torch.cat([p.grad.flatten() for p in m.parameters()]) / world
+    assert float((grads[0] - want).abs().max()) < 1e-6
+
+
 class _FusedLinear(torch.autograd.Function):
     """CPU stand-in for the HIP layers' main-grad protocol (ops.LinearBNAct): the weight gradient is ADDED into the
     bucket view by the layer itself, autograd gets None for it, and the all-reduce is told through note_use / use_done."""

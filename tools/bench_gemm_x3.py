@@ -1,5 +1,5 @@
 """Split-bf16 ("bf16x3") product against the fp32 and plain-bf16 MFMA entries: error versus an fp64 product on a row
-sample, and throughput at the GEMM shapes of the KITTI bench workload (profiles/r01m_kitti_gemm_shapes.txt)."""
+sample, and throughput at the GEMM shapes of the KITTI bench workload (profiles/archive/r01m_kitti_gemm_shapes.txt)."""
 import sys
 import torch
 from curvecloudnet_amd._lib import call, ptr, lib
