@@ -488,6 +488,8 @@ def main():
 
     site = [0, 0]          # [launch sites of the dominant kernel seen in this step, steps started]
 
+    threaded = not args.no_pipeline and os.environ.get("CCN_BENCH_PREPARE_THREAD", "1") != "0"
+
     def step():
         site[0], site[1] = 0, site[1] + 1
         marks = [time.perf_counter()]
@@ -495,13 +497,20 @@ def main():
         plan = staged["plan"]
         if plan is None:
             torch.manual_seed(7)                             # fixes the CurveFPS phase draws
+        pending = None
+        if threaded and plan is not None:
+            # the next batch's sampling / neighbour search: on the side stream, driven by a worker thread whose waits for
+            # the element counts overlap this thread's queueing of forward and backward (ModelBase.prepare_async) -- what
+            # a training loop does with the loader's next batch
+            pending = model.prepare_async(data, seed=7)
         loss = segmentation_loss(model(data, plan=plan), labels)
         marks.append(time.perf_counter())
         loss.backward()
         marks.append(time.perf_counter())
-        if not args.no_pipeline:
-            # the next batch's sampling / neighbour search is queued on the side stream while this batch's backward pass
-            # (already queued) runs: what a training loop does with the loader's next batch (ModelBase.prepare)
+        if pending is not None:
+            staged["plan"] = pending.result()
+        elif not args.no_pipeline:
+            # (first step, or CCN_BENCH_PREPARE_THREAD=0: queued from this thread while the backward pass, already queued, runs)
             torch.manual_seed(7)
             staged["plan"] = model.prepare(data)
         marks.append(time.perf_counter())
@@ -542,6 +551,10 @@ def main():
         step()
         for row in _ops.LAZY_ACT_LOG:
             print("deferred input: rows %8d  N %5d  K %5d  %s" % (row[0], row[1], row[2], "fused" if row[3] else "written out"))
+        return
+    if os.environ.get("CCN_BENCH_ENGINE_OPS") == "1":           # diagnostics: what the autograd engine itself launches
+        from tools.aten_engine_ops import table as engine_table
+        engine_table(step)
         return
     if os.environ.get("CCN_BENCH_ATEN_TABLE") == "1":           # diagnostics: who issues torch-side device ops in a step
         from tools.aten_callers import table

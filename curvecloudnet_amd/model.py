@@ -17,6 +17,9 @@ _DOWNSAMPLING_STEPS = ("sa", "sa-geo", "sa-global", "pt-transition-down")
 _FEATURE_ONLY_STEPS = ("mlp", "skip-connect")
 
 
+_PREPARE_POOL = None            # one worker thread for ModelBase.prepare_async
+
+
 class ModelBase(torch.nn.Module):
     def __init__(self, in_dim, n_out, steps=("conv1d", "dgcnn", "conv1d", "sa", "sa", "sa-global"),
                  feat_dims=((32, 32, 64), (64, 128), (128, 128), (128, 128, 256), (256, 512, 1024), (1024,)),
@@ -117,7 +120,7 @@ class ModelBase(torch.nn.Module):
         raise NotImplementedError("Have not implemented step %s yet!" % step_name)
 
     # ---- ref base.py:133-209
-    def prepare(self, data, inputs_ready=True):
+    def prepare(self, data, inputs_ready=True, main_stream=None):
         """Optional pipelining hook for a training loop: computes the position-only part of ``forward(data)`` (sampling,
         neighbour search, index tables of every step) on the side stream NOW -- typically right after
         ``loss.backward()`` of the previous batch has been queued, so that it overlaps that backward pass -- and returns
@@ -126,10 +129,34 @@ class ModelBase(torch.nn.Module):
         when there is no side stream or a step searches in feature space; ``forward`` then does everything itself."""
         pos, batch, p2c = data.pos, data.batch, data.curve_idxs
         num_clouds = getattr(data, "num_clouds", None) or getattr(data, "num_graphs", None)
-        ctx = ForwardContext(num_clouds, device=pos.device, inputs_ready=inputs_ready)
+        ctx = ForwardContext(num_clouds, device=pos.device, inputs_ready=inputs_ready, main_stream=main_stream)
         kwargs = {"_ccn_ctx": ctx}
         tables = self._geometry_prepass(ctx, pos, batch, p2c, kwargs)
         return None if tables is None else (ctx, tables, data)
+
+    def prepare_async(self, data, inputs_ready=True, seed=None):
+        """``prepare(data)`` on a worker thread: returns a ``concurrent.futures.Future`` whose ``result()`` is the plan.
+
+        The position-only pass reads element counts back between its kernels (sampled points, edges per level: the sizes
+        of everything the feature pass allocates), so its HOST time is mostly waiting for the side stream -- 50 ms per
+        step on BASELINE configs[4], where exact farthest point sampling over ~17 k-point clouds is a chain of ~6 k
+        dependent rounds.  Those waits release the interpreter lock: started at the top of a step, the next batch's
+        geometry proceeds while this thread queues the current forward and backward pass.  ``seed``: ``torch.manual_seed``
+        applied on the worker before the pass (the sampling draws come from torch's global CPU generator; the caller's
+        thread must not draw from it meanwhile -- a forward with a plan does not)."""
+        import concurrent.futures
+        global _PREPARE_POOL
+        if _PREPARE_POOL is None:
+            _PREPARE_POOL = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="ccn-geometry")
+        device = data.pos.device
+        main = torch.cuda.current_stream(device)          # (the worker thread has a current stream of its own)
+
+        def work():
+            torch.cuda.set_device(device)                 # (the current device is per thread as well)
+            if seed is not None:
+                torch.manual_seed(seed)
+            return self.prepare(data, inputs_ready=inputs_ready, main_stream=main)
+        return _PREPARE_POOL.submit(work)
 
     def forward(self, data, plan=None, **kwargs):
         x, pos, batch, p2c = data.x, data.pos, data.batch, data.curve_idxs

@@ -665,6 +665,9 @@ class LinearBNAct(torch.autograd.Function):
         # xf_par / xf_act: ``x`` is such a deferred product of the previous layer (its 4 x K table and activation code)
         x = _mat(x)
         require_gpu(weight)
+        # the second output (the BatchNorm table / an empty placeholder) is not differentiable: without this the engine
+        # materialises a zeros tensor for its gradient on every backward call (79 fill launches per KITTI step)
+        ctx.set_materialize_grads(False)
         m, k = x.shape
         n = weight.size(0)
         if weight.size(1) != k:
@@ -730,6 +733,8 @@ class LinearBNAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _gpar=None):
+        if g is None:                              # (grads are not materialised: nothing flowed into this layer's output)
+            return (None,) * 15
         g = _mat(g)
         dev = g.device
         if ctx.has_bn:

@@ -85,7 +85,9 @@ class ForwardContext:
     """Per-forward state: the ``CurveTopology`` cache for the (batch, curve-id) pairs seen, and the
     side stream the geometry blocks run on."""
 
-    def __init__(self, num_clouds=None, device=None, inputs_ready=False):
+    def __init__(self, num_clouds=None, device=None, inputs_ready=False, main_stream=None):
+        # main_stream: the stream the FEATURE pass will run on when that is not this thread's current stream
+        # (ModelBase.prepare_async builds the context on a worker thread, whose current stream is its own)
         self.num_clouds = num_clouds
         self._topo = {}
         self._zeros = {}
@@ -94,7 +96,7 @@ class ForwardContext:
         if device is not None:
             self.side, mode = _geometry_stream(device)
             if self.side is not None:
-                self.main = torch.cuda.current_stream(device)
+                self.main = main_stream if main_stream is not None else torch.cuda.current_stream(device)
                 self.stress = mode == "stress"
                 if not inputs_ready:
                     self.side.wait_stream(self.main)      # the level-0 inputs were produced on the main stream

@@ -371,12 +371,16 @@ def test_geometry_stream_modes_agree(monkeypatch):
     data = batch_to(make_batch([3, 4], n_curves=160), DEV)
     y = _labels(data.pos.size(0), 20, 8).to(DEV)
     runs = {}
-    for mode in ("0", "1", "stress", "stress", "prepared"):
-        monkeypatch.setenv("CCN_GEOMETRY_STREAM", "stress" if mode == "prepared" else mode)
+    for mode in ("0", "1", "stress", "stress", "prepared", "async"):
+        monkeypatch.setenv("CCN_GEOMETRY_STREAM", "stress" if mode in ("prepared", "async") else mode)
         model.zero_grad(set_to_none=True)
         torch.manual_seed(11)
         if mode == "prepared":       # ModelBase.prepare: all position-only work first, features afterwards
             plan = model.prepare(data)
+            assert plan is not None
+            out = model(data, plan=plan)
+        elif mode == "async":        # ... driven by the worker thread (ModelBase.prepare_async), seeded there
+            plan = model.prepare_async(data, seed=11).result()
             assert plan is not None
             out = model(data, plan=plan)
         else:
