@@ -739,6 +739,16 @@ def main():
             if world == 1 and os.environ.get("CCN_WGRAD_STREAM", "0") != "0":
                 result["roofline"]["note"] = ("CCN_WGRAD_STREAM is on: launch durations include the time this kernel shares the "
                                               "chip with the weight-gradient stream (ops._WgradScope)")
+            if full_records and os.environ.get("CCN_BENCH_DUMP_RECORDS"):
+                # diagnostics: every launch of the two instrumented steps with its integer arguments, duration and floor
+                from curvecloudnet_amd import costs as _costs
+                with open(os.environ["CCN_BENCH_DUMP_RECORDS"], "w") as f:
+                    for r in full_records:
+                        fam, fl, by, ok = _costs.entry_cost(r[0], r[1], r[5] if len(r) > 5 else None)
+                        ms = max(r[2].elapsed_time(r[3]) - bracket, 0.0)
+                        f.write("%s\t%s\t%.4f\t%.4f\t%.3f\t%.3f\t%s\n" % (
+                            r[0], fam, ms, max(fl / (PEAK_F32_MFMA_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)) * 1e3,
+                            fl / 1e9, by / 1e6, ",".join(str(v) for v in r[1])))
             if full_records:
                 result["roofline"]["step"] = step_roofline(full_records, 2, 1e3 * elapsed / args.steps, ref_event,
                                                            PEAK_BF16_MFMA_TFLOPS if args.mlp_dtype in ("bf16", "fp16") else

@@ -62,8 +62,13 @@ __device__ __forceinline__ float from_h(u16 v) {
 // (the sums per output element are the same fma chains in the same k order: a*b commutes).  No statistics in that form.
 // DIAG: the timing-only ablation build behind ccn_gemm_h_opt (include/ccn_hip_debug.h); in the shipping instantiations
 // (DIAG = false) ``opt`` is the constant 0 and every branch on it is compiled out.
-template <bool F16, bool OUT16, bool DIAG = false>
-__global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __restrict__ A, int64_t lda,
+// BN: columns of a tile.  128: two workgroups per CU (64 KB of LDS each).  64 (round 4): 128 x 64 tiles, 48 KB of LDS and
+// ~120 VGPRs per workgroup, THREE workgroups per CU -- the kernel is HBM-bound at the network's widths and a workgroup
+// cannot have copies land past its own pending stores (vmcnt retires in order), so the store burst of one tile only
+// overlaps OTHER workgroups' loads: more, smaller workgroups per CU keep more of both in flight.  The A tile is then read
+// by N / 64 column tiles instead of N / 128: they sit on one XCD in the same step (tile_of) and share it through that L2.
+template <bool F16, bool OUT16, bool DIAG = false, int BN = HB_BN>
+__global__ __launch_bounds__(HB_TPB, BN == 128 ? 2 : 3) void gemm_h_pair_kernel(const u16* __restrict__ A, int64_t lda,
                                                                 const u16* __restrict__ B, int64_t ldb,
                                                                 const float* __restrict__ bias, void* __restrict__ Cv,
                                                                 int64_t ldc, int64_t M, int64_t N, int64_t K, int64_t tiles,
@@ -71,10 +76,13 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
                                                                 int opt_rt) {
   // opt (diagnostics, ccn_gemm_h_opt; results WRONG when set): bit 0 = no epilogue stores, bit 1 = no wait for the LDS-DMA
   const int opt = DIAG ? opt_rt : 0;
-  constexpr int AF = HB_BM * HB_BK, BF = HB_BN * HB_BK, STAGE = AF + BF;   // 16-bit elements
-  constexpr int NC = 4;   // LDS-DMA copies (8 rows x 128 B) per wave, slice and operand
+  static_assert(BN == 128 || (BN == 64 && !OUT16), "tile widths: 128, or 64 for the fp32-result form");
+  constexpr int AF = HB_BM * HB_BK, BF = BN * HB_BK, STAGE = AF + BF;   // 16-bit elements
+  constexpr int NC = 4;         // LDS-DMA copies (8 rows x 128 B) per wave and slice of A
+  constexpr int NCB = BN / 32;  // ... of B
+  constexpr int NTW = BN / 64;  // 32-column blocks per wave (waves: 2 x 2 quadrants of 64 x BN/2)
   __shared__ __attribute__((aligned(16))) u16 lds[2 * STAGE];
-  __shared__ float stat_part[2 * HB_BN * 2];   // [wm][column][sum, sum of squares] of the finished tile
+  __shared__ float stat_part[2 * BN * 2];   // [wm][column][sum, sum of squares] of the finished tile
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: SGPR addressing)
   const int wm = wave & 1, wn = wave >> 1;
@@ -83,16 +91,17 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
   const int lr = lane >> 3, lc = lane & 7;
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
   const uint32_t a_off = (uint32_t)((wm * 64 + i) * HB_BK * 2);            // bytes: A fragment row of block ab = 0
-  const uint32_t b_off = (uint32_t)((AF + (wn * 64 + i) * HB_BK) * 2);     // bytes: B fragment row of block t = 0
+  const uint32_t b_off = (uint32_t)((AF + (wn * (BN / 2) + i) * HB_BK) * 2);   // bytes: B fragment row of block t = 0
   const int T = (int)(K / HB_BK);
   const int has_tail = (K % HB_BK) != 0;
   const int TT = T + has_tail;
 
   const uint32_t gnu = (uint32_t)gn;
   const uint32_t gm_tiles = (uint32_t)tiles / gnu;
-  const bool xcd_map = xcd_order && gridDim.x == 512 && gnu <= 64 && 64 % gnu == 0;
+  // (workgroups go to the 8 XCDs round-robin: the gridDim.x / 8 slots of an XCD take whole rows of tiles, gnu at a time)
+  const bool xcd_map = xcd_order && gridDim.x >= 512 && (gridDim.x & 7) == 0 && (gridDim.x >> 3) % gnu == 0;
   const uint32_t slot = blockIdx.x >> 3;
-  const uint32_t rows_per_step = 512u / gnu, slot_row = (slot / gnu) * 8 + (blockIdx.x & 7), slot_col = slot % gnu;
+  const uint32_t rows_per_step = gridDim.x / gnu, slot_row = (slot / gnu) * 8 + (blockIdx.x & 7), slot_col = slot % gnu;
   auto tile_of = [&](int64_t j) -> int64_t {
     if (xcd_map) {
       const uint32_t m = (uint32_t)j * rows_per_step + slot_row;
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
 
   // ---- issue cursor: one slice ahead of the compute cursor, across tile boundaries
   // (a copy's source = scalar tile base + 32-bit lane offset: no vector address arithmetic per copy, as in ccn_gemm.hip)
-  uint32_t a_off32[NC], b_off32[NC];
+  uint32_t a_off32[NC], b_off32[NCB];
   const char* a_tile = reinterpret_cast<const char*>(A);
   const char* b_tile = reinterpret_cast<const char*>(B);
   int64_t it_j = 0, it_tile = tile_of(0), gi = 0;
@@ -115,15 +124,20 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
     if (it_tile >= tiles) return;
     if (it_u == 0) {
       im0 = tile_row(it_tile) * HB_BM;
-      in0 = tile_col(it_tile) * HB_BN;
+      in0 = tile_col(it_tile) * BN;
       a_tile = reinterpret_cast<const char*>(A + im0 * lda);
       b_tile = reinterpret_cast<const char*>(B + in0 * ldb);
       const int64_t a_rows = M - im0, b_rows = N - in0;
 #pragma unroll
       for (int q = 0; q < NC; ++q) {
         const int r = 8 * (wave * NC + q) + lr;
-        const int64_t ra = r < a_rows ? r : a_rows - 1, rb = r < b_rows ? r : b_rows - 1;
+        const int64_t ra = r < a_rows ? r : a_rows - 1;
         a_off32[q] = (uint32_t)((ra * lda + 8 * (lc ^ ((r >> 1) & 7))) * 2);
+      }
+#pragma unroll
+      for (int q = 0; q < NCB; ++q) {
+        const int r = 8 * (wave * NCB + q) + lr;
+        const int64_t rb = r < b_rows ? r : b_rows - 1;
         b_off32[q] = (uint32_t)((rb * ldb + 8 * (lc ^ ((r >> 1) & 7))) * 2);
       }
     }
@@ -135,12 +149,12 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
 #pragma unroll
       for (int q = 0; q < NC; ++q) glds16h(reinterpret_cast<const u16*>(a_sl + a_off32[q]), st + (8 * (wave * NC + q)) * HB_BK);
 #pragma unroll
-      for (int q = 0; q < NC; ++q) glds16h(reinterpret_cast<const u16*>(b_sl + b_off32[q]), st + AF + (8 * (wave * NC + q)) * HB_BK);
+      for (int q = 0; q < NCB; ++q) glds16h(reinterpret_cast<const u16*>(b_sl + b_off32[q]), st + AF + (8 * (wave * NCB + q)) * HB_BK);
     } else {
       // K remainder (< 64 elements): both operands through registers, zero filled beyond K, into the same swizzled image
       // (nothing else is in flight here: every iteration waits vmcnt(0))
 #pragma unroll
-      for (int it = 0; it < 2 * HB_BM * 8 / HB_TPB; ++it) {
+      for (int it = 0; it < (HB_BM + BN) * 8 / HB_TPB; ++it) {
         const int sl0 = threadIdx.x + it * HB_TPB;
         const bool isA = sl0 < HB_BM * 8;
         const int sl = isA ? sl0 : sl0 - HB_BM * 8;
@@ -176,13 +190,13 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
 
   int64_t stat_tile = -1;
   auto stats_readout = [&]() {
-    const int64_t pm = tile_row(stat_tile), pn0 = tile_col(stat_tile) * HB_BN;
-    for (int c = threadIdx.x; c < HB_BN; c += HB_TPB) {
+    const int64_t pm = tile_row(stat_tile), pn0 = tile_col(stat_tile) * BN;
+    for (int c = threadIdx.x; c < BN; c += HB_TPB) {
       const int64_t n = pn0 + c;
       if (n < N) {
         double* dst = colstats + pm * 2 * N;   // one partial row per 128-row block (ccn_stats_rows)
-        dst[n] = (double)stat_part[c * 2] + (double)stat_part[(HB_BN + c) * 2];
-        dst[N + n] = (double)stat_part[c * 2 + 1] + (double)stat_part[(HB_BN + c) * 2 + 1];
+        dst[n] = (double)stat_part[c * 2] + (double)stat_part[(BN + c) * 2];
+        dst[N + n] = (double)stat_part[c * 2 + 1] + (double)stat_part[(BN + c) * 2 + 1];
       }
     }
     stat_tile = -1;
@@ -190,13 +204,13 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
 
   int64_t g = 0;
   for (int64_t j = 0, tile; (tile = tile_of(j)) < tiles; ++j) {
-    const int64_t m0 = tile_row(tile) * HB_BM, n0 = tile_col(tile) * HB_BN;
-    f32x16 acc[2][2];
+    const int64_t m0 = tile_row(tile) * HB_BM, n0 = tile_col(tile) * BN;
+    f32x16 acc[2][NTW];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NTW; ++t) {
       float bv = 0.f;
       if (!OUT16) {
-        const int64_t n = n0 + wn * 64 + t * 32 + i;
+        const int64_t n = n0 + wn * (BN / 2) + t * 32 + i;
         bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
       }
 #pragma unroll
@@ -211,20 +225,21 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
       issue_next();
       if (u == 0 && stat_tile >= 0) stats_readout();
       const uint32_t stage_b = lds_base + (uint32_t)((g & 1) * STAGE * 2);
-      f32x4 fa[2][2], fb[2][2];   // [k-step parity][block]
-      auto read_group = [&](int s, f32x4 (&da)[2], f32x4 (&db)[2]) {
+      f32x4 fa[2][2], fb[2][NTW];   // [k-step parity][block]
+      auto read_group = [&](int s, f32x4 (&da)[2], f32x4 (&db)[NTW]) {
         const uint32_t ch = 16u * (uint32_t)((2 * s + h) ^ swz);
         asm volatile("ds_read_b128 %0, %1" : "=v"(da[0]) : "v"(stage_b + a_off + ch) : "memory");
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(da[1]) : "v"(stage_b + a_off + ch), "n"(32 * HB_BK * 2) : "memory");
         asm volatile("ds_read_b128 %0, %1" : "=v"(db[0]) : "v"(stage_b + b_off + ch) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(db[1]) : "v"(stage_b + b_off + ch), "n"(32 * HB_BK * 2) : "memory");
+        if (NTW == 2)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(db[NTW - 1]) : "v"(stage_b + b_off + ch), "n"(32 * HB_BK * 2) : "memory");
       };
       read_group(0, fa[0], fb[0]);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         if (s < 3) {
           read_group(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
-          asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+          asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(2 + NTW) : "memory");   // the group issued last stays in flight
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -232,7 +247,7 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
 #pragma unroll
         for (int ab = 0; ab < 2; ++ab)
 #pragma unroll
-          for (int t = 0; t < 2; ++t) {
+          for (int t = 0; t < NTW; ++t) {
             if (OUT16) acc[ab][t] = mfma_h<F16>(fb[s & 1][t], fa[s & 1][ab], acc[ab][t]);
             else acc[ab][t] = mfma_h<F16>(fa[s & 1][ab], fb[s & 1][t], acc[ab][t]);
           }
@@ -241,7 +256,7 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
 
     // ---- tile epilogue
     if (opt & 1) {
-      if (acc[0][0][0] == 1.2345e30f) reinterpret_cast<float*>(Cv)[0] = acc[1][1][3] + acc[0][1][5] + acc[1][0][7];   // (keeps the MFMAs alive)
+      if (acc[0][0][0] == 1.2345e30f) reinterpret_cast<float*>(Cv)[0] = acc[1][NTW - 1][3] + acc[0][NTW - 1][5] + acc[1][0][7];   // (keeps the MFMAs alive)
       continue;
     }
     if (OUT16 && (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)Cv & 15) == 0) {
@@ -308,10 +323,10 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
       continue;
     }
     float* const C = reinterpret_cast<float*>(Cv);
-    const bool interior = m0 + HB_BM <= M && n0 + HB_BN <= N;
+    const bool interior = m0 + HB_BM <= M && n0 + BN <= N;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int ncol = wn * 64 + t * 32 + i;
+    for (int t = 0; t < NTW; ++t) {
+      const int ncol = wn * (BN / 2) + t * 32 + i;
       const int64_t n = n0 + ncol;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -342,8 +357,8 @@ __global__ __launch_bounds__(HB_TPB, 2) void gemm_h_pair_kernel(const u16* __res
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
         if (h == 0) {
-          stat_part[(wm * HB_BN + ncol) * 2] = s1;
-          stat_part[(wm * HB_BN + ncol) * 2 + 1] = s2;
+          stat_part[(wm * BN + ncol) * 2] = s1;
+          stat_part[(wm * BN + ncol) * 2 + 1] = s2;
         }
       }
     }
@@ -942,6 +957,24 @@ static int g_h_opt = 0;      // diagnostics (ccn_gemm_h_opt)
 template <bool F16, bool OUT16>
 int launch_nt_h(const u16* A, int64_t lda, const u16* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
                 int64_t N, int64_t K, double* colstats, hipStream_t s) {
+  if constexpr (!OUT16) {
+    // fp32 result, N <= 64 or a last 128-wide tile at most half used (192, 320): 128 x 64 tiles, three workgroups per CU.
+    // Measured stand-alone (tools/bench_gemm_h_tiles.py, profiles/r04_gemm_h_tiles.txt): 557 k x 64 x 64 1.59x, 1.87 M x 192 x
+    // 128 1.08x; at N = 256 ... 1024 the 128-wide form wins (0.85-0.97x: the A tile is read by twice as many column tiles),
+    // so the "more, smaller workgroups" lever of DESIGN r3 section 7 does not exist at the network's main widths.
+    // A/B hooks (ccn_gemm_h_opt): bit 4 = never, bit 5 = always.
+    const bool narrow = N <= 64 || (N % HB_BN != 0 && N % HB_BN <= 64);
+    if (((narrow && g_h_opt == 0) || g_h_opt == 32)) {
+      const int64_t gm6 = (M + HB_BM - 1) / HB_BM, gn6 = (N + 63) / 64;
+      const int64_t tiles6 = gm6 * gn6;
+      if (tiles6 < ((int64_t)1 << 31)) {
+        const int64_t grid6 = tiles6 < 768 ? tiles6 : 768;
+        hipLaunchKernelGGL((gemm_h_pair_kernel<F16, false, false, 64>), dim3((unsigned)grid6), dim3(HB_TPB), 0, s, A, lda, W, ldw,
+                           bias, Y, ldy, M, N, K, tiles6, gn6, 1, colstats, 0);
+        return CCN_OK;
+      }
+    }
+  }
   const int64_t gm = (M + HB_BM - 1) / HB_BM, gn = (N + HB_BN - 1) / HB_BN;
   const int64_t tiles = gm * gn;
   if (tiles >= ((int64_t)1 << 31)) {
