@@ -73,7 +73,8 @@ __global__ __launch_bounds__(HB_TPB, BN == 128 ? 2 : 3) void gemm_h_pair_kernel(
                                                                 const float* __restrict__ bias, void* __restrict__ Cv,
                                                                 int64_t ldc, int64_t M, int64_t N, int64_t K, int64_t tiles,
                                                                 int64_t gn, int xcd_order, double* __restrict__ colstats,
-                                                                int opt_rt) {
+                                                                int opt_rt, int64_t a_extent) {
+  // a_extent: 16-bit elements readable from the start of an A row (= lda, or K when rows overlap: ccn_conv_rows_nt_h)
   // opt (diagnostics, ccn_gemm_h_opt; results WRONG when set): bit 0 = no epilogue stores, bit 1 = no wait for the LDS-DMA
   const int opt = DIAG ? opt_rt : 0;
   static_assert(BN == 128 || (BN == 64 && !OUT16), "tile widths: 128, or 64 for the fp32-result form");
@@ -165,7 +166,8 @@ __global__ __launch_bounds__(HB_TPB, BN == 128 ? 2 : 3) void gemm_h_pair_kernel(
         const int64_t lim = isA ? M : N;
         row = row < lim ? row : lim - 1;
         const int64_t k = k0 + kq * 8;
-        const int64_t kc = k <= ld - 8 ? k : ld - 8;     // (k > ld - 8 implies k >= K: everything is zeroed below)
+        const int64_t ext = isA ? a_extent : ldb;
+        const int64_t kc = k <= ext - 8 ? k : ext - 8;   // (k > extent - 8 implies k >= K: everything is zeroed below)
         uint4 v = *reinterpret_cast<const uint4*>(p + row * ld + kc);
         uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -693,7 +695,7 @@ __global__ __launch_bounds__(HT_TPB, 2) void gemm_h_tn_kernel(const u16* __restr
                                                               const u16* __restrict__ B, int64_t ldb, float* __restrict__ C,
                                                               int64_t ldc, int64_t M, int64_t N, int64_t K, int tiles_k,
                                                               int tiles, int split, int64_t slices_per_chunk, int64_t n_ids,
-                                                              int xcd_order, float* __restrict__ slabs) {
+                                                              int xcd_order, float* __restrict__ slabs, int64_t b_extent) {
   constexpr int AF = HT_SL * HT_T, STAGE = 2 * AF;      // 16-bit elements: 16 KB per operand image, 32 KB per stage
   __shared__ __attribute__((aligned(16))) u16 lds[2 * STAGE];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: SGPR addressing)
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(HT_TPB, 2) void gemm_h_tn_kernel(const u16* __restr
         const int f = ((lane >> 4) << 2) | qn;                 // f(R) of image row R = 4 (4 wave + qn) + (lane >> 4)
         const int64_t ca = n0 + 8 * ((lane & 15) ^ f), cb = k0 + 8 * ((lane & 15) ^ f);
         a_col[qn] = ca <= lda - 8 ? ca : lda - 8;              // (clamped columns only feed elements that are never stored)
-        b_col[qn] = cb <= ldb - 8 ? cb : ldb - 8;
+        b_col[qn] = cb <= b_extent - 8 ? cb : b_extent - 8;    // (b_extent = ldb, or K when the X rows overlap: ccn_conv_rows_tn_h)
       }
       uint32_t a_off32[4], b_off32[4];      // lane offsets inside a slice: (row * ld + column) bytes
 #pragma unroll
@@ -956,7 +958,7 @@ static int g_h_opt = 0;      // diagnostics (ccn_gemm_h_opt)
 
 template <bool F16, bool OUT16>
 int launch_nt_h(const u16* A, int64_t lda, const u16* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
-                int64_t N, int64_t K, double* colstats, hipStream_t s) {
+                int64_t N, int64_t K, double* colstats, hipStream_t s, int64_t a_extent) {
   if constexpr (!OUT16) {
     // fp32 result, N <= 64 or a last 128-wide tile at most half used (192, 320): 128 x 64 tiles, three workgroups per CU.
     // Measured stand-alone (tools/bench_gemm_h_tiles.py, profiles/r04_gemm_h_tiles.txt): 557 k x 64 x 64 1.59x, 1.87 M x 192 x
@@ -970,7 +972,7 @@ int launch_nt_h(const u16* A, int64_t lda, const u16* W, int64_t ldw, const floa
       if (tiles6 < ((int64_t)1 << 31)) {
         const int64_t grid6 = tiles6 < 768 ? tiles6 : 768;
         hipLaunchKernelGGL((gemm_h_pair_kernel<F16, false, false, 64>), dim3((unsigned)grid6), dim3(HB_TPB), 0, s, A, lda, W, ldw,
-                           bias, Y, ldy, M, N, K, tiles6, gn6, 1, colstats, 0);
+                           bias, Y, ldy, M, N, K, tiles6, gn6, 1, colstats, 0, a_extent);
         return CCN_OK;
       }
     }
@@ -984,10 +986,10 @@ int launch_nt_h(const u16* A, int64_t lda, const u16* W, int64_t ldw, const floa
   const int64_t grid = tiles < 512 ? tiles : 512;  // two workgroups per CU
   if (g_h_opt != 0)
     hipLaunchKernelGGL((gemm_h_pair_kernel<F16, OUT16, true>), dim3((unsigned)grid), dim3(HB_TPB), 0, s, A, lda, W, ldw, bias, Y,
-                       ldy, M, N, K, tiles, gn, 1, colstats, g_h_opt);
+                       ldy, M, N, K, tiles, gn, 1, colstats, g_h_opt, a_extent);
   else
     hipLaunchKernelGGL((gemm_h_pair_kernel<F16, OUT16>), dim3((unsigned)grid), dim3(HB_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
-                       M, N, K, tiles, gn, 1, colstats, 0);
+                       M, N, K, tiles, gn, 1, colstats, 0, a_extent);
   return CCN_OK;
 }
 
@@ -1000,10 +1002,10 @@ int ccn_gemm_h_opt(int opt) {
   return CCN_OK;
 }
 
-int ccn_gemm_nt_h(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
-                  int64_t N, int64_t K, double* colstats, int f16, int out16, void* stream) {
+static int gemm_nt_h_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
+                          int64_t N, int64_t K, double* colstats, int f16, int out16, void* stream, int64_t a_extent) {
   CCN_REQUIRE(A && W && Y, "gemm_nt_h: null pointer");
-  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, "gemm_nt_h: bad sizes");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && a_extent >= K && lda >= 8 && ldw >= K && ldy >= N, "gemm_nt_h: bad sizes");
   CCN_REQUIRE(aligned16(A) && aligned16(W) && lda % 8 == 0 && ldw % 8 == 0,
               "gemm_nt_h: 16-bit operands must be 16-byte aligned with leading dimensions that are multiples of 8");
   CCN_REQUIRE(!out16 || (colstats == nullptr && bias == nullptr && ((uintptr_t)Y & 7) == 0 && ldy % 4 == 0),
@@ -1013,13 +1015,28 @@ int ccn_gemm_nt_h(const void* A, int64_t lda, const void* W, int64_t ldw, const 
   const u16* a = (const u16*)A;
   const u16* w = (const u16*)W;
   int rc;
-  if (f16) rc = out16 ? launch_nt_h<true, true>(a, lda, w, ldw, bias, Y, ldy, M, N, K, colstats, s)
-                      : launch_nt_h<true, false>(a, lda, w, ldw, bias, Y, ldy, M, N, K, colstats, s);
-  else rc = out16 ? launch_nt_h<false, true>(a, lda, w, ldw, bias, Y, ldy, M, N, K, colstats, s)
-                  : launch_nt_h<false, false>(a, lda, w, ldw, bias, Y, ldy, M, N, K, colstats, s);
+  if (f16) rc = out16 ? launch_nt_h<true, true>(a, lda, w, ldw, bias, Y, ldy, M, N, K, colstats, s, a_extent)
+                      : launch_nt_h<true, false>(a, lda, w, ldw, bias, Y, ldy, M, N, K, colstats, s, a_extent);
+  else rc = out16 ? launch_nt_h<false, true>(a, lda, w, ldw, bias, Y, ldy, M, N, K, colstats, s, a_extent)
+                  : launch_nt_h<false, false>(a, lda, w, ldw, bias, Y, ldy, M, N, K, colstats, s, a_extent);
   if (rc) return rc;
   CCN_LAUNCH_OK("gemm_nt_h");
   return CCN_OK;
+}
+
+int ccn_gemm_nt_h(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
+                  int64_t N, int64_t K, double* colstats, int f16, int out16, void* stream) {
+  CCN_REQUIRE(lda >= K, "gemm_nt_h: bad sizes (lda < K)");
+  return gemm_nt_h_impl(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, f16, out16, stream, lda);
+}
+
+// Implicit-GEMM curve convolution on a 16-bit row sequence (the 16-bit form of ccn_conv_rows_nt): row i of the shifted-row
+// matrix is the contiguous span of K = taps * lda elements starting at A + i * lda -- overlapping operand rows, read in place
+// from a sequence with taps / 2 zero halo rows at both ends of the same allocation.
+int ccn_conv_rows_nt_h(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
+                       int64_t N, int64_t K, double* colstats, int f16, int out16, void* stream) {
+  CCN_REQUIRE(lda > 0 && K % lda == 0, "conv_rows_nt_h: K must be a whole number of sequence rows");
+  return gemm_nt_h_impl(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, f16, out16, stream, K);
 }
 
 size_t ccn_gemm_tn_h_workspace_bytes(int64_t M, int64_t N, int64_t K) {
@@ -1028,9 +1045,11 @@ size_t ccn_gemm_tn_h_workspace_bytes(int64_t M, int64_t N, int64_t K) {
 }
 
 static int gemm_tn_h_impl(const void* dY, int64_t lddy, const void* X, int x_f16, int64_t ldx, float* dW, int64_t lddw, int64_t M,
-                          int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+                          int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream, int64_t x_extent = 0) {
+  // x_extent: 16-bit elements readable from the start of an X row (0 = ldx; K when the X rows overlap: ccn_conv_rows_tn_h)
+  if (x_extent == 0) x_extent = ldx;
   CCN_REQUIRE(dY && X && dW, "gemm_tn_h: null pointer");
-  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "gemm_tn_h: bad sizes");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && x_extent >= K && lddw >= K, "gemm_tn_h: bad sizes");
   CCN_REQUIRE(aligned16(dY) && aligned16(X) && lddy % 8 == 0 && ldx % 8 == 0 && lddy >= 8 && ldx >= 8,
               "gemm_tn_h: bf16 operands must be 16-byte aligned with leading dimensions that are multiples of 8");
   if (M == 0) return CCN_OK;
@@ -1043,10 +1062,10 @@ static int gemm_tn_h_impl(const void* dY, int64_t lddy, const void* X, int x_f16
   do {                                                                                                                        \
     if (x_f16)                                                                                                                \
       hipLaunchKernelGGL((gemm_h_tn_kernel<EPI_, true>), dim3((unsigned)grid), dim3(HT_TPB), 0, s, a, lddy, b, ldx, dW, lddw,  \
-                         M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, SLABS_);           \
+                         M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, SLABS_, x_extent); \
     else                                                                                                                      \
       hipLaunchKernelGGL((gemm_h_tn_kernel<EPI_, false>), dim3((unsigned)grid), dim3(HT_TPB), 0, s, a, lddy, b, ldx, dW, lddw, \
-                         M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, SLABS_);           \
+                         M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, SLABS_, x_extent); \
   } while (0)
   if (p.split == 1) {
     CCN_TN_H(2, (float*)nullptr);
@@ -1068,6 +1087,14 @@ static int gemm_tn_h_impl(const void* dY, int64_t lddy, const void* X, int x_f16
 int ccn_gemm_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
                   int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
   return gemm_tn_h_impl(dY, lddy, X, 0, ldx, dW, lddw, M, N, K, workspace, workspace_bytes, stream);
+}
+
+// Weight gradient of the implicit-GEMM curve convolution on 16-bit row sequences (the 16-bit form of ccn_conv_rows_tn): X row i
+// is the span of K = taps * ldx elements starting at X + i * ldx (overlapping rows); x_f16 != 0: X holds fp16 rows.
+int ccn_conv_rows_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, int x_f16, float* dW, int64_t lddw, int64_t M,
+                       int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
+  CCN_REQUIRE(ldx > 0 && K % ldx == 0, "conv_rows_tn_h: K must be a whole number of sequence rows");
+  return gemm_tn_h_impl(dY, lddy, X, x_f16 ? 1 : 0, ldx, dW, lddw, M, N, K, workspace, workspace_bytes, stream, K);
 }
 
 // ... with X as fp16 rows (the fp16 mode's forward operand): dW += dY^T bf16(X), converted inside the kernel

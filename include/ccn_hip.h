@@ -253,6 +253,14 @@ int ccn_gemm_tn_bf16(const float* dY, int64_t lddy, const float* X, int64_t ldx,
  *                  (ccn_gemm_tn_h_workspace_bytes), summed in chunk order (deterministic). */
 int ccn_gemm_nt_h(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
                   int64_t N, int64_t K, double* colstats, int f16, int out16, void* stream);
+/* round 4: the implicit-GEMM curve convolution of ccn_conv_rows_nt / _tn (fast_conv1d.py:173-184 over the zero-separated
+ * sequence of :48-61 / :115-126) on 16-BIT row sequences: row i of the shifted-row matrix is the span of K = taps * lda
+ * elements starting at A + i * lda, read in place (lda % 8 == 0, taps / 2 zero halo rows at both ends of the allocation).
+ * Same outputs as ccn_gemm_nt_h / ccn_gemm_tn_h on the materialised matrix (same products, same order). */
+int ccn_conv_rows_nt_h(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
+                       int64_t N, int64_t K, double* colstats, int f16, int out16, void* stream);
+int ccn_conv_rows_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, int x_f16, float* dW, int64_t lddw, int64_t M,
+                       int64_t N, int64_t K, void* workspace, size_t workspace_bytes, void* stream);
 size_t ccn_gemm_tn_h_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int ccn_gemm_tn_h(const void* dY, int64_t lddy, const void* X, int64_t ldx, float* dW, int64_t lddw, int64_t M, int64_t N,
                   int64_t K, void* workspace, size_t workspace_bytes, void* stream);
