@@ -35,6 +35,8 @@ GEMM_MNK = {
     "gemm_tn_ws_xf": lambda i: i[4:7],         # (lddy, ldx, x_act, lddw, M, N, K, workspace_bytes)
     "conv_rows_nt": lambda i: i[3:6],          # (lda, ldw, ldy, M, N, K): K = taps x ld over overlapping rows of stride lda
     "conv_rows_tn": lambda i: i[3:6],          # (lddy, ldx, lddw, M, N, K, workspace_bytes)
+    "conv_rows_nt_h": lambda i: i[3:6],        # (lda, ldw, ldy, M, N, K, f16, out16): 16-bit sequence rows
+    "conv_rows_tn_h": lambda i: i[4:7],        # (lddy, ldx, x_f16, lddw, M, N, K, workspace_bytes)
 }
 
 
@@ -49,6 +51,10 @@ def _gemm_cost(name, ints):
         return _gemm(m, n, k, el_a=2.0, el_w=2.0, el_y=2.0 if len(ints) > 7 and ints[7] else F32)
     if name in ("gemm_tn_h", "gemm_tn_h_xf16"):  # dW (fp32, read + written) += dY^T X on 16-bit rows: M = rows
         return 2.0 * m * n * k, 2.0 * m * (n + k) + 2 * F32 * n * k
+    if name == "conv_rows_nt_h":               # rows overlap: M x lda distinct 16-bit elements of A
+        return _gemm(m, n, k, a_row_floats=ints[0], el_a=2.0, el_w=2.0, el_y=2.0 if len(ints) > 7 and ints[7] else F32)
+    if name == "conv_rows_tn_h":
+        return 2.0 * m * n * k, 2.0 * (m * n + m * ints[1]) + 2 * F32 * n * k
     if name == "conv_rows_nt":                 # rows overlap: M x lda distinct floats of A
         return _gemm(m, n, k, a_row_floats=ints[0])
     if name == "conv_rows_tn":                 # X rows overlap likewise (ldx); dW written

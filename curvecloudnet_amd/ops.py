@@ -2367,13 +2367,131 @@ class ConvRowsBNAct(torch.autograd.Function):
         return dx, dgw, db, dgb[0], dgb[1], None, None, None, None, None, None, None, None
 
 
+class ConvRowsBNActH(torch.autograd.Function):
+    """ConvRowsBNAct for the 16-bit storage modes (r4): the implicit GEMM runs on a 16-BIT copy of the row sequence
+    (ccn_conv_rows_nt_h / _tn_h) instead of on a materialised 16-bit shifted-row matrix -- one cast of the sequence (6 B per
+    element) where ccn_im2col_fwd_h moved 4 + 2 * taps, and no col2im pass in backward: the data gradient is the same implicit
+    product over the bf16 dY sequence with the taps reversed.  Operands rounded exactly as the shifted-row form rounds them
+    (forward: bf16 / fp16 of x and W; backward: bf16 of dY, of W and of the forward operand), fp32 accumulation; the
+    activation between layers stays an fp32 sequence (DiffConcat runs on it).  Same ``excl`` semantics as ConvRowsBNAct."""
+
+    @staticmethod
+    def forward(ctx, x, gw, bias, gamma, beta, running_mean, running_var, training, act, eps, momentum, taps, excl):
+        x = _mat(x)
+        rows, cin = x.shape
+        cout = gw.size(0)
+        h = taps // 2
+        dev = x.device
+        if gw.size(1) != taps * cin:
+            raise ValueError("conv: input has %d channels, weight expects %d" % (cin, gw.size(1) // taps))
+        if _halo_of(x, h) is None:
+            xh = _rows_halo(rows, cin, h, dev)
+            xh.copy_(x)
+            x = xh
+        buf, hh = _halo_of(x, h)
+        fdt = _fwd16()
+        f16 = 1 if fdt == torch.float16 else 0
+        ld16 = (cin + 7) // 8 * 8
+        # the sequence INCLUDING its halo rows as 16-bit rows (padding columns zeroed by the cast)
+        x16 = torch.empty((rows + 2 * h, ld16), dtype=fdt, device=dev)
+        first = buf[hh - h:hh + rows + h]
+        call("cast_rows_h", ptr(first), first.stride(0), rows + 2 * h, cin, ptr(x16), ld16, f16)
+        k = taps * ld16
+        wp = torch.zeros((cout, taps, ld16), dtype=torch.float32, device=dev)
+        wp[:, :, :cin] = gw.detach().view(cout, taps, cin)
+        wp16 = _cast16(wp.view(cout, k), fdt)
+        ctx.act, ctx.training, ctx.taps, ctx.has_bias, ctx.cin = ACT[act], bool(training), taps, bias is not None, cin
+        ctx.f16 = f16
+        n_excl = 0 if excl is None else excl.numel()
+        ctx.count = float(rows - n_excl)
+        y = _rows(rows, cout, dev)
+        par = torch.empty((4, cout), dtype=torch.float32, device=dev)
+        a_ptr = ptr(x16)                       # (row 0 of x16 is the first halo row: the span of row i starts at row i)
+        if training:
+            if rows - n_excl < 2:
+                raise ValueError("Expected more than 1 value per channel when training")
+            nparts = lib().ccn_stats_rows(rows)
+            stats = torch.zeros((nparts + 2) * 2 * cout, dtype=torch.float64, device=dev)
+            call("conv_rows_nt_h", a_ptr, ld16, ptr(wp16), _ld(wp16), ptr(bias), ptr(y), _ld(y), rows, cout, k, ptr(stats), f16, 0)
+            if n_excl:
+                ye = y.index_select(0, excl)
+                acc = torch.empty((lib().ccn_stats_rows(n_excl) + 1) * 2 * cout, dtype=torch.float64, device=dev)
+                call("colstats_weighted", ptr(ye), _ld(ye), None, n_excl, cout, ptr(acc))
+                stats[nparts * 2 * cout:(nparts + 1) * 2 * cout] = -acc[:2 * cout]
+            call("bn_finalize_n", ptr(stats), nparts + 1, int(ctx.count), cout, ptr(gamma), ptr(beta), float(eps),
+                 float(momentum), ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        else:
+            call("conv_rows_nt_h", a_ptr, ld16, ptr(wp16), _ld(wp16), ptr(bias), ptr(y), _ld(y), rows, cout, k, None, f16, 0)
+            call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), cout,
+                 ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        z = _rows_halo(rows, cout, h, dev)
+        call("bn_act_fwd", ptr(y), _ld(y), rows, cout, ptr(par[0]), ptr(par[1]), ctx.act, LEAKY_SLOPE, ptr(z), _ld(z))
+        if n_excl:
+            z.index_fill_(0, excl, 0.0)
+        ctx.save_for_backward(x16, wp, y, par, excl if n_excl else x.new_empty(0, dtype=torch.int64))
+        _trace_act(z, ctx.act)
+        return z
+
+    @staticmethod
+    def backward(ctx, g):
+        x16, wp, y, par, excl = ctx.saved_tensors
+        g = _mat(g)
+        dev = g.device
+        rows, cout = y.shape
+        taps, cin = ctx.taps, ctx.cin
+        h = taps // 2
+        ld16 = x16.stride(0)
+        k = taps * ld16
+        pp = (ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+        if excl.numel():
+            g = g.index_fill(0, excl, 0.0)
+        sums = _stats_buffer(rows, cout, dev)
+        call("bn_act_bwd_reduce", ptr(g), _ld(g), ptr(y), _ld(y), rows, cout, *pp, ctx.act, LEAKY_SLOPE, ptr(sums))
+        ldo = (cout + 7) // 8 * 8
+        dy16 = torch.zeros((rows + 2 * h, ldo), dtype=torch.bfloat16, device=dev)     # bf16 dY sequence, zero halo and padding
+        dyv = dy16[h:h + rows]
+        dgb = torch.empty((2, cout), dtype=torch.float32, device=dev)
+        call("bn_act_bwd_apply_h", ptr(g), 0, _ld(g), ptr(y), _ld(y), rows, cout, *pp, ctx.act, LEAKY_SLOPE, ptr(sums),
+             ctx.count, 1 if ctx.training else 0, 0, ptr(dyv), ldo, ptr(dgb[0]), ptr(dgb[1]), 0)
+        if excl.numel():
+            dyv.index_fill_(0, excl, 0.0)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wf = torch.zeros((cin, taps, ldo), dtype=torch.float32, device=dev)
+            wf[:, :, :cout] = wp[:, :, :cin].flip(1).permute(2, 1, 0)
+            wf16 = _cast16(wf.view(cin, taps * ldo))
+            dx = _rows(rows, cin, dev)
+            call("conv_rows_nt_h", ptr(dy16), ldo, ptr(wf16), _ld(wf16), None, ptr(dx), _ld(dx), rows, cin, taps * ldo, None, 0, 0)
+        dgw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((cout, k), dtype=torch.float32, device=dev)
+            nb = lib().ccn_gemm_tn_h_workspace_bytes(rows, cout, k)
+            ws = _tn_scratch(nb, dev)
+            call("conv_rows_tn_h", ptr(dyv), ldo, ptr(x16), ld16, ctx.f16, ptr(dw), k, rows, cout, k, ptr(ws), nb)
+            dgw = dw.view(cout, taps, ld16)[:, :, :cin].reshape(cout, taps * cin)
+        db = None
+        if ctx.has_bias:
+            db = dyv[:, :cout].float().sum(0)       # (in front of a BatchNorm: identically zero up to rounding)
+        return dx, dgw, db, dgb[0], dgb[1], None, None, None, None, None, None, None, None
+
+
 def conv_rows_implicit(x, gemm_weight, bias, bn, training, act, taps, excl=None):
-    """conv + BatchNorm + activation over a row sequence without the shifted-row matrix (ConvRowsBNAct)."""
+    """conv + BatchNorm + activation over a row sequence without the shifted-row matrix (ConvRowsBNAct; ConvRowsBNActH in
+    the 16-bit storage modes)."""
     if training and bn.track_running_stats:
         bn.num_batches_tracked += 1
     use_batch_stats = training or not bn.track_running_stats
-    return ConvRowsBNAct.apply(x, gemm_weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats,
-                               act, bn.eps, bn.momentum if bn.momentum is not None else 0.1, taps, excl)
+    fn = ConvRowsBNActH if conv_implicit_16bit() else ConvRowsBNAct
+    return fn.apply(x, gemm_weight, bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, use_batch_stats,
+                    act, bn.eps, bn.momentum if bn.momentum is not None else 0.1, taps, excl)
+
+
+CONV_IMPLICIT_H = os.environ.get("CCN_CONV_IMPLICIT_H", "1") != "0"     # (A/B and tests: 0 = the 16-bit shifted-row matrix)
+
+
+def conv_implicit_16bit():
+    """The 16-bit storage modes run the curve convolutions as implicit GEMMs on a 16-bit sequence (ConvRowsBNActH)."""
+    return bool(CONV_IMPLICIT_H and EDGE_OUT16 and STORE16 and _MLP_DTYPE in ("bf16", "fp16") and ACT_TRACE is None)
 
 
 def conv_rows_bn_act(x, gemm_weight, bias, bn, training, act, taps):

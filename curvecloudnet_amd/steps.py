@@ -189,9 +189,10 @@ CONV_IMPLICIT = os.environ.get("CCN_CONV_IMPLICIT", "1") != "0"
 
 
 def _conv_implicit():
-    """The implicit-GEMM kernels are the fp32 MFMA ones: the 16-bit MLP modes (whose conv products round their operands
-    to bf16 / fp16, as the oracle's emulation does) keep the shifted-row matrix + 16-bit GEMM."""
-    return CONV_IMPLICIT and ops.mlp_dtype() in ("fp32", "bf16x3")
+    """fp32 / bf16x3: the fp32 MFMA implicit-GEMM kernels (ops.ConvRowsBNAct); the 16-bit storage modes (r4): the same on a
+    16-bit copy of the sequence (ops.ConvRowsBNActH), operands rounded as the oracle's emulation rounds them.  The
+    fp32-storage 16-bit forms (CCN_STORE16=0 / CCN_EDGE_OUT16=0) keep the shifted-row matrix + GEMM."""
+    return CONV_IMPLICIT and (ops.mlp_dtype() in ("fp32", "bf16x3") or ops.conv_implicit_16bit())
 
 
 class SymmetricCurve1DConvFastV1(nn.Module):
