@@ -648,6 +648,9 @@ def _grad_sink_take(x, m, k):
     return grad
 
 
+_EXP_SKIP_REDUCE = os.environ.get("CCN_EXP_SKIP_REDUCE") == "1"     # timing-only experiment (wrong gradients), see DESIGN section 5
+
+
 class LinearBNAct(torch.autograd.Function):
     """y = act(BN(x W^T + b)) with batch statistics taken in the GEMM epilogue.
 
@@ -724,6 +727,7 @@ class LinearBNAct(torch.autograd.Function):
                  ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
         ctx.save_for_backward(x, w, y, par, xf_par if lazy else none)
         ctx.mark_non_differentiable(par)
+        ctx.deferred = bool(defer)
         if defer:
             return y, par
         z = _rows(m, n, dev)
@@ -741,8 +745,9 @@ class LinearBNAct(torch.autograd.Function):
             x, w, y, par, xf_par = ctx.saved_tensors
             m, n = y.shape
             sums = _stats_buffer(m, n, dev)
-            call("bn_act_bwd_reduce", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
-                 ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums))
+            if not (_EXP_SKIP_REDUCE and ctx.deferred):
+                call("bn_act_bwd_reduce", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                     ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums))
             dy = _rows(m, n, dev)
             refs = ctx.bn_refs
             gview = _main_grad_vec(refs[0], n) if refs else None
