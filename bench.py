@@ -39,7 +39,7 @@ def gemm_label(name, ints, nulls=()):
         return None, 0.0
     m, n, k = shape
     flops = 2.0 * m * n * k
-    if name in ("gemm_nt_xf", "gemm_tn_ws_xf", "gemm_nt_acc", "conv_rows_nt", "conv_rows_tn", "conv_rows_nt_h", "conv_rows_tn_h"):
+    if name in ("gemm_nt_xf", "gemm_tn_ws_xf", "gemm_nt_acc", "gemm_nt_red", "conv_rows_nt", "conv_rows_tn", "conv_rows_nt_h", "conv_rows_tn_h"):
         return name, flops
     ld_a, ld_b = ints[0], ints[1]
     if name == "gemm_nt_h":       # (16-bit rows: the LDS-DMA kernels of csrc/ccn_gemm_h.hip)

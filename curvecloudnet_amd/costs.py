@@ -32,6 +32,7 @@ GEMM_MNK = {
     "gemm_tn_bf16": lambda i: i[3:6], "gemm_nt_x3": lambda i: i[3:6],
     "gemm_nt_h": lambda i: i[3:6], "gemm_tn_h": lambda i: i[3:6], "gemm_tn_h_xf16": lambda i: i[3:6],
     "gemm_nt_xf": lambda i: i[4:7],            # (lda, a_act, ldw, ldy, M, N, K)
+    "gemm_nt_red": lambda i: i[3:6],           # (lda, ldw, ldy, M, N, K, ldyp, act): + the y tile of the previous layer
     "gemm_tn_ws_xf": lambda i: i[4:7],         # (lddy, ldx, x_act, lddw, M, N, K, workspace_bytes)
     "conv_rows_nt": lambda i: i[3:6],          # (lda, ldw, ldy, M, N, K): K = taps x ld over overlapping rows of stride lda
     "conv_rows_tn": lambda i: i[3:6],          # (lddy, ldx, lddw, M, N, K, workspace_bytes)
@@ -61,6 +62,9 @@ def _gemm_cost(name, ints):
         return 2.0 * m * n * k, F32 * (m * n + m * ints[1] + n * k)
     if name in ("gemm_tn", "gemm_tn_ws", "gemm_tn_ws_xf", "gemm_tn_bf16"):   # dW[N x K] += dY[M x N]^T X[M x K]
         return 2.0 * m * n * k, F32 * (m * n + m * k + 2 * n * k)
+    if name == "gemm_nt_red":                  # + y (M x N) read for the fused BatchNorm-backward sums
+        f, b = _gemm(m, n, k)
+        return f, b + F32 * m * n
     if name == "gemm_nt_acc":                  # Y read and written
         f, b = _gemm(m, n, k)
         return f, b + F32 * m * n

@@ -1111,7 +1111,13 @@ __device__ unsigned long long* g_pair_dbg_dev = nullptr;
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
 
-template <bool ACC, bool XF, int TAG = 0, bool STAMP = false>
+// RED (round 4): this product is the DATA GRADIENT dZ = dY W of a layer whose input was the deferred (pre-normalisation)
+// output y of the previous layer: the column sums that layer's BatchNorm backward needs -- sum(g) and sum(g * xhat) with
+// g = dZ * act'(y * scale + shift), xhat = (y - mean) * rstd -- are taken in THIS epilogue, from the dZ tile in the
+// accumulators and the matching y tile (16 loads per 32 x 32 block, issued in front of the block's stores and waited for
+// behind them), into the same partial-row table the forward statistics use.  ccn_bn_act_bwd_reduce's pass over (dZ, y)
+// -- 8 bytes per element, 2.3 ms per KITTI step -- then does not run for that layer (ccn_gemm_nt_red).
+template <bool ACC, bool XF, int TAG = 0, bool STAMP = false, bool RED = false>
 __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* __restrict__ A, int64_t lda,
                                                                    const float* __restrict__ B, int64_t ldb,
                                                                    const float* __restrict__ bias, float* __restrict__ C,
@@ -1120,8 +1126,11 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
                                                                    double* __restrict__ colstats, int64_t a_extent,
                                                                    const float* __restrict__ xf_scale,
                                                                    const float* __restrict__ xf_shift, int xf_act,
-                                                                   float xf_slope) {
+                                                                   float xf_slope, int64_t red_ldy = 0) {
   // a_extent: floats readable from the start of an A row (= lda, or K when rows overlap: ccn_conv_rows_nt)
+  // RED: xf_scale = the previous layer's 4 x N table (scale | shift | mean | rstd, rows N floats apart), xf_shift = its
+  // pre-normalisation output y (leading dimension red_ldy), xf_act / xf_slope = its activation
+  const float red_neg = xf_act == CCN_ACT_RELU ? 0.f : (xf_act == CCN_ACT_LEAKY ? xf_slope : 1.f);   // act'(z <= 0)
   constexpr int AF = PR_BM * BK, BF = PR_BN * BK, STAGE = AF + BF;
   constexpr int NC = 4;  // LDS-DMA copies (8 rows x 128 B) per wave, slice and operand
   __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
@@ -1421,6 +1430,13 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       const int ncol = wn * 64 + t * 32 + i;
       const int64_t n = n0 + ncol;
       float s1 = 0.f, s2 = 0.f;
+      float r_sc = 0.f, r_sh = 0.f, r_mu = 0.f, r_rs = 0.f;     // RED: this lane's column of the previous layer's table
+      if (RED && n < N) {
+        r_sc = xf_scale[n];
+        r_sh = xf_scale[N + n];
+        r_mu = xf_scale[2 * N + n];
+        r_rs = xf_scale[3 * N + n];
+      }
 #pragma unroll
       for (int ab = 0; ab < 2; ++ab) {
         if (interior) {
@@ -1429,11 +1445,38 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
           // (inline asm: hipcc folds a uniform base + lane offset back into 64-bit vector address arithmetic per store)
           float* const cbase = C + (m0 + wm * 64 + ab * 32) * ldc + n0 + wn * 64 + t * 32;
           const uint32_t lane_off = (uint32_t)((4 * h * ldc + i) * 4);
+          float yv[16];
+          if (RED) {
+            const float* const ybase = xf_shift + (m0 + wm * 64 + ab * 32) * red_ldy + n0 + wn * 64 + t * 32;
+            const uint32_t lane_off_y = (uint32_t)((4 * h * red_ldy + i) * 4);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float* const rowp = ybase + (int64_t)((r & 3) + 8 * (r >> 2)) * red_ldy;
+              asm volatile("global_load_dword %0, %1, %2" : "=v"(yv[r]) : "v"(lane_off_y), "s"(rowp) : "memory");
+            }
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float* const rowp = cbase + (int64_t)((r & 3) + 8 * (r >> 2)) * ldc;
             asm volatile("global_store_dword %0, %1, %2" : : "v"(lane_off), "v"(acc[ab][t][r]), "s"(rowp) : "memory");
           }
+          if (RED) {
+            // the 16 loads were issued in front of the 16 stores and vmcnt retires in order: all but the newest 16 done =
+            // the loads have landed.  The wait names the registers, so nothing reads them in front of it.
+            asm volatile("s_waitcnt vmcnt(16)"
+                         : "+v"(yv[0]), "+v"(yv[1]), "+v"(yv[2]), "+v"(yv[3]), "+v"(yv[4]), "+v"(yv[5]), "+v"(yv[6]), "+v"(yv[7]),
+                           "+v"(yv[8]), "+v"(yv[9]), "+v"(yv[10]), "+v"(yv[11]), "+v"(yv[12]), "+v"(yv[13]), "+v"(yv[14]),
+                           "+v"(yv[15])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float yy = yv[r], v = acc[ab][t][r];
+              const float g = (yy * r_sc + r_sh) > 0.f ? v : v * red_neg;
+              s1 += g;
+              s2 += g * ((yy - r_mu) * r_rs);
+            }
+          } else
           if (colstats != nullptr) {
             // column statistics only where a BatchNorm follows (a data-gradient launch skips 128 vector instructions per tile
             // and wave), two accumulator registers per packed instruction (v_pk_add_f32 / v_pk_fma_f32)
@@ -1454,8 +1497,15 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
             if (m < M && n < N) {
               const float v = acc[ab][t][r];
               C[m * ldc + n] = v;
-              s1 += v;
-              s2 += v * v;
+              if (RED) {
+                const float yy = xf_shift[m * red_ldy + n];
+                const float g = (yy * r_sc + r_sh) > 0.f ? v : v * red_neg;
+                s1 += g;
+                s2 += g * ((yy - r_mu) * r_rs);
+              } else {
+                s1 += v;
+                s2 += v * v;
+              }
             }
           }
         }
@@ -1505,7 +1555,7 @@ constexpr int64_t PAIR_MIN_TILES = 128;
 int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                      int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s, int64_t a_extent, bool accumulate = false,
                      const float* xf_scale = nullptr, const float* xf_shift = nullptr, int xf_act = 0, float xf_slope = 0.f,
-                     bool split_part = false) {
+                     bool split_part = false, int64_t red_ldy = 0) {
   const int64_t gm = (M + PR_BM - 1) / PR_BM, gn = (N + PR_BN - 1) / PR_BN;
   const int64_t tiles = gm * gn;
   if (tiles >= ((int64_t)1 << 31)) {
@@ -1517,6 +1567,10 @@ int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, c
   if (g_pair_dbg_host != nullptr && xf_scale == nullptr && !accumulate && !split_part)
     hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 0, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y,
                        ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, nullptr, nullptr, 0, 0.f);
+  else if (red_ldy > 0)      // (xf_scale = the previous layer's table, xf_shift = its output y: see RED)
+    hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 0, false, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W,
+                       ldw, bias, Y, ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, xf_scale, xf_shift, xf_act,
+                       xf_slope, red_ldy);
   else if (xf_scale != nullptr)
     hipLaunchKernelGGL((gemm_glds_pair_kernel<false, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
                        M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, xf_scale, xf_shift, xf_act, xf_slope);
@@ -2113,6 +2167,25 @@ int ccn_gemm_nt_acc(const float* A, int64_t lda, const float* W, int64_t ldw, fl
   int rc = launch_glds_pair(A, lda, W, ldw, nullptr, Y, ldy, M, N, K, nullptr, (hipStream_t)stream, lda, true);
   if (rc) return rc;
   CCN_LAUNCH_OK("gemm_nt_acc");
+  return CCN_OK;
+}
+
+// dZ = dY W^T-form product (as ccn_gemm_nt, no bias) + the BatchNorm-backward column sums of the layer that produced the
+// deferred input y (see RED above).  par: that layer's 4 x N table (scale | shift | mean | rstd), rows N floats apart.
+// sums: 2 N totals followed by [ccn_stats_rows(M)][2 N] doubles of scratch -- what ccn_bn_act_bwd_reduce writes.
+int ccn_gemm_nt_red(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M, int64_t N,
+                    int64_t K, const float* y_prev, int64_t ldyp, const float* par, int act, float slope, double* sums,
+                    void* stream) {
+  CCN_REQUIRE(A && W && Y && y_prev && par && sums, "gemm_nt_red: null pointer");
+  CCN_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N && ldyp >= N, "gemm_nt_red: bad sizes");
+  CCN_REQUIRE(ccn_gemm_nt_acc_ok(lda, ldw, M, N, K) && aligned16(A) && aligned16(W) && ldyp < ((int64_t)1 << 27),
+              "gemm_nt_red: shape / alignment outside the paired LDS-DMA kernel (ask ccn_gemm_nt_acc_ok first)");
+  hipStream_t s = (hipStream_t)stream;
+  double* partial = sums + 2 * N;
+  int rc = launch_glds_pair(A, lda, W, ldw, nullptr, Y, ldy, M, N, K, partial, s, lda, false, par, y_prev, act, slope, false, ldyp);
+  if (rc) return rc;
+  launch_col_reduce(partial, ccn_stats_rows(M), 2 * N, sums, s);
+  CCN_LAUNCH_OK("gemm_nt_red");
   return CCN_OK;
 }
 

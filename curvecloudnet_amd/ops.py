@@ -648,7 +648,28 @@ def _grad_sink_take(x, m, k):
     return grad
 
 
-_EXP_SKIP_REDUCE = os.environ.get("CCN_EXP_SKIP_REDUCE") == "1"     # timing-only experiment (wrong gradients), see DESIGN section 5
+# BatchNorm-backward column sums of a DEFERRED layer taken in the epilogue of its consumer's data-gradient product
+# (ccn_gemm_nt_red): the consumer's backward leaves (sums, dZ) here under the address of the deferred output y; the
+# producer's backward -- which runs next, a deferred output has exactly one consumer -- takes them when the gradient it is
+# handed IS that dZ, and skips its ccn_bn_act_bwd_reduce pass over (dZ, y).  CCN_BN_RED=0 disables.  Cleared after every
+# backward pass.
+_BN_SUMS = {}
+BN_RED = os.environ.get("CCN_BN_RED", "1") != "0"
+
+
+def _bn_sums_offer(y_prev, sums, dz):
+    torch.autograd.Variable._execution_engine.queue_callback(_BN_SUMS.clear)
+    _BN_SUMS[y_prev.data_ptr()] = (sums, dz)
+
+
+def _bn_sums_take(y, g):
+    hit = _BN_SUMS.pop(y.data_ptr(), None) if _BN_SUMS else None
+    if hit is None:
+        return None
+    sums, dz = hit
+    if dz.data_ptr() != g.data_ptr() or tuple(dz.shape) != tuple(g.shape) or dz.stride(0) != g.stride(0):
+        return None
+    return sums
 
 
 class LinearBNAct(torch.autograd.Function):
@@ -744,8 +765,9 @@ class LinearBNAct(torch.autograd.Function):
         if ctx.has_bn:
             x, w, y, par, xf_par = ctx.saved_tensors
             m, n = y.shape
-            sums = _stats_buffer(m, n, dev)
-            if not (_EXP_SKIP_REDUCE and ctx.deferred):
+            sums = _bn_sums_take(y, g) if ctx.deferred else None     # taken in the consumer's data-gradient epilogue?
+            if sums is None:
+                sums = _stats_buffer(m, n, dev)
                 call("bn_act_bwd_reduce", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
                      ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums))
             dy = _rows(m, n, dev)
@@ -783,6 +805,15 @@ class LinearBNAct(torch.autograd.Function):
                     and lib().ccn_gemm_nt_acc_ok(_ld(dy), _ld(wt), m, k, n)):
                 # the other consumer of x has written its gradient already: add this one to it (autograd gets None)
                 call("gemm_nt_acc", ptr(dy), _ld(dy), ptr(wt), _ld(wt), ptr(sink), _ld(sink), m, k, n)
+            elif (BN_RED and ctx.xf_act is not None and ctx.gemm_nt == "gemm_nt" and not (k > 128 and 0 < k % 128 <= 64)
+                  and dy.data_ptr() % 16 == 0 and wt.data_ptr() % 16 == 0 and lib().ccn_gemm_nt_acc_ok(_ld(dy), _ld(wt), m, k, n)):
+                # x is the previous layer's deferred output y: its BatchNorm-backward column sums come out of this product's
+                # epilogue (widths whose plain product is split into a 128-wide and a 64-wide launch keep the separate pass)
+                dx = _rows(m, k, dev)
+                sums_prev = _stats_buffer(m, k, dev)
+                call("gemm_nt_red", ptr(dy), _ld(dy), ptr(wt), _ld(wt), ptr(dx), _ld(dx), m, k, n, ptr(x), _ld(x), ptr(xf_par),
+                     ctx.xf_act, LEAKY_SLOPE, ptr(sums_prev))
+                _bn_sums_offer(x, sums_prev, dx)
             else:
                 dx = _rows(m, k, dev)
                 _gemm_nt(_GEMM_BWD[ctx.gemm_nt], dy, wt, None, dx, m, k, n, None)

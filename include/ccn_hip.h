@@ -205,6 +205,15 @@ int ccn_gemm_nt_acc(const float* A, int64_t lda, const float* W, int64_t ldw, fl
  * with that layer's BatchNorm + activation (ccn_bn_act_fwd: z = act(a * scale[k] + shift[k]), same bits) applied between LDS and
  * the matrix cores -- the activation tensor of a hidden MLP layer (torch_geometric.nn.MLP: lin -> norm -> act -> lin,
  * src/models/base.py:90-125) is then never written.  Paired LDS-DMA kernel only, K % 32 == 0, K <= 1024: ask _ok. */
+/* round 4: the data-gradient product dZ = dY Wt^T of a layer whose input was a DEFERRED activation (ccn_gemm_nt_xf), with the
+ * BatchNorm-backward column sums of the layer that produced it taken in the epilogue: sum(g), sum(g * xhat), g = dZ *
+ * act'(y scale + shift), xhat = (y - mean) rstd, from the dZ tile in registers and the matching tile of y (y_prev, its
+ * pre-normalisation output).  par: that layer's 4 x N table (scale | shift | mean | rstd).  sums: as ccn_bn_act_bwd_reduce
+ * writes it (2 N totals + ccn_stats_rows(M) partial rows) -- that pass over (dZ, y) is not needed for the layer any more.
+ * Shapes: those ccn_gemm_nt_acc_ok accepts.  Replaces autograd of BatchNorm1d inside PyG MLP (base.py:90-125). */
+int ccn_gemm_nt_red(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M, int64_t N,
+                    int64_t K, const float* y_prev, int64_t ldyp, const float* par, int act, float slope, double* sums,
+                    void* stream);
 int ccn_gemm_nt_xf_ok(int64_t lda, int64_t ldw, int64_t M, int64_t N, int64_t K);
 int ccn_gemm_nt_xf(const float* A, int64_t lda, const float* a_scale, const float* a_shift, int a_act, float a_slope,
                    const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,

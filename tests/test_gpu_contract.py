@@ -387,3 +387,36 @@ def test_weight_gradient_remainder_block_on_a_tight_allocation(M, N, K):
     err = float(((dw[:, :K].double() - ref).abs() / bound).max())
     assert err < 5e-6, err
     assert bool((dw[:, K:] == 0).all())                                              # padding columns of dW untouched
+
+
+@pytest.mark.parametrize("M,N,K,act", [(40000, 256, 256, 1), (33000, 192, 128, 2), (20000, 259, 512, 2), (16500, 128, 1027, 0)])
+def test_gemm_nt_red_equals_product_plus_reduce(M, N, K, act):
+    """ccn_gemm_nt_red (round 4): the data-gradient product with the previous layer's BatchNorm-backward column sums taken in
+    its epilogue == ccn_gemm_nt followed by ccn_bn_act_bwd_reduce over (dZ, y): same dZ bits, sums to fp32-summation accuracy.
+    Ragged last tiles (M, N not multiples of 128), a K remainder, every activation code."""
+    from curvecloudnet_amd._lib import lib, ptr
+    gen = torch.Generator().manual_seed(M + N)
+    lda = (K + 3) // 4 * 4
+    a = torch.randn(M, lda, generator=gen).to(DEV)
+    w = (torch.randn(N, lda, generator=gen) / K ** 0.5).to(DEV)
+    ldy = (N + 3) // 4 * 4 + 4
+    y_prev = torch.randn(M, ldy, generator=gen).to(DEV)
+    par = torch.stack([torch.rand(N, generator=gen) + 0.5, torch.randn(N, generator=gen) * 0.3,
+                       torch.randn(N, generator=gen) * 0.2, torch.rand(N, generator=gen) + 0.5]).to(DEV).contiguous()
+    assert lib().ccn_gemm_nt_acc_ok(lda, lda, M, N, K)
+    nparts = lib().ccn_stats_rows(M)
+    dz_ref = torch.empty(M, N, device=DEV)
+    sums_ref = torch.zeros((nparts + 1) * 2 * N, dtype=torch.float64, device=DEV)
+    assert lib().ccn_gemm_nt(ptr(a), lda, ptr(w), lda, None, ptr(dz_ref), N, M, N, K, None, None) == 0
+    assert lib().ccn_bn_act_bwd_reduce(ptr(dz_ref), N, ptr(y_prev), ldy, M, N, ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]),
+                                       act, 0.01, ptr(sums_ref), None) == 0
+    dz = torch.empty(M, N, device=DEV)
+    sums = torch.zeros((nparts + 1) * 2 * N, dtype=torch.float64, device=DEV)
+    rc = lib().ccn_gemm_nt_red(ptr(a), lda, ptr(w), lda, ptr(dz), N, M, N, K, ptr(y_prev), ldy, ptr(par), act, 0.01, ptr(sums), None)
+    assert rc == 0, lib().ccn_last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(dz, dz_ref)
+    got, want = sums[: 2 * N], sums_ref[: 2 * N]
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-6 * scale * (M ** 0.5), (float((got - want).abs().max()), scale)
+    assert float((got - want).abs().max()) <= 1e-4 * scale
