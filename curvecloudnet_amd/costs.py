@@ -148,6 +148,9 @@ _TABLE = {
     "add_cast_rows_h": ("curve", lambda i, r: 8.0 * _rc(i, 2, 3)),                       # (lda, ldb, rows, C, ldy): fp32 + bf16 -> bf16
     "transpose_cast_h": ("curve", lambda i, r: 6.0 * _rc(i, 1, 2)),
     "f16_to_bf16_rows": ("curve", lambda i, r: 4.0 * _rc(i, 1, 2)),
+    # ---- FRNN (12 (P1 + P2) + 8 K P1 bytes per cloud and call; padded sizes here)
+    "frnn_grid_build": ("geometry", lambda i, r: 12.0 * i[0] * i[1] + float(i[2])),                     # (B, P2, grid_bytes)
+    "frnn_query": ("geometry", lambda i, r: 12.0 * i[0] * (i[1] + i[3]) + I64 * i[2] * i[0] * i[1]),    # (B, P1, K, P2)
     # ---- loss / optimiser
     "nll_loss_fwd": ("loss_optim", lambda i, r: F32 * _rc(i, 1, 2) + I64 * i[1]),        # (ld, rows, C, ignore)
     "nll_loss_bwd": ("loss_optim", lambda i, r: 2 * F32 * _rc(i, 1, 2) + I64 * i[1]),

@@ -852,7 +852,10 @@ def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
     if which == "sgcnn":      # ... and the max over a point's rows hands its gradient to the plain last layer as bf16 rows
         assert "cg_max_bwd_h" in calls[0] and "cg_max_bwd" not in calls[0] and "cg_max_bwd" in calls[1]
         assert casts(calls[0]) <= casts(calls[1]) - 2
-    assert torch.equal(res[0][0], res[1][0]), "forward must not change: same fp32 value, same rounding"
+    if which == "conv-v1":     # same rounded operands, another summation order (the K slices fall on other boundaries)
+        _close(res[0][0], res[1][0], 1e-4, "implicit vs shifted-row convolution, 16-bit operands")
+    else:
+        assert torch.equal(res[0][0], res[1][0]), "forward must not change: same fp32 value, same rounding"
     gmax = max(float(b.norm()) for b in res[1][1:])
     worst = 0.0
     for a, b in zip(res[0][1:], res[1][1:]):
