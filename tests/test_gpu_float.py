@@ -852,8 +852,13 @@ def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
     if which == "sgcnn":      # ... and the max over a point's rows hands its gradient to the plain last layer as bf16 rows
         assert "cg_max_bwd_h" in calls[0] and "cg_max_bwd" not in calls[0] and "cg_max_bwd" in calls[1]
         assert casts(calls[0]) <= casts(calls[1]) - 2
-    if which == "conv-v1":     # same rounded operands, another summation order (the K slices fall on other boundaries)
-        _close(res[0][0], res[1][0], 1e-4, "implicit vs shifted-row convolution, 16-bit operands")
+    if which == "conv-v1":
+        # same rounded operands, another summation order (the K slices fall on other boundaries): 2e-5 per layer in l2
+        # (tools/check_conv_h.py); a 1e-6 difference in an fp32 activation can move ONE 16-bit rounding of the next layer's
+        # operand (4e-3 of that element), so the bound is in l2 with a loose cap on single elements
+        rel = float((res[0][0] - res[1][0]).norm() / res[1][0].norm())
+        assert rel < 5e-4, rel
+        _close(res[0][0], res[1][0], 2e-3, "implicit vs shifted-row convolution, 16-bit operands")
     else:
         assert torch.equal(res[0][0], res[1][0]), "forward must not change: same fp32 value, same rounding"
     gmax = max(float(b.norm()) for b in res[1][1:])
