@@ -2507,7 +2507,9 @@ class ConvRowsBNActH(torch.autograd.Function):
             dgw = dw.view(cout, taps, ld16)[:, :, :cin].reshape(cout, taps * cin)
         db = None
         if ctx.has_bias:
-            db = dyv[:, :cout].float().sum(0)       # (in front of a BatchNorm: identically zero up to rounding)
+            # the bias sits in front of the BatchNorm: with batch statistics its gradient is identically zero (the column sums
+            # of the bf16 dY rows would be rounding noise), with running statistics it is scale * sum(g act') from the first pass
+            db = torch.zeros(cout, dtype=torch.float32, device=dev) if ctx.training else par[0] * sums[:cout].float()
         return dx, dgw, db, dgb[0], dgb[1], None, None, None, None, None, None, None, None
 
 

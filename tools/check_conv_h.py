@@ -24,12 +24,25 @@ for mode in ("bf16", "fp16"):
         x = torch.randn(d.pos.size(0), dims[0] - 3, generator=torch.Generator().manual_seed(1))
         ops.set_mlp_dtype(mode); R.set_mlp_dtype(mode); R.STORE16 = ops.STORE16
         try:
-            outs = {}
+            outs, grads = {}, {}
+            cot = torch.randn(d.pos.size(0), dims[-1], generator=torch.Generator().manual_seed(3))
             for flag in (True, False):
                 ops.CONV_IMPLICIT_H = flag
-                outs[flag] = mine(x.to(dev), d.pos.to(dev), d.batch.to(dev), d.curve_idxs.to(dev))[0].detach().cpu()
+                xi = x.to(dev).requires_grad_(True)
+                o = mine(xi, d.pos.to(dev), d.batch.to(dev), d.curve_idxs.to(dev))[0]
+                grads[flag] = [g.detach().cpu() for g in torch.autograd.grad((o * cot.to(dev)).sum(), [xi] + list(mine.parameters()))]
+                outs[flag] = o.detach().cpu()
             ops.CONV_IMPLICIT_H = True
-            out_r = ref(x, d.pos, d.batch, d.curve_idxs)[0].detach()
+            xr = x.clone().requires_grad_(True)
+            o_r = ref(xr, d.pos, d.batch, d.curve_idxs)[0]
+            g_r = [g.detach() for g in torch.autograd.grad((o_r * cot).sum(), [xr] + list(ref.parameters()))]
+            out_r = o_r.detach()
+            names = ["x"] + [n for n, _ in ref.named_parameters()]
+            gm = max(float(g.norm()) for g in g_r)
+            for n, a, b, r in zip(names, grads[True], grads[False], g_r):
+                den = max(float(r.norm()), 1e-3 * gm)
+                print("      grad %-28s implicit vs emulation %.2e   shifted-row vs emulation %.2e   implicit vs shifted-row %.2e"
+                      % (n, float((a - r).norm()) / den, float((b - r).norm()) / den, float((a - b).norm()) / den))
             ops.set_mlp_dtype("fp32")
             out_f = mine(x.to(dev), d.pos.to(dev), d.batch.to(dev), d.curve_idxs.to(dev))[0].detach().cpu()
         finally:
