@@ -1773,13 +1773,16 @@ __global__ __launch_bounds__(256) void col_partial_vec_kernel(const float* __res
                                                               const float* __restrict__ shift,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int act, float slope,
-                                                              double* __restrict__ partial) {
+                                                              double* __restrict__ partial, int64_t ccols) {
+  // gridDim.y slices of ccols columns (a multiple of 64): a layer with few rows and many channels (10 550 x 1024, 3 168 x
+  // 2048: 83 / 25 row blocks) otherwise runs 16-32 column passes per workgroup on a tenth of the CUs
   __shared__ double red[4][64][2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cq = lane & 15, rsub = lane >> 4;
   const int64_t r0 = (int64_t)blockIdx.x * RED_ROWS;
   const int64_t r1 = r0 + RED_ROWS < rows ? r0 + RED_ROWS : rows;
-  for (int64_t c0 = 0; c0 < C; c0 += 64) {
+  const int64_t cbeg = (int64_t)blockIdx.y * ccols, cend = cbeg + ccols < C ? cbeg + ccols : C;
+  for (int64_t c0 = cbeg; c0 < cend; c0 += 64) {
     const int64_t c = c0 + 4 * cq;
     const bool in = c < C;
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
@@ -2421,6 +2424,16 @@ int ccn_bn_act_fwd(const float* Y, int64_t ldy, int64_t rows, int64_t C, const f
   return CCN_OK;
 }
 
+// columns per gridDim.y slice of col_partial_vec_kernel: enough slices for ~1024 workgroups, whole 64-column groups
+static inline int64_t col_slice_cols(int64_t nparts, int64_t C, unsigned* gy) {
+  const int64_t groups = (C + 63) / 64;
+  int64_t want = nparts >= 1024 ? 1 : (1024 + nparts - 1) / nparts;
+  if (want > groups) want = groups;
+  const int64_t per = (groups + want - 1) / want;       // 64-column groups per slice
+  *gy = (unsigned)((groups + per - 1) / per);
+  return per * 64;
+}
+
 int ccn_bn_act_bwd_reduce(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t rows, int64_t C,
                           const float* scale, const float* shift, const float* mean, const float* rstd, int act,
                           float slope, double* sums, void* stream) {
@@ -2429,10 +2442,12 @@ int ccn_bn_act_bwd_reduce(const float* dZ, int64_t lddz, const float* Y, int64_t
   CCN_REQUIRE(dZ && Y && scale && shift && mean && rstd && sums && rows > 0 && C > 0, "bn_act_bwd_reduce: bad arguments");
   const int64_t nparts = ccn_stats_rows(rows);
   double* partial = sums + 2 * C;
-  if (col_vec_ok(dZ, lddz, Y, ldy, C) && ((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)rstd) % 16 == 0)
-    hipLaunchKernelGGL(col_partial_vec_kernel<1>, dim3((unsigned)nparts), dim3(256), 0, s, dZ, lddz, Y, ldy, rows, C,
-                       scale, shift, mean, rstd, act, slope, partial);
-  else
+  if (col_vec_ok(dZ, lddz, Y, ldy, C) && ((uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)rstd) % 16 == 0) {
+    unsigned gy;
+    const int64_t ccols = col_slice_cols(nparts, C, &gy);
+    hipLaunchKernelGGL(col_partial_vec_kernel<1>, dim3((unsigned)nparts, gy), dim3(256), 0, s, dZ, lddz, Y, ldy, rows, C,
+                       scale, shift, mean, rstd, act, slope, partial, ccols);
+  } else
     hipLaunchKernelGGL(col_partial_kernel<1>, dim3((unsigned)nparts), dim3(256), 0, s, dZ, lddz, Y, ldy, rows, C, scale,
                        shift, mean, rstd, act, slope, partial);
   launch_col_reduce(partial, nparts, 2 * C, sums, s);
@@ -2511,11 +2526,13 @@ int ccn_colsum(const float* X, int64_t ldx, int64_t rows, int64_t C, double* acc
   CCN_REQUIRE(X && acc && out && rows > 0 && C > 0 && ldx >= C, "colsum: bad arguments");
   const int64_t nparts = ccn_stats_rows(rows);
   double* partial = acc + 2 * C;
-  if (col_vec_ok(X, ldx, nullptr, 0, C))
-    hipLaunchKernelGGL(col_partial_vec_kernel<0>, dim3((unsigned)nparts), dim3(256), 0, s, X, ldx, (const float*)nullptr,
+  if (col_vec_ok(X, ldx, nullptr, 0, C)) {
+    unsigned gy;
+    const int64_t ccols = col_slice_cols(nparts, C, &gy);
+    hipLaunchKernelGGL(col_partial_vec_kernel<0>, dim3((unsigned)nparts, gy), dim3(256), 0, s, X, ldx, (const float*)nullptr,
                        (int64_t)0, rows, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, 0, 0.f, partial);
-  else
+                       (const float*)nullptr, 0, 0.f, partial, ccols);
+  } else
     hipLaunchKernelGGL(col_partial_kernel<0>, dim3((unsigned)nparts), dim3(256), 0, s, X, ldx, (const float*)nullptr,
                        (int64_t)0, rows, C, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, 0, 0.f, partial);
