@@ -128,3 +128,51 @@ def test_kitti_config_equals_reference_yaml_when_available():
                                        (kitti_config(), 4, 20, 28767232), (shapenet_seg_config(), 3, 50, 11747378)):
         from curvecloudnet_amd.model import build_model
         assert sum(p.numel() for p in build_model(cfg, in_dim, n_out).parameters()) == params
+
+
+def test_cost_table_matches_the_header():
+    """curvecloudnet_amd/costs.py prices a launch from its integer arguments in prototype order: every entry it names must be
+    declared in include/ccn_hip.h, and its formula must be evaluable on exactly as many integers as the prototype carries
+    (an argument-order slip was what printed a 223 TFLOP/s line in round 3)."""
+    import re
+    from curvecloudnet_amd import costs
+    text = open(os.path.join(ROOT, "include", "ccn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    ints = {}
+    for m in re.finditer(r"([\w\s\*]+?)\b(ccn_\w+)\s*\(([^)]*)\)\s*;", text):
+        args = [a.strip() for a in m.group(3).split(",")]
+        ints[m.group(2)[4:]] = [a.split()[-1] for a in args if "*" not in a and a.split()[0] in ("int", "int64_t", "size_t")]
+    for name in list(costs._TABLE) + list(costs.GEMM_MNK):
+        assert name in ints, "costs.py names an entry the header does not declare: %s" % name
+        sample = tuple(100 + 7 * i for i in range(len(ints[name])))
+        fam, flops, nbytes, modelled = costs.entry_cost(name, sample, rows=1000)
+        assert fam in ("gemm", "batchnorm", "edge", "aggregation", "curve", "geometry", "loss_optim", "other"), (name, fam)
+        assert flops >= 0 and nbytes >= 0
+        if name in costs.GEMM_MNK:
+            shape = costs.gemm_shape(name, sample)
+            got = [ints[name][sample.index(v)] for v in shape]
+            assert got == ["M", "N", "K"], (name, got)          # the product's (M, N, K) really are the prototype's M, N, K
+            assert flops == 2.0 * shape[0] * shape[1] * shape[2]
+
+
+def test_draw_log_records_and_replays():
+    """oracle/draws.py: the draws of a block are recorded in order and handed back in order; a different draw order, a
+    missing draw or a left-over draw is an error; draws from an explicit generator pass through."""
+    import pytest
+    from oracle.draws import Draws
+    rec = Draws()
+    g = torch.Generator().manual_seed(1)
+    with rec:
+        a = torch.rand(1)
+        b = torch.randint(7, (1,))
+        c = torch.randperm(5)
+        passthrough = torch.rand(3, generator=g)
+    assert [n for n, _ in rec.log] == ["rand", "randint", "randperm"] and passthrough.shape == (3,)
+    with Draws(replay=rec.log):
+        assert torch.equal(torch.rand(1), a) and torch.equal(torch.randint(7, (1,)), b) and torch.equal(torch.randperm(5), c)
+    with pytest.raises(AssertionError):
+        with Draws(replay=rec.log):
+            torch.randperm(5)                      # recorded first: rand
+    with pytest.raises(AssertionError):
+        with Draws(replay=rec.log):
+            torch.rand(1)                          # two recorded draws never taken
