@@ -817,6 +817,444 @@ __global__ __launch_bounds__(Q_TPB, 2) void gemm_x3_pair_kernel(const float* __r
   }
 }
 
+
+// ------------------------------------------------------------------ round 4: the paired kernel, software-pipelined ("lean")
+// What the paired kernel above leaves on the table (0.36-0.39 of the split product's matrix-core ceiling): a wave's step is
+// "14 LDS reads . wait . 41 vector instructions of the split . 24 MFMAs", so its own MFMAs never hide its own vector work,
+// and the partner wave of the SIMD (the other workgroup) cannot hide it either -- while one wave streams MFMAs the other
+// one's vector instructions issue at about one per MFMA (profiles/r03_pair_kernel_anatomy.txt); and with 32-deep slices in
+// a two-stage ring a copy has one slice (~1.3 us at the full matrix rate, 2.7x less than in the fp32 kernel) to arrive from
+// HBM.  This kernel keeps the tile (128 x 128 per 4-wave workgroup, wave w = rows 32 w ..., two workgroups per CU) and
+// changes the schedule:
+//   * one step = 16 contraction elements = 24 MFMAs per wave; the LDS reads and the three-way split of step s + 1 are
+//     placed BETWEEN the MFMAs of step s (2 reads or 3 single-issue vector instructions per MFMA gap: an MFMA holds the
+//     SIMD's issue port for 8 of its 32 cycles) into a second set of fragment registers;
+//   * A (fp32 rows, from HBM): a 4-stage ring of 16-deep pieces PRIVATE to the wave that consumes them (32 rows x 64 B per
+//     stage and wave, two LDS-DMA copies of 16 rows x 64 B; source chunk c of row r lands in slot 4 r + (c ^ (r >> 2 & 3)),
+//     which makes a lane's two ds_read_b128 conflict-free) -- no barrier guards it, only the wave's own vmcnt, and a copy
+//     has three steps to arrive;
+//   * W: the three bf16 images are laid out by the split kernel in FRAGMENT order -- per (column tile, step) 12 pieces of
+//     1 KiB = [image][32-column block][k half][column] x 16 B -- so a step's W operand is one contiguous 12 KiB, copied
+//     by three fully coalesced LDS-DMA instructions per wave into a 3-stage ring and read back with one conflict-free
+//     ds_read_b128 per fragment at immediate offsets; one barrier per step orders the ring;
+//   * vmcnt is counted (loads, LDS-DMA and stores retire in issue order): a step waits for the copies of step s + 1 and
+//     leaves the 7 younger ones in flight; behind a tile's 64 stores the count saturates at 63, which is still enough
+//     (the copies waited for are older than the stores);
+//   * lean issue streams as in the fp32 kernel: wave index as a scalar, copy sources as scalar base + 32-bit lane offset,
+//     stores as scalar row base + lane offset, tile arithmetic in 32 bits.
+// LDS: A 4 waves x 4 stages x 2 KiB + W 3 x 12 KiB + 4 KiB for the BatchNorm partial sums = 72 KiB per workgroup.
+constexpr int L_TPB = 256;
+constexpr int L_BM = 128, L_BN = 128;
+constexpr int L_A_RING = 4, L_B_RING = 3;
+constexpr int L_A_STAGE = 32 * 64;                      // bytes per wave and stage: 32 rows x 16 fp32
+constexpr int L_B_STAGE = 12 * 1024;                    // bytes per stage: 3 images x 4 column blocks x 1 KiB
+constexpr int L_LDS_A = 4 * L_A_RING * L_A_STAGE;       // 32 KiB
+constexpr int L_LDS_B = L_B_RING * L_B_STAGE;           // 36 KiB
+constexpr int L_LDS_STAT = 4 * L_BN * 2 * 4;            // 4 KiB
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+// W (N x K fp32) -> the three bf16 images in fragment order: element (n, k) of image s sits at bf16 index
+//   (((n / 128) T16 + k / 16) 3 + s) 2048 + ((n / 32) % 4) 512 + ((k / 8) % 2) 256 + (n % 32) 8 + k % 8;   rows >= N, columns >= K: 0
+__global__ __launch_bounds__(256) void x3_split_weights_frag_kernel(const float* __restrict__ W, int64_t ldw, int64_t N,
+                                                                    int64_t K, int64_t Np, int64_t T16,
+                                                                    __bf16* __restrict__ img) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t Kp = T16 * 16;
+  if (e >= Np * Kp) return;
+  const int64_t n = e / Kp, k = e - n * Kp;
+  const float x = (n < N && k < K) ? W[n * ldw + k] : 0.f;
+  __bf16 h, m, l;
+  split3(x, h, m, l);
+  const int64_t stage = (n >> 7) * T16 + (k >> 4);
+  const int64_t in = ((n >> 5) & 3) * 512 + ((k >> 3) & 1) * 256 + (n & 31) * 8 + (k & 7);
+  img[(stage * 3 + 0) * 2048 + in] = h;
+  img[(stage * 3 + 1) * 2048 + in] = m;
+  img[(stage * 3 + 2) * 2048 + in] = l;
+}
+
+// diagnostic build (ccn_gemm_x3_debug): per wave, where its cycles go (s_memtime stamps), 16 words per wave
+__device__ unsigned long long* g_x3_dbg_dev = nullptr;
+#define X3_STAMP(t)                                                              \
+  do {                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+  } while (0)
+
+__device__ __forceinline__ uint32_t x3_cvt_pk(float a, float b) {   // (bf16(a), bf16(b)), round to nearest even
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// (inline asm: the compiler otherwise pairs the subtractions into v_pk_add_f32, which costs an MFMA gap far more than two
+// plain ones -- MI355X_MICROARCH.md, per-instruction cycle constants)
+__device__ __forceinline__ float x3_sub(float a, float b) {
+  float r;
+  asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+struct X3Frag {
+  u32x4 a[3];      // this lane's 8 contraction elements of its A row: high / middle / low terms
+  f32x4 b[4][3];   // [32-column block][image]
+};
+
+template <bool STAMP>
+__global__ __launch_bounds__(L_TPB, 2) void gemm_x3_lean_kernel(const float* __restrict__ A, int64_t lda,
+                                                                const unsigned char* __restrict__ Wfrag,
+                                                                const float* __restrict__ bias, float* __restrict__ C,
+                                                                int64_t ldc, int64_t M, int64_t N, int64_t K, int64_t tiles,
+                                                                int64_t gn, int xcd_order, double* __restrict__ colstats) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[L_LDS_A + L_LDS_B + L_LDS_STAT];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int i = lane & 31, h = lane >> 5;
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
+  const uint32_t ldsA_w = lds_base + (uint32_t)(wave * L_A_RING * L_A_STAGE);
+  const uint32_t ldsB = lds_base + L_LDS_A;
+  float* const stat_part = reinterpret_cast<float*>(lds + L_LDS_A + L_LDS_B);   // [4 waves][128 columns][sum, sum of squares]
+  const int T16 = (int)(K / 16);
+
+  // fragment reads: A row i, source chunks 2 h and 2 h + 1 (slot 4 r + (c ^ (r >> 2 & 3))); W column i, k half h
+  const uint32_t a_sw = (uint32_t)((i >> 2) & 3);
+  const uint32_t a_rd0 = (uint32_t)(4 * i + ((2 * h) ^ a_sw)) * 16u, a_rd1 = (uint32_t)(4 * i + ((2 * h + 1) ^ a_sw)) * 16u;
+  const uint32_t b_rd = (uint32_t)(h * 512 + i * 16);
+
+  // ---- tiles of this workgroup (as gemm_glds_pair_kernel: 64 workgroup slots per XCD walk the column tiles of a row block)
+  const uint32_t gnu = (uint32_t)gn;
+  const uint32_t gm_tiles = (uint32_t)tiles / gnu;
+  const bool xcd_map = xcd_order && gridDim.x == 512 && gnu <= 64 && 64 % gnu == 0;
+  const uint32_t slot = blockIdx.x >> 3;
+  const uint32_t rows_per_step = 512u / gnu, slot_row = (slot / gnu) * 8 + (blockIdx.x & 7), slot_col = slot % gnu;
+  auto tile_of = [&](int64_t j) -> int64_t {
+    if (xcd_map) {
+      const uint32_t m = (uint32_t)j * rows_per_step + slot_row;
+      return m < gm_tiles ? (int64_t)(m * gnu + slot_col) : tiles;
+    }
+    return j * gridDim.x + blockIdx.x;
+  };
+  auto tile_row = [&](int64_t t) -> int64_t { return (int64_t)((uint32_t)t / gnu); };
+  auto tile_col = [&](int64_t t) -> int64_t { return (int64_t)((uint32_t)t % gnu); };
+
+  // ---- copy cursors: each walks the steps of this workgroup's tiles in order (A runs one step ahead of W)
+  // An exhausted cursor keeps re-copying its last step (valid memory, into stages nobody reads any more): every step then
+  // issues the same five copies and the counted waits below hold to the end.
+  int64_t bj = 0, b_tile = tile_of(0);
+  int b_u = 0, b_stage = 0;
+  const unsigned char* b_ptr = Wfrag;
+  unsigned char* b_dst = lds;
+  const uint32_t b_lane = (uint32_t)(lane * 16);
+  auto b_begin = [&]() {
+    if (b_u == 0 && b_tile < tiles) b_ptr = Wfrag + ((tile_col(b_tile) * T16) * 12 + 3 * wave) * 1024;
+    b_dst = lds + L_LDS_A + b_stage * L_B_STAGE + 3 * wave * 1024;
+  };
+  auto b_piece = [&](int p) {
+    const unsigned char* const piece = b_ptr + p * 1024;   // (scalar base + 32-bit lane offset: no 64-bit vector arithmetic)
+    glds16(piece + b_lane, b_dst + p * 1024);
+  };
+  auto b_end = [&]() {
+    b_stage = b_stage == L_B_RING - 1 ? 0 : b_stage + 1;
+    if (b_tile < tiles) {
+      if (++b_u == T16) {
+        b_u = 0;
+        b_tile = tile_of(++bj);
+        if (b_tile >= tiles) b_u = 1;   // exhausted: b_ptr stays on the last step
+      } else {
+        b_ptr += 12 * 1024;
+      }
+    }
+  };
+  int64_t aj = 0, a_tile = tile_of(0);
+  int a_u = 0, a_stage = 0;
+  const char* a_ptr = reinterpret_cast<const char*>(A);
+  unsigned char* a_dst = lds;
+  uint32_t a_off32[2] = {0u, 0u};
+  auto a_begin = [&]() {
+    if (a_u == 0 && a_tile < tiles) {
+      const int64_t m0 = tile_row(a_tile) * L_BM;
+      a_ptr = reinterpret_cast<const char*>(A + m0 * lda);
+      const int64_t rows_left = M - m0;   // >= 1; rows beyond the matrix re-read its last row (they feed outputs never stored)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int r = 16 * q + (lane >> 2);
+        const int c = (lane & 3) ^ ((r >> 2) & 3);
+        int64_t rr = 32 * wave + r;
+        rr = rr < rows_left ? rr : rows_left - 1;
+        a_off32[q] = (uint32_t)((rr * lda + 4 * c) * 4);
+      }
+    }
+    a_dst = lds + (wave * L_A_RING + a_stage) * L_A_STAGE;
+  };
+  auto a_piece = [&](int q) { glds16(a_ptr + a_off32[q], a_dst + q * 1024); };
+  auto a_end = [&]() {
+    a_stage = (a_stage + 1) & (L_A_RING - 1);
+    if (a_tile < tiles) {
+      if (++a_u == T16) {
+        a_u = 0;
+        a_tile = tile_of(++aj);
+        if (a_tile >= tiles) a_u = 1;   // exhausted: a_ptr stays on the last step
+      } else {
+        a_ptr += 64;
+      }
+    }
+  };
+  auto issue_b = [&]() { b_begin(); b_piece(0); b_piece(1); b_piece(2); b_end(); };
+  auto issue_a = [&]() { a_begin(); a_piece(0); a_piece(1); a_end(); };
+
+  X3Frag F0, F1;
+  f32x16 acc[4];
+  int rdA = 1, rdB = 1;   // ring stages the NEXT step's operands sit in
+
+  // ---- BatchNorm partial sums of a finished tile: parked in stat_part by its epilogue, written out behind the next barrier
+  int64_t stat_tile = -1;
+  auto stats_readout = [&]() {
+    const int64_t pm = tile_row(stat_tile), pn0 = tile_col(stat_tile) * L_BN;
+    for (int c = threadIdx.x; c < L_BN; c += L_TPB) {
+      const int64_t n = pn0 + c;
+      if (n < N) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          s1 += (double)stat_part[(w * L_BN + c) * 2];
+          s2 += (double)stat_part[(w * L_BN + c) * 2 + 1];
+        }
+        double* dst = colstats + pm * 2 * N;   // one partial row per 128-row block (ccn_stats_rows)
+        dst[n] = s1;
+        dst[N + n] = s2;
+      }
+    }
+    stat_tile = -1;
+  };
+
+  unsigned long long st_t0 = 0, st_a = 0, st_b = 0, st_r0 = 0;
+  uint32_t sum_w = 0, sum_b = 0, sum_i = 0, sum_c = 0, sum_e = 0, n_st = 0;
+
+  // ---- prologue: W(0) A(0) W(1) A(1) W(2) A(2) A(3) issued, the fragments of step 0 in F0
+  issue_b(); issue_a();
+  issue_b(); issue_a();
+  issue_b(); issue_a();
+  issue_a();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  {
+    f32x4 r0, r1;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r0) : "v"(ldsA_w + a_rd0) : "memory");
+    asm volatile("ds_read_b128 %0, %1" : "=v"(r1) : "v"(ldsA_w + a_rd1) : "memory");
+#pragma unroll
+    for (int q = 0; q < 12; ++q)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(F0.b[q & 3][q >> 2]) : "v"(ldsB + b_rd), "n"(q * 1024) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(r0), "+v"(r1), "+v"(F0.b[0][0]), "+v"(F0.b[1][0]), "+v"(F0.b[2][0]), "+v"(F0.b[3][0]), "+v"(F0.b[0][1]),
+                   "+v"(F0.b[1][1]), "+v"(F0.b[2][1]), "+v"(F0.b[3][1]), "+v"(F0.b[0][2]), "+v"(F0.b[1][2]), "+v"(F0.b[2][2]),
+                   "+v"(F0.b[3][2])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      const float x0 = pr < 2 ? r0[2 * pr] : r1[2 * pr - 4], x1 = pr < 2 ? r0[2 * pr + 1] : r1[2 * pr - 3];
+      const uint32_t ph = x3_cvt_pk(x0, x1);
+      const float q0 = x3_sub(x0, __uint_as_float(ph << 16)), q1 = x3_sub(x1, __uint_as_float(ph & 0xffff0000u));
+      const uint32_t pm = x3_cvt_pk(q0, q1);
+      const float s0 = x3_sub(q0, __uint_as_float(pm << 16)), s1 = x3_sub(q1, __uint_as_float(pm & 0xffff0000u));
+      F0.a[0][pr] = ph;
+      F0.a[1][pr] = pm;
+      F0.a[2][pr] = x3_cvt_pk(s0, s1);
+    }
+  }
+
+  if (STAMP) {
+    X3_STAMP(st_t0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_r0) : : "memory");
+  }
+
+  int epi_age = 8;          // step tops since the last full-tile epilogue (its 64 stores sit in the vmcnt queue for two of them)
+  bool drain_next = false;  // an edge tile's epilogue (fewer stores than 63): drain the queue once
+  // One step: [wait for the copies of step s + 1] [barrier] [issue W(s + 3), A(s + 4)] then the 24 MFMAs of step s on the
+  // fragments in `cur`, with the LDS reads and the split of step s + 1 into `nxt` between them.
+  auto step = [&](X3Frag& cur, X3Frag& nxt) {
+    if (STAMP) X3_STAMP(st_a);
+    if (epi_age < 2)
+      asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+    else if (drain_next)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    drain_next = false;
+    ++epi_age;
+    if (STAMP) { X3_STAMP(st_b); sum_w += (uint32_t)(st_b - st_a); }
+    __builtin_amdgcn_s_barrier();
+    if (STAMP) { X3_STAMP(st_a); sum_b += (uint32_t)(st_a - st_b); }
+    if (stat_tile >= 0) stats_readout();
+    if (STAMP) { X3_STAMP(st_b); sum_i += (uint32_t)(st_b - st_a); }
+
+    const uint32_t at = ldsA_w + (uint32_t)(rdA * L_A_STAGE);
+    const uint32_t bt = ldsB + (uint32_t)(rdB * L_B_STAGE) + b_rd;
+    rdA = (rdA + 1) & (L_A_RING - 1);
+    rdB = rdB == L_B_RING - 1 ? 0 : rdB + 1;
+    f32x4 r0, r1;
+    uint32_t ph = 0, pm = 0;
+    float x0 = 0.f, x1 = 0.f, q0 = 0.f, q1 = 0.f, f0 = 0.f, f1 = 0.f, s0 = 0.f;
+    constexpr int SA[6] = {2, 0, 1, 1, 0, 0};   // smallest partial products first
+    constexpr int SB[6] = {0, 2, 1, 0, 1, 0};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < 24; ++m) {
+      const int p = m >> 2, t = m & 3;
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a[SA[p]]),
+                                                       __builtin_bit_cast(bf16x8, cur.b[t][SB[p]]), acc[t], 0, 0, 0);
+      if (m == 0) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(r0) : "v"(at + a_rd0) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(r1) : "v"(at + a_rd1) : "memory");
+      } else if (m <= 6) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int q = 2 * (m - 1) + qq;   // piece = image * 4 + column block
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(nxt.b[q & 3][q >> 2]) : "v"(bt), "n"(q * 1024) : "memory");
+        }
+      } else if (m <= 22) {
+        const int pr = (m - 7) >> 2, c = (m - 7) & 3;   // pair of contraction elements, quarter of its split
+        if (m == 7) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(r0), "+v"(r1) : : "memory");   // the two A reads have landed
+        if (c == 0) {
+          x0 = pr < 2 ? r0[2 * pr] : r1[2 * pr - 4];
+          x1 = pr < 2 ? r0[2 * pr + 1] : r1[2 * pr - 3];
+          ph = x3_cvt_pk(x0, x1);
+          f0 = __uint_as_float(ph << 16);
+          f1 = __uint_as_float(ph & 0xffff0000u);
+          nxt.a[0][pr] = ph;
+        } else if (c == 1) {
+          q0 = x3_sub(x0, f0);
+          q1 = x3_sub(x1, f1);
+          pm = x3_cvt_pk(q0, q1);
+          nxt.a[1][pr] = pm;
+        } else if (c == 2) {
+          f0 = __uint_as_float(pm << 16);
+          f1 = __uint_as_float(pm & 0xffff0000u);
+          s0 = x3_sub(q0, f0);
+        } else {
+          nxt.a[2][pr] = x3_cvt_pk(s0, x3_sub(q1, f1));
+        }
+      }
+      // the copies of W(s + 3) and A(s + 4), one per third gap of the split (the stages they go to were read a step ago:
+      // this workgroup's barrier above is behind those reads)
+      if (m == 9) { b_begin(); b_piece(0); }
+      if (m == 12) b_piece(1);
+      if (m == 15) { b_piece(2); b_end(); }
+      if (m == 18) { a_begin(); a_piece(0); }
+      if (m == 21) { a_piece(1); a_end(); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(nxt.b[0][0]), "+v"(nxt.b[1][0]), "+v"(nxt.b[2][0]), "+v"(nxt.b[3][0]), "+v"(nxt.b[0][1]), "+v"(nxt.b[1][1]),
+                   "+v"(nxt.b[2][1]), "+v"(nxt.b[3][1]), "+v"(nxt.b[0][2]), "+v"(nxt.b[1][2]), "+v"(nxt.b[2][2]), "+v"(nxt.b[3][2])
+                 :
+                 : "memory");
+    if (STAMP) { X3_STAMP(st_a); sum_c += (uint32_t)(st_a - st_b); ++n_st; }
+  };
+
+  for (int64_t j = 0, tile; (tile = tile_of(j)) < tiles; ++j) {
+    const int64_t m0 = tile_row(tile) * L_BM, n0 = tile_col(tile) * L_BN;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int64_t n = n0 + t * 32 + i;
+      const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = bv;
+    }
+    for (int u = 0; u < T16; u += 2) {
+      step(F0, F1);
+      step(F1, F0);
+    }
+
+    // ---- tile epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+    if (STAMP) X3_STAMP(st_a);
+    const bool interior = m0 + L_BM <= M && n0 + L_BN <= N;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int ncol = t * 32 + i;
+      const int64_t n = n0 + ncol;
+      float s1 = 0.f, s2 = 0.f;
+      if (interior) {
+        // store address = a scalar row base (tile, wave band, register's row) + this lane's 32-bit offset (its 4 h rows, its column)
+        float* const cbase = C + (m0 + wave * 32) * ldc + n0 + t * 32;
+        const uint32_t lane_off = (uint32_t)((4 * h * ldc + i) * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* const rowp = cbase + (int64_t)((r & 3) + 8 * (r >> 2)) * ldc;
+          asm volatile("global_store_dword %0, %1, %2" : : "v"(lane_off), "v"(acc[t][r]), "s"(rowp) : "memory");
+        }
+        if (colstats != nullptr) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[t][r];
+            s1 += v;
+            s2 = __builtin_fmaf(v, v, s2);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (m < M && n < N) {
+            const float v = acc[t][r];
+            C[m * ldc + n] = v;
+            s1 += v;
+            s2 = __builtin_fmaf(v, v, s2);
+          }
+        }
+      }
+      if (colstats != nullptr) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (h == 0) {
+          stat_part[(wave * L_BN + ncol) * 2] = s1;
+          stat_part[(wave * L_BN + ncol) * 2 + 1] = s2;
+        }
+      }
+    }
+    if (colstats != nullptr) {
+      stat_tile = tile;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // table written before this wave reaches the next barrier
+    }
+    if (interior)
+      epi_age = 0;
+    else
+      drain_next = true;
+    if (STAMP) { X3_STAMP(st_b); sum_e += (uint32_t)(st_b - st_a); }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA copy of this wave may land after the workgroup has gone
+  if (STAMP && g_x3_dbg_dev != nullptr) {
+    unsigned long long t1, r1;
+    X3_STAMP(t1);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1) : : "memory");
+    if (lane == 0) {
+      unsigned long long* d = g_x3_dbg_dev + ((int64_t)blockIdx.x * 4 + wave) * 16;
+      d[0] = t1 - st_t0; d[1] = r1 - st_r0; d[2] = sum_w; d[3] = sum_b; d[4] = sum_i; d[5] = sum_c; d[6] = sum_e; d[7] = n_st;
+      d[8] = st_t0; d[9] = t1; d[10] = st_r0; d[11] = r1;
+    }
+  }
+  if (stat_tile >= 0) {   // statistics of the last tile
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stats_readout();
+  }
+}
+
+static void* g_x3_dbg_host = nullptr;
+static bool g_use_lean = true;   // A/B hook (ccn_gemm_x3_use_persistent(3) = the round-1 paired kernel instead)
+
+void launch_x3_lean(const float* A, int64_t lda, const __bf16* img, const float* bias, float* Y, int64_t ldy, int64_t M,
+                    int64_t N, int64_t K, double* colstats, hipStream_t s) {
+  const int64_t gm = (M + L_BM - 1) / L_BM, gn = (N + L_BN - 1) / L_BN;
+  const int64_t tiles = gm * gn;
+  const int64_t grid = tiles < 512 ? tiles : 512;   // two workgroups per CU
+  const unsigned char* wf = reinterpret_cast<const unsigned char*>(img);
+  if (g_x3_dbg_host != nullptr)
+    hipLaunchKernelGGL((gemm_x3_lean_kernel<true>), dim3((unsigned)grid), dim3(L_TPB), 0, s, A, lda, wf, bias, Y, ldy, M, N, K,
+                       tiles, gn, 1, colstats);
+  else
+    hipLaunchKernelGGL((gemm_x3_lean_kernel<false>), dim3((unsigned)grid), dim3(L_TPB), 0, s, A, lda, wf, bias, Y, ldy, M, N, K,
+                       tiles, gn, 1, colstats);
+}
+
 static bool g_use_pair = true;   // A/B hook (ccn_gemm_x3_use_persistent(2) = no paired kernel)
 
 void launch_x3_pair(const float* A, int64_t lda, const __bf16* img, int64_t Np, int64_t Kp, const float* bias, float* Y,
@@ -847,8 +1285,15 @@ extern "C" {
 
 int ccn_gemm_x3_use_persistent(int on) {
   g_use_persistent = on != 0;
-  g_use_pair = on == 1;
+  g_use_pair = on == 1 || on == 3;
+  g_use_lean = on == 1;
   return CCN_OK;
+}
+
+int ccn_gemm_x3_debug(void* buf) {   // diagnostic: 512 x 4 x 16 uint64 words (see STAMP in gemm_x3_lean_kernel); nullptr = off
+  g_x3_dbg_host = buf;
+  unsigned long long* p = reinterpret_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_x3_dbg_dev), &p, sizeof(p)) == hipSuccess ? CCN_OK : CCN_ERR_ARG;
 }
 
 int64_t ccn_gemm_x3_workspace_bytes(int64_t N, int64_t K) {
@@ -872,6 +1317,17 @@ int ccn_gemm_nt_x3(const float* A, int64_t lda, const float* W, int64_t ldw, con
   const int64_t gm = (M + X_BM - 1) / X_BM;
   CCN_REQUIRE((gm + 7) / 8 * 8 * ((N + 31) / 32) <= 2147483647LL, "gemm_nt_x3: grid too large");
   __bf16* img = reinterpret_cast<__bf16*>(wsplit);
+  // the software-pipelined paired kernel: N > 64, whole 32-deep slices, at least 128 tiles of 128 x 128 (< 2^31 of them)
+  if (g_use_persistent && g_use_pair && g_use_lean && N > 64 && K % XK == 0 && K >= 64 &&
+      ((M + L_BM - 1) / L_BM) * ((N + L_BN - 1) / L_BN) >= 128 && ((M + L_BM - 1) / L_BM) * ((N + L_BN - 1) / L_BN) < (1LL << 31) &&
+      (L_BM - 1) * lda < (1LL << 29)) {
+    const int64_t T16 = K / 16;
+    hipLaunchKernelGGL(x3_split_weights_frag_kernel, dim3((unsigned)((Np * K + 255) / 256)), dim3(256), 0, s, W, ldw, N, K, Np,
+                       T16, img);
+    launch_x3_lean(A, lda, img, bias, Y, ldy, M, N, K, colstats, s);
+    CCN_LAUNCH_OK("gemm_nt_x3");
+    return CCN_OK;
+  }
   hipLaunchKernelGGL(x3_split_weights_kernel, dim3((unsigned)((Np * Kp + 255) / 256)), dim3(256), 0, s, W, ldw, N, K, Np,
                      Kp, img);
   // many 256-row tiles and whole K slices: the persistent LDS-DMA kernel (one workgroup per CU, 256 CUs)
