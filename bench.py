@@ -58,7 +58,7 @@ def gemm_label(name, ints, nulls=()):
         return "gemm_bf16_kernel<128, %d, 4, true>" % (32 if n <= 32 else (64 if n <= 64 else 128)), flops
     if name == "gemm_nt_x3":
         if k % 32 == 0 and k >= 64 and n > 64 and ((m + 127) // 128) * ((n + 127) // 128) >= 128:
-            return "gemm_x3_pair_kernel", flops
+            return "gemm_x3_lean_kernel", flops
         if k % 32 == 0 and k >= 64 and ((m + 255) // 256) * ((n + 127) // 128) >= 512:
             return "gemm_x3_persistent_kernel<%d>" % (32 if n <= 32 else (64 if n <= 64 else 128)), flops
         return "gemm_x3_kernel<%s>" % ("32, 4" if n <= 32 else ("64, 2" if n <= 64 else "128, 2")), flops
@@ -567,7 +567,7 @@ def main():
         dominant = {"fp32": "gemm_glds_pair_kernel",
                     "bf16": "gemm_h_pair_kernel<false, false>" if ops.STORE16 else "gemm_bf16_kernel<128, 128",
                     "fp16": "gemm_h_pair_kernel<true, false>" if ops.STORE16 else "gemm_bf16_kernel<128, 128",
-                    "bf16x3": "gemm_x3_pair_kernel"}[args.mlp_dtype]
+                    "bf16x3": "gemm_x3_lean_kernel"}[args.mlp_dtype]
 
         def only_dominant(name, cargs):
             # ... and of those every eighth one, the phase moving on by one launch site each step (eight steps visit
