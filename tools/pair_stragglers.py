@@ -10,11 +10,9 @@ from curvecloudnet_amd._lib import call, lib, ptr  # noqa: E402
 from curvecloudnet_amd.ops import _ld, _rows  # noqa: E402
 
 m, n, k = (int(a) for a in sys.argv[1:4])
-opt = int(sys.argv[4], 0) if len(sys.argv) > 4 else 0
 dev = "cuda"
 x = _rows(m, k, dev); x.normal_(); w = _rows(n, k, dev, zero=True); w.normal_(); w.mul_(0.05); y = _rows(m, n, dev)
 dbg = torch.zeros(512 * 4 * 16, dtype=torch.int64, device=dev)
-lib().ccn_gemm_pair_opt(opt)
 for _ in range(200):
     call("gemm_nt", ptr(x), _ld(x), ptr(w), _ld(w), None, ptr(y), _ld(y), m, n, k, None)
 torch.cuda.synchronize()
