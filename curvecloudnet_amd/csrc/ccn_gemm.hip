@@ -13,9 +13,6 @@
 // Workgroup = 4 waves; WM waves along M (32 rows each), 4/WM along N.
 #include "ccn_common.h"
 
-#ifndef CCN_EXP_PRIO
-#define CCN_EXP_PRIO 0
-#endif
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -1325,14 +1322,8 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       if (STAMP) { PR_STAMP(st_b); sum_w += (uint32_t)(st_b - st_a); }
       __builtin_amdgcn_s_barrier();
       if (STAMP) { PR_STAMP(st_a); sum_b += (uint32_t)(st_a - st_b); }
-#if CCN_EXP_PRIO >= 2
-      __builtin_amdgcn_s_setprio(3);
-#endif
       issue_next();
       if (u == 0 && stat_tile >= 0) stats_readout();
-#if CCN_EXP_PRIO >= 2
-      __builtin_amdgcn_s_setprio(0);
-#endif
       if (STAMP) { PR_STAMP(st_b); sum_i += (uint32_t)(st_b - st_a); }
       const uint32_t stage_b = lds_base + (uint32_t)((g & 1) * STAGE * 4);
       f32x4 fa[2][2], fb[2][2];   // [K group parity][block]
@@ -1433,9 +1424,6 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     if (STAMP) PR_STAMP(st_a);
 
     // ---- tile epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
-#if CCN_EXP_PRIO >= 1
-    __builtin_amdgcn_s_setprio(3);
-#endif
     const bool interior = m0 + PR_BM <= M && n0 + PR_BN <= N;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -1535,9 +1523,6 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       stat_tile = tile;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // table written before this wave reaches the next barrier
     }
-#if CCN_EXP_PRIO >= 1
-    __builtin_amdgcn_s_setprio(0);
-#endif
     if (STAMP) { PR_STAMP(st_b); sum_e += (uint32_t)(st_b - st_a); }
   }
   if (STAMP && g_pair_dbg_dev != nullptr) {
