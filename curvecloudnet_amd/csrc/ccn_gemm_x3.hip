@@ -592,240 +592,18 @@ void launch_x3_persistent(const float* A, int64_t lda, const __bf16* img, int64_
 
 
 
-// ------------------------------------------------------------------ two independent workgroups per CU (N > 64)
+// ------------------------------------------------------------------ two independent workgroups per CU (N > 64), software-pipelined
 // The split product leaves ~1.6 us of matrix-core work per 32-deep slice of a 256 x 128 tile, which no longer hides the
 // per-tile costs of the 8-wave kernel above (knock-out runs at K = N = 256: LDS-DMA traffic 0.33 ms and store epilogue
 // 0.25 ms exposed out of 1.24 ms; matrix pipe 45 % busy).  As for the fp32 product (gemm_glds_pair_kernel), the cure is
 // two 4-wave workgroups per CU on 128 x 128 tiles that share nothing: while one waits for its copies, stores a tile or sits
-// at its barrier, the other one issues MFMAs.  Each owns exactly half of the LDS (80 KB): A fp32 two stages x 16 KB, W
-// images two stages x 24 KB; wave w copies and reads its own 32-row band of A (W is shared).  The BatchNorm partial sums
-// of a finished tile are parked in the A stage that was read last (free until the next copy into it, which is held back
-// by one extra barrier after the read-out).
-constexpr int Q_TPB = 256;
-constexpr int Q_BM = 128, Q_BN = 128;
-
-__global__ __launch_bounds__(Q_TPB, 2) void gemm_x3_pair_kernel(const float* __restrict__ A, int64_t lda,
-                                                                const __bf16* __restrict__ Wimg, int64_t Np, int64_t Kp,
-                                                                const float* __restrict__ bias, float* __restrict__ C,
-                                                                int64_t ldc, int64_t M, int64_t N, int64_t K, int64_t gm,
-                                                                int gn, int xcd_order, double* __restrict__ colstats) {
-  constexpr int NT = Q_BN / 32;
-  constexpr int A_ST = Q_BM * XK;        // floats per A stage (16 KiB)
-  constexpr int B_ST = 3 * Q_BN * 64;    // bytes per W stage (24 KiB)
-  constexpr int NA = 4;                  // A copies per wave and slice: its own band, 8 rows x 128 B each
-  constexpr int NB = 6;                  // W copies per wave and slice (24 groups of 16 rows x 64 B over 4 waves)
-  __shared__ __attribute__((aligned(16))) float ldsA[2 * A_ST];
-  __shared__ __attribute__((aligned(16))) unsigned char ldsB[2 * B_ST];
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = lane & 31, h = lane >> 5;
-  const uint32_t ldsA_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ldsA;
-  const uint32_t ldsB_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ldsB;
-  const uint32_t a_row = (uint32_t)((wave * 32 + i) * 128);
-  const uint32_t a_swz = (uint32_t)((i >> 1) & 7);
-  const uint32_t b_row = (uint32_t)(i * 64);
-  const uint32_t b_swz = (uint32_t)((i >> 2) & 3);
-  const int T = (int)(K / XK);
-  const int64_t tiles = gm * gn;
-
-  const bool xcd_map = xcd_order && gridDim.x == 512 && gn <= 64 && 64 % gn == 0;
-  auto tile_of = [&](int64_t j) -> int64_t {   // m * gn + n, or >= tiles: no tile for this workgroup in step j
-    if (xcd_map) {
-      const int64_t slot = blockIdx.x >> 3;
-      const int64_t m = j * (512 / gn) + (slot / gn) * 8 + (blockIdx.x & 7);
-      return m < gm ? m * gn + slot % gn : tiles;
-    }
-    return j * gridDim.x + blockIdx.x;
-  };
-
-  // ---- issue cursor: one slice ahead of the compute cursor, across tile boundaries
-  const int lr8 = lane >> 3, lc8 = lane & 7, lr4 = lane >> 2, lc4 = lane & 3;
-  const float* a_src[NA];
-  const __bf16* b_src[NB];
-  int64_t it_j = 0, it_tile = tile_of(0), gi = 0;
-  int it_u = 0;
-  auto issue_next = [&]() {
-    if (it_tile >= tiles) return;
-    if (it_u == 0) {
-      const int64_t im = it_tile / gn, in = it_tile - im * gn;
-#pragma unroll
-      for (int q = 0; q < NA; ++q) {
-        const int r = 8 * (wave * NA + q) + lr8;
-        int64_t row = im * Q_BM + r;
-        row = row < M ? row : M - 1;
-        a_src[q] = A + row * lda + 4 * (lc8 ^ ((r >> 1) & 7));
-      }
-#pragma unroll
-      for (int q = 0; q < NB; ++q) {
-        const int gidx = wave * NB + q;
-        const int img = gidx / (Q_BN / 16), rb = gidx - img * (Q_BN / 16);
-        const int r = rb * 16 + lr4;
-        b_src[q] = Wimg + ((int64_t)img * Np + in * Q_BN + r) * Kp + 8 * (lc4 ^ ((r >> 2) & 3));
-      }
-    }
-    float* stA = ldsA + (gi & 1) * A_ST;
-    unsigned char* stB = ldsB + (gi & 1) * B_ST;
-    // (letting every workgroup start its K walk at a different slice, so that 512 workgroups do not read the same 24 KB
-    // of W at the same moment, was tried: +2 % at K = 256, -6 % at K = 1024, where the W images then no longer fit in L2)
-    const int64_t k0 = (int64_t)it_u * XK;
-#pragma unroll
-    for (int q = 0; q < NB; ++q) glds16(b_src[q] + k0, stB + (wave * NB + q) * 1024);
-#pragma unroll
-    for (int q = 0; q < NA; ++q) glds16(a_src[q] + k0, stA + (8 * (wave * NA + q)) * XK);
-    ++gi;
-    if (++it_u == T) {
-      it_u = 0;
-      it_tile = tile_of(++it_j);
-    }
-  };
-  issue_next();
-
-  f32x16 acc[NT];
-  f32x4 fb[NT][3];
-  bf16x8 ah, am, al;
-  auto load_frags = [&](int stage, int st) {
-    const uint32_t aB = ldsA_base + (uint32_t)(stage * A_ST * 4) + a_row;
-    const uint32_t bB = ldsB_base + (uint32_t)(stage * B_ST) + b_row + 16u * ((uint32_t)(2 * st + h) ^ b_swz);
-    const uint32_t c0 = 16u * ((uint32_t)(4 * st + 2 * h) ^ a_swz), c1 = 16u * ((uint32_t)(4 * st + 2 * h + 1) ^ a_swz);
-    f32x4 a0, a1;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(a0) : "v"(aB + c0) : "memory");
-    asm volatile("ds_read_b128 %0, %1" : "=v"(a1) : "v"(aB + c1) : "memory");
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int sp = 0; sp < 3; ++sp)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[t][sp]) : "v"(bB), "n"(sp * Q_BN * 64 + t * 32 * 64) : "memory");
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(3 * NT) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    split8(a0, a1, ah, am, al);       // under the latency of the W reads
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto products = [&]() {   // the 6 NT MFMAs of one step, smallest partial products first
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const bf16x8 bh = __builtin_bit_cast(bf16x8, fb[t][0]), bm = __builtin_bit_cast(bf16x8, fb[t][1]),
-                   bl = __builtin_bit_cast(bf16x8, fb[t][2]);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-
-  int64_t stat_tile = -1;     // tile whose partial sums wait in LDS ...
-  float* stat_part = ldsA;    // ... in this A stage: [4 waves][Q_BN][2] floats = 4 KB
-  auto stats_readout = [&]() {
-    const int64_t pm = stat_tile / gn, pn0 = (stat_tile - pm * gn) * Q_BN;
-    for (int c = threadIdx.x; c < Q_BN; c += Q_TPB) {
-      const int64_t n = pn0 + c;
-      if (n < N) {
-        double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          s1 += (double)stat_part[(w * Q_BN + c) * 2];
-          s2 += (double)stat_part[(w * Q_BN + c) * 2 + 1];
-        }
-        double* dst = colstats + pm * 2 * N;   // one partial row per 128-row block (ccn_stats_rows)
-        dst[n] = s1;
-        dst[N + n] = s2;
-      }
-    }
-    stat_tile = -1;
-  };
-
-  int64_t g = 0;
-  for (int64_t j = 0, tile; (tile = tile_of(j)) < tiles; ++j) {
-    const int64_t tm = tile / gn, tn = tile - tm * gn;
-    const int64_t m0 = tm * Q_BM, n0 = tn * Q_BN;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int64_t n = n0 + t * 32 + i;
-      const float bv = (bias != nullptr && n < N) ? bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = bv;
-    }
-    for (int u = 0; u < T; ++u, ++g) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice g has landed (and the previous tile's stores retired)
-      __builtin_amdgcn_s_barrier();
-      if (u == 0 && stat_tile >= 0) {   // read the parked partial sums out before the next copy lands on them
-        stats_readout();
-        __builtin_amdgcn_s_barrier();
-      }
-      issue_next();
-      const int stage = (int)(g & 1);
-      load_frags(stage, 0);
-      products();
-      load_frags(stage, 1);
-      products();
-    }
-
-    // ---- tile epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
-    if (colstats != nullptr) {
-      __builtin_amdgcn_s_barrier();             // every wave is done with the stage the partial sums go to
-      stat_part = ldsA + ((g - 1) & 1) * A_ST;  // (the copy of the NEXT slice is in flight to the other stage)
-    }
-    const bool interior = m0 + Q_BM <= M && n0 + Q_BN <= N;
-    float* const crow = C + (m0 + wave * 32 + 4 * h) * ldc + n0 + i;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int ncol = t * 32 + i;
-      const int64_t n = n0 + ncol;
-      float s1 = 0.f, s2 = 0.f;
-      if (interior) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[t][r];
-          crow[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc + t * 32] = v;
-          s1 += v;
-          s2 += v * v;
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (m < M && n < N) {
-            const float v = acc[t][r];
-            C[m * ldc + n] = v;
-            s1 += v;
-            s2 += v * v;
-          }
-        }
-      }
-      if (colstats != nullptr) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (h == 0) {
-          stat_part[(wave * Q_BN + ncol) * 2] = s1;
-          stat_part[(wave * Q_BN + ncol) * 2 + 1] = s2;
-        }
-      }
-    }
-    if (colstats != nullptr) {
-      stat_tile = tile;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // table written before this wave reaches the next barrier
-    }
-  }
-  if (stat_tile >= 0) {   // statistics of the last tile
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    stats_readout();
-  }
-}
-
-
-// ------------------------------------------------------------------ round 4: the paired kernel, software-pipelined ("lean")
-// What the paired kernel above leaves on the table (0.36-0.39 of the split product's matrix-core ceiling): a wave's step is
-// "14 LDS reads . wait . 41 vector instructions of the split . 24 MFMAs", so its own MFMAs never hide its own vector work,
-// and the partner wave of the SIMD (the other workgroup) cannot hide it either -- while one wave streams MFMAs the other
-// one's vector instructions issue at about one per MFMA (profiles/r03_pair_kernel_anatomy.txt); and with 32-deep slices in
-// a two-stage ring a copy has one slice (~1.3 us at the full matrix rate, 2.7x less than in the fp32 kernel) to arrive from
-// HBM.  This kernel keeps the tile (128 x 128 per 4-wave workgroup, wave w = rows 32 w ..., two workgroups per CU) and
-// changes the schedule:
+// at its barrier, the other one issues MFMAs.  The first form of that kernel (rounds 1-3: wave w = rows 32 w ..., a step =
+// "14 LDS reads . wait . 41 vector instructions of the split . 24 MFMAs", 32-deep slices in a two-stage ring) reached
+// 0.36-0.39 of the split product's matrix-core ceiling: a wave's own MFMAs never hid its own vector work, and the partner
+// wave of the SIMD cannot hide it either -- while one wave streams MFMAs the other one's vector instructions issue at about
+// one per MFMA (profiles/r03_pair_kernel_anatomy.txt); and a copy had one slice (~1.3 us at the full matrix rate, 2.7x less
+// than in the fp32 kernel) to arrive from HBM.  Round 4 keeps the tile and changes the schedule (same bits as the first
+// form on 13 shapes, profiles/r04_gemm_x3_anatomy.txt):
 //   * one step = 16 contraction elements = 24 MFMAs per wave; the LDS reads and the three-way split of step s + 1 are
 //     placed BETWEEN the MFMAs of step s (2 reads or 3 single-issue vector instructions per MFMA gap: an MFMA holds the
 //     SIMD's issue port for 8 of its 32 cycles) into a second set of fragment registers;
@@ -1239,7 +1017,7 @@ __global__ __launch_bounds__(L_TPB, 2) void gemm_x3_lean_kernel(const float* __r
 }
 
 static void* g_x3_dbg_host = nullptr;
-static bool g_use_lean = true;   // A/B hook (ccn_gemm_x3_use_persistent(3) = the round-1 paired kernel instead)
+static bool g_use_pair = true;   // A/B hook (ccn_gemm_x3_use_persistent(2) = no paired kernel)
 
 void launch_x3_lean(const float* A, int64_t lda, const __bf16* img, const float* bias, float* Y, int64_t ldy, int64_t M,
                     int64_t N, int64_t K, double* colstats, hipStream_t s) {
@@ -1253,18 +1031,6 @@ void launch_x3_lean(const float* A, int64_t lda, const __bf16* img, const float*
   else
     hipLaunchKernelGGL((gemm_x3_lean_kernel<false>), dim3((unsigned)grid), dim3(L_TPB), 0, s, A, lda, wf, bias, Y, ldy, M, N, K,
                        tiles, gn, 1, colstats);
-}
-
-static bool g_use_pair = true;   // A/B hook (ccn_gemm_x3_use_persistent(2) = no paired kernel)
-
-void launch_x3_pair(const float* A, int64_t lda, const __bf16* img, int64_t Np, int64_t Kp, const float* bias, float* Y,
-                    int64_t ldy, int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s) {
-  const int64_t gm = (M + Q_BM - 1) / Q_BM;
-  const int gn = (int)((N + Q_BN - 1) / Q_BN);
-  const int64_t tiles = gm * gn;
-  const int64_t grid = tiles < 512 ? tiles : 512;   // two workgroups per CU
-  hipLaunchKernelGGL(gemm_x3_pair_kernel, dim3((unsigned)grid), dim3(Q_TPB), 0, s, A, lda, img, Np, Kp, bias, Y, ldy, M, N, K,
-                     gm, gn, 1, colstats);
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -1285,8 +1051,7 @@ extern "C" {
 
 int ccn_gemm_x3_use_persistent(int on) {
   g_use_persistent = on != 0;
-  g_use_pair = on == 1 || on == 3;
-  g_use_lean = on == 1;
+  g_use_pair = on == 1;
   return CCN_OK;
 }
 
@@ -1318,7 +1083,7 @@ int ccn_gemm_nt_x3(const float* A, int64_t lda, const float* W, int64_t ldw, con
   CCN_REQUIRE((gm + 7) / 8 * 8 * ((N + 31) / 32) <= 2147483647LL, "gemm_nt_x3: grid too large");
   __bf16* img = reinterpret_cast<__bf16*>(wsplit);
   // the software-pipelined paired kernel: N > 64, whole 32-deep slices, at least 128 tiles of 128 x 128 (< 2^31 of them)
-  if (g_use_persistent && g_use_pair && g_use_lean && N > 64 && K % XK == 0 && K >= 64 &&
+  if (g_use_persistent && g_use_pair && N > 64 && K % XK == 0 && K >= 64 &&
       ((M + L_BM - 1) / L_BM) * ((N + L_BN - 1) / L_BN) >= 128 && ((M + L_BM - 1) / L_BM) * ((N + L_BN - 1) / L_BN) < (1LL << 31) &&
       (L_BM - 1) * lda < (1LL << 29)) {
     const int64_t T16 = K / 16;
@@ -1333,12 +1098,6 @@ int ccn_gemm_nt_x3(const float* A, int64_t lda, const float* W, int64_t ldw, con
   // many 256-row tiles and whole K slices: the persistent LDS-DMA kernel (one workgroup per CU, 256 CUs)
   const bool persistent = g_use_persistent && K % XK == 0 && K >= 64 &&
                           ((M + P_BM - 1) / P_BM) * ((N + 127) / 128) >= 512;
-  if (g_use_persistent && g_use_pair && N > 64 && K % XK == 0 && K >= 64 &&
-      ((M + Q_BM - 1) / Q_BM) * ((N + Q_BN - 1) / Q_BN) >= 128) {
-    launch_x3_pair(A, lda, img, Np, Kp, bias, Y, ldy, M, N, K, colstats, s);
-    CCN_LAUNCH_OK("gemm_nt_x3");
-    return CCN_OK;
-  }
   if (persistent) {
     if (N <= 32)
       launch_x3_persistent<32>(A, lda, img, Np, Kp, bias, Y, ldy, M, N, K, colstats, s);

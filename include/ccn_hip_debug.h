@@ -16,7 +16,7 @@ int ccn_gemm_force_generic(int on); /* test hook: route every GEMM through the u
 /* diagnostics of ccn_gemm_nt_h (timing only, results wrong when set; a separate instantiation of the kernel): bit 0 = no epilogue stores, bit 1 = no wait for the copies, bit 2 = start stagger of the second workgroup of a CU */
 int ccn_gemm_h_opt(int opt);
 int ccn_frnn_query_mode(int mode); /* A/B hook: 0 = automatic, 1 = one thread per query, 2 / 3 = a team of 32 / 64 lanes per query */
-int ccn_gemm_x3_use_persistent(int on); /* A/B hook: 0 = the register-staged kernel for every shape, 2 = no paired 4-wave workgroups (8-wave persistent kernel for every N), 3 = the round-1 paired kernel instead of the software-pipelined one, 1 = default */
+int ccn_gemm_x3_use_persistent(int on); /* A/B hook: 0 = the register-staged kernel for every shape, 2 = no paired 4-wave workgroups (8-wave persistent kernel for every N), 1 = default */
 int ccn_gemm_x3_debug(void* buf);       /* diagnostic: a device buffer of 512 x 4 x 16 uint64 words switches ccn_gemm_nt_x3's software-pipelined kernel to a build that stamps (s_memtime) where every wave's cycles go; NULL = off (tools/x3_stamps.py) */
 int ccn_gemm_tn_use_dma(int on);    /* A/B hook: 0 = always the register-staged split-K kernel of ccn_gemm_tn */
 int ccn_fps_set_lds_claim(int bytes); /* A/B hook: dynamic LDS a sampling workgroup claims to keep its CU free of GEMM workgroups (default and maximum 98304, 0 = none) */

@@ -48,14 +48,6 @@ for m, n, k in SHAPES:
         fn = lambda: call(name, ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats), *extra)
         res[name] = timeit(fn)
         ys[name] = y
-    if not os.environ.get("X3_HOOK"):       # the round-1 paired kernel on the same operands
-        lib().ccn_gemm_x3_use_persistent(3)
-        name = "gemm_nt_x3"
-        y = _rows(m, n, dev)
-        fn = lambda: call(name, ptr(x), _ld(x), ptr(w), _ld(w), ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats), ptr(scratch), nb)
-        res["x3_r1"] = timeit(fn)
-        lib().ccn_gemm_x3_use_persistent(1)
-        res["dev"] = float((y[:, :n] - ys["gemm_nt_x3"][:, :n]).abs().max())
     rows = torch.randint(0, m, (512,), device=dev)
     xs, wd = x[rows, :k].double(), w[:, :k].double()
     ref = xs @ wd.t() + bias.double()
@@ -64,7 +56,5 @@ for m, n, k in SHAPES:
     fl = 2.0 * m * n * k
     print("%9d x %4d -> %4d  %8.1f %8.1f %8.1f   %9.2e %9.2e %9.2e   ms %.3f %.3f %.3f" % (
         (m, k, n) + tuple(fl / (res[nm] * 1e-3) / 1e12 for nm in ("gemm_nt", "gemm_nt_x3", "gemm_nt_bf16")) + tuple(errs)
-        + tuple(res[nm] for nm in ("gemm_nt", "gemm_nt_x3", "gemm_nt_bf16")))
-          + ("   r1 paired kernel %.1f TFLOP/s (%.3f ms), max |difference| %.2e" % (fl / (res["x3_r1"] * 1e-3) / 1e12, res["x3_r1"], res["dev"])
-             if "x3_r1" in res else ""), flush=True)
+        + tuple(res[nm] for nm in ("gemm_nt", "gemm_nt_x3", "gemm_nt_bf16"))), flush=True)
     del x, w, ys, stats
