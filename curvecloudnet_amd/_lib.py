@@ -96,6 +96,11 @@ PROFILE_ONLY = None     # optional name prefix: only these entry points are time
 PROFILE_FILTER = None   # optional predicate(name, args): only the launches it accepts are timed
 
 
+# entries that are the same product with caller-owned scratch (the last two arguments): recorded as the product, so that
+# bench.py's labels and curvecloudnet_amd.costs key on ONE name and ONE argument order per product
+PROFILE_ALIAS = {"gemm_nt_ws": "gemm_nt", "gemm_nt_acc_ws": "gemm_nt_acc", "gemm_nt_xf_ws": "gemm_nt_xf",
+                 "gemm_nt_red_ws": "gemm_nt_red"}
+
 EXTRA_LAUNCH = None     # experiment (tools/launch_cost.py): a callable launching one trivial kernel after every call
 
 
@@ -106,8 +111,13 @@ def call(name, *args, work_rows=None):
     fn = getattr(lib(), "ccn_" + name)
     if EXTRA_LAUNCH is not None:
         EXTRA_LAUNCH()
-    if (PROFILE is None or (PROFILE_ONLY is not None and not name.startswith(PROFILE_ONLY))
-            or (PROFILE_FILTER is not None and not PROFILE_FILTER(name, args))):
+    if PROFILE is None:
+        check(fn(*args, stream()), name)
+        return
+    # (a product with scratch is recorded as the product: its name, its arguments without the trailing scratch pair)
+    pname, pargs = (PROFILE_ALIAS[name], args[:-2]) if name in PROFILE_ALIAS else (name, args)
+    if ((PROFILE_ONLY is not None and not pname.startswith(PROFILE_ONLY))
+            or (PROFILE_FILTER is not None and not PROFILE_FILTER(pname, pargs))):
         check(fn(*args, stream()), name)
         return
     # torch.cuda.Event records on torch's current stream, which is exactly the stream passed to the kernel
@@ -116,8 +126,8 @@ def call(name, *args, work_rows=None):
     check(fn(*args, stream()), name)
     end.record()
     # integer arguments (sizes / leading dimensions) and the positions of NULL pointers identify the kernel variant
-    PROFILE.append((name, tuple(a for a in args if isinstance(a, int)), beg, end,
-                    tuple(i for i, a in enumerate(args) if a is None), work_rows))
+    PROFILE.append((pname, tuple(a for a in pargs if isinstance(a, int)), beg, end,
+                    tuple(i for i, a in enumerate(pargs) if a is None), work_rows))
 
 
 def require_gpu(*tensors):

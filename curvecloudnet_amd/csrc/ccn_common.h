@@ -5,6 +5,7 @@
 #include <stddef.h>
 
 #include "../../include/ccn_hip.h"
+#include "../../include/ccn_hip_debug.h"   // (included so that a drift between a hook's prototype and its definition is a compile error)
 
 // ---- error reporting (never throws; negative return + ccn_last_error()) ----
 void ccn_set_error(const char* fmt, ...);

@@ -1126,7 +1126,15 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
                                                                    double* __restrict__ colstats, int64_t a_extent,
                                                                    const float* __restrict__ xf_scale,
                                                                    const float* __restrict__ xf_shift, int xf_act,
-                                                                   float xf_slope, int64_t red_ldy = 0) {
+                                                                   float xf_slope, int64_t red_ldy, int64_t full_tiles,
+                                                                   int split_s, float* __restrict__ split_ws) {
+  // full_tiles / split_s / split_ws (round 5, "split tails"): tiles [0, full_tiles) are walked whole by the persistent loop, in
+  // rounds of gridDim.x; the tiles [full_tiles, tiles) of the last, partly filled round are cut into split_s parts along K, one
+  // part per workgroup, so that the round takes 1 / split_s of a tile time instead of a whole one with most CUs idle
+  // (10 550 x 1024 -> 1024: 664 tiles over 512 slots = 2 rounds for 1.3 rounds of work).  A part writes its accumulators to
+  // split_ws; the LAST part of a tile to arrive (a counter per tile in front of the partials, left at zero again) adds the
+  // parts in part order -- its own included, so the sum does not depend on who came last -- and runs the tile's epilogue.
+  // split_s <= 1: no tail round (full_tiles == tiles).
   // a_extent: floats readable from the start of an A row (= lda, or K when rows overlap: ccn_conv_rows_nt)
   // RED: xf_scale = the previous layer's 4 x N table (scale | shift | mean | rstd, rows N floats apart), xf_shift = its
   // pre-normalisation output y (leading dimension red_ldy), xf_act / xf_slope = its activation
@@ -1162,17 +1170,25 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   // (tile arithmetic in 32 bits -- a 64-bit division is ~130 dependent scalar instructions and there were eight per tile;
   // measured neutral on speed, 12 VGPRs and 14 spilled SGPRs fewer; the launcher checks tiles < 2^31)
   const uint32_t gnu = (uint32_t)gn;
-  const uint32_t gm_tiles = (uint32_t)tiles / gnu;
+  const uint32_t gm_tiles = (uint32_t)full_tiles / gnu;     // (a tail round starts at a whole tile row: 512 % gnu == 0 there)
   const bool xcd_map = xcd_order && gridDim.x == 512 && gnu <= 64 && 64 % gnu == 0;
   const uint32_t slot = blockIdx.x >> 3;
   const uint32_t rows_per_step = 512u / gnu, slot_row = (slot / gnu) * 8 + (blockIdx.x & 7), slot_col = slot % gnu;
-  auto tile_of = [&](int64_t j) -> int64_t {   // as in the 8-wave kernel, with 64 workgroup slots per XCD
+  auto tile_of = [&](int64_t j) -> int64_t {   // as in the 8-wave kernel, with 64 workgroup slots per XCD (>= tiles: none)
     if (xcd_map) {
       const uint32_t m = (uint32_t)j * rows_per_step + slot_row;
       return m < gm_tiles ? (int64_t)(m * gnu + slot_col) : tiles;
     }
-    return j * gridDim.x + blockIdx.x;
+    const int64_t t = j * gridDim.x + blockIdx.x;
+    return t < full_tiles ? t : tiles;
   };
+  // this workgroup's part of the tail round: tile full_tiles + (id % rem), slices [tail_u0, tail_u1)
+  const int64_t tail_rem = tiles - full_tiles;
+  const bool has_tail_item = split_s > 1 && (int64_t)blockIdx.x < tail_rem * split_s;
+  const int tail_idx = has_tail_item ? (int)((int64_t)blockIdx.x % tail_rem) : 0;
+  const int tail_part = has_tail_item ? (int)((int64_t)blockIdx.x / tail_rem) : 0;
+  const int tail_u0 = tail_part * TT / (split_s > 1 ? split_s : 1), tail_u1 = (tail_part + 1) * TT / (split_s > 1 ? split_s : 1);
+  __shared__ int split_flag;
   auto tile_row = [&](int64_t t) -> int64_t { return (int64_t)((uint32_t)t / gnu); };
   auto tile_col = [&](int64_t t) -> int64_t { return (int64_t)((uint32_t)t % gnu); };
 
@@ -1184,10 +1200,18 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   const char* b_tile = reinterpret_cast<const char*>(B);
   int64_t it_j = 0, it_tile = tile_of(0), gi = 0;
   int64_t im0 = 0, in0 = 0;
-  int it_u = 0;
+  int it_u = 0, it_uend = TT;
+  bool it_first = true, it_tail_left = has_tail_item;
+  if (it_tile >= tiles && it_tail_left) {     // no whole tile for this workgroup: the tail part is its first item
+    it_tail_left = false;
+    it_tile = full_tiles + tail_idx;
+    it_u = tail_u0;
+    it_uend = tail_u1;
+  }
   auto issue_next = [&]() {
     if (it_tile >= tiles) return;
-    if (it_u == 0) {
+    if (it_first) {
+      it_first = false;
       im0 = tile_row(it_tile) * PR_BM;
       in0 = tile_col(it_tile) * PR_BN;
       a_tile = reinterpret_cast<const char*>(A + im0 * lda);
@@ -1239,9 +1263,17 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written before this wave reaches the next barrier
     }
     ++gi;
-    if (++it_u == TT) {
+    if (++it_u == it_uend) {
       it_u = 0;
+      it_uend = TT;
+      it_first = true;
       it_tile = tile_of(++it_j);
+      if (it_tile >= tiles && it_tail_left) {
+        it_tail_left = false;
+        it_tile = full_tiles + tail_idx;
+        it_u = tail_u0;
+        it_uend = tail_u1;
+      }
     }
   };
   // (in-kernel experiments of rounds 2-3 -- a start stagger / instruction priorities for the second workgroup of a CU, a
@@ -1270,9 +1302,28 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_r0) : : "memory");
   }
   int64_t g = 0;
-  for (int64_t j = 0, tile; (tile = tile_of(j)) < tiles; ++j) {
+  bool tail_left = has_tail_item;
+  for (int64_t j = 0;; ++j) {
+    int64_t tile = tile_of(j);
+    int u_beg = 0, u_end = TT, part = -1;     // part >= 0: this item is part `part` of a split tile
+    if (tile >= tiles) {
+      if (!tail_left) break;
+      tail_left = false;
+      tile = full_tiles + tail_idx;
+      u_beg = tail_u0;
+      u_end = tail_u1;
+      part = tail_part;
+    }
     const int64_t m0 = tile_row(tile) * PR_BM, n0 = tile_col(tile) * PR_BN;
     f32x16 acc[2][2];
+    if (part > 0) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ab][t][r] = 0.f;
+    } else
     if (ACC) {
       const bool inside = m0 + PR_BM <= M && n0 + PR_BN <= N;
 #pragma unroll
@@ -1316,14 +1367,14 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     }
     }
 
-    for (int u = 0; u < TT; ++u, ++g) {
+    for (int u = u_beg; u < u_end; ++u, ++g) {
       if (STAMP) PR_STAMP(st_a);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice g has landed (and the previous tile's stores retired)
       if (STAMP) { PR_STAMP(st_b); sum_w += (uint32_t)(st_b - st_a); }
       __builtin_amdgcn_s_barrier();
       if (STAMP) { PR_STAMP(st_a); sum_b += (uint32_t)(st_a - st_b); }
       issue_next();
-      if (u == 0 && stat_tile >= 0) stats_readout();
+      if (u == u_beg && stat_tile >= 0) stats_readout();
       if (STAMP) { PR_STAMP(st_b); sum_i += (uint32_t)(st_b - st_a); }
       const uint32_t stage_b = lds_base + (uint32_t)((g & 1) * STAGE * 4);
       f32x4 fa[2][2], fb[2][2];   // [K group parity][block]
@@ -1357,16 +1408,22 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
         // a handful of VALU instructions of the NEXT group's transform.  A wave issues in order and the matrix pipe takes
         // one MFMA per 64 cycles, so VALU work placed between MFMAs is free, VALU work behind all sixteen is not (first
         // form: transform after the group's MFMAs, 10-25 % slower than the plain product).
-        auto xform_comp = [&](int par, int comp) {
+        // (round 5: TWO K components per call in packed form -- v_pk_fma_f32, v_pk_mul_f32 and two v_max_f32 per block instead
+        // of fma / mul / cmp / cndmask + the VCC hazard's wait states per element: 8 vector instructions per call where the
+        // round-2 form issued 16 + 8 s_nop.  max(v, v * neg) == (v > 0 ? v : v * neg) for 0 <= neg <= 1, the entry point checks it.)
+        const f32x2 neg2 = {xf_neg, xf_neg};
+        auto xform_pair = [&](int par, int c2) {
           __builtin_amdgcn_sched_barrier(0);
+          const f32x2 sc = {xs[par][2 * c2], xs[par][2 * c2 + 1]}, sh = {xh[par][2 * c2], xh[par][2 * c2 + 1]};
 #pragma unroll
-          for (int ab = 0; ab < 2; ++ab)
-          {
-            // branch-free form of bn_act_value (the run-time switch on the activation compiled to scalar branches around
-            // every element: 304 s_cbranch in the kernel): same bits, except that ReLU gives -0.0 instead of +0.0 for a
-            // negative input -- equal under comparison and in every sum it enters
-            const float v = fa[par][ab][comp] * xs[par][comp] + xh[par][comp];
-            fa[par][ab][comp] = v > 0.f ? v : v * xf_neg;
+          for (int ab = 0; ab < 2; ++ab) {
+            // branch-free form of bn_act_value: same bits, except that ReLU gives -0.0 instead of +0.0 for a negative
+            // input -- equal under comparison and in every sum it enters
+            const f32x2 a = {fa[par][ab][2 * c2], fa[par][ab][2 * c2 + 1]};
+            const f32x2 v = __builtin_elementwise_fma(a, sc, sh);
+            const f32x2 w = v * neg2;
+            fa[par][ab][2 * c2] = __builtin_fmaxf(v.x, w.x);
+            fa[par][ab][2 * c2 + 1] = __builtin_fmaxf(v.y, w.y);
           }
         };
         auto mfma_comp = [&](int par, int comp) {
@@ -1382,8 +1439,8 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
         read_group(0, fa[0], fb[0]);
         xf_read(0, xs[0], xh[0]);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(xs[0]), "+v"(xh[0]) : : "memory");
-#pragma unroll
-        for (int comp = 0; comp < 4; ++comp) xform_comp(0, comp);
+        xform_pair(0, 0);
+        xform_pair(0, 1);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int par = q & 1, nxt = (q + 1) & 1;
@@ -1394,14 +1451,10 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
           mfma_comp(par, 0);
           if (q < 3) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[nxt][0]), "+v"(fa[nxt][1]), "+v"(xs[nxt]), "+v"(xh[nxt]) : : "memory");   // (issued before four MFMAs: long landed)
-            xform_comp(nxt, 0);
-            xform_comp(nxt, 1);
+            xform_pair(nxt, 0);
           }
           mfma_comp(par, 1);
-          if (q < 3) {
-            xform_comp(nxt, 2);
-            xform_comp(nxt, 3);
-          }
+          if (q < 3) xform_pair(nxt, 1);
           mfma_comp(par, 2);
           mfma_comp(par, 3);
         }
@@ -1422,6 +1475,66 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       if (STAMP) { PR_STAMP(st_a); sum_c += (uint32_t)(st_a - st_b); ++n_sl; }
     }
     if (STAMP) PR_STAMP(st_a);
+
+    if (part >= 0) {
+      // ---- part of a split tile: accumulators -> split_ws in register order (every store instruction of a wave writes 256
+      // contiguous bytes), release, count; the last part to arrive acquires, re-reads ALL parts in part order and goes on to
+      // the epilogue, the others are done.  (Agent-scope fences: the parts of a tile run on different XCDs, whose L2s are
+      // not coherent for plain stores -- __threadfence() is buffer_wbl2 / buffer_inv on gfx950.)
+      int* const counters = reinterpret_cast<int*>(split_ws);
+      float* const parts = split_ws + 1024 + (int64_t)tail_idx * split_s * (PR_BM * PR_BN);
+      float* const mine = parts + (int64_t)part * (PR_BM * PR_BN);
+      // (scalar base per register + one 32-bit lane offset, as the epilogue's stores: 64 different 64-bit vector addresses --
+      // the offsets exceed the instruction's immediate -- cost 128 registers and spilled the accumulators)
+      const uint32_t lane_off = (uint32_t)threadIdx.x * 4u;
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float* const rowp = mine + ((ab * 2 + t) * 16 + r) * PR_TPB;
+            asm volatile("global_store_dword %0, %1, %2" : : "v"(lane_off), "v"(acc[ab][t][r]), "s"(rowp) : "memory");
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __threadfence();
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const int old = atomicAdd(&counters[tail_idx], 1);
+        split_flag = old;
+        if (old == split_s - 1) counters[tail_idx] = 0;     // (every part has counted: left at zero for the next launch)
+      }
+      __syncthreads();
+      if (split_flag != split_s - 1) break;                  // (the tail part is a workgroup's last item)
+      __threadfence();
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float* const rowp = parts + ((ab * 2 + t) * 16 + r) * PR_TPB;
+            asm volatile("global_load_dword %0, %1, %2" : "=v"(acc[ab][t][r]) : "v"(lane_off), "s"(rowp) : "memory");
+          }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) : : "memory");
+      for (int pp = 1; pp < split_s; ++pp) {
+        const float* const pq = parts + (int64_t)pp * (PR_BM * PR_BN);
+#pragma unroll
+        for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            // (one 32 x 32 block = 16 loads at a time: all 64 in flight would need 64 registers beside the accumulators)
+            f32x16 tmp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float* const rowp = pq + ((ab * 2 + t) * 16 + r) * PR_TPB;
+              asm volatile("global_load_dword %0, %1, %2" : "=v"(tmp[r]) : "v"(lane_off), "s"(rowp) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(tmp) : : "memory");
+            acc[ab][t] += tmp;
+          }
+      }
+    }
 
     // ---- tile epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
     const bool interior = m0 + PR_BM <= M && n0 + PR_BN <= N;
@@ -1552,37 +1665,55 @@ static bool g_use_pair = true;  // A-B hook (ccn_gemm_use_dma(4) = the 8-wave pe
 // the register-staged kernel, 10550 x 1024 -> 1024 (664 tiles) 99 vs 84, 35151 x 512 -> 512 107 vs 88 on the 8-wave kernel)
 constexpr int64_t PAIR_MIN_TILES = 128;
 
+// Tail split (see the kernel): parts per tile of the last, partly filled round.  1 = none.  Needs caller-owned scratch
+// (ccn_gemm_nt_split_workspace_bytes: 4 KiB of counters, zero on first use and left zero, + one 64 KiB partial per part).
+constexpr int64_t PAIR_SLOTS = 512;                // two workgroups per CU
+constexpr size_t SPLIT_WS_HEAD = 4096;             // counters
+constexpr size_t SPLIT_WS_BYTES = SPLIT_WS_HEAD + (size_t)PAIR_SLOTS * PR_BM * PR_BN * 4;
+static int pair_split_parts(int64_t tiles, int64_t K, const void* ws, size_t ws_bytes) {
+  if (ws == nullptr || (g_pair_opt & (4 | 512)) || ((uintptr_t)ws & 15)) return 1;      // (512: A-B hook, no split)
+  const int64_t rem = tiles % PAIR_SLOTS, TT = K / BK + (K % BK != 0);
+  if (rem == 0 || rem > PAIR_SLOTS / 2 || TT < 8) return 1;
+  int64_t sp = PAIR_SLOTS / rem;
+  if (sp > 8) sp = 8;
+  if (sp > TT / 4) sp = TT / 4;                    // a part is at least four slices long
+  while (sp >= 2 && SPLIT_WS_HEAD + (size_t)(rem * sp) * PR_BM * PR_BN * 4 > ws_bytes) --sp;
+  return sp >= 2 ? (int)sp : 1;
+}
+
 int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                      int64_t M, int64_t N, int64_t K, double* colstats, hipStream_t s, int64_t a_extent, bool accumulate = false,
                      const float* xf_scale = nullptr, const float* xf_shift = nullptr, int xf_act = 0, float xf_slope = 0.f,
-                     bool split_part = false, int64_t red_ldy = 0) {
+                     bool split_part = false, int64_t red_ldy = 0, void* ws = nullptr, size_t ws_bytes = 0) {
   const int64_t gm = (M + PR_BM - 1) / PR_BM, gn = (N + PR_BN - 1) / PR_BN;
   const int64_t tiles = gm * gn;
   if (tiles >= ((int64_t)1 << 31)) {
     ccn_set_error("gemm_nt: more than 2^31 output tiles");
     return CCN_ERR_ARG;
   }
-  const int64_t slots = (g_pair_opt & 4) ? 256 : 512;
-  const int64_t grid = tiles < slots ? tiles : slots;  // two workgroups per CU
+  const int64_t slots = (g_pair_opt & 4) ? 256 : PAIR_SLOTS;
+  const int sp = pair_split_parts(tiles, K, ws, ws_bytes);
+  const int64_t rem = tiles % PAIR_SLOTS;
+  const int64_t full_tiles = sp > 1 ? tiles - rem : tiles;
+  const int64_t grid = sp > 1 ? (full_tiles > 0 ? PAIR_SLOTS : rem * sp) : (tiles < slots ? tiles : slots);
+  float* const sws = sp > 1 ? (float*)ws : nullptr;
+#define CCN_PAIR_LAUNCH(...)                                                                                                      \
+  hipLaunchKernelGGL((gemm_glds_pair_kernel<__VA_ARGS__>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy, M,  \
+                     N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, xf_scale, xf_shift, xf_act, xf_slope, red_ldy,        \
+                     full_tiles, sp, sws)
   if (g_pair_dbg_host != nullptr && xf_scale == nullptr && !accumulate && !split_part)
-    hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 0, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y,
-                       ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, nullptr, nullptr, 0, 0.f);
+    CCN_PAIR_LAUNCH(false, false, 0, true);
   else if (red_ldy > 0)      // (xf_scale = the previous layer's table, xf_shift = its output y: see RED)
-    hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 0, false, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W,
-                       ldw, bias, Y, ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, xf_scale, xf_shift, xf_act,
-                       xf_slope, red_ldy);
+    CCN_PAIR_LAUNCH(false, false, 0, false, true);
   else if (xf_scale != nullptr)
-    hipLaunchKernelGGL((gemm_glds_pair_kernel<false, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
-                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, xf_scale, xf_shift, xf_act, xf_slope);
+    CCN_PAIR_LAUNCH(false, true);
   else if (accumulate)
-    hipLaunchKernelGGL((gemm_glds_pair_kernel<true, false>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
-                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, nullptr, nullptr, 0, 0.f);
+    CCN_PAIR_LAUNCH(true, false);
   else if (split_part)
-    hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 1>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y,
-                       ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, nullptr, nullptr, 0, 0.f);
+    CCN_PAIR_LAUNCH(false, false, 1);
   else
-    hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
-                       M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, nullptr, nullptr, 0, 0.f);
+    CCN_PAIR_LAUNCH(false, false);
+#undef CCN_PAIR_LAUNCH
   return CCN_OK;
 }
 
@@ -2145,7 +2276,8 @@ int ccn_gemm_nt_f16(const float* A, int64_t lda, const float* W, int64_t ldw, co
 }
 
 static int gemm_nt_impl(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
-                        int64_t M, int64_t N, int64_t K, double* colstats, void* stream, bool overlap);
+                        int64_t M, int64_t N, int64_t K, double* colstats, void* stream, bool overlap, void* ws = nullptr,
+                        size_t ws_bytes = 0);
 
 int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
                 int64_t M, int64_t N, int64_t K, double* colstats, void* stream) {
@@ -2155,22 +2287,46 @@ int ccn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const 
   return gemm_nt_impl(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, stream, false);
 }
 
+// ---- the same products with caller-owned scratch for the tail split of the paired kernel (round 5; launch_glds_pair).  The
+// scratch is used only when the split applies; its first 4 KiB must be zero on first use and are left zero.  One buffer per
+// stream (two launches that may overlap must not share it).
+size_t ccn_gemm_nt_split_workspace_bytes(void) { return SPLIT_WS_BYTES; }
+
+int ccn_gemm_nt_split_parts(int64_t M, int64_t N, int64_t K, size_t workspace_bytes) {   // what the launch would do (diagnostic)
+  static const char dummy[16] __attribute__((aligned(16))) = {0};
+  return pair_split_parts(((M + PR_BM - 1) / PR_BM) * ((N + PR_BN - 1) / PR_BN), K, dummy, workspace_bytes);
+}
+
+int ccn_gemm_nt_ws(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                   int64_t M, int64_t N, int64_t K, double* colstats, void* workspace, size_t workspace_bytes, void* stream) {
+  CCN_REQUIRE(A && W && Y, "gemm_nt_ws: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, "gemm_nt_ws: bad sizes M=%lld N=%lld K=%lld",
+              (long long)M, (long long)N, (long long)K);
+  return gemm_nt_impl(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, stream, false, workspace, workspace_bytes);
+}
+
 int ccn_gemm_nt_acc_ok(int64_t lda, int64_t ldw, int64_t M, int64_t N, int64_t K) {
   return lda % 4 == 0 && ldw % 4 == 0 && lda >= 4 && ldw >= 4 && !g_force_generic && g_use_glds && g_use_persistent &&
          g_use_pair && M >= 1024 && K >= g_dma_min_k && N > 64 &&
          ((M + PR_BM - 1) / PR_BM) * ((N + PR_BN - 1) / PR_BN) >= PAIR_MIN_TILES;
 }
 
-int ccn_gemm_nt_acc(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M, int64_t N,
-                    int64_t K, void* stream) {
+int ccn_gemm_nt_acc_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M, int64_t N,
+                       int64_t K, void* workspace, size_t workspace_bytes, void* stream) {
   CCN_REQUIRE(A && W && Y, "gemm_nt_acc: null pointer");
   CCN_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, "gemm_nt_acc: bad sizes");
   CCN_REQUIRE(ccn_gemm_nt_acc_ok(lda, ldw, M, N, K) && aligned16(A) && aligned16(W),
               "gemm_nt_acc: shape / alignment outside the paired LDS-DMA kernel (ask ccn_gemm_nt_acc_ok first)");
-  int rc = launch_glds_pair(A, lda, W, ldw, nullptr, Y, ldy, M, N, K, nullptr, (hipStream_t)stream, lda, true);
+  int rc = launch_glds_pair(A, lda, W, ldw, nullptr, Y, ldy, M, N, K, nullptr, (hipStream_t)stream, lda, true, nullptr, nullptr, 0,
+                            0.f, false, 0, workspace, workspace_bytes);
   if (rc) return rc;
   CCN_LAUNCH_OK("gemm_nt_acc");
   return CCN_OK;
+}
+
+int ccn_gemm_nt_acc(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M, int64_t N,
+                    int64_t K, void* stream) {
+  return ccn_gemm_nt_acc_ws(A, lda, W, ldw, Y, ldy, M, N, K, nullptr, 0, stream);
 }
 
 // dZ = dY W^T-form product (as ccn_gemm_nt, no bias) + the BatchNorm-backward column sums of the layer that produced the
@@ -2179,13 +2335,20 @@ int ccn_gemm_nt_acc(const float* A, int64_t lda, const float* W, int64_t ldw, fl
 int ccn_gemm_nt_red(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M, int64_t N,
                     int64_t K, const float* y_prev, int64_t ldyp, const float* par, int act, float slope, double* sums,
                     void* stream) {
+  return ccn_gemm_nt_red_ws(A, lda, W, ldw, Y, ldy, M, N, K, y_prev, ldyp, par, act, slope, sums, nullptr, 0, stream);
+}
+
+int ccn_gemm_nt_red_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M, int64_t N,
+                       int64_t K, const float* y_prev, int64_t ldyp, const float* par, int act, float slope, double* sums,
+                       void* workspace, size_t workspace_bytes, void* stream) {
   CCN_REQUIRE(A && W && Y && y_prev && par && sums, "gemm_nt_red: null pointer");
   CCN_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N && ldyp >= N, "gemm_nt_red: bad sizes");
   CCN_REQUIRE(ccn_gemm_nt_acc_ok(lda, ldw, M, N, K) && aligned16(A) && aligned16(W) && ldyp < ((int64_t)1 << 27),
               "gemm_nt_red: shape / alignment outside the paired LDS-DMA kernel (ask ccn_gemm_nt_acc_ok first)");
   hipStream_t s = (hipStream_t)stream;
   double* partial = sums + 2 * N;
-  int rc = launch_glds_pair(A, lda, W, ldw, nullptr, Y, ldy, M, N, K, partial, s, lda, false, par, y_prev, act, slope, false, ldyp);
+  int rc = launch_glds_pair(A, lda, W, ldw, nullptr, Y, ldy, M, N, K, partial, s, lda, false, par, y_prev, act, slope, false, ldyp,
+                            workspace, workspace_bytes);
   if (rc) return rc;
   launch_col_reduce(partial, ccn_stats_rows(M), 2 * N, sums, s);
   CCN_LAUNCH_OK("gemm_nt_red");
@@ -2199,12 +2362,19 @@ int ccn_gemm_nt_xf_ok(int64_t lda, int64_t ldw, int64_t M, int64_t N, int64_t K)
 int ccn_gemm_nt_xf(const float* A, int64_t lda, const float* a_scale, const float* a_shift, int a_act, float a_slope,
                    const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
                    double* colstats, void* stream) {
+  return ccn_gemm_nt_xf_ws(A, lda, a_scale, a_shift, a_act, a_slope, W, ldw, bias, Y, ldy, M, N, K, colstats, nullptr, 0, stream);
+}
+
+int ccn_gemm_nt_xf_ws(const float* A, int64_t lda, const float* a_scale, const float* a_shift, int a_act, float a_slope,
+                      const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                      double* colstats, void* workspace, size_t workspace_bytes, void* stream) {
   CCN_REQUIRE(A && a_scale && a_shift && W && Y, "gemm_nt_xf: null pointer");
   CCN_REQUIRE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldy >= N, "gemm_nt_xf: bad sizes");
+  CCN_REQUIRE(a_act != CCN_ACT_LEAKY || (a_slope >= 0.f && a_slope <= 1.f), "gemm_nt_xf: LeakyReLU slope outside [0, 1]");
   CCN_REQUIRE(ccn_gemm_nt_xf_ok(lda, ldw, M, N, K) && aligned16(A) && aligned16(W),
               "gemm_nt_xf: shape / alignment outside the paired LDS-DMA kernel (ask ccn_gemm_nt_xf_ok first)");
   int rc = launch_glds_pair(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, (hipStream_t)stream, lda, false, a_scale, a_shift,
-                            a_act, a_slope);
+                            a_act, a_slope, false, 0, workspace, workspace_bytes);
   if (rc) return rc;
   CCN_LAUNCH_OK("gemm_nt_xf");
   return CCN_OK;
@@ -2220,7 +2390,8 @@ int ccn_conv_rows_nt(const float* A, int64_t lda, const float* W, int64_t ldw, c
 }
 
 static int gemm_nt_impl(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
-                        int64_t M, int64_t N, int64_t K, double* colstats, void* stream, bool overlap) {
+                        int64_t M, int64_t N, int64_t K, double* colstats, void* stream, bool overlap, void* ws,
+                        size_t ws_bytes) {
   hipStream_t s = (hipStream_t)stream;
   if (M == 0) return CCN_OK;
   int rc;
@@ -2241,12 +2412,13 @@ static int gemm_nt_impl(const float* A, int64_t lda, const float* W, int64_t ldw
     if ((g_pair_opt & 64) == 0 && colstats == nullptr && N > PR_BN && N % PR_BN != 0 && N % PR_BN <= 64 &&
         ((M + PR_BM - 1) / PR_BM) * (n_main / PR_BN) >= PAIR_MIN_TILES) {
       rc = launch_glds_pair(A, lda, W, ldw, bias, Y, ldy, M, n_main, K, nullptr, s, overlap ? K : lda, false, nullptr, nullptr, 0,
-                            0.f, true);
+                            0.f, true, 0, ws, ws_bytes);
       if (rc) return rc;
       return gemm_nt_impl(A, lda, W + n_main * ldw, ldw, bias ? bias + n_main : nullptr, Y + n_main, ldy, M, N - n_main, K,
                           nullptr, stream, overlap);
     }
-    rc = launch_glds_pair(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s, overlap ? K : lda);
+    rc = launch_glds_pair(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, s, overlap ? K : lda, false, nullptr, nullptr, 0, 0.f,
+                          false, 0, ws, ws_bytes);
     if (rc) return rc;
     CCN_LAUNCH_OK("gemm_nt");
     return CCN_OK;

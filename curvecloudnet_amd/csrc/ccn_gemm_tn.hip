@@ -112,10 +112,15 @@ __global__ __launch_bounds__(TN_TPB, 2) void gemm_tn_glds_kernel(const float* __
         xsh[c] = xf_shift[k];
       }
     }
-    auto xform = [&](f32x2& b) {      // (branch-free; bits of act(b * scale + shift), ReLU's zero may be -0.0)
-      const float v0 = b.x * xsc[0] + xsh[0], v1 = b.y * xsc[1] + xsh[1];
-      b.x = v0 > 0.f ? v0 : v0 * xf_neg;
-      b.y = v1 > 0.f ? v1 : v1 * xf_neg;
+    // (branch-free; bits of act(b * scale + shift), ReLU's zero may be -0.0.  Round 5: packed -- v_pk_fma_f32, v_pk_mul_f32 and
+    // two v_max_f32 instead of two each of fma / mul / cmp / cndmask + the VCC hazard's wait states; max(v, v * neg) equals
+    // (v > 0 ? v : v * neg) for 0 <= neg <= 1, which the entry point checks.)
+    const f32x2 xsc2 = {xsc[0], xsc[1]}, xsh2 = {xsh[0], xsh[1]}, neg2 = {xf_neg, xf_neg};
+    auto xform = [&](f32x2& b) {
+      const f32x2 v = __builtin_elementwise_fma(b, xsc2, xsh2);
+      const f32x2 w = v * neg2;
+      b.x = __builtin_fmaxf(v.x, w.x);
+      b.y = __builtin_fmaxf(v.y, w.y);
     };
     if (s_beg < s_end) {
       // ---- per-lane DMA source columns (clamped into the row: lda, ldb are multiples of 4 and >= 4)
@@ -540,6 +545,7 @@ int ccn_gemm_tn_ws_xf(const float* dY, int64_t lddy, const float* X, int64_t ldx
                       size_t workspace_bytes, void* stream) {
   CCN_REQUIRE(dY && X && dW && x_scale && x_shift, "gemm_tn_ws_xf: null pointer");
   CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "gemm_tn_ws_xf: bad sizes");
+  CCN_REQUIRE(x_act != CCN_ACT_LEAKY || (x_slope >= 0.f && x_slope <= 1.f), "gemm_tn_ws_xf: LeakyReLU slope outside [0, 1]");
   const TnXf xf{x_scale, x_shift, x_act == CCN_ACT_RELU ? 0.f : (x_act == CCN_ACT_LEAKY ? x_slope : 1.f)};
   return tn_ws_impl(dY, lddy, X, ldx, dW, lddw, M, N, K, workspace, workspace_bytes, stream, false, &xf);
 }

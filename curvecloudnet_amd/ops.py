@@ -398,6 +398,28 @@ def _nt_name():
     return _GEMM_NT[_MLP_DTYPE]
 
 
+_NT_SCRATCH = {}
+NT_SPLIT = os.environ.get("CCN_NT_SPLIT", "1") != "0"      # A/B: the paired kernel's tail split (ccn_gemm_nt_ws)
+
+
+def _nt_scratch(device):
+    """Scratch of the paired fp32 kernel's tail split (``ccn_gemm_nt_ws`` and its siblings): ONE buffer per (device,
+    stream) -- launches on a stream run in order -- whose leading counters start at zero and are left at zero by every
+    launch.  -> (pointer, bytes), (None, 0) when the split is switched off."""
+    if not NT_SPLIT:
+        return None, 0
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    buf = _NT_SCRATCH.get(key)
+    if buf is None:
+        nbytes = int(lib().ccn_gemm_nt_split_workspace_bytes())
+        if torch.cuda.is_current_stream_capturing():
+            buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)     # the capture's private pool (zeroed per replay)
+            return ptr(buf), nbytes
+        buf = _NT_SCRATCH[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    return ptr(buf), buf.numel()
+
+
 def _gemm_nt(name, x, w, bias, y, m, n, k, stats, xp=None, yp=None):
     """Y = X W^T + b through the entry ``name``; ``xp`` / ``yp`` override the row pointers (a row offset into x / y)."""
     xp = ptr(x) if xp is None else xp
@@ -409,6 +431,9 @@ def _gemm_nt(name, x, w, bias, y, m, n, k, stats, xp=None, yp=None):
             call(name, xp, _ld(x), ptr(w), _ld(w), ptr(bias), yp, _ld(y), m, n, k, ptr(stats), ptr(scratch), nb)
             return
         name = "gemm_nt"
+    if name == "gemm_nt":
+        call("gemm_nt_ws", xp, _ld(x), ptr(w), _ld(w), ptr(bias), yp, _ld(y), m, n, k, ptr(stats), *_nt_scratch(x.device))
+        return
     call(name, xp, _ld(x), ptr(w), _ld(w), ptr(bias), yp, _ld(y), m, n, k, ptr(stats))
 
 
@@ -724,8 +749,8 @@ class LinearBNAct(torch.autograd.Function):
 
         def product(stats):
             if lazy:      # act(BatchNorm(x)) of the previous layer applied between LDS and the matrix cores
-                call("gemm_nt_xf", ptr(x), _ld(x), ptr(xf_par[0]), ptr(xf_par[1]), ctx.xf_act, LEAKY_SLOPE, ptr(w), _ld(w),
-                     ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats))
+                call("gemm_nt_xf_ws", ptr(x), _ld(x), ptr(xf_par[0]), ptr(xf_par[1]), ctx.xf_act, LEAKY_SLOPE, ptr(w), _ld(w),
+                     ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats), *_nt_scratch(dev))
             else:
                 _gemm_nt(gemm_nt, x, w, bias, y, m, n, k, stats)
 
@@ -804,15 +829,15 @@ class LinearBNAct(torch.autograd.Function):
             if (sink is not None and dy.data_ptr() % 16 == 0 and wt.data_ptr() % 16 == 0
                     and lib().ccn_gemm_nt_acc_ok(_ld(dy), _ld(wt), m, k, n)):
                 # the other consumer of x has written its gradient already: add this one to it (autograd gets None)
-                call("gemm_nt_acc", ptr(dy), _ld(dy), ptr(wt), _ld(wt), ptr(sink), _ld(sink), m, k, n)
+                call("gemm_nt_acc_ws", ptr(dy), _ld(dy), ptr(wt), _ld(wt), ptr(sink), _ld(sink), m, k, n, *_nt_scratch(dev))
             elif (BN_RED and ctx.xf_act is not None and ctx.gemm_nt == "gemm_nt" and not (k > 128 and 0 < k % 128 <= 64)
                   and dy.data_ptr() % 16 == 0 and wt.data_ptr() % 16 == 0 and lib().ccn_gemm_nt_acc_ok(_ld(dy), _ld(wt), m, k, n)):
                 # x is the previous layer's deferred output y: its BatchNorm-backward column sums come out of this product's
                 # epilogue (widths whose plain product is split into a 128-wide and a 64-wide launch keep the separate pass)
                 dx = _rows(m, k, dev)
                 sums_prev = _stats_buffer(m, k, dev)
-                call("gemm_nt_red", ptr(dy), _ld(dy), ptr(wt), _ld(wt), ptr(dx), _ld(dx), m, k, n, ptr(x), _ld(x), ptr(xf_par),
-                     ctx.xf_act, LEAKY_SLOPE, ptr(sums_prev))
+                call("gemm_nt_red_ws", ptr(dy), _ld(dy), ptr(wt), _ld(wt), ptr(dx), _ld(dx), m, k, n, ptr(x), _ld(x), ptr(xf_par),
+                     ctx.xf_act, LEAKY_SLOPE, ptr(sums_prev), *_nt_scratch(dev))
                 _bn_sums_offer(x, sums_prev, dx)
             else:
                 dx = _rows(m, k, dev)

@@ -224,6 +224,26 @@ int ccn_gemm_tn_xf_ok(const float* dY, int64_t lddy, const float* X, int64_t ldx
 int ccn_gemm_tn_ws_xf(const float* dY, int64_t lddy, const float* X, int64_t ldx, const float* x_scale, const float* x_shift,
                       int x_act, float x_slope, float* dW, int64_t lddw, int64_t M, int64_t N, int64_t K, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* round 5, "split tails": ccn_gemm_nt / _acc / _xf / _red with caller-owned scratch for the paired LDS-DMA kernel (same
+ * products, same callers: F.linear inside PyG MLP, src/models/base.py:90-125).  The kernel walks 128 x 128 output tiles in
+ * rounds of 512 workgroups; when the last round is at most half full (10 550 x 1024 -> 1024: 664 tiles = 2 rounds for 1.3
+ * rounds of work) its tiles are cut into 2..8 parts along K, one per workgroup, the parts' accumulators go to the scratch
+ * and the last part of a tile to arrive adds them IN PART ORDER (deterministic) and runs the tile's epilogue.  workspace:
+ * ccn_gemm_nt_split_workspace_bytes() bytes, 16-byte aligned, its first 4 KiB zero on first use (the library leaves them
+ * zero); one buffer per stream.  NULL / too small: the product runs unsplit, as the entry without _ws does.
+ * ccn_gemm_nt_split_parts: the number of parts a launch of that shape would use (1 = no split). */
+size_t ccn_gemm_nt_split_workspace_bytes(void);
+int ccn_gemm_nt_split_parts(int64_t M, int64_t N, int64_t K, size_t workspace_bytes);
+int ccn_gemm_nt_ws(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                   int64_t M, int64_t N, int64_t K, double* colstats, void* workspace, size_t workspace_bytes, void* stream);
+int ccn_gemm_nt_acc_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M, int64_t N,
+                       int64_t K, void* workspace, size_t workspace_bytes, void* stream);
+int ccn_gemm_nt_red_ws(const float* A, int64_t lda, const float* W, int64_t ldw, float* Y, int64_t ldy, int64_t M, int64_t N,
+                       int64_t K, const float* y_prev, int64_t ldyp, const float* par, int act, float slope, double* sums,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int ccn_gemm_nt_xf_ws(const float* A, int64_t lda, const float* a_scale, const float* a_shift, int a_act, float a_slope,
+                      const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                      double* colstats, void* workspace, size_t workspace_bytes, void* stream);
 /* ---- A4-A6: the symmetric curve convolution as an IMPLICIT GEMM over the row sequence (no shifted-row matrix) ----
  * Replaces F.conv1d(input(1,C,L), weight, bias, 1, 'same') at src/models/modules/fast_conv1d.py:183 (called from
  * SymmetricCurve1DConvV2 :71 and SymmetricCurve1DConvFastV1 :140) on the reference's own zero-separated sequence

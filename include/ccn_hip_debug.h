@@ -11,7 +11,7 @@ extern "C" {
 
 int ccn_gemm_use_dma(int on);       /* A/B hook: 0 = register-staged kernels only, 2 = LDS-DMA without the persistent tile loop, 3 = persistent with round-robin tiles, 4 = the 8-wave persistent kernel for every N (no paired 4-wave workgroups), 1 = default */
 int ccn_gemm_pair_debug(void* buf);  /* diagnostic: a device buffer of 512 x 4 x 16 uint64 words switches ccn_gemm_nt's paired kernel to a build that stamps (s_memtime) where every wave's cycles go; NULL = off (tools/pair_stamps.py) */
-int ccn_gemm_pair_opt(int bits);    /* A/B hook of the paired kernel's LAUNCHER: bit 2 = one workgroup per CU, bit 6 = no split of a wide product into a 128-wide and a 64-wide launch, bit 8 = the 8-wave kernel for N <= 64 (the in-kernel experiments of rounds 2-3 are no longer compiled) */
+int ccn_gemm_pair_opt(int bits);    /* A/B hook of the paired kernel's LAUNCHER: bit 2 = one workgroup per CU, bit 6 = no split of a wide product into a 128-wide and a 64-wide launch, bit 8 = the 8-wave kernel for N <= 64, bit 9 = no tail split even with scratch (the in-kernel experiments of rounds 2-3 are no longer compiled) */
 int ccn_gemm_force_generic(int on); /* test hook: route every GEMM through the unaligned-operand kernel */
 /* diagnostics of ccn_gemm_nt_h (timing only, results wrong when set; a separate instantiation of the kernel): bit 0 = no epilogue stores, bit 1 = no wait for the copies, bit 2 = start stagger of the second workgroup of a CU */
 int ccn_gemm_h_opt(int opt);

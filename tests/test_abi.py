@@ -70,3 +70,28 @@ def test_product_never_imports_the_oracle():
                 names = [node.module or ""]
             for n in names:
                 assert not n.startswith("oracle") and "torch_ref" not in n, (fn, n)
+
+
+def test_frnn_compat_offers_the_third_party_signatures():
+    """reference call sites: src/models/utils/point_ops.py:459 (frnn_grid_points, six positional arguments, four results) and
+    src/models/modules/dgcnn.py:172 (frnn_gather, three positional arguments)."""
+    import inspect
+    import sys
+    from curvecloudnet_amd import frnn_compat
+    sig = inspect.signature(frnn_compat.frnn_grid_points)
+    assert list(sig.parameters)[:6] == ["points1", "points2", "lengths1", "lengths2", "K", "r"]
+    for name in ("grid", "return_nn", "return_sorted", "radius_cell_ratio"):
+        assert name in sig.parameters
+    assert list(inspect.signature(frnn_compat.frnn_gather).parameters) == ["x", "idxs", "lengths"]
+    saved = sys.modules.get("frnn")
+    try:
+        assert frnn_compat.install() is frnn_compat
+        import frnn
+        assert frnn.frnn_grid_points is frnn_compat.frnn_grid_points and frnn.frnn_gather is frnn_compat.frnn_gather
+        with pytest.raises(RuntimeError, match="GPU only"):
+            frnn.frnn_gather(torch.zeros(1, 4, 3), torch.zeros(1, 4, 2, dtype=torch.int64), torch.tensor([4]))
+    finally:
+        if saved is None:
+            sys.modules.pop("frnn", None)
+        else:
+            sys.modules["frnn"] = saved
