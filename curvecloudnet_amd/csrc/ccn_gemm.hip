@@ -1117,7 +1117,10 @@ __device__ unsigned long long* g_pair_dbg_dev = nullptr;
 // accumulators and the matching y tile (16 loads per 32 x 32 block, issued in front of the block's stores and waited for
 // behind them), into the same partial-row table the forward statistics use.  ccn_bn_act_bwd_reduce's pass over (dZ, y)
 // -- 8 bytes per element, 2.3 ms per KITTI step -- then does not run for that layer (ccn_gemm_nt_red).
-template <bool ACC, bool XF, int TAG = 0, bool STAMP = false, bool RED = false>
+// SPLIT (round 5): the instantiation that also walks a split tail round (see full_tiles / split_s below).  The launches without
+// a tail round take the instantiation without it: carried along as run-time state the tail bookkeeping cost the plain product
+// 2 % (117.5 against 120.5 TFLOP/s in the KITTI step, one box, profiles/r05_split_tails.txt).
+template <bool ACC, bool XF, int TAG = 0, bool STAMP = false, bool RED = false, bool SPLIT = false>
 __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* __restrict__ A, int64_t lda,
                                                                    const float* __restrict__ B, int64_t ldb,
                                                                    const float* __restrict__ bias, float* __restrict__ C,
@@ -1170,7 +1173,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   // (tile arithmetic in 32 bits -- a 64-bit division is ~130 dependent scalar instructions and there were eight per tile;
   // measured neutral on speed, 12 VGPRs and 14 spilled SGPRs fewer; the launcher checks tiles < 2^31)
   const uint32_t gnu = (uint32_t)gn;
-  const uint32_t gm_tiles = (uint32_t)full_tiles / gnu;     // (a tail round starts at a whole tile row: 512 % gnu == 0 there)
+  const uint32_t gm_tiles = (uint32_t)(SPLIT ? full_tiles : tiles) / gnu;     // (a tail round starts at a whole tile row: 512 % gnu == 0 there)
   const bool xcd_map = xcd_order && gridDim.x == 512 && gnu <= 64 && 64 % gnu == 0;
   const uint32_t slot = blockIdx.x >> 3;
   const uint32_t rows_per_step = 512u / gnu, slot_row = (slot / gnu) * 8 + (blockIdx.x & 7), slot_col = slot % gnu;
@@ -1180,11 +1183,12 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       return m < gm_tiles ? (int64_t)(m * gnu + slot_col) : tiles;
     }
     const int64_t t = j * gridDim.x + blockIdx.x;
+    if (!SPLIT) return t;
     return t < full_tiles ? t : tiles;
   };
   // this workgroup's part of the tail round: tile full_tiles + (id % rem), slices [tail_u0, tail_u1)
   const int64_t tail_rem = tiles - full_tiles;
-  const bool has_tail_item = split_s > 1 && (int64_t)blockIdx.x < tail_rem * split_s;
+  const bool has_tail_item = SPLIT && split_s > 1 && (int64_t)blockIdx.x < tail_rem * split_s;
   const int tail_idx = has_tail_item ? (int)((int64_t)blockIdx.x % tail_rem) : 0;
   const int tail_part = has_tail_item ? (int)((int64_t)blockIdx.x / tail_rem) : 0;
   const int tail_u0 = tail_part * TT / (split_s > 1 ? split_s : 1), tail_u1 = (tail_part + 1) * TT / (split_s > 1 ? split_s : 1);
@@ -1202,7 +1206,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   int64_t im0 = 0, in0 = 0;
   int it_u = 0, it_uend = TT;
   bool it_first = true, it_tail_left = has_tail_item;
-  if (it_tile >= tiles && it_tail_left) {     // no whole tile for this workgroup: the tail part is its first item
+  if (SPLIT && it_tile >= tiles && it_tail_left) {     // no whole tile for this workgroup: the tail part is its first item
     it_tail_left = false;
     it_tile = full_tiles + tail_idx;
     it_u = tail_u0;
@@ -1210,7 +1214,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   }
   auto issue_next = [&]() {
     if (it_tile >= tiles) return;
-    if (it_first) {
+    if (SPLIT ? it_first : it_u == 0) {
       it_first = false;
       im0 = tile_row(it_tile) * PR_BM;
       in0 = tile_col(it_tile) * PR_BN;
@@ -1263,12 +1267,12 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written before this wave reaches the next barrier
     }
     ++gi;
-    if (++it_u == it_uend) {
+    if (++it_u == (SPLIT ? it_uend : TT)) {
       it_u = 0;
       it_uend = TT;
       it_first = true;
       it_tile = tile_of(++it_j);
-      if (it_tile >= tiles && it_tail_left) {
+      if (SPLIT && it_tile >= tiles && it_tail_left) {
         it_tail_left = false;
         it_tile = full_tiles + tail_idx;
         it_u = tail_u0;
@@ -1307,7 +1311,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     int64_t tile = tile_of(j);
     int u_beg = 0, u_end = TT, part = -1;     // part >= 0: this item is part `part` of a split tile
     if (tile >= tiles) {
-      if (!tail_left) break;
+      if (!SPLIT || !tail_left) break;
       tail_left = false;
       tile = full_tiles + tail_idx;
       u_beg = tail_u0;
@@ -1316,7 +1320,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     }
     const int64_t m0 = tile_row(tile) * PR_BM, n0 = tile_col(tile) * PR_BN;
     f32x16 acc[2][2];
-    if (part > 0) {
+    if (SPLIT && part > 0) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1367,14 +1371,14 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     }
     }
 
-    for (int u = u_beg; u < u_end; ++u, ++g) {
+    for (int u = SPLIT ? u_beg : 0; u < (SPLIT ? u_end : TT); ++u, ++g) {
       if (STAMP) PR_STAMP(st_a);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice g has landed (and the previous tile's stores retired)
       if (STAMP) { PR_STAMP(st_b); sum_w += (uint32_t)(st_b - st_a); }
       __builtin_amdgcn_s_barrier();
       if (STAMP) { PR_STAMP(st_a); sum_b += (uint32_t)(st_a - st_b); }
       issue_next();
-      if (u == u_beg && stat_tile >= 0) stats_readout();
+      if (u == (SPLIT ? u_beg : 0) && stat_tile >= 0) stats_readout();
       if (STAMP) { PR_STAMP(st_b); sum_i += (uint32_t)(st_b - st_a); }
       const uint32_t stage_b = lds_base + (uint32_t)((g & 1) * STAGE * 4);
       f32x4 fa[2][2], fb[2][2];   // [K group parity][block]
@@ -1476,16 +1480,24 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
     }
     if (STAMP) PR_STAMP(st_a);
 
-    if (part >= 0) {
+    if (SPLIT && part >= 0) {
       // ---- part of a split tile: accumulators -> split_ws in register order (every store instruction of a wave writes 256
-      // contiguous bytes), release, count; the last part to arrive acquires, re-reads ALL parts in part order and goes on to
-      // the epilogue, the others are done.  (Agent-scope fences: the parts of a tile run on different XCDs, whose L2s are
-      // not coherent for plain stores -- __threadfence() is buffer_wbl2 / buffer_inv on gfx950.)
+      // contiguous bytes), count; the last part to arrive re-reads ALL parts in part order and goes on to the epilogue, the
+      // others are done.  The parts of a tile may run on different XCDs, whose L2s are not coherent for plain accesses: the
+      // partials are stored and loaded with AGENT scope (`sc1`: what a relaxed agent-scope atomic store / load is on
+      // gfx942 / gfx950 -- written through to, and fetched from, the memory side), ordered against the counter by
+      // s_waitcnt vmcnt(0) + the workgroup barrier.  (First form: plain accesses between two __threadfence() = buffer_wbl2 +
+      // buffer_inv of the XCD's WHOLE L2 per part: every part flushed the finished C tiles of its neighbours and evicted
+      // their operand tiles -- 10 550 x 1024 x 1024 took 0.261 ms split against 0.220 unsplit.)
       int* const counters = reinterpret_cast<int*>(split_ws);
       float* const parts = split_ws + 1024 + (int64_t)tail_idx * split_s * (PR_BM * PR_BN);
       float* const mine = parts + (int64_t)part * (PR_BM * PR_BN);
       // (scalar base per register + one 32-bit lane offset, as the epilogue's stores: 64 different 64-bit vector addresses --
-      // the offsets exceed the instruction's immediate -- cost 128 registers and spilled the accumulators)
+      // the offsets exceed the instruction's immediate -- cost 128 registers and spilled the accumulators.  s_nop 4 in front
+      // of every access: with this many row pointers live the compiler parks them in VGPR lanes and fetches each with
+      // v_readlane right in front of the inline asm -- a VALU write of an SGPR needs five wait states before a VMEM
+      // instruction may use it as an address, and the hazard recogniser does not look inside inline asm: without the nops
+      // a load took the PREVIOUS register's row, every now and then)
       const uint32_t lane_off = (uint32_t)threadIdx.x * 4u;
 #pragma unroll
       for (int ab = 0; ab < 2; ++ab)
@@ -1494,10 +1506,9 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             float* const rowp = mine + ((ab * 2 + t) * 16 + r) * PR_TPB;
-            asm volatile("global_store_dword %0, %1, %2" : : "v"(lane_off), "v"(acc[ab][t][r]), "s"(rowp) : "memory");
+            asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 sc1" : : "v"(lane_off), "v"(acc[ab][t][r]), "s"(rowp) : "memory");
           }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __threadfence();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's partial is written through
       __syncthreads();
       if (threadIdx.x == 0) {
         const int old = atomicAdd(&counters[tail_idx], 1);
@@ -1506,7 +1517,6 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
       }
       __syncthreads();
       if (split_flag != split_s - 1) break;                  // (the tail part is a workgroup's last item)
-      __threadfence();
 #pragma unroll
       for (int ab = 0; ab < 2; ++ab)
 #pragma unroll
@@ -1514,7 +1524,7 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float* const rowp = parts + ((ab * 2 + t) * 16 + r) * PR_TPB;
-            asm volatile("global_load_dword %0, %1, %2" : "=v"(acc[ab][t][r]) : "v"(lane_off), "s"(rowp) : "memory");
+            asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1" : "=v"(acc[ab][t][r]) : "v"(lane_off), "s"(rowp) : "memory");
           }
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]) : : "memory");
       for (int pp = 1; pp < split_s; ++pp) {
@@ -1524,14 +1534,22 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             // (one 32 x 32 block = 16 loads at a time: all 64 in flight would need 64 registers beside the accumulators)
-            f32x16 tmp;
+            // (sixteen scalars, each named by the wait, as the y tile of the RED epilogue: an element of a vector as the
+            // output of an inline-asm load may be copied into the vector's registers BEFORE the wait the compiler cannot see)
+            float tmp[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const float* const rowp = pq + ((ab * 2 + t) * 16 + r) * PR_TPB;
-              asm volatile("global_load_dword %0, %1, %2" : "=v"(tmp[r]) : "v"(lane_off), "s"(rowp) : "memory");
+              asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1" : "=v"(tmp[r]) : "v"(lane_off), "s"(rowp) : "memory");
             }
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(tmp) : : "memory");
-            acc[ab][t] += tmp;
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(tmp[0]), "+v"(tmp[1]), "+v"(tmp[2]), "+v"(tmp[3]), "+v"(tmp[4]), "+v"(tmp[5]), "+v"(tmp[6]),
+                           "+v"(tmp[7]), "+v"(tmp[8]), "+v"(tmp[9]), "+v"(tmp[10]), "+v"(tmp[11]), "+v"(tmp[12]), "+v"(tmp[13]),
+                           "+v"(tmp[14]), "+v"(tmp[15])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ab][t][r] += tmp[r];
           }
       }
     }
@@ -1673,7 +1691,10 @@ constexpr size_t SPLIT_WS_BYTES = SPLIT_WS_HEAD + (size_t)PAIR_SLOTS * PR_BM * P
 static int pair_split_parts(int64_t tiles, int64_t K, const void* ws, size_t ws_bytes) {
   if (ws == nullptr || (g_pair_opt & (4 | 512)) || ((uintptr_t)ws & 15)) return 1;      // (512: A-B hook, no split)
   const int64_t rem = tiles % PAIR_SLOTS, TT = K / BK + (K % BK != 0);
-  if (rem == 0 || rem > PAIR_SLOTS / 2 || TT < 8) return 1;
+  // (K >= 512 only: at K = 256 the fix-up -- a 64 KiB partial written through, the count, up to eight partials read back --
+  // costs what the split saves: 78 136 x 256 x 256 0.096 -> 0.104 ms.  A lone workgroup on a CU runs ~1.85x as fast as one of a
+  // pair, so an unsplit tail round costs ~0.54 of a tile time, not a whole one: the split's ceiling is ~13 % of such a launch.)
+  if (rem == 0 || rem > PAIR_SLOTS / 2 || TT < 16) return 1;
   int64_t sp = PAIR_SLOTS / rem;
   if (sp > 8) sp = 8;
   if (sp > TT / 4) sp = TT / 4;                    // a part is at least four slices long
@@ -1697,22 +1718,31 @@ int launch_glds_pair(const float* A, int64_t lda, const float* W, int64_t ldw, c
   const int64_t full_tiles = sp > 1 ? tiles - rem : tiles;
   const int64_t grid = sp > 1 ? (full_tiles > 0 ? PAIR_SLOTS : rem * sp) : (tiles < slots ? tiles : slots);
   float* const sws = sp > 1 ? (float*)ws : nullptr;
-#define CCN_PAIR_LAUNCH(...)                                                                                                      \
-  hipLaunchKernelGGL((gemm_glds_pair_kernel<__VA_ARGS__>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy, M,  \
-                     N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, xf_scale, xf_shift, xf_act, xf_slope, red_ldy,        \
-                     full_tiles, sp, sws)
+#define CCN_PAIR_LAUNCH(ACC_, XF_, TAG_, STAMP_, RED_)                                                                           \
+  do {                                                                                                                          \
+    if (sp > 1)                                                                                                                 \
+      hipLaunchKernelGGL((gemm_glds_pair_kernel<ACC_, XF_, TAG_, STAMP_, RED_, true>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, \
+                         lda, W, ldw, bias, Y, ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, xf_scale,       \
+                         xf_shift, xf_act, xf_slope, red_ldy, full_tiles, sp, sws);                                             \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((gemm_glds_pair_kernel<ACC_, XF_, TAG_, STAMP_, RED_, false>), dim3((unsigned)grid), dim3(PR_TPB), 0, s, A, \
+                         lda, W, ldw, bias, Y, ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent, xf_scale,       \
+                         xf_shift, xf_act, xf_slope, red_ldy, full_tiles, sp, sws);                                             \
+  } while (0)
   if (g_pair_dbg_host != nullptr && xf_scale == nullptr && !accumulate && !split_part)
-    CCN_PAIR_LAUNCH(false, false, 0, true);
+    hipLaunchKernelGGL((gemm_glds_pair_kernel<false, false, 0, true, false, false>), dim3((unsigned)(tiles < slots ? tiles : slots)),
+                       dim3(PR_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy, M, N, K, tiles, gn, g_xcd_map ? 1 : 0, colstats, a_extent,
+                       xf_scale, xf_shift, xf_act, xf_slope, red_ldy, tiles, 1, (float*)nullptr);
   else if (red_ldy > 0)      // (xf_scale = the previous layer's table, xf_shift = its output y: see RED)
     CCN_PAIR_LAUNCH(false, false, 0, false, true);
   else if (xf_scale != nullptr)
-    CCN_PAIR_LAUNCH(false, true);
+    CCN_PAIR_LAUNCH(false, true, 0, false, false);
   else if (accumulate)
-    CCN_PAIR_LAUNCH(true, false);
+    CCN_PAIR_LAUNCH(true, false, 0, false, false);
   else if (split_part)
-    CCN_PAIR_LAUNCH(false, false, 1);
+    CCN_PAIR_LAUNCH(false, false, 1, false, false);
   else
-    CCN_PAIR_LAUNCH(false, false);
+    CCN_PAIR_LAUNCH(false, false, 0, false, false);
 #undef CCN_PAIR_LAUNCH
   return CCN_OK;
 }

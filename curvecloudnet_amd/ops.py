@@ -400,6 +400,7 @@ def _nt_name():
 
 _NT_SCRATCH = {}
 NT_SPLIT = os.environ.get("CCN_NT_SPLIT", "1") != "0"      # A/B: the paired kernel's tail split (ccn_gemm_nt_ws)
+_WS, _WS_ARGS = ("_ws", 2) if NT_SPLIT else ("", 0)       # off: the entries without scratch (what an older library build has)
 
 
 def _nt_scratch(device):
@@ -431,7 +432,7 @@ def _gemm_nt(name, x, w, bias, y, m, n, k, stats, xp=None, yp=None):
             call(name, xp, _ld(x), ptr(w), _ld(w), ptr(bias), yp, _ld(y), m, n, k, ptr(stats), ptr(scratch), nb)
             return
         name = "gemm_nt"
-    if name == "gemm_nt":
+    if name == "gemm_nt" and NT_SPLIT:
         call("gemm_nt_ws", xp, _ld(x), ptr(w), _ld(w), ptr(bias), yp, _ld(y), m, n, k, ptr(stats), *_nt_scratch(x.device))
         return
     call(name, xp, _ld(x), ptr(w), _ld(w), ptr(bias), yp, _ld(y), m, n, k, ptr(stats))
@@ -749,8 +750,8 @@ class LinearBNAct(torch.autograd.Function):
 
         def product(stats):
             if lazy:      # act(BatchNorm(x)) of the previous layer applied between LDS and the matrix cores
-                call("gemm_nt_xf_ws", ptr(x), _ld(x), ptr(xf_par[0]), ptr(xf_par[1]), ctx.xf_act, LEAKY_SLOPE, ptr(w), _ld(w),
-                     ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats), *_nt_scratch(dev))
+                call("gemm_nt_xf" + _WS, ptr(x), _ld(x), ptr(xf_par[0]), ptr(xf_par[1]), ctx.xf_act, LEAKY_SLOPE, ptr(w), _ld(w),
+                     ptr(bias), ptr(y), _ld(y), m, n, k, ptr(stats), *_nt_scratch(dev)[:_WS_ARGS])
             else:
                 _gemm_nt(gemm_nt, x, w, bias, y, m, n, k, stats)
 
@@ -829,15 +830,16 @@ class LinearBNAct(torch.autograd.Function):
             if (sink is not None and dy.data_ptr() % 16 == 0 and wt.data_ptr() % 16 == 0
                     and lib().ccn_gemm_nt_acc_ok(_ld(dy), _ld(wt), m, k, n)):
                 # the other consumer of x has written its gradient already: add this one to it (autograd gets None)
-                call("gemm_nt_acc_ws", ptr(dy), _ld(dy), ptr(wt), _ld(wt), ptr(sink), _ld(sink), m, k, n, *_nt_scratch(dev))
+                call("gemm_nt_acc" + _WS, ptr(dy), _ld(dy), ptr(wt), _ld(wt), ptr(sink), _ld(sink), m, k, n,
+                     *_nt_scratch(dev)[:_WS_ARGS])
             elif (BN_RED and ctx.xf_act is not None and ctx.gemm_nt == "gemm_nt" and not (k > 128 and 0 < k % 128 <= 64)
                   and dy.data_ptr() % 16 == 0 and wt.data_ptr() % 16 == 0 and lib().ccn_gemm_nt_acc_ok(_ld(dy), _ld(wt), m, k, n)):
                 # x is the previous layer's deferred output y: its BatchNorm-backward column sums come out of this product's
                 # epilogue (widths whose plain product is split into a 128-wide and a 64-wide launch keep the separate pass)
                 dx = _rows(m, k, dev)
                 sums_prev = _stats_buffer(m, k, dev)
-                call("gemm_nt_red_ws", ptr(dy), _ld(dy), ptr(wt), _ld(wt), ptr(dx), _ld(dx), m, k, n, ptr(x), _ld(x), ptr(xf_par),
-                     ctx.xf_act, LEAKY_SLOPE, ptr(sums_prev), *_nt_scratch(dev))
+                call("gemm_nt_red" + _WS, ptr(dy), _ld(dy), ptr(wt), _ld(wt), ptr(dx), _ld(dx), m, k, n, ptr(x), _ld(x), ptr(xf_par),
+                     ctx.xf_act, LEAKY_SLOPE, ptr(sums_prev), *_nt_scratch(dev)[:_WS_ARGS])
                 _bn_sums_offer(x, sums_prev, dx)
             else:
                 dx = _rows(m, k, dev)
