@@ -19,30 +19,46 @@ def streams_in_use(device):
     return [torch.cuda.current_stream(device)] + extra
 
 
-def reserve_headroom(device=None, fraction=0.25, small_blocks=128, streams=None):
+LAST_REPORT = {}        # what the last reserve_headroom call did: {"budget", "wanted", "scaled", "cut_short": [streams]}
+
+
+def reserve_headroom(device=None, fraction=0.25, small_blocks=128, streams=None, margin_bytes=4 << 30):
     """Keep ``fraction`` of the bytes reserved so far (``torch.cuda.max_memory_reserved`` after the warm-up steps) as free
-    cached blocks in every stream's pool: a ladder from a quarter of that amount down to 4 MB, two blocks per size, plus
-    ``small_blocks`` blocks of just under 1 MB for the small-block pool.  Stops quietly at the first allocation the device
-    cannot satisfy (several ranks on one card, a smaller device).  Returns the bytes kept per stream."""
+    cached blocks in every stream's pool (the current stream first): a ladder from a quarter of the amount down to 4 MB, two
+    blocks per size, plus ``small_blocks`` blocks of just under 1 MB for the small-block pool.  The total over all streams is
+    capped by the device's free memory minus ``margin_bytes`` (``torch.cuda.mem_get_info``) -- ladders that do not fit are
+    scaled down together, so that the side streams' pools can never take what the main stream's next allocation needs
+    (an allocator out-of-memory retry frees every cached block with synchronous hipFree calls: the stall this helper exists to
+    avoid).  Returns the bytes kept per stream; ``memory.LAST_REPORT`` says whether a ladder was cut short."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    total = int(fraction * torch.cuda.max_memory_reserved(device))
-    sizes, size = [], max(total // 4, 4 << 20)
-    while size >= (4 << 20):
-        sizes += [size, size]
-        size //= 2
-    kept = {}
-    for st in (streams if streams is not None else streams_in_use(device)):
+    sts = list(streams if streams is not None else streams_in_use(device))
+    base = int(fraction * torch.cuda.max_memory_reserved(device))
+    wanted = [base for _ in sts]
+    free, _ = torch.cuda.mem_get_info(device)
+    budget = max(0, int(free) - int(margin_bytes))
+    # (two blocks per size from total / 4 down: a ladder holds ~total bytes; the small blocks come on top)
+    need = sum(wanted) + len(sts) * small_blocks * (1 << 20)
+    scale = min(1.0, budget / need) if need > 0 else 1.0
+    kept, cut = {}, []
+    for st, total in zip(sts, wanted):
+        total = int(total * scale)
+        sizes, size = [], max(total // 4, 4 << 20)
+        while size >= (4 << 20) and total >= (8 << 20):
+            sizes += [size, size]
+            size //= 2
         held, got = [], 0
         with torch.cuda.stream(st):
             try:
                 for nbytes in sizes:
                     held.append(torch.empty(nbytes, dtype=torch.uint8, device=device))
                     got += nbytes
-                for _ in range(small_blocks):
+                for _ in range(int(small_blocks * scale)):
                     held.append(torch.empty((1 << 20) - 512, dtype=torch.uint8, device=device))
                     got += (1 << 20) - 512
             except torch.cuda.OutOfMemoryError:
-                pass
+                cut.append(st)
             del held
         kept[st] = got
+    LAST_REPORT.clear()
+    LAST_REPORT.update({"budget": budget, "wanted": sum(wanted), "scaled": scale < 1.0, "cut_short": cut})
     return kept

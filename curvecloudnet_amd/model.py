@@ -141,9 +141,13 @@ class ModelBase(torch.nn.Module):
         of everything the feature pass allocates), so its HOST time is mostly waiting for the side stream -- 50 ms per
         step on BASELINE configs[4], where exact farthest point sampling over ~17 k-point clouds is a chain of ~6 k
         dependent rounds.  Those waits release the interpreter lock: started at the top of a step, the next batch's
-        geometry proceeds while this thread queues the current forward and backward pass.  ``seed``: ``torch.manual_seed``
-        applied on the worker before the pass (the sampling draws come from torch's global CPU generator; the caller's
-        thread must not draw from it meanwhile -- a forward with a plan does not)."""
+        geometry proceeds while this thread queues the current forward and backward pass.  ``seed``: seeds torch's global CPU
+        generator ONLY (``torch.default_generator.manual_seed``), on the worker, before the pass: the sampling draws (CurveFPS
+        phase, random / VoxelFPS / FPS starts) come from that generator; the CUDA generators -- the dropout masks of the
+        caller's forward pass -- are left alone (``torch.manual_seed`` would reseed them from another thread at an arbitrary
+        point of the caller's queueing: ADVICE r4).  The caller's thread must not draw from the CPU generator meanwhile; a
+        forward with a plan does not.  The worker shares ``_lib.PROFILE`` with the caller: records of the two threads interleave
+        in arrival order (bench.py's per-kernel tables sum per name, so the order does not matter there)."""
         import concurrent.futures
         global _PREPARE_POOL
         if _PREPARE_POOL is None:
@@ -154,7 +158,7 @@ class ModelBase(torch.nn.Module):
         def work():
             torch.cuda.set_device(device)                 # (the current device is per thread as well)
             if seed is not None:
-                torch.manual_seed(seed)
+                torch.default_generator.manual_seed(seed)
             return self.prepare(data, inputs_ready=inputs_ready, main_stream=main)
         return _PREPARE_POOL.submit(work)
 

@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define CCN_ABI_VERSION 1
+/* ABI version: bumped when the prototype of an EXISTING entry changes (additions do not bump it).
+ *   1 -> 2 (round 4, recorded in round 5 / ADVICE r4): ccn_edge_feat_bwd_csr gained `int64_t N` in front of `int64_t E`. */
+#define CCN_ABI_VERSION 2
 
 #define CCN_OK 0
 #define CCN_ERR_ARG (-1)

@@ -212,6 +212,7 @@ def routed_abs(v):
     n = int(diff.sum())
     trace["mismatch"] += n
     trace["entries"] += v.numel()
+    trace.setdefault("per_layer", []).append(("abs", tuple(v.shape), n))
     if n:
         trace["max_abs"] = max(trace["max_abs"], float(v.detach()[diff].abs().max()))
     return v * sign.to(v.dtype)
@@ -229,6 +230,7 @@ def activation(z, kind):
     n = int(diff.sum())
     trace["mismatch"] += n
     trace["entries"] += z.numel()
+    trace.setdefault("per_layer", []).append((kind, tuple(z.shape), n))       # (forward order: which layer's kinks flipped)
     if n:
         trace["max_abs"] = max(trace["max_abs"], float(z.detach()[diff].abs().max()))
     return _RoutedAct.apply(z, mask, 0.0 if kind == "relu" else 0.01)

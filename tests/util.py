@@ -142,7 +142,12 @@ def routed_parity(ref, mine, data, labels, dev, seed=5, fwd_kwargs=None, backwar
     entries = sum(a.numel() for a in natural)
     res = dict(out_d=out_d, out_r=out_r, loss_d=loss_d, loss_r=loss_r, flips=flips, entries=entries, grad_err=[],
                grad_scale=0.0, max_gap=max_gap, sign_flips=act["mismatch"], sign_entries=act["entries"],
-               sign_max_abs=act["max_abs"])
+               sign_max_abs=act["max_abs"],
+               # where the flips sit, in forward order: (kind, shape, flipped entries) per activation / |.| layer, flipped
+               # entries per max aggregation
+               sign_flips_per_layer=[e for e in act.get("per_layer", []) if e[2]],
+               flips_per_table=[(i, tuple(a.shape), int((a != b).sum())) for i, (a, b) in enumerate(zip(natural, tables))
+                                if int((a != b).sum())])
     if fp64:
         R.MAX_TRACE = {"record": [], "force": [t.clone() for t in tables]}
         R.ACT_TRACE = {"force": list(signs), "mismatch": 0, "entries": 0, "max_abs": 0.0}
