@@ -103,6 +103,8 @@ PROFILE_FILTER = None   # optional predicate(name, args): only the launches it a
 PROFILE_ALIAS = {"gemm_nt_ws": "gemm_nt", "gemm_nt_acc_ws": "gemm_nt_acc", "gemm_nt_xf_ws": "gemm_nt_xf",
                  "gemm_nt_red_ws": "gemm_nt_red"}
 
+DEBUG_SYNC = os.environ.get("CCN_DEBUG_SYNC") or None
+
 EXTRA_LAUNCH = None     # experiment (tools/launch_cost.py): a callable launching one trivial kernel after every call
 
 
@@ -113,6 +115,14 @@ def call(name, *args, work_rows=None):
     fn = getattr(lib(), "ccn_" + name)
     if EXTRA_LAUNCH is not None:
         EXTRA_LAUNCH()
+    if DEBUG_SYNC is not None:
+        # diagnostics (CCN_DEBUG_SYNC=<file>): name + integer arguments of every launch appended BEFORE it, device synchronised
+        # AFTER it -- the last line of the file is the launch that faulted
+        with open(DEBUG_SYNC, "a") as f:
+            f.write("%s %s\n" % (name, [a for a in args if isinstance(a, int)]))
+        check(fn(*args, stream()), name)
+        torch.cuda.synchronize()
+        return
     if PROFILE is None:
         check(fn(*args, stream()), name)
         return

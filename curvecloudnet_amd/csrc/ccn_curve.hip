@@ -412,9 +412,12 @@ __global__ void group_subset_kernel(const int32_t* __restrict__ cid, const int32
                                     const int64_t* __restrict__ p2c, int64_t Q, const int64_t* __restrict__ idx,
                                     int64_t M, const float* __restrict__ budget, int32_t* __restrict__ counts,
                                     const int32_t* __restrict__ offsets, int64_t* __restrict__ row,
-                                    int64_t* __restrict__ col) {
+                                    int64_t* __restrict__ col, int64_t cap) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= M) return;
+  // (cap: entries row / col hold; a group that would end past it is not written -- only with bounded counts whose
+  // capacity was exceeded, the caller's overflow flag is up then)
+  if (FILL && (int64_t)offsets[q + 1] > cap) return;
   const int64_t centre = idx[q];
   const int32_t c = cid[centre];
   int64_t local = p2c[centre];  // quirk Q3: LOCAL id indexes the global table
@@ -949,7 +952,7 @@ int ccn_curve_group_subset_count(const float* pos, const int32_t* cid, const int
                      maxbits);
   hipLaunchKernelGGL(curve_reach_kernel, dim3(1), dim3(64), 0, s, maxbits, budget, Q);
   hipLaunchKernelGGL(group_subset_kernel<false>, dim3(ccn_blocks(M, TPB)), dim3(TPB), 0, s, cid, curve_ptr, p2c, Q, idx,
-                     M, budget, counts, (const int32_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr);
+                     M, budget, counts, (const int32_t*)nullptr, (int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0);
   int rc = ccn_scan_i32(counts, offsets, M, false, offsets + M, scratch, s);
   if (rc) return rc;
   hipLaunchKernelGGL(widen_total_kernel, dim3(1), dim3(64), 0, s, offsets, M, total);
@@ -960,11 +963,17 @@ int ccn_curve_group_subset_count(const float* pos, const int32_t* cid, const int
 int ccn_curve_group_subset_fill(const int32_t* cid, const int32_t* curve_ptr, const int64_t* p2c, int64_t n,
                                 int64_t Q, const int64_t* idx, int64_t M, const float* budget,
                                 const int32_t* offsets, int64_t* row, int64_t* col, void* stream) {
+  return ccn_curve_group_subset_fill_cap(cid, curve_ptr, p2c, n, Q, idx, M, budget, offsets, row, col, INT64_MAX, stream);
+}
+
+int ccn_curve_group_subset_fill_cap(const int32_t* cid, const int32_t* curve_ptr, const int64_t* p2c, int64_t n,
+                                    int64_t Q, const int64_t* idx, int64_t M, const float* budget,
+                                    const int32_t* offsets, int64_t* row, int64_t* col, int64_t cap, void* stream) {
   (void)n;
-  CCN_REQUIRE(cid && curve_ptr && p2c && idx && budget && offsets && row && col, "group_subset_fill: null pointer");
+  CCN_REQUIRE(cid && curve_ptr && p2c && idx && budget && offsets && row && col && cap >= 0, "group_subset_fill: bad arguments");
   if (M == 0) return CCN_OK;
   hipLaunchKernelGGL(group_subset_kernel<true>, dim3(ccn_blocks(M, TPB)), dim3(TPB), 0, (hipStream_t)stream, cid,
-                     curve_ptr, p2c, Q, idx, M, budget, (int32_t*)nullptr, offsets, row, col);
+                     curve_ptr, p2c, Q, idx, M, budget, (int32_t*)nullptr, offsets, row, col, cap);
   CCN_LAUNCH_OK("group_subset_fill");
   return CCN_OK;
 }

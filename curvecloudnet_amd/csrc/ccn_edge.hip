@@ -354,6 +354,11 @@ __global__ void cg_count_kernel(const int64_t* __restrict__ idx, const int64_t* 
   const int64_t b = blockIdx.y, i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
   if (i >= len) return;
+  if (i >= Nmax) {            // (a cloud longer than the padded table -- bounded counts, capacity exceeded: no row to read)
+    cnt[base + i] = 1;
+    has_rep[base + i] = 1;
+    return;
+  }
   const int64_t* row = idx + (b * Nmax + i) * K;
   int found = 0;
   for (int s = 0; s < K; ++s) found += row[s] >= 0;
@@ -368,14 +373,17 @@ __global__ void cg_fill_kernel(const int64_t* __restrict__ idx, const int64_t* _
   const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
   if (i >= len) return;
   const int64_t p = base + i;
-  const int64_t* row = idx + (b * Nmax + i) * K;
+  const int64_t* row = idx + (b * Nmax + (i < Nmax ? i : 0)) * K;
   int32_t at = grp_ptr[p];
-  row_src[at++] = (int32_t)p;
+  // (at < E: E is the true number of real rows, or -- with bounded counts -- the capacity of row_src: never write past it)
+  if (at < E) row_src[at] = (int32_t)p;
+  ++at;
   int found = 0;
-  for (int s = 0; s < K; ++s) {
+  for (int s = 0; s < K && i < Nmax; ++s) {
     const int64_t j = row[s];
     if (j >= 0) {
-      row_src[at++] = (int32_t)(base + j);
+      if (at < E) row_src[at] = (int32_t)(base + j);
+      ++at;
       ++found;
     }
   }

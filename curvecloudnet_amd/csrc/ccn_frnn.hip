@@ -86,7 +86,7 @@ __global__ __launch_bounds__(BUILD_TPB) void grid_insert_kernel(const float* __r
                                                                 float4* __restrict__ sorted_pts) {
   const int64_t b = blockIdx.y;
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= lengths[b]) return;
+  if (j >= lengths[b] || j >= P2) return;     // (a length beyond the padded row: never read past it)
   const float* p = pts + (b * P2 + j) * 3;
   const float x = p[0], y = p[1], z = p[2];
   const int3 c = cell_of(x, y, z, inv_cell_of(radius[b]));

@@ -53,3 +53,151 @@ class CapturedForward:
         """One graph launch; returns the (static) logits tensor of the captured pass."""
         self.graph.replay()
         return self.out
+
+
+class CapturedWholeForward:
+    """The WHOLE inference forward -- sampling, neighbour searches, index tables AND the feature pass -- in one hipGraph
+    (BASELINE configs[4] "hipGraph-captured fwd"; SURVEY.md section 7.8 / 8(b) "hipGraph-capturable").
+
+    The reference turns every data-dependent size into a host integer with a device -> host synchronisation
+    (``torch.where`` in ``batch2ptr``, point_ops.py:50; boolean flattening :101-107; ``fps_ops.py:31-33``), and so does this
+    package by default: a graph cannot contain those.  Here the counts stay on the device (``ops.CountBounds``):
+
+    1. a CALIBRATION forward over the batch logs every count in program order (``ops.CountRecorder``);
+    2. each becomes a capacity (count x ``headroom``, rounded up); buffers are allocated and kernels launched for the
+       capacities, the true counts live in the CSR offsets / group pointers / per-cloud lengths the kernels read anyway;
+    3. the slack has to be SOMETHING: one phantom point is appended to the batch as a cloud of its own (cloud B, its own
+       curve); index lists are padded with it, so every entry past a true count is one more point of that cloud -- the
+       per-cloud searches, per-curve operations and per-row layers of the real clouds never see it, and in inference
+       mode (BatchNorm from running statistics) nothing reduces over rows;
+    4. ``overflow`` (one device flag) is raised when a true count exceeds its capacity or an ordering check fails:
+       ``replay()`` reads it back -- the ONE read-back of a forward -- and raises ``CapacityExceeded``; the caller then runs
+       the eager path (or re-captures with the new batch as calibration).
+
+    A replay is valid for the captured batch (new FEATURES may be written into it: ``load_features``) and for any batch of
+    the same shape that ``load()`` has checked against the capacities; the random draws of the samplers (CurveFPS phase ...)
+    are those of construction time."""
+
+    class CapacityExceeded(RuntimeError):
+        pass
+
+    def __init__(self, model, data, headroom=1.0625, **forward_kwargs):
+        from . import ops
+        if model.training:
+            raise RuntimeError("CapturedWholeForward captures the inference forward: call model.eval() first")
+        self.model, self.kwargs = model, forward_kwargs
+        self.n = data.pos.size(0)
+        dev = data.pos.device
+        self.data = self._with_phantom(data)
+        # the samplers' random draws (CurveFPS phase, FPS starts ...) come from torch's CPU generator and end up as kernel
+        # ARGUMENTS, i.e. inside the graph: every pass of this object starts from the generator state of construction time
+        self._rng = torch.get_rng_state()
+        # 1. the ordinary forward (reference value for the tests)
+        with torch.no_grad():
+            torch.set_rng_state(self._rng)
+            self.reference = model(self.data, **forward_kwargs)[: self.n].clone()
+        # 2. calibration: one eager pass in which every count is read back, turned into a capacity and used as such at
+        # once (ops.CountBounds); afterwards the same pass without any read-back, off the default stream (allocator warm-up)
+        self.bounds = ops.CountBounds(None, dev, headroom)
+        ops.COUNTS = self.bounds
+        try:
+            with torch.no_grad():
+                torch.set_rng_state(self._rng)
+                model(self.data, **forward_kwargs)
+        finally:
+            ops.COUNTS = None
+        self.counts, self.caps = list(self.bounds.counts), list(self.bounds.caps)
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            self.bounded_eager()
+        cur.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        # 3. capture
+        self.graph = torch.cuda.CUDAGraph()
+        ops.COUNTS = self.bounds
+        try:
+            torch.set_rng_state(self._rng)
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.bounds.rewind()
+                self.out = model(self.data, **forward_kwargs)
+        finally:
+            ops.COUNTS = None
+
+    @staticmethod
+    def _with_phantom(data):
+        """The batch + one phantom point: cloud id B, curve 0 of that cloud, zero features, the position of the last point."""
+        from types import SimpleNamespace
+        out = SimpleNamespace(**vars(data))
+        b = int(getattr(data, "num_clouds", None) or getattr(data, "num_graphs", None) or (int(data.batch[-1]) + 1))
+        out.pos = torch.cat([data.pos, data.pos[-1:]], 0).contiguous()
+        out.batch = torch.cat([data.batch, torch.full((1,), b, dtype=data.batch.dtype, device=data.batch.device)])
+        out.curve_idxs = torch.cat([data.curve_idxs, torch.zeros(1, dtype=data.curve_idxs.dtype, device=data.batch.device)])
+        if getattr(data, "x", None) is not None:
+            out.x = torch.cat([data.x, torch.zeros_like(data.x[-1:])], 0).contiguous()
+        if hasattr(data, "labels"):
+            out.labels = torch.cat([data.labels, data.labels[-1:]])
+        out.num_clouds = b + 1
+        if hasattr(out, "num_graphs"):
+            out.num_graphs = b + 1
+        return out
+
+    def load_features(self, x):
+        """New point features for the captured batch (same positions: the counts cannot change, no check needed)."""
+        self.data.x[: self.n].copy_(x)
+
+    def load(self, data, verify=True):
+        """Write another batch of the same shape (points, clouds) into the captured input tensors.  New positions mean new
+        counts: ``verify`` runs ONE eager pass that reads every count back and raises ``CapacityExceeded`` before a count that
+        does not fit is used (ops.CountBounds, verifying) -- a count past its capacity would leave the later stages of a
+        replay with inconsistent tables, which the device flag reports only afterwards.  After a successful check every
+        replay over this batch is safe."""
+        from . import ops
+        if data.pos.size(0) != self.n:
+            raise ValueError("the graph was captured for %d points" % self.n)
+        self.data.pos[: self.n].copy_(data.pos)
+        self.data.pos[self.n].copy_(data.pos[-1])
+        self.data.batch[: self.n].copy_(data.batch)
+        self.data.curve_idxs[: self.n].copy_(data.curve_idxs)
+        if getattr(data, "x", None) is not None:
+            self.data.x[: self.n].copy_(data.x)
+        if verify:
+            ops.COUNTS = self.bounds
+            try:
+                self.bounds.rewind(verifying=True)
+                torch.set_rng_state(self._rng)
+                with torch.no_grad():
+                    self.model(self.data, **self.kwargs)
+            except ops.CountBounds.Exceeded as e:
+                raise self.CapacityExceeded(str(e)) from None
+            finally:
+                self.bounds.rewind()
+                ops.COUNTS = None
+
+    def bounded_eager(self):
+        """The captured computation launched kernel by kernel (bounded counts, no read-back)."""
+        from . import ops
+        ops.COUNTS = self.bounds
+        try:
+            self.bounds.rewind()
+            torch.set_rng_state(self._rng)
+            with torch.no_grad():
+                return self.model(self.data, **self.kwargs)[: self.n]
+        finally:
+            ops.COUNTS = None
+
+    def eager(self):
+        """The ordinary forward over the same batch (host read-back per count), for A/B timing."""
+        torch.set_rng_state(self._rng)
+        with torch.no_grad():
+            return self.model(self.data, **self.kwargs)[: self.n]
+
+    def replay(self, check=True):
+        """One graph launch; the logits of the real points.  ``check``: read the overflow flag back (the forward's one
+        synchronisation) and raise ``CapacityExceeded`` if a count did not fit."""
+        self.graph.replay()
+        if check and int(self.bounds.overflow.item()) != 0:
+            raise self.CapacityExceeded("a data-dependent count exceeded the capacity this graph was captured with "
+                                        "(or the batch is not sorted): run the eager forward, or capture again")
+        return self.out[: self.n]

@@ -138,6 +138,104 @@ def _i64(t):
 
 
 # --------------------------------------------------------------------------------------
+# Data-dependent element counts (sampled points, edges, compact rows, curves ...)
+# --------------------------------------------------------------------------------------
+# The reference turns every such count into a host integer with a device -> host synchronisation (``torch.where`` in
+# ``batch2ptr`` point_ops.py:50, boolean-mask flattening :101-107, ``fps_ops.py:31-33``); by default this package does the same
+# with one small read-back per count (``_count``).  ``COUNTS`` switches that:
+#   * ``CountRecorder``: read back as usual and LOG every count in program order (the calibration pass of
+#     ``graph.CapturedWholeForward``);
+#   * ``CountBounds``: no read-back at all -- the host integer is a CAPACITY fixed beforehand (the calibrated count plus
+#     head-room), every buffer is allocated for it, every kernel launched for it; the true count stays on the device, where
+#     the producing kernel left it for its consumers (CSR offsets, group pointers, per-cloud lengths), the unused tail of an
+#     index list is pre-filled with a harmless entry, and ``overflow`` -- a device flag -- is raised when a true count exceeds
+#     its capacity (or a sortedness check fails).  One read-back of that flag per forward replaces all the others, and the
+#     whole forward, geometry included, is hipGraph-capturable ("device-side counts").
+COUNTS = None
+
+
+class CountRecorder:
+    def __init__(self):
+        self.log = []               # (what, value) in program order
+
+    def resolve(self, values, whats):
+        for w, v in zip(whats, values):
+            self.log.append((w, int(v)))
+        return [int(v) for v in values]
+
+
+class CountBounds:
+    """``caps``: the capacities, ``[(what, capacity)]`` in program order -- or None to CALIBRATE: the first pass then reads
+    every true count back (as the synchronous path does), turns it into a capacity (``headroom`` x count, rounded up to 64)
+    and USES that capacity at once, so that whatever the slack of one stage adds to the counts of the next -- the phantom
+    points of a padded sample list have neighbours, rows and edges of their own -- is part of the later calibrations.
+    After ``rewind()`` the same object replays the capacities without any read-back; ``rewind(verifying=True)`` replays them
+    but reads every count back first and raises ``Exceeded`` BEFORE an overflowing count is used -- the safe way to find out
+    whether another batch fits (a count past its capacity leaves later stages with inconsistent tables: the device flag
+    reports that after the fact, it cannot make the pass memory-safe)."""
+
+    class Exceeded(RuntimeError):
+        pass
+
+    def __init__(self, caps, device, headroom=1.0625):
+        self.calibrating = caps is None
+        self.verifying = False      # replay the capacities but READ every count back and raise before it is used if it does not fit
+        self.caps, self.at, self.headroom = ([] if caps is None else list(caps)), 0, float(headroom)
+        self.counts = []            # (what, true count) of the calibration pass
+        self.overflow = torch.zeros((), dtype=torch.int32, device=device)
+
+    def rewind(self, verifying=False):
+        self.at = 0
+        self.calibrating, self.verifying = False, verifying
+        self.overflow.zero_()
+
+    def take(self, dev_values, whats):
+        out = []
+        if self.calibrating:
+            for w, v in zip(whats, dev_values.tolist()):
+                cap = int(-(-int(v * self.headroom + 32) // 64) * 64)
+                self.counts.append((w, int(v)))
+                self.caps.append((w, cap))
+                out.append(cap)
+            self.at = len(self.caps)
+            return out
+        vals = dev_values.tolist() if self.verifying else None
+        for i, w in enumerate(whats):
+            if vals is not None and self.at < len(self.caps) and vals[i] > self.caps[self.at][1]:
+                raise self.Exceeded("%s: %d exceeds the capacity %d" % (w, vals[i], self.caps[self.at][1]))
+            if self.at >= len(self.caps) or self.caps[self.at][0] != w:
+                raise RuntimeError("count site %r out of step with the calibration (%s)" % (
+                    w, self.caps[self.at][0] if self.at < len(self.caps) else "past the end"))
+            cap = int(self.caps[self.at][1])
+            self.at += 1
+            self.overflow.copy_(torch.maximum(self.overflow, (dev_values[i] > cap).to(torch.int32)))
+            out.append(cap)
+        return out
+
+    def flag(self, dev_bad):
+        """A device-side consistency check (ids sorted ...) that the synchronous path raises on: folded into the flag."""
+        if self.calibrating or self.verifying:
+            if int(dev_bad.item()) != 0:
+                raise AssertionError("batch / curve ids are not sorted (or cloud ids are not 0..B-1)")
+            return
+        self.overflow.copy_(torch.maximum(self.overflow, (dev_bad != 0).to(torch.int32)))
+
+
+def bounded():
+    return isinstance(COUNTS, CountBounds)
+
+
+def _count(dev, whats):
+    """Host integers for the device-side counts ``dev`` (a 1-D int tensor, one entry per name in ``whats``)."""
+    if bounded():
+        return COUNTS.take(dev, whats)
+    vals = dev.tolist()                                   # host sync, as torch.where / nonzero in the reference
+    if COUNTS is not None:
+        return COUNTS.resolve(vals, whats)
+    return [int(v) for v in vals]
+
+
+# --------------------------------------------------------------------------------------
 # A1 / A2: segment pointers and curve topology
 # --------------------------------------------------------------------------------------
 
@@ -173,15 +271,24 @@ class CurveTopology:
         self.n, self.num_clouds, self.batch, self.p2c = n, num_clouds, batch, p2c
         self.glob = torch.empty(n, dtype=torch.int64, device=dev)
         self.cid = torch.empty(n, dtype=torch.int32, device=dev)
-        curve_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        # (bounded counts: the curves beyond the true number are empty runs at the end -- every entry starts as n)
+        curve_ptr = (torch.full((n + 1,), n, dtype=torch.int32, device=dev) if bounded()
+                     else torch.empty(n + 1, dtype=torch.int32, device=dev))
         self.cloud_ptr = torch.empty(num_clouds + 1, dtype=torch.int64, device=dev)
         meta = torch.empty(4, dtype=torch.int64, device=dev)
         ws = workspace(lib().ccn_curve_topology_workspace_bytes(n, num_clouds), dev)
         call("curve_topology", ptr(batch), ptr(p2c), n, num_clouds, ptr(self.glob), ptr(self.cid), ptr(curve_ptr),
              ptr(self.cloud_ptr), ptr(meta), ptr(ws), ws.numel())
-        q, bad, longest, _ = (int(v) for v in meta.tolist())
-        if bad:
-            raise AssertionError("batch / curve ids are not sorted (or cloud ids are not 0..B-1)")
+        if bounded():
+            COUNTS.flag(meta[1])
+            q, longest = _count(meta[0:3:2], ("curves", "longest cloud"))
+            q, longest = min(q, n), min(longest, n)
+        else:
+            q, bad, longest, _ = (int(v) for v in meta.tolist())
+            if COUNTS is not None:
+                COUNTS.resolve((q, longest), ("curves", "longest cloud"))
+            if bad:
+                raise AssertionError("batch / curve ids are not sorted (or cloud ids are not 0..B-1)")
         self.num_curves, self.max_cloud = q, longest
         self.curve_ptr = curve_ptr[: q + 1]
         self.lengths = self.cloud_ptr[1:] - self.cloud_ptr[:-1]
@@ -1264,12 +1371,15 @@ def curve_fps(pos, topo, spacing, u):
     """ref src/models/modules/fps_ops.py:16-39; ``u`` = the reference's torch.rand(1) draw."""
     pos = _pos(pos)
     n, dev = pos.size(0), pos.device
-    idx = torch.empty(n, dtype=torch.int64, device=dev)
+    # (bounded counts: the tail of the list names the LAST point -- the phantom point graph.CapturedWholeForward appends as
+    # a cloud of its own -- so that every sample past the true count is one more point of that cloud)
+    idx = (torch.full((n,), n - 1, dtype=torch.int64, device=dev) if bounded()
+           else torch.empty(n, dtype=torch.int64, device=dev))
     count = torch.empty(1, dtype=torch.int64, device=dev)
     ws = workspace(lib().ccn_curve_fps_workspace_bytes(n), dev)
     call("curve_fps", ptr(pos), ptr(topo.cid), ptr(topo.curve_ptr), n, float(spacing), float(u), ptr(idx), ptr(count),
          ptr(ws), ws.numel())
-    return idx[: int(count.item())]
+    return idx[: min(_count(count, ("curve-FPS samples",))[0], n)]
 
 
 # --------------------------------------------------------------------------------------
@@ -1295,11 +1405,14 @@ def radius_1d_group_subset(pos, idx, topo, radius):
     ws = workspace(lib().ccn_curve_group_subset_workspace_bytes(n, q, m), dev)
     call("curve_group_subset_count", ptr(pos), ptr(topo.cid), ptr(topo.curve_ptr), ptr(topo.p2c), n, q, ptr(idx), m,
          float(radius), ptr(budget), ptr(offsets), ptr(total), ptr(ws), ws.numel())
-    e = int(total.item())
-    row = torch.empty(e, dtype=torch.int64, device=dev)
-    col = torch.empty(e, dtype=torch.int64, device=dev)
-    call("curve_group_subset_fill", ptr(topo.cid), ptr(topo.curve_ptr), ptr(topo.p2c), n, q, ptr(idx), m, ptr(budget),
-         ptr(offsets), ptr(row), ptr(col))
+    e = _count(total, ("curve-group edges",))[0]
+    if bounded():
+        offsets.clamp_(max=e)           # (capacity exceeded -- the flag is up: every group still ends inside row / col)
+    # (bounded counts: edges past the true total belong to no group -- offsets[m] is the true total -- and name point 0)
+    row = torch.zeros(e, dtype=torch.int64, device=dev) if bounded() else torch.empty(e, dtype=torch.int64, device=dev)
+    col = torch.zeros(e, dtype=torch.int64, device=dev) if bounded() else torch.empty(e, dtype=torch.int64, device=dev)
+    call("curve_group_subset_fill_cap", ptr(topo.cid), ptr(topo.curve_ptr), ptr(topo.p2c), n, q, ptr(idx), m, ptr(budget),
+         ptr(offsets), ptr(row), ptr(col), e)
     return EdgeList(row, col, offsets, m)
 
 
@@ -1400,8 +1513,8 @@ def fast_knn(points1, points2, lengths1, lengths2, K, r, return_dists=False):
     p1, p2 = _mat(points1), _mat(points2)
     b, n1, n2, dev = p1.size(0), p1.size(1), p2.size(1), p1.device
     if isinstance(r, (float, int)):
-        r = torch.full((b,), float(r), dtype=torch.float32)
-    r = r.to(torch.float32)
+        r = torch.full((b,), float(r), dtype=torch.float32, device=dev)    # (on the device at once: no host -> device copy,
+    r = r.to(torch.float32)                                                # which a hipGraph capture could not hold)
     if r.numel() == 1:
         r = r.expand(b)
     if r.numel() != b:
@@ -1423,10 +1536,13 @@ def to_batch_padded(t, topo):
     if b == 1:
         return t.unsqueeze(0), torch.ones((1, t.size(0)), dtype=torch.bool, device=t.device)
     local = torch.arange(topo.n, device=t.device) - topo.cloud_ptr[topo.batch]
+    if bounded():
+        local = local.clamp(max=nmax - 1)     # (a cloud longer than the capacity: the overflow flag is up, stay in bounds)
     out = torch.zeros((b, nmax) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     out[topo.batch, local] = t
-    mask = torch.zeros((b, nmax), dtype=torch.bool, device=t.device)
-    mask[topo.batch, local] = True
+    # (rows i < length of the cloud: the same table as scattering True at every point's slot, without an index_put whose
+    # scalar operand is a host -> device copy -- not capturable in a hipGraph)
+    mask = torch.arange(nmax, device=t.device)[None, :] < topo.lengths[:, None]
     return out, mask
 
 
@@ -2041,11 +2157,18 @@ class SGCompact:
         ws = workspace(lib().ccn_exclusive_scan_workspace_bytes(n), dev)
         call("exclusive_scan_i32", ptr(cnt), n, ptr(self.grp_ptr), ptr(totals[0:1]), ptr(ws), ws.numel())
         call("exclusive_scan_i32", ptr(has), n, ptr(rep_off), ptr(totals[1:2]), ptr(ws), ws.numel())
-        e, ne = (int(v) for v in totals.tolist())
+        if bounded():
+            # real rows [0, e_cap) (the true total is grp_ptr[n]; rows past it belong to no group and name point 0),
+            # representatives [e_cap, e_cap + n) -- any point may have one --, the padding row behind them
+            e, ne = _count(totals, ("compact SGCNN rows", "compact SGCNN representatives"))[0], n
+            self.grp_ptr.clamp_(max=e)  # (capacity exceeded -- the flag is up: every group still ends inside row_src / the rows)
+        else:
+            e, ne = _count(totals, ("compact SGCNN rows", "compact SGCNN representatives"))
         self.n, self.k, self.e, self.ne = n, k, e, ne
         self.rows = e + ne + 1
         self.count = float(b * nmax * (k + 1))                    # rows of the dense layout = sum of all weights
-        self.row_src = torch.empty(e, dtype=torch.int32, device=dev)
+        self.row_src = (torch.zeros(e, dtype=torch.int32, device=dev) if bounded()
+                        else torch.empty(e, dtype=torch.int32, device=dev))
         self.rep_row = torch.empty(n, dtype=torch.int32, device=dev)
         self.row_w = torch.empty(ne + 1, dtype=torch.float32, device=dev)
         call("cg_fill", ptr(nbr), ptr(topo.cloud_ptr), b, nmax, k, ptr(self.grp_ptr), ptr(rep_off), e, ptr(self.row_src),

@@ -115,6 +115,12 @@ int ccn_curve_group_subset_count(const float* pos, const int32_t* cid, const int
 int ccn_curve_group_subset_fill(const int32_t* cid, const int32_t* curve_ptr, const int64_t* p2c, int64_t n,
                                 int64_t Q, const int64_t* idx, int64_t M, const float* budget,
                                 const int32_t* offsets, int64_t* row, int64_t* col, void* stream);
+/* round 5 (device-side counts): the same with the capacity of row / col given -- a group that would end past `cap`
+ * entries is not written.  For a caller that sizes row / col from a bound instead of reading `total` back (the reference
+ * reads it back: boolean flattening at point_ops.py:186-193). */
+int ccn_curve_group_subset_fill_cap(const int32_t* cid, const int32_t* curve_ptr, const int64_t* p2c, int64_t n,
+                                    int64_t Q, const int64_t* idx, int64_t M, const float* budget,
+                                    const int32_t* offsets, int64_t* row, int64_t* col, int64_t cap, void* stream);
 
 /* ---- A9: point_ops.py:196-260 knn_1d_group_superset + :344-355 knn_interpolate_1D ----------------
  * nbr: int64 (n, k) position inside idx of the k nearest sampled points on the same curve, ascending

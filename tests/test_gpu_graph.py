@@ -41,3 +41,98 @@ def test_captured_forward_is_bit_identical_to_eager(which, dtype, train):
         assert torch.equal(plain, eager)
     finally:
         ops.set_mlp_dtype("fp32")
+
+
+# ---- round 5: the WHOLE forward (geometry + features) captured, data-dependent counts kept on the device
+def _prepared_indices(model, data, num_real):
+    """Index tables of a geometry pass, cut to the entries that belong to the real points: per step the sampled indices and
+    the curve-group / FRNN edge lists (what the reference reads back with torch.where / nonzero)."""
+    plan = model.prepare(data)
+    ctx, tables, _ = plan
+    ctx.side.synchronize()
+    out = []
+    for t in tables:
+        if t is None:
+            continue
+        g = t[0]
+        for name in ("idx", "nbr"):
+            v = getattr(g, name, None)
+            if torch.is_tensor(v):
+                out.append((name, v))
+        e = getattr(g, "edges", None)
+        if e is not None:
+            out.append(("edges", e))
+    return out
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_whole_forward_captured_with_device_side_counts(dtype):
+    """``graph.CapturedWholeForward`` on the section-8(a) hot-path network: sampling, curve groups, FRNN tables, compact rows
+    and the feature pass replayed from ONE hipGraph with no host read-back inside it (reference sync points being replaced:
+    point_ops.py:50, :101-107, fps_ops.py:31-33).  The logits of the real points equal the ordinary forward's (the products'
+    K chains are the same; a tile of the split tail round may group them differently: 1e-5), replays are bit-identical to
+    each other and to the bounded eager pass, and the sampled indices of the bounded pass are bit-identical to the ordinary
+    pass's on the real points."""
+    from curvecloudnet_amd import configs, ops
+    from curvecloudnet_amd.graph import CapturedWholeForward
+    from curvecloudnet_amd.model import build_model
+    from curvecloudnet_amd.synth import make_batch
+    torch.manual_seed(4)
+    model = build_model(configs.hotpath_config(0.5), in_dim=4, n_out=20).to(DEV).eval()
+    data = batch_to(make_batch([0, 1, 2], n_curves=200), DEV)
+    n = data.pos.size(0)
+    ops.set_mlp_dtype(dtype)
+    try:
+        torch.manual_seed(9)
+        with torch.no_grad():
+            plain = model(data).clone()
+        torch.manual_seed(9)
+        cap = CapturedWholeForward(model, data)
+        assert len(cap.counts) >= 6 and all(c >= v for (_, c), (_, v) in zip(cap.caps, cap.counts))
+        first = cap.replay().clone()
+        second = cap.replay().clone()
+        torch.manual_seed(9)
+        bounded = cap.bounded_eager().clone()
+        torch.cuda.synchronize()
+        assert first.shape == plain.shape and bool(torch.isfinite(first).all())
+        assert torch.equal(first, second) and torch.equal(first, bounded)
+        tol = (1e-5 if dtype == "fp32" else 2e-2) * max(1.0, float(plain.abs().max()))
+        assert float((first - plain).abs().max()) <= tol, float((first - plain).abs().max())
+        assert int(cap.bounds.overflow.item()) == 0
+        # indices: ordinary pass over the real batch vs bounded pass over the batch + phantom cloud
+        torch.manual_seed(9)
+        want = _prepared_indices(model, data, n)
+        ops.COUNTS = cap.bounds
+        try:
+            cap.bounds.rewind()
+            torch.manual_seed(9)
+            got = _prepared_indices(model, cap.data, n)
+        finally:
+            ops.COUNTS = None
+        assert len(want) == len(got) and len(want) >= 3
+        for (name, a), (_, b) in zip(want, got):
+            if name == "idx":
+                assert torch.equal(b[: a.numel()], a), "sampled indices differ"
+                assert bool((b[a.numel():] >= n).all()) or b.numel() == a.numel()     # the slack is the phantom cloud
+            elif name == "nbr":
+                assert torch.equal(b[: a.size(0), : a.size(1)], a), "FRNN table of the real clouds differs"
+            else:
+                e = a.num_edges
+                assert torch.equal(b.row[:e], a.row) and torch.equal(b.col[:e], a.col), "curve-group edges differ"
+                assert torch.equal(b.offsets[: a.num_dst + 1], a.offsets)
+        # another batch of the same shape: load() checks it against the capacities with one eager, synchronous pass and
+        # raises BEFORE a count that does not fit is used; a batch that fits replays like the first
+        other = batch_to(make_batch([3, 4, 5], n_curves=200), DEV)
+        if other.pos.size(0) == n:
+            cap.load(other)
+            assert bool(torch.isfinite(cap.replay()).all())
+        cap.load(data)
+        assert torch.equal(cap.replay(), first)
+        tight = CapturedWholeForward(model, data, headroom=1.0)
+        dense = batch_to(make_batch([0, 1, 2], n_curves=200), DEV)
+        dense.pos = dense.pos * 0.5                      # half the spacing: more points within every radius
+        with pytest.raises(CapturedWholeForward.CapacityExceeded):
+            tight.load(dense)
+    finally:
+        ops.COUNTS = None
+        ops.set_mlp_dtype("fp32")
