@@ -371,10 +371,11 @@ __global__ void dense_fill_kernel(const int64_t* __restrict__ idx, const int64_t
   const int64_t* row = idx + (b * P1 + i) * K;
   const int64_t q = cloud_ptr1[b] + i;
   int32_t at = offsets[q];
-  const int64_t base2 = cloud_ptr2[b];
+  const int32_t end = offsets[q + 1];       // (== at + this query's count; smaller only when the caller clamped the offsets to
+  const int64_t base2 = cloud_ptr2[b];      //  the capacity of row_out / col_out: bounded counts, capacity exceeded)
   for (int64_t s = 0; s < K; ++s) {
     const int64_t j = row[s];
-    if (j != -1) {
+    if (j != -1 && at < end) {
       row_out[at] = q;
       col_out[at] = base2 + j;
       ++at;

@@ -92,13 +92,18 @@ class CapturedWholeForward:
         # the samplers' random draws (CurveFPS phase, FPS starts ...) come from torch's CPU generator and end up as kernel
         # ARGUMENTS, i.e. inside the graph: every pass of this object starts from the generator state of construction time
         self._rng = torch.get_rng_state()
-        # 1. the ordinary forward (reference value for the tests)
-        with torch.no_grad():
-            torch.set_rng_state(self._rng)
-            self.reference = model(self.data, **forward_kwargs)[: self.n].clone()
+        # 1. the ordinary forward (reference value for the tests); its counts and its samplers' random draws are logged
+        rec = ops.COUNTS = ops.CountRecorder()
+        try:
+            with torch.no_grad():
+                torch.set_rng_state(self._rng)
+                self.reference = model(self.data, **forward_kwargs)[: self.n].clone()
+        finally:
+            ops.COUNTS = None
+        self.draws = rec.draws
         # 2. calibration: one eager pass in which every count is read back, turned into a capacity and used as such at
         # once (ops.CountBounds); afterwards the same pass without any read-back, off the default stream (allocator warm-up)
-        self.bounds = ops.CountBounds(None, dev, headroom)
+        self.bounds = ops.CountBounds(None, dev, headroom, draws=self.draws)
         ops.COUNTS = self.bounds
         try:
             with torch.no_grad():

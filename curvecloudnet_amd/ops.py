@@ -155,13 +155,23 @@ COUNTS = None
 
 
 class CountRecorder:
-    def __init__(self):
+    """Ordinary counts (read back), logged; the samplers' host-side random draws logged as well -- or, given ``replay``
+    (the ``draws`` of an earlier recorder), replayed instead of drawn."""
+
+    def __init__(self, replay=None):
         self.log = []               # (what, value) in program order
+        self.draws = []             # host tensors, in program order
+        self.replay = None if replay is None else list(replay)
 
     def resolve(self, values, whats):
         for w, v in zip(whats, values):
             self.log.append((w, int(v)))
         return [int(v) for v in values]
+
+    def draw(self, make, fit, device):
+        t = self.replay.pop(0) if self.replay is not None else make()
+        self.draws.append(t.clone())
+        return t if device is None else t.to(device)
 
 
 class CountBounds:
@@ -177,17 +187,35 @@ class CountBounds:
     class Exceeded(RuntimeError):
         pass
 
-    def __init__(self, caps, device, headroom=1.0625):
+    def __init__(self, caps, device, headroom=1.0625, draws=None):
+        self.given_draws = None if draws is None else list(draws)     # the draws of the ordinary pass, to calibrate with
         self.calibrating = caps is None
         self.verifying = False      # replay the capacities but READ every count back and raise before it is used if it does not fit
         self.caps, self.at, self.headroom = ([] if caps is None else list(caps)), 0, float(headroom)
         self.counts = []            # (what, true count) of the calibration pass
+        self.consts, self.const_at = [], 0      # device tensors made from host random draws, in program order
         self.overflow = torch.zeros((), dtype=torch.int32, device=device)
 
     def rewind(self, verifying=False):
-        self.at = 0
+        self.at = self.const_at = 0
         self.calibrating, self.verifying = False, verifying
         self.overflow.zero_()
+
+    def draw(self, make, fit, device):
+        """A sampler's host-side random draw (CurveFPS phase, VoxelFPS scores, FPS start points).  Calibration: the draw of the
+        ordinary pass if one was recorded (``draws``) -- fitted to this pass's sizes by ``fit``: the real points come first in
+        every list, so their values carry over and the bounded pass samples exactly what the ordinary pass sampled --, else
+        ``make()``; moved to the device once.  Afterwards: that same device tensor (a host -> device copy is not something a
+        graph capture can hold, and the draw is a constant of the captured computation anyway)."""
+        if self.calibrating:
+            t = self.given_draws.pop(0) if self.given_draws else make()
+            if fit is not None:
+                t = fit(t)
+            self.consts.append(t if device is None else t.to(device))
+            return self.consts[-1]
+        t = self.consts[self.const_at]
+        self.const_at += 1
+        return t
 
     def take(self, dev_values, whats):
         out = []
@@ -223,6 +251,24 @@ class CountBounds:
 
 def bounded():
     return isinstance(COUNTS, CountBounds)
+
+
+def draw(make, fit=None, device=None):
+    """A host-side random draw of a sampler, through the count resolver when there is one (recorded / replayed / kept as a
+    device constant: see CountRecorder.draw, CountBounds.draw)."""
+    if COUNTS is None:
+        t = make()
+        return t if device is None else t.to(device)
+    return COUNTS.draw(make, fit, device)
+
+
+def _fit_rows(n, fill):
+    """fit for draw(): the first entries of the recorded draw, then ``fill`` up to n entries."""
+    def fit(t):
+        if t.numel() >= n:
+            return t[:n].clone()
+        return torch.cat([t, torch.full((n - t.numel(),), fill, dtype=t.dtype)])
+    return fit
 
 
 def _count(dev, whats):
@@ -1583,15 +1629,18 @@ def frnn_edges(pos_q, topo_q, pos_s, topo_s, k, radius, operation="knn", accel_k
         nbr = fast_knn(qp, sp, topo_q.lengths, topo_s.lengths, k, EXACT_KNN_RADIUS)
     b, p1, dev = nbr.size(0), nbr.size(1), nbr.device
     m = topo_q.n
-    counts = torch.empty(m + 1, dtype=torch.int32, device=dev)
+    counts = (torch.zeros if bounded() else torch.empty)(m + 1, dtype=torch.int32, device=dev)
     call("dense_to_csr_count", ptr(nbr), ptr(topo_q.cloud_ptr), b, p1, k, ptr(counts))
     offsets = torch.empty(m + 1, dtype=torch.int32, device=dev)
     total = torch.empty(1, dtype=torch.int64, device=dev)
     ws = workspace(lib().ccn_exclusive_scan_workspace_bytes(m), dev)
     call("exclusive_scan_i32", ptr(counts), m, ptr(offsets), ptr(total), ptr(ws), ws.numel())
-    e = int(total.item())
-    row = torch.empty(e, dtype=torch.int64, device=dev)
-    col = torch.empty(e, dtype=torch.int64, device=dev)
+    e = _count(total, ("neighbour-search edges",))[0]
+    if bounded():
+        offsets.clamp_(max=e)           # (capacity exceeded -- the flag is up: the fill kernel stops at the next offset)
+    # (bounded counts: edges past the true total belong to no group and name point 0)
+    row = (torch.zeros if bounded() else torch.empty)(e, dtype=torch.int64, device=dev)
+    col = (torch.zeros if bounded() else torch.empty)(e, dtype=torch.int64, device=dev)
     call("dense_to_csr_fill", ptr(nbr), ptr(topo_q.cloud_ptr), ptr(topo_s.cloud_ptr), b, p1, k, ptr(offsets), ptr(row),
          ptr(col))
     return EdgeList(row, col, offsets, m)
@@ -1908,7 +1957,9 @@ def voxel_fps(pos, batch, voxel_size, rnd=None):
     pos, batch = _pos(pos), _i64(batch)
     n, dev = pos.size(0), pos.device
     if rnd is None:
-        rnd = torch.rand(n)
+        # (the phantom point -- last -- and the slack behind the real points get score 0.5: they never share a voxel with
+        # a real point, their scores decide nothing)
+        rnd = draw(lambda: torch.rand(n), fit=_fit_rows(n, 0.5), device=dev)
     rnd = rnd.to(device=dev, dtype=torch.float32).contiguous()
     key = torch.empty(n, dtype=torch.int64, device=dev)
     score = torch.empty(n, dtype=torch.float32, device=dev)
@@ -1918,18 +1969,26 @@ def voxel_fps(pos, batch, voxel_size, rnd=None):
     # ccn_rank_keys (radix sort on the digits in which the keys differ at all)
     meta = torch.empty(2, dtype=torch.int64, device=dev)              # [spread of the keys, number of distinct keys]
     call("key_spread", ptr(key), n, ptr(meta))
-    spread, n_bad = int(meta[0].item()), int(bad.item())
-    if n_bad:
-        raise ValueError("voxel_fps: voxel coordinates exceed the 18-bit key range")
-    digits = sum(1 << b for b in range(8) if (spread >> (8 * b)) & 255)
+    if bounded() and not COUNTS.calibrating and not COUNTS.verifying:
+        COUNTS.flag(bad[0])
+        digits = 255                    # (no read-back of the key spread: sort on all eight digits)
+    else:
+        spread, n_bad = int(meta[0].item()), int(bad.item())
+        if n_bad:
+            raise ValueError("voxel_fps: voxel coordinates exceed the 18-bit key range")
+        digits = 255 if bounded() else sum(1 << b for b in range(8) if (spread >> (8 * b)) & 255)
     voxel_of = torch.empty(n, dtype=torch.int64, device=dev)
     nb = lib().ccn_rank_keys_workspace_bytes(n)
     ws = workspace(nb, dev)
     call("rank_keys", ptr(key), n, digits, ptr(voxel_of), ptr(meta[1:]), ptr(ws), nb)
-    m = int(meta[1].item())
+    m = min(_count(meta[1:2], ("voxel samples",))[0], n)
     scratch = torch.empty(m, dtype=torch.int64, device=dev)
     idx = torch.empty(m, dtype=torch.int64, device=dev)
     call("voxel_argmin", ptr(score), ptr(voxel_of), n, m, ptr(scratch), ptr(idx))
+    if bounded():
+        # voxels past the true number hold no point (index 2^32 - 1 out of the kernel): they name the phantom point, like
+        # the tail of every other bounded sample list
+        idx = torch.where(idx >= n, torch.full_like(idx, n - 1), idx)
     return idx
 
 
@@ -1937,15 +1996,32 @@ def fps(pos, topo, ratio, start=None):
     """ref point_ops.py:57-70 fps_pytorch3d (sample_farthest_points, random start): sorted packed indices."""
     pos = _pos(pos)
     dev = pos.device
-    lengths = topo.lengths.cpu()
-    keep = torch.ceil(lengths * ratio).long()                        # the reference's float32 arithmetic
-    out_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(keep, 0)])
-    if start is None:
-        start = torch.tensor([int(torch.randint(int(l), (1,))) for l in lengths.tolist()], dtype=torch.int64)
-    total = int(out_ptr[-1])
+    if bounded():
+        # per-cloud sample counts and output offsets stay on the device (the reference's float32 arithmetic, the same
+        # torch ops on the other device)
+        lengths_d = topo.lengths
+        keep = torch.ceil(lengths_d * ratio).long()
+        out_ptr_d = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(keep, 0)])
+        # the random start points: drawn like the synchronous path draws them (torch.randint(length) per cloud) during the
+        # calibration pass, the same tensor afterwards (clamped into the cloud: another batch may have shorter clouds)
+        start_d = (draw(lambda: torch.tensor([int(torch.randint(max(int(l), 1), (1,))) for l in lengths_d.tolist()],
+                                              dtype=torch.int64), device=dev) if start is None else start.to(dev))
+        start_d = torch.minimum(start_d, (lengths_d - 1).clamp(min=0))
+        total = min(_count(out_ptr_d[-1:], ("FPS samples",))[0], topo.n)
+        out_ptr_d = out_ptr_d.clamp(max=total)
+        out = torch.full((total,), topo.n - 1, dtype=torch.int64, device=dev)      # (tail: the phantom point)
+    else:
+        lengths = topo.lengths.cpu()
+        keep = torch.ceil(lengths * ratio).long()                        # the reference's float32 arithmetic
+        out_ptr = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(keep, 0)])
+        if start is None:
+            start = draw(lambda: torch.tensor([int(torch.randint(int(l), (1,))) for l in lengths.tolist()], dtype=torch.int64))
+        total = int(out_ptr[-1])
+        if COUNTS is not None:
+            COUNTS.resolve((total,), ("FPS samples",))
+        out = torch.empty(total, dtype=torch.int64, device=dev)
+        start_d, out_ptr_d = start.to(dev), out_ptr.to(dev)     # named: must outlive the asynchronous launch
     mind = torch.empty(topo.n, dtype=torch.float32, device=dev)
-    out = torch.empty(total, dtype=torch.int64, device=dev)
-    start_d, out_ptr_d = start.to(dev), out_ptr.to(dev)     # named: must outlive the asynchronous launch
     call("fps", ptr(pos), ptr(topo.cloud_ptr), ptr(start_d), ptr(out_ptr_d), topo.num_clouds, topo.max_cloud, ptr(mind),
          ptr(out))
     # ascending packed indices (the reference sorts them too): ccn_sort_keys on the digits an index < n can differ in

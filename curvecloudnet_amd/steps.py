@@ -217,9 +217,11 @@ class SymmetricCurve1DConvFastV1(nn.Module):
             cid = topo.cid.long()
             g.rows = torch.arange(topo.n, device=pos.device) + pad * cid
             g.n_rows = topo.n + (topo.num_curves - 1) * pad
-            is_sep = torch.ones(g.n_rows, dtype=torch.bool, device=pos.device)
-            is_sep[g.rows] = False
-            g.sep = torch.nonzero(is_sep).flatten()
+            # the separator rows in closed form (no torch.nonzero: that is a device -> host synchronisation and cannot be
+            # captured): the pad rows in front of curve c >= 1 start at curve_ptr[c] + pad * (c - 1)
+            q = topo.num_curves
+            first = topo.curve_ptr[1:q].long() + pad * torch.arange(q - 1, device=pos.device)
+            g.sep = (first[:, None] + torch.arange(pad, device=pos.device)[None, :]).flatten()
             g.cid_seq = torch.full((g.n_rows,), -1, dtype=torch.int32, device=pos.device)
             g.cid_seq[g.rows] = topo.cid
         return g
@@ -313,7 +315,7 @@ class CurveFPS(nn.Module):
 
     def forward(self, pos, batch, point2curveidx, u=None, **kwargs):
         if u is None:
-            u = torch.rand(1)
+            u = ops.draw(lambda: torch.rand(1))
         with _geometry(kwargs) as geo:
             topo = _topology(batch, point2curveidx, kwargs)
             return geo.publish(ops.curve_fps(pos, topo, self.arclen_spacing, float(u)))
@@ -399,7 +401,7 @@ class SAModule(nn.Module):
         if self.downsample_type == "random":
             idx = torch.sort(torch.randperm(pos.size(0))[: int(pos.size(0) * self.ratio)])[0].to(pos.device)
         elif self.downsample_type == "curve-fps":
-            idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
+            idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(ops.draw(lambda: torch.rand(1))))
         elif self.downsample_type == "voxel":
             idx = ops.voxel_fps(pos, batch, self.voxel_size)
         else:
@@ -437,7 +439,7 @@ class CurveSAModule(nn.Module):
         if not self.use_curve_fps:
             idx = ops.fps(pos, topo, self.ratio)              # ref pointnet2.py:165-166 fps_pytorch3d
         else:
-            idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(torch.rand(1)))
+            idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(ops.draw(lambda: torch.rand(1))))
         edges = ops.radius_1d_group_subset(pos, idx, topo, self.r)
         return SimpleNamespace(edges=edges, out=(pos[idx], batch[idx], point2curveidx[idx], None, idx))
 

@@ -62,11 +62,12 @@ def _prepared_indices(model, data, num_real):
         e = getattr(g, "edges", None)
         if e is not None:
             out.append(("edges", e))
+            out.append(("pos", g.out[0]))          # the sampled points themselves (curve-FPS / voxel / farthest-point samplers)
     return out
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
-def test_whole_forward_captured_with_device_side_counts(dtype):
+@pytest.mark.parametrize("which,dtype", [("hotpath", "fp32"), ("hotpath", "fp16"), ("a2d2", "fp16"), ("kitti", "fp32")])
+def test_whole_forward_captured_with_device_side_counts(which, dtype):
     """``graph.CapturedWholeForward`` on the section-8(a) hot-path network: sampling, curve groups, FRNN tables, compact rows
     and the feature pass replayed from ONE hipGraph with no host read-back inside it (reference sync points being replaced:
     point_ops.py:50, :101-107, fps_ops.py:31-33).  The logits of the real points equal the ordinary forward's (the products'
@@ -78,8 +79,10 @@ def test_whole_forward_captured_with_device_side_counts(dtype):
     from curvecloudnet_amd.model import build_model
     from curvecloudnet_amd.synth import make_batch
     torch.manual_seed(4)
-    model = build_model(configs.hotpath_config(0.5), in_dim=4, n_out=20).to(DEV).eval()
-    data = batch_to(make_batch([0, 1, 2], n_curves=200), DEV)
+    cfg, n_out = {"hotpath": (configs.hotpath_config(0.5), 20), "a2d2": (configs.a2d2_config(0.25), 55),
+                  "kitti": (configs.kitti_config(0.25), 20)}[which]
+    model = build_model(cfg, in_dim=4, n_out=n_out).to(DEV).eval()
+    data = batch_to(make_batch([0, 1, 2], n_curves=200, mixed_lengths=(which == "a2d2")), DEV)
     n = data.pos.size(0)
     ops.set_mlp_dtype(dtype)
     try:
@@ -96,40 +99,58 @@ def test_whole_forward_captured_with_device_side_counts(dtype):
         torch.cuda.synchronize()
         assert first.shape == plain.shape and bool(torch.isfinite(first).all())
         assert torch.equal(first, second) and torch.equal(first, bounded)
+        # against the ordinary forward (host read-back per count) over the same batch + phantom point -- and, where the
+        # samplers draw the same number of random values with and without it (hot path: one CurveFPS phase), over the
+        # plain batch as well
         tol = (1e-5 if dtype == "fp32" else 2e-2) * max(1.0, float(plain.abs().max()))
-        assert float((first - plain).abs().max()) <= tol, float((first - plain).abs().max())
+        assert float((first - cap.reference).abs().max()) <= tol, float((first - cap.reference).abs().max())
+        if which == "hotpath":
+            assert float((first - plain).abs().max()) <= tol, float((first - plain).abs().max())
         assert int(cap.bounds.overflow.item()) == 0
-        # indices: ordinary pass over the real batch vs bounded pass over the batch + phantom cloud
-        torch.manual_seed(9)
-        want = _prepared_indices(model, data, n)
+        # indices: ordinary pass vs bounded pass (whose sample lists carry the phantom cloud's slack at their ends)
+        ops.COUNTS = ops.CountRecorder(replay=cap.draws)        # the ordinary pass, with the draws the capture was made with
+        try:
+            want = _prepared_indices(model, cap.data, n)
+        finally:
+            ops.COUNTS = None
         ops.COUNTS = cap.bounds
         try:
             cap.bounds.rewind()
-            torch.manual_seed(9)
+            torch.set_rng_state(cap._rng)
             got = _prepared_indices(model, cap.data, n)
         finally:
             ops.COUNTS = None
         assert len(want) == len(got) and len(want) >= 3
+        real_clouds = cap.data.num_clouds - 1
         for (name, a), (_, b) in zip(want, got):
+            # `a`: the ordinary pass (its lists end with the ONE phantom point's entries), `b`: the bounded pass (the same
+            # entries for the real points, then the phantom cloud's, then the slack)
             if name == "idx":
-                assert torch.equal(b[: a.numel()], a), "sampled indices differ"
-                assert bool((b[a.numel():] >= n).all()) or b.numel() == a.numel()     # the slack is the phantom cloud
+                assert torch.equal(b[: a.numel() - 1], a[:-1]) and int(a[-1]) == n, "sampled indices differ"
+                assert bool((b[a.numel() - 1:] >= n).all())                              # phantom cloud + slack
+            elif name == "nbr" and a.dim() == 3:
+                assert torch.equal(b[:real_clouds, : a.size(1)], a[:real_clouds]), "FRNN table of the real clouds differs"
             elif name == "nbr":
-                assert torch.equal(b[: a.size(0), : a.size(1)], a), "FRNN table of the real clouds differs"
+                m = a.size(0) - 1                          # queries of the real clouds (the ordinary pass's last one is the phantom)
+                assert torch.equal(b[:m], a[:m]), "interpolation neighbours of the real points differ"
+            elif name == "pos":
+                m = a.size(0) - 1
+                assert torch.equal(b[:m], a[:m]), "sampled points differ"
             else:
-                e = a.num_edges
-                assert torch.equal(b.row[:e], a.row) and torch.equal(b.col[:e], a.col), "curve-group edges differ"
-                assert torch.equal(b.offsets[: a.num_dst + 1], a.offsets)
+                m = a.num_dst - 1                          # queries of the real clouds
+                e = int(a.offsets[m])
+                assert torch.equal(b.offsets[: m + 1], a.offsets[: m + 1]), "group offsets differ"
+                assert torch.equal(b.row[:e], a.row[:e]) and torch.equal(b.col[:e], a.col[:e]), "edges differ"
         # another batch of the same shape: load() checks it against the capacities with one eager, synchronous pass and
         # raises BEFORE a count that does not fit is used; a batch that fits replays like the first
-        other = batch_to(make_batch([3, 4, 5], n_curves=200), DEV)
+        other = batch_to(make_batch([3, 4, 5], n_curves=200, mixed_lengths=(which == "a2d2")), DEV)
         if other.pos.size(0) == n:
             cap.load(other)
             assert bool(torch.isfinite(cap.replay()).all())
         cap.load(data)
         assert torch.equal(cap.replay(), first)
         tight = CapturedWholeForward(model, data, headroom=1.0)
-        dense = batch_to(make_batch([0, 1, 2], n_curves=200), DEV)
+        dense = batch_to(make_batch([0, 1, 2], n_curves=200, mixed_lengths=(which == "a2d2")), DEV)
         dense.pos = dense.pos * 0.5                      # half the spacing: more points within every radius
         with pytest.raises(CapturedWholeForward.CapacityExceeded):
             tight.load(dense)
