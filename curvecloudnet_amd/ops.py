@@ -262,6 +262,19 @@ def draw(make, fit=None, device=None):
     return COUNTS.draw(make, fit, device)
 
 
+def spread_phantoms(pos_q, idx, n_src):
+    """Bounded counts only: the slack of a padded sample list names the phantom point (index n_src - 1) over and over, i.e.
+    hundreds to thousands of points of the phantom cloud at ONE position -- a worst case for every neighbour search over that
+    cloud (one grid cell holds them all: 12 k phantoms cost the A2D2 forward 4 ms).  They are moved onto a lattice of spacing
+    16 (no radius of a shipped section exceeds 0.8): isolated points, the cheapest neighbourhoods there are.  The real clouds
+    never see the phantom cloud, so nothing of theirs changes."""
+    if not bounded():
+        return pos_q
+    j = torch.arange(idx.numel(), device=idx.device)
+    lattice = torch.stack([(j % 64), (j // 64) % 64, j // 4096], dim=1).to(pos_q.dtype) * 16.0
+    return torch.where((idx == n_src - 1)[:, None], pos_q + lattice, pos_q)
+
+
 def _fit_rows(n, fill):
     """fit for draw(): the first entries of the recorded draw, then ``fill`` up to n entries."""
     def fit(t):

@@ -406,7 +406,7 @@ class SAModule(nn.Module):
             idx = ops.voxel_fps(pos, batch, self.voxel_size)
         else:
             idx = ops.fps(pos, topo, self.ratio)
-        pos_q, batch_q = pos[idx], batch[idx]
+        pos_q, batch_q = ops.spread_phantoms(pos[idx], idx, pos.size(0)), batch[idx]
         p2c_q = None if point2curveidx is None else point2curveidx[idx]
         topo_q = _topology(batch_q, p2c_q, kwargs, curves=False)
         edges = ops.frnn_edges(pos_q, topo_q, pos, topo, self.knn, self.r,
@@ -441,7 +441,8 @@ class CurveSAModule(nn.Module):
         else:
             idx = ops.curve_fps(pos, topo, self.curve_fps_arclen, float(ops.draw(lambda: torch.rand(1))))
         edges = ops.radius_1d_group_subset(pos, idx, topo, self.r)
-        return SimpleNamespace(edges=edges, out=(pos[idx], batch[idx], point2curveidx[idx], None, idx))
+        return SimpleNamespace(edges=edges, out=(ops.spread_phantoms(pos[idx], idx, pos.size(0)), batch[idx],
+                                                 point2curveidx[idx], None, idx))
 
     def features(self, x, pos, g):
         x = _with_xyz(x, pos[:, :3], self.with_xyz)
