@@ -8,7 +8,7 @@ shift
 repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-bench="python3 $repo/bench.py --no-cpu-baseline --no-kernel-timing $*"
+bench="python3 $repo/bench.py --no-cpu-baseline --no-kernel-timing --no-second-line $*"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o s -- $bench > $out/${tag}_stats_run.log 2>&1 || exit 1
 cp "$(find /tmp/p_stats -name '*kernel_stats.csv' | head -1)" $out/${tag}_kitti_kernel_stats.csv
 for pass in fetch:FETCH_SIZE write:WRITE_SIZE "mfma:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
