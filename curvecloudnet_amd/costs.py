@@ -100,6 +100,13 @@ _TABLE = {
     "cg_edge_bwd_stats": ("edge", lambda i, r: 2 * F32 * _rc(i, 1, 4) + I32 * i[2] + F32 * (i[2] + i[3]) * i[4]),   # + dz rows
     "cg_edge_bwd_stats_h": ("edge", lambda i, r: 2 * F32 * _rc(i, 1, 4) + I32 * i[2] + 2.0 * (i[2] + i[3]) * i[4]),
     "cg_edge_bwd": ("edge", lambda i, r: 4 * F32 * _rc(i, 1, 3) + I32 * i[2] + F32 * _rc(i, 2, 3)),   # (ldps, N, E, Co, …): ps, dps, dz
+    # round 5, atomics-free backward: _sums = (ldps, N, E, Ne, Co, dz16, lddz, act, ldpt): ps (unique rows), dz rows, pt written;
+    # _gather = (ldps, N, Co, dz16, lddz, act, ldpp): ps, the dz rows once more (in source order: rows = E, the launch's work_rows),
+    # two index lists, pp written; _finish = (ldpt, ldpp, N, E, Co, training, lddps): pt, pp read, dps written
+    "cg_edge_bwd_sums": ("edge", lambda i, r: 2 * F32 * _rc(i, 1, 4) + I32 * i[2] + (2.0 if i[5] else F32) * (i[2] + i[3]) * i[4]
+                         + 2 * F32 * _rc(i, 1, 4)),
+    "cg_edge_bwd_gather": ("edge", lambda i, r: 4 * F32 * _rc(i, 1, 2) + ((2.0 if i[3] else F32) * i[2] + 2 * I32) * (r or 0)),
+    "cg_edge_bwd_finish": ("edge", lambda i, r: 6 * F32 * _rc(i, 2, 4)),
     "cg_edge_bwd_h": ("edge", lambda i, r: 4 * F32 * _rc(i, 1, 3) + I32 * i[2] + 2.0 * _rc(i, 2, 3)),
     # ---- PointNetConv2 first layer: px (source rows, L2-resident gathers) -> E x Co rows
     "pn_edge_stats": ("edge", lambda i, r: (I64 * 2 + 2 * 12.0) * i[2]),                 # (ldpx, ldwp, E, Co): indices + positions

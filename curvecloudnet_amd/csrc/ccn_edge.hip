@@ -407,7 +407,9 @@ __global__ __launch_bounds__(TPB) void cg_edge_stats_kernel(
     const int32_t* __restrict__ rep_row, const float* __restrict__ row_w, int64_t N, int64_t E, int64_t Ne, int Co,
     const void* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope, int pts,
-    double* __restrict__ partial) {
+    double* __restrict__ partial, float* __restrict__ pt = nullptr, int64_t ldpt = 0) {
+  // pt (MODE 1, nullable; round 5): per point p the weighted sums over ITS rows, pt[p][c] = sum w g, pt[p][Co + c] = sum w xhat
+  // -- what dS[p] is made of once the column sums are known (cg_edge_finish_kernel), so that no second pass over dZ is needed
   __shared__ double red[4][64][2];
   CCN_LANES;
   const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * pts;
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(TPB) void cg_edge_stats_kernel(
     const int32_t rrow = pad ? (int32_t)(E + Ne) : rep_row[p];
     const int mysrc = cx < cnt ? row_src[g0 + cx] : 0;
     const float si = pad ? 0.f : ps[p * ldps + Co + cc];
+    float pg = 0.f, px = 0.f;         // this point's sums (MODE 1 with pt)
     for (int s0 = 0; s0 < cnt; s0 += SG_UNROLL) {
       float pv[SG_UNROLL], dz[SG_UNROLL];
 #pragma unroll
@@ -450,8 +453,11 @@ __global__ __launch_bounds__(TPB) void cg_edge_stats_kernel(
           s2 += (double)y * (double)y;
         } else {
           const float g = dz[u] * edge_act_grad(y * sc + sh, act, slope);
+          const float xh = (y - mu) * rs;
           s1 += (double)g;
-          s2 += (double)(g * ((y - mu) * rs));
+          s2 += (double)(g * xh);
+          pg += g;
+          px += xh;
         }
       }
     }
@@ -463,9 +469,16 @@ __global__ __launch_bounds__(TPB) void cg_edge_stats_kernel(
         s2 += w * (double)y * (double)y;
       } else {
         const float g = ld_el<DT>(dZ, (int64_t)rrow * lddz + cc) * edge_act_grad(y * sc + sh, act, slope);
+        const float xh = (y - mu) * rs;
         s1 += w * (double)g;
-        s2 += w * (double)(g * ((y - mu) * rs));
+        s2 += w * (double)(g * xh);
+        pg += (float)w * g;
+        px += (float)w * xh;
       }
+    }
+    if (MODE == 1 && pt != nullptr && !pad && c < Co) {
+      pt[p * ldpt + c] = pg;
+      pt[p * ldpt + Co + c] = px;
     }
   }
   red[ry][cx][0] = s1;
@@ -565,6 +578,80 @@ __global__ __launch_bounds__(TPB) void cg_edge_bwd_kernel(
       ds += row_w[rrow - E] * dy;
     }
     if (c < Co) dps[p * lddps + Co + c] = ds;
+  }
+}
+
+// ---- round 5: the same backward WITHOUT atomics and with ONE pass over dZ per index order.
+// dy_r = sc (g_r - m1 - xhat_r m2) is linear in (g_r, 1, xhat_r), so the sums over a point's rows commute with the BatchNorm
+// correction:   dS[p] = sc (sum_w g - W_p m1 - m2 sum_w xhat)  over the rows OF p (cg_edge_stats_kernel<1> writes the two sums
+// next to the column sums it takes anyway),   dP[j] = sc (sum g - n_j m1 - m2 sum xhat)  over the rows whose SOURCE is j --
+// gathered here through the inverse of row_src (built with the geometry: rows sorted by source, ascending row numbers, so the
+// summation order is fixed).  The round-1..4 form read dZ a second time and added dy into dP[src] with fp32 atomics: 1.3 TB/s of
+// added bytes at best (MI355X_MICROARCH.md), 39 % of HBM measured (profiles/r04_kitti_hbm_table.md), summation order free.
+template <int DT>
+__global__ __launch_bounds__(TPB) void cg_edge_gather_kernel(
+    const float* __restrict__ ps, int64_t ldps, const int32_t* __restrict__ inv_ptr, const int32_t* __restrict__ inv_row,
+    const int32_t* __restrict__ row_dst, int64_t N, int Co, const void* __restrict__ dZ, int64_t lddz,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ rstd, int act, float slope, float* __restrict__ pp, int64_t ldpp) {
+  CCN_LANES;
+  const int64_t j = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (j >= N) return;
+  const int32_t t0 = inv_ptr[j], t1 = inv_ptr[j + 1];
+  for (int c0 = 0; c0 < Co; c0 += 64) {
+    const int c = c0 + cx, cc = c < Co ? c : Co - 1;
+    const float pj = ps[j * ldps + cc];
+    const float sc = scale[cc], sh = shift[cc], mu = mean[cc], rs = rstd[cc];
+    float pg = 0.f, px = 0.f;
+    for (int32_t tb = t0; tb < t1; tb += 64) {      // 64 list entries at a time: lane s holds entry s (row and its destination)
+      const int nb = t1 - tb < 64 ? t1 - tb : 64;
+      const int myrow = cx < nb ? inv_row[tb + cx] : 0;
+      const int mydst = cx < nb ? row_dst[myrow] : 0;
+      for (int s0 = 0; s0 < nb; s0 += SG_UNROLL) {
+        float sv[SG_UNROLL], dz[SG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SG_UNROLL; ++u) {
+          const bool ok = s0 + u < nb;
+          const int r = cg_src(myrow, (s0 + u) & 63), d = cg_src(mydst, (s0 + u) & 63);
+          const float a = ps[(int64_t)d * ldps + Co + cc];
+          const float v = ld_el<DT>(dZ, (int64_t)r * lddz + cc);
+          sv[u] = ok ? a : 0.f;
+          dz[u] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < SG_UNROLL; ++u) {
+          if (s0 + u >= nb) continue;
+          const float y = pj + sv[u];
+          pg += dz[u] * edge_act_grad(y * sc + sh, act, slope);
+          px += (y - mu) * rs;
+        }
+      }
+    }
+    if (c < Co) {
+      pp[j * ldpp + c] = pg;
+      pp[j * ldpp + Co + c] = px;
+    }
+  }
+}
+
+// dps[j] = [dP[j] | dS[j]] from the per-point sums (pp: over the rows whose source is j, pt: over the rows of j) and the column sums
+__global__ __launch_bounds__(TPB) void cg_edge_finish_kernel(
+    const float* __restrict__ pt, int64_t ldpt, const float* __restrict__ pp, int64_t ldpp, const int32_t* __restrict__ grp_ptr,
+    const int32_t* __restrict__ rep_row, const float* __restrict__ row_w, const int32_t* __restrict__ inv_ptr, int64_t N,
+    int64_t E, int Co, const float* __restrict__ scale, const double* __restrict__ sums, double count, int training,
+    float* __restrict__ dps, int64_t lddps) {
+  CCN_LANES;
+  const int64_t j = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (j >= N) return;
+  const float inv_n = (float)(1.0 / count);
+  const int32_t rrow = rep_row[j];
+  const float wsum = (float)(grp_ptr[j + 1] - grp_ptr[j]) + (rrow >= 0 ? row_w[rrow - E] : 0.f);
+  const float nsrc = (float)(inv_ptr[j + 1] - inv_ptr[j]);
+  for (int c = cx; c < Co; c += 64) {
+    const float sc = scale[c];
+    const float m1 = training ? (float)sums[c] * inv_n : 0.f, m2 = training ? (float)sums[Co + c] * inv_n : 0.f;
+    dps[j * lddps + c] = sc * (pp[j * ldpp + c] - nsrc * m1 - m2 * pp[j * ldpp + Co + c]);
+    dps[j * lddps + Co + c] = sc * (pt[j * ldpt + c] - wsum * m1 - m2 * pt[j * ldpt + Co + c]);
   }
 }
 
@@ -1590,6 +1677,60 @@ int ccn_cg_edge_bwd_h(const float* ps, int64_t ldps, const int32_t* grp_ptr, con
                       const double* sums, double count, int training, float* dps, int64_t lddps, void* stream) {
   return cg_edge_bwd_impl(ps, ldps, grp_ptr, row_src, rep_row, row_w, N, E, Co, dZ, 1, lddz, scale, shift, mean, rstd, act, slope,
                           sums, count, training, dps, lddps, stream);
+}
+
+// ---- round 5: atomics-free backward of the compact first SGCNN layer (see cg_edge_gather_kernel).  Three launches:
+//   ccn_cg_edge_bwd_sums    = ccn_cg_edge_bwd_stats (column sums of g, g xhat) + the per-point sums pt (N x 2 Co) -- ONE pass over dZ
+//   ccn_cg_edge_bwd_gather  per SOURCE point the sums pp (N x 2 Co) over the rows that read it, through the inverse row list
+//   ccn_cg_edge_bwd_finish  dps = [dP | dS] from pt, pp and the reduced column sums (`sums`: 2 Co totals; ignored unless training)
+// scale / shift / mean / rstd: the layer's BatchNorm table; without BatchNorm pass scale = 1, shift = mean = rstd = 0, training = 0.
+int ccn_cg_edge_bwd_sums(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src, const int32_t* rep_row,
+                         const float* row_w, int64_t N, int64_t E, int64_t Ne, int64_t Co, const void* dZ, int dz16, int64_t lddz,
+                         const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                         double* partial, float* pt, int64_t ldpt, void* stream) {
+  CCN_REQUIRE(ps && grp_ptr && row_src && rep_row && row_w && dZ && scale && shift && mean && rstd && partial && pt && N > 0 &&
+                  CCN_SMALL_INT(Co) && ldps >= 2 * Co && lddz >= Co && ldpt >= 2 * Co,
+              "cg_edge_bwd_sums: bad arguments");
+  const dim3 grid((unsigned)ccn_cg_edge_stats_rows(N, Co), (unsigned)((Co + 63) / 64));
+  if (dz16)
+    hipLaunchKernelGGL((cg_edge_stats_kernel<1, 1>), grid, dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr, row_src,
+                       rep_row, row_w, N, E, Ne, (int)Co, dZ, lddz, scale, shift, mean, rstd, act, slope, cg_pts(N, Co), partial,
+                       pt, ldpt);
+  else
+    hipLaunchKernelGGL((cg_edge_stats_kernel<1, 0>), grid, dim3(TPB), 0, (hipStream_t)stream, ps, ldps, grp_ptr, row_src,
+                       rep_row, row_w, N, E, Ne, (int)Co, dZ, lddz, scale, shift, mean, rstd, act, slope, cg_pts(N, Co), partial,
+                       pt, ldpt);
+  CCN_LAUNCH_OK("cg_edge_bwd_sums");
+  return CCN_OK;
+}
+
+int ccn_cg_edge_bwd_gather(const float* ps, int64_t ldps, const int32_t* inv_ptr, const int32_t* inv_row, const int32_t* row_dst,
+                           int64_t N, int64_t Co, const void* dZ, int dz16, int64_t lddz, const float* scale, const float* shift,
+                           const float* mean, const float* rstd, int act, float slope, float* pp, int64_t ldpp, void* stream) {
+  CCN_REQUIRE(ps && inv_ptr && inv_row && row_dst && dZ && scale && shift && mean && rstd && pp && N > 0 && CCN_SMALL_INT(Co) &&
+                  ldps >= 2 * Co && lddz >= Co && ldpp >= 2 * Co,
+              "cg_edge_bwd_gather: bad arguments");
+  if (dz16)
+    hipLaunchKernelGGL(cg_edge_gather_kernel<1>, dim3(row_blocks(N)), dim3(TPB), 0, (hipStream_t)stream, ps, ldps, inv_ptr,
+                       inv_row, row_dst, N, (int)Co, dZ, lddz, scale, shift, mean, rstd, act, slope, pp, ldpp);
+  else
+    hipLaunchKernelGGL(cg_edge_gather_kernel<0>, dim3(row_blocks(N)), dim3(TPB), 0, (hipStream_t)stream, ps, ldps, inv_ptr,
+                       inv_row, row_dst, N, (int)Co, dZ, lddz, scale, shift, mean, rstd, act, slope, pp, ldpp);
+  CCN_LAUNCH_OK("cg_edge_bwd_gather");
+  return CCN_OK;
+}
+
+int ccn_cg_edge_bwd_finish(const float* pt, int64_t ldpt, const float* pp, int64_t ldpp, const int32_t* grp_ptr,
+                           const int32_t* rep_row, const float* row_w, const int32_t* inv_ptr, int64_t N, int64_t E, int64_t Co,
+                           const float* scale, const double* sums, double count, int training, float* dps, int64_t lddps,
+                           void* stream) {
+  CCN_REQUIRE(pt && pp && grp_ptr && rep_row && row_w && inv_ptr && scale && dps && N > 0 && CCN_SMALL_INT(Co) && ldpt >= 2 * Co &&
+                  ldpp >= 2 * Co && lddps >= 2 * Co && count > 0 && (sums || !training),
+              "cg_edge_bwd_finish: bad arguments");
+  hipLaunchKernelGGL(cg_edge_finish_kernel, dim3(row_blocks(N)), dim3(TPB), 0, (hipStream_t)stream, pt, ldpt, pp, ldpp, grp_ptr,
+                     rep_row, row_w, inv_ptr, N, E, (int)Co, scale, sums, count, training, dps, lddps);
+  CCN_LAUNCH_OK("cg_edge_bwd_finish");
+  return CCN_OK;
 }
 
 int ccn_cg_max_fwd(const float* f, int64_t ldf, const int32_t* grp_ptr, const int32_t* rep_row, int64_t N, int64_t C,

@@ -2230,6 +2230,9 @@ def pn_edge_layer(px, wp, bias, pos_src, pos_dst, edges, radius, bn, training, a
 # A15 on compact rows: the dense SGCNN computation without its duplicate rows (see ccn_hip.h, "COMPACT rows")
 # --------------------------------------------------------------------------------------
 
+CG_BWD_GATHER = os.environ.get("CCN_CG_BWD_GATHER", "1") != "0"     # A/B: 0 = the round-1..4 backward with fp32 atomics
+
+
 class SGCompact:
     """Row structure of one SGCNN call: real rows grouped by point, one weighted representative per point with empty
     FRNN slots, one weighted row for all padding rows.  Index-only: built inside a geometry block."""
@@ -2263,6 +2266,18 @@ class SGCompact:
         call("cg_fill", ptr(nbr), ptr(topo.cloud_ptr), b, nmax, k, ptr(self.grp_ptr), ptr(rep_off), e, ptr(self.row_src),
              ptr(self.rep_row), ptr(self.row_w))
         self.row_w[ne:].fill_(float((b * nmax - n) * (k + 1)))    # the padding row stands for all padding rows
+        # the inverse of row_src (rows sorted by SOURCE point, ascending row numbers) + the owner of every row: what the
+        # atomics-free backward of the first layer gathers through (ccn_cg_edge_bwd_gather).  Index-only, built with the
+        # geometry; not needed when no gradient is being recorded.
+        self.inv = None
+        if CG_BWD_GATHER and torch.is_grad_enabled() and not bounded():
+            order = torch.sort(self.row_src, stable=True)[1].to(torch.int32)
+            counts = torch.bincount(self.row_src, minlength=n)[:n]
+            inv_ptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+            inv_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+            sizes = (self.grp_ptr[1:] - self.grp_ptr[:-1]).long()
+            row_dst = torch.repeat_interleave(torch.arange(n, dtype=torch.int32, device=dev), sizes, output_size=e)
+            self.inv = (inv_ptr, order, row_dst)
 
     def tensors(self):
         return (self.grp_ptr, self.row_src, self.rep_row, self.row_w)
@@ -2289,7 +2304,8 @@ class CGEdgeLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, ps, grp_ptr, row_src, rep_row, row_w, dims, gamma, beta, running_mean, running_var, training, act,
-                eps, momentum, out16=False):
+                eps, momentum, out16=False, inv=None):
+        ctx.inv = inv
         ps = _mat(ps)
         n, e, ne, count = dims
         co = ps.size(1) // 2
@@ -2334,6 +2350,34 @@ class CGEdgeLayer(torch.autograd.Function):
         idx = (ptr(grp_ptr), ptr(row_src), ptr(rep_row))
         sums = dgamma = dbeta = None
         pp = [None] * 4
+        if ctx.inv is not None:
+            # round 5: no atomics, one pass over dZ per index order (ccn_cg_edge_bwd_sums / _gather / _finish)
+            inv_ptr, inv_row, row_dst = ctx.inv
+            if ctx.has_bn:
+                tab = par
+            else:       # no BatchNorm: identity table
+                tab = torch.zeros((4, co), dtype=torch.float32, device=dev)
+                tab[0].fill_(1.0)
+            pp = [ptr(tab[0]), ptr(tab[1]), ptr(tab[2]), ptr(tab[3])]
+            dz16 = 1 if h else 0
+            nparts = lib().ccn_cg_edge_stats_rows(n, co)
+            partial = torch.empty((nparts + 1) * 2 * co, dtype=torch.float64, device=dev)
+            pt, pq = _rows(n, 2 * co, dev), _rows(n, 2 * co, dev)
+            call("cg_edge_bwd_sums", ptr(ps), _ld(ps), *idx, ptr(row_w), n, e, ne, co, ptr(g), dz16, _ld(g), *pp, ctx.act,
+                 LEAKY_SLOPE, ptr(partial), ptr(pt), _ld(pt))
+            call("cg_edge_bwd_gather", ptr(ps), _ld(ps), ptr(inv_ptr), ptr(inv_row), ptr(row_dst), n, co, ptr(g), dz16, _ld(g),
+                 *pp, ctx.act, LEAKY_SLOPE, ptr(pq), _ld(pq), work_rows=e)
+            sums = partial[nparts * 2 * co:]
+            call("reduce_partials", ptr(partial), nparts, 2 * co, ptr(sums))
+            if ctx.has_bn:
+                dgb = sums[:2 * co].float()
+                dbeta, dgamma = dgb[:co], dgb[co:]
+            dps = _rows(ps.size(0), 2 * co, dev)
+            if ps.size(0) > n:
+                dps[n:].zero_()
+            call("cg_edge_bwd_finish", ptr(pt), _ld(pt), ptr(pq), _ld(pq), ptr(grp_ptr), ptr(rep_row), ptr(row_w), ptr(inv_ptr),
+                 n, e, co, pp[0], ptr(sums), float(count), 1 if (ctx.training and ctx.has_bn) else 0, ptr(dps), _ld(dps))
+            return (dps,) + (None,) * 5 + (dgamma, dbeta) + (None,) * 8
         if ctx.has_bn:
             pp = [ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3])]
             nparts = lib().ccn_cg_edge_stats_rows(n, co)
@@ -2350,19 +2394,20 @@ class CGEdgeLayer(torch.autograd.Function):
         call("cg_edge_bwd" + h, ptr(ps), _ld(ps), *idx, ptr(row_w), n, e, co, ptr(g), _ld(g), *pp, ctx.act, LEAKY_SLOPE,
              ptr(sums) if sums is not None else None, float(count), 1 if (ctx.training and ctx.has_bn) else 0, ptr(dps),
              _ld(dps))
-        return dps, None, None, None, None, None, dgamma, dbeta, None, None, None, None, None, None, None
+        return (dps,) + (None,) * 5 + (dgamma, dbeta) + (None,) * 8
 
 
 def cg_edge_layer(ps, comp, bn, training, act, out16=False):
     dims = (comp.n, comp.e, comp.ne, comp.count)
+    inv = getattr(comp, "inv", None)
     if bn is None:
-        return CGEdgeLayer.apply(ps, *comp.tensors(), dims, None, None, None, None, False, None, 0.0, 0.0)
+        return CGEdgeLayer.apply(ps, *comp.tensors(), dims, None, None, None, None, False, None, 0.0, 0.0, False, inv)
     if training and bn.track_running_stats:
         bn.num_batches_tracked += 1
     use_batch_stats = training or not bn.track_running_stats
     return _mark16(CGEdgeLayer.apply(ps, *comp.tensors(), dims, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      use_batch_stats, act, bn.eps, bn.momentum if bn.momentum is not None else 0.1,
-                                     bool(out16)), out16)
+                                     bool(out16), inv), out16)
 
 
 class LinearBNActTail(torch.autograd.Function):

@@ -534,6 +534,25 @@ int ccn_cg_edge_bwd_h(const float* ps, int64_t ldps, const int32_t* grp_ptr, con
                       const float* row_w, int64_t N, int64_t E, int64_t Co, const void* dZ, int64_t lddz,
                       const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
                       const double* sums, double count, int training, float* dps, int64_t lddps, void* stream);
+/* round 5: the backward of the compact first SGCNN layer (autograd of the gather + first Linear / BatchNorm / activation of
+ * src/models/modules/dgcnn.py:172-177) WITHOUT atomics and with one pass over dZ per index order.  dy_r = scale (g_r - m1 -
+ * xhat_r m2) is linear in (g_r, 1, xhat_r): _sums takes the BatchNorm-backward column sums (as ccn_cg_edge_bwd_stats: `partial`)
+ * and, in the same pass, per point the sums pt = [sum w g | sum w xhat] over ITS rows; _gather takes pp = [sum g | sum xhat] per
+ * SOURCE point over the rows that read it, through the inverse of row_src (inv_ptr int32 (N+1), inv_row int32 (E): rows sorted by
+ * source, ascending; row_dst int32 (E): the point that owns row r); _finish combines them with the reduced column sums into
+ * dps = [dP | dS] (N x 2 Co).  Deterministic; replaces ccn_cg_edge_bwd_stats + ccn_cg_edge_bwd (kept: the round-1..4 form with
+ * fp32 atomics).  dz16: dZ as bf16 rows.  Without BatchNorm: scale = 1, shift = mean = rstd = 0, training = 0. */
+int ccn_cg_edge_bwd_sums(const float* ps, int64_t ldps, const int32_t* grp_ptr, const int32_t* row_src, const int32_t* rep_row,
+                         const float* row_w, int64_t N, int64_t E, int64_t Ne, int64_t Co, const void* dZ, int dz16, int64_t lddz,
+                         const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                         double* partial, float* pt, int64_t ldpt, void* stream);
+int ccn_cg_edge_bwd_gather(const float* ps, int64_t ldps, const int32_t* inv_ptr, const int32_t* inv_row, const int32_t* row_dst,
+                           int64_t N, int64_t Co, const void* dZ, int dz16, int64_t lddz, const float* scale, const float* shift,
+                           const float* mean, const float* rstd, int act, float slope, float* pp, int64_t ldpp, void* stream);
+int ccn_cg_edge_bwd_finish(const float* pt, int64_t ldpt, const float* pp, int64_t ldpp, const int32_t* grp_ptr,
+                           const int32_t* rep_row, const float* row_w, const int32_t* inv_ptr, int64_t N, int64_t E, int64_t Co,
+                           const float* scale, const double* sums, double count, int training, float* dps, int64_t lddps,
+                           void* stream);
 int ccn_pn_edge_apply_h(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
                         const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
                         int64_t Co, float radius, const float* scale, const float* shift, int act, float slope, void* Z,

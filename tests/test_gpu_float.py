@@ -836,8 +836,14 @@ def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
         assert not any(n.startswith("im2col") for n in calls[0]) and "im2col_fwd" in calls[1]
     elif which != "sgcnn-sparse-attend":
         kind = "cg" if which == "sgcnn" else "pn"
-        assert kind + "_edge_apply_h" in calls[0] and kind + "_edge_bwd_h" in calls[0] and kind + "_edge_bwd_stats_h" in calls[0]
-        assert kind + "_edge_apply" in calls[1] and kind + "_edge_bwd" in calls[1]
+        if kind == "cg" and ops.CG_BWD_GATHER:
+            # (round 5: the compact SGCNN layer's backward is the atomics-free triple, whatever the storage mode; the 16-bit
+            # gradient is read in place -- dz16 -- by _sums and _gather)
+            assert kind + "_edge_apply_h" in calls[0] and "cg_edge_bwd_sums" in calls[0] and "cg_edge_bwd_gather" in calls[0]
+            assert kind + "_edge_apply" in calls[1] and "cg_edge_bwd_finish" in calls[1]
+        else:
+            assert kind + "_edge_apply_h" in calls[0] and kind + "_edge_bwd_h" in calls[0] and kind + "_edge_bwd_stats_h" in calls[0]
+            assert kind + "_edge_apply" in calls[1] and kind + "_edge_bwd" in calls[1]
     def casts(log):
         return log.count("cast_rows_h")
 
@@ -1170,3 +1176,38 @@ def test_bf16_storage_mlp_chain(dims, bias, plain_last, mode):
         assert float(diff.abs().max()) / denom < 0.25, (nme, float(diff.abs().max()) / denom)
         l2 = float(diff.norm() / max(float(b.norm()), 1e-3 * gmax * b.numel() ** 0.5))
         assert l2 < 3e-2, (nme, l2)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_sgcnn_first_layer_backward_without_atomics(dtype):
+    """Round 5: the backward of the compact first SGCNN layer through per-point sums and the inverse row list
+    (ccn_cg_edge_bwd_sums / _gather / _finish; autograd of dgcnn.py:172-177) against the round-1..4 form with fp32 atomics:
+    the same gradients to fp32 re-association, and -- what the atomics could not give -- the SAME bits in every run."""
+    from curvecloudnet_amd import ops, steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([0, 1, 2], n_curves=120)
+    c = 29
+    ops.set_mlp_dtype(dtype)
+    try:
+        torch.manual_seed(0)
+        mod = steps.SGCNNLayer(MLP([2 * (c + 3), 64, 32], bias=False), 20, r=0.05, with_xyz=True).to(DEV).train()
+        x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4)).to(DEV)
+        cot = torch.randn(d.pos.size(0), 32, generator=torch.Generator().manual_seed(5)).to(DEV)
+        runs = []
+        for gather in (True, True, False):
+            ops.CG_BWD_GATHER = gather
+            for bn in mod.nn.norms:
+                bn.module.reset_running_stats()
+            xi = x.clone().requires_grad_(True)
+            out = mod(xi, d.pos.to(DEV), d.batch.to(DEV), d.curve_idxs.to(DEV))[0]
+            runs.append([out.detach()] + [g.detach().clone() for g in
+                                          torch.autograd.grad((out * cot).sum(), [xi] + list(mod.parameters()))])
+        for a, b in zip(runs[0], runs[1]):
+            assert torch.equal(a, b), "two runs of the atomics-free backward differ in bits"
+        tol = 1e-4 if dtype == "fp32" else 2e-2
+        for a, b in zip(runs[0], runs[2]):
+            _close(a, b, tol, "gather backward vs atomic backward")
+    finally:
+        ops.CG_BWD_GATHER = True
+        ops.set_mlp_dtype("fp32")
