@@ -107,6 +107,11 @@ _TABLE = {
                          + 2 * F32 * _rc(i, 1, 4)),
     "cg_edge_bwd_gather": ("edge", lambda i, r: 4 * F32 * _rc(i, 1, 2) + ((2.0 if i[3] else F32) * i[2] + 2 * I32) * (r or 0)),
     "cg_edge_bwd_finish": ("edge", lambda i, r: 6 * F32 * _rc(i, 2, 4)),
+    # PointNetConv2's first layer, the same three: _sums = (ldpx, ldwp, E, Co, dz16, lddz, act): px rows (<= E unique), dz, 28 B of
+    # geometry per edge; _gather = (ldpx, ldwp, Nsrc, Co, dz16, lddz, act, ldpp), rows = E; _finish = (ldpp, Nsrc, E, Co, training, lddpx)
+    "pn_edge_bwd_sums": ("edge", lambda i, r: (F32 + (2.0 if i[4] else F32)) * _rc(i, 2, 3) + 28.0 * i[2]),
+    "pn_edge_bwd_gather": ("edge", lambda i, r: 3 * F32 * _rc(i, 2, 3) + ((2.0 if i[4] else F32) * i[3] + 24.0) * (r or 0)),
+    "pn_edge_bwd_finish": ("edge", lambda i, r: 3 * F32 * _rc(i, 1, 3)),
     "cg_edge_bwd_h": ("edge", lambda i, r: 4 * F32 * _rc(i, 1, 3) + I32 * i[2] + 2.0 * _rc(i, 2, 3)),
     # ---- PointNetConv2 first layer: px (source rows, L2-resident gathers) -> E x Co rows
     "pn_edge_stats": ("edge", lambda i, r: (I64 * 2 + 2 * 12.0) * i[2]),                 # (ldpx, ldwp, E, Co): indices + positions

@@ -932,6 +932,174 @@ __global__ __launch_bounds__(TPB) void pn_edge_bwd_kernel(
   }
 }
 
+// ---- round 5: the same backward WITHOUT atomics (as cg_edge_gather_kernel for the SGCNN layer).  dy_e = sc (g_e - m1 - xhat_e m2)
+// is linear in (g_e, 1, xhat_e), so everything the backward needs is a SUM that can be taken before m1, m2 are known:
+//   column sums (one pass over dZ in edge order): g, g xhat (BatchNorm backward), g rel_k, xhat, xhat rel_k, and rel_k itself
+//   -> dWp[c][k] = sc (sum g rel_k - m1 sum rel_k - m2 sum xhat rel_k),  dbias[c] = sc (sum g - E m1 - m2 sum xhat);
+//   per SOURCE point j the sums of g and xhat over the edges that read it, gathered through the inverse of `src`
+//   -> dPX[j] = sc (sum g - n_j m1 - m2 sum xhat).
+// partial: [gridDim.x][9 Co + 4] doubles: rows of [g | g xhat | g r0 | g r1 | g r2 | xhat | xhat r0 | xhat r1 | xhat r2 | r0 r1 r2 -].
+template <int DT>
+__global__ __launch_bounds__(TPB) void pn_edge_sums_kernel(
+    const float* __restrict__ px, int64_t ldpx, const float* __restrict__ wp, int64_t ldwp,
+    const float* __restrict__ bias, const float* __restrict__ pos_src, const float* __restrict__ pos_dst,
+    const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, int Co, float radius,
+    const void* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope, int per_wave,
+    double* __restrict__ partial) {
+  __shared__ double red[4][64][9];
+  __shared__ double redr[4][3];
+  CCN_LANES;
+  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * per_wave;  // per_wave <= 64
+  const int64_t last = first + per_wave < E ? first + per_wave : E;
+  const int c = blockIdx.y * 64 + cx, cc = c < Co ? c : Co - 1;
+  double a[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, rr[3] = {0.0, 0.0, 0.0};
+  const float w0 = wp[cc * ldwp], w1 = wp[cc * ldwp + 1], w2 = wp[cc * ldwp + 2];
+  const float bv = bias ? bias[cc] : 0.f;
+  const float sc = scale[cc], sh = shift[cc], mu = mean[cc], rs = rstd[cc];
+  const PnEdge mine = pn_edge_lane(pos_src, pos_dst, src, dst, first + cx, last, radius);
+  const int cnt = first < last ? (int)(last - first) : 0;
+  for (int t0 = 0; t0 < cnt; t0 += 4) {
+    PnEdge ed[4];
+    float pv[4], dz[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ed[u] = pn_edge_bcast(mine, (t0 + u) & 63);
+      const bool ok = t0 + u < cnt;
+      pv[u] = ok ? px[ed[u].j * ldpx + cc] : 0.f;
+      const float v = ld_el<DT>(dZ, (first + (ok ? t0 + u : 0)) * lddz + cc);
+      dz[u] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (t0 + u >= cnt) continue;
+      const float y = pv[u] + (w0 * ed[u].r0 + w1 * ed[u].r1 + w2 * ed[u].r2) + bv;
+      const float g = dz[u] * edge_act_grad(y * sc + sh, act, slope);
+      const float xh = (y - mu) * rs;
+      a[0] += (double)g;
+      a[1] += (double)(g * xh);
+      a[2] += (double)(g * ed[u].r0);
+      a[3] += (double)(g * ed[u].r1);
+      a[4] += (double)(g * ed[u].r2);
+      a[5] += (double)xh;
+      a[6] += (double)(xh * ed[u].r0);
+      a[7] += (double)(xh * ed[u].r1);
+      a[8] += (double)(xh * ed[u].r2);
+      rr[0] += (double)ed[u].r0;
+      rr[1] += (double)ed[u].r1;
+      rr[2] += (double)ed[u].r2;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) red[ry][cx][k] = a[k];
+  if (cx == 0) {
+    redr[ry][0] = rr[0];
+    redr[ry][1] = rr[1];
+    redr[ry][2] = rr[2];
+  }
+  __syncthreads();
+  double* const o = partial + (int64_t)blockIdx.x * (9 * Co + 4);
+  if (ry == 0 && c < Co) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k * Co + c] = red[0][cx][k] + red[1][cx][k] + red[2][cx][k] + red[3][cx][k];
+  }
+  if (blockIdx.y == 0 && threadIdx.x < 4)
+    o[9 * Co + threadIdx.x] = threadIdx.x < 3 ? redr[0][threadIdx.x] + redr[1][threadIdx.x] + redr[2][threadIdx.x] + redr[3][threadIdx.x] : 0.0;
+}
+
+template <int DT>
+__global__ __launch_bounds__(TPB) void pn_edge_gather_kernel(
+    const float* __restrict__ px, int64_t ldpx, const float* __restrict__ wp, int64_t ldwp, const float* __restrict__ bias,
+    const float* __restrict__ pos_src, const float* __restrict__ pos_dst, const int64_t* __restrict__ dst,
+    const int32_t* __restrict__ inv_ptr, const int32_t* __restrict__ inv_edge, int64_t Nsrc, int Co, float radius,
+    const void* __restrict__ dZ, int64_t lddz, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope, float* __restrict__ pp,
+    int64_t ldpp) {
+  CCN_LANES;
+  const int64_t j = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (j >= Nsrc) return;
+  const int32_t t0 = inv_ptr[j], t1 = inv_ptr[j + 1];
+  const float sx = pos_src[3 * j], sy = pos_src[3 * j + 1], sz = pos_src[3 * j + 2];
+  for (int c0 = 0; c0 < Co; c0 += 64) {
+    const int c = c0 + cx, cc = c < Co ? c : Co - 1;
+    const float pj = px[j * ldpx + cc] + (bias ? bias[cc] : 0.f);
+    const float w0 = wp[cc * ldwp], w1 = wp[cc * ldwp + 1], w2 = wp[cc * ldwp + 2];
+    const float sc = scale[cc], sh = shift[cc], mu = mean[cc], rs = rstd[cc];
+    float pg = 0.f, pxh = 0.f;
+    for (int32_t tb = t0; tb < t1; tb += 64) {        // 64 list entries at a time: lane s holds edge s and its relative position
+      const int nb = t1 - tb < 64 ? t1 - tb : 64;
+      int myedge = 0;
+      float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+      if (cx < nb) {
+        myedge = inv_edge[tb + cx];
+        const int64_t q = dst[myedge];
+        r0 = sx - pos_dst[3 * q];
+        r1 = sy - pos_dst[3 * q + 1];
+        r2 = sz - pos_dst[3 * q + 2];
+        if (radius > 0.f) {
+          r0 = __fdiv_rn(r0, radius);
+          r1 = __fdiv_rn(r1, radius);
+          r2 = __fdiv_rn(r2, radius);
+        }
+      }
+      for (int s0 = 0; s0 < nb; s0 += SG_UNROLL) {
+        float dz[SG_UNROLL], rel[SG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SG_UNROLL; ++u) {
+          const int l = (s0 + u) & 63;
+          const bool ok = s0 + u < nb;
+          const int e = cg_src(myedge, l);
+          const float a0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0), l));
+          const float a1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1), l));
+          const float a2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r2), l));
+          const float v = ld_el<DT>(dZ, (int64_t)e * lddz + cc);
+          dz[u] = ok ? v : 0.f;
+          rel[u] = w0 * a0 + w1 * a1 + w2 * a2;
+        }
+#pragma unroll
+        for (int u = 0; u < SG_UNROLL; ++u) {
+          if (s0 + u >= nb) continue;
+          const float y = (px[j * ldpx + cc] + rel[u]) + (bias ? bias[cc] : 0.f);     // (the forward's order of the three terms)
+          pg += dz[u] * edge_act_grad(y * sc + sh, act, slope);
+          pxh += (y - mu) * rs;
+        }
+      }
+    }
+    (void)pj;
+    if (c < Co) {
+      pp[j * ldpp + c] = pg;
+      pp[j * ldpp + Co + c] = pxh;
+    }
+  }
+}
+
+// dpx[j] from the per-source sums; block 0 also turns the column sums into dw4 = [dWp[:, 0] | dWp[:, 1] | dWp[:, 2] | dbias] (4 x Co)
+__global__ __launch_bounds__(TPB) void pn_edge_finish_kernel(const float* __restrict__ pp, int64_t ldpp,
+                                                             const int32_t* __restrict__ inv_ptr, int64_t Nsrc, int64_t E,
+                                                             int Co, const float* __restrict__ scale,
+                                                             const double* __restrict__ sums, int training,
+                                                             float* __restrict__ dpx, int64_t lddpx, float* __restrict__ dw4) {
+  CCN_LANES;
+  const double inv_e = 1.0 / (double)E;
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < Co; c += TPB) {
+      const double sc = (double)scale[c];
+      const double m1 = training ? sums[c] * inv_e : 0.0, m2 = training ? sums[Co + c] * inv_e : 0.0;
+      for (int k = 0; k < 3; ++k)
+        dw4[k * Co + c] = (float)(sc * (sums[(2 + k) * Co + c] - m1 * sums[9 * Co + k] - m2 * sums[(6 + k) * Co + c]));
+      dw4[3 * Co + c] = (float)(sc * (sums[c] - (double)E * m1 - m2 * sums[5 * Co + c]));
+    }
+  }
+  const int64_t j = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  if (j >= Nsrc) return;
+  const float nj = (float)(inv_ptr[j + 1] - inv_ptr[j]);
+  for (int c = cx; c < Co; c += 64) {
+    const float sc = scale[c];
+    const float m1 = training ? (float)(sums[c] * inv_e) : 0.f, m2 = training ? (float)(sums[Co + c] * inv_e) : 0.f;
+    dpx[j * lddpx + c] = sc * (pp[j * ldpp + c] - nj * m1 - m2 * pp[j * ldpp + Co + c]);
+  }
+}
+
 // ------------------------------------------------------------------ A13: PointNetConv2 message
 __global__ __launch_bounds__(TPB) void msg_build_fwd_kernel(const float* __restrict__ x_src, int64_t ldx,
                                                             const float* __restrict__ pos_src,
@@ -1916,6 +2084,60 @@ int ccn_pn_edge_bwd_h(const float* px, int64_t ldpx, const float* wp, int64_t ld
                       float* dpx, int64_t lddpx, double* wpart, void* stream) {
   return pn_edge_bwd_impl(px, ldpx, wp, ldwp, bias, pos_src, pos_dst, src, dst, E, Co, radius, dZ, 1, lddz, scale, shift, mean,
                           rstd, act, slope, sums, training, dpx, lddpx, wpart, stream);
+}
+
+// ---- round 5: atomics-free backward of PointNetConv2's algebraic first layer (see pn_edge_sums_kernel)
+//   ccn_pn_edge_bwd_sums    column sums: partial = [ccn_pn_edge_stats_rows(E, Co)][9 Co + 4] doubles -- ONE pass over dZ
+//   ccn_pn_edge_bwd_gather  per SOURCE point the sums pp (Nsrc x 2 Co) over the edges that read it (inverse of src: inv_ptr, inv_edge)
+//   ccn_pn_edge_bwd_finish  dpx (Nsrc x Co) and dw4 = [dWp[:, 0] | dWp[:, 1] | dWp[:, 2] | dbias] (4 x Co) from pp and the reduced sums
+int ccn_pn_edge_bwd_sums(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias, const float* pos_src,
+                         const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E, int64_t Co, float radius,
+                         const void* dZ, int dz16, int64_t lddz, const float* scale, const float* shift, const float* mean,
+                         const float* rstd, int act, float slope, double* partial, void* stream) {
+  CCN_REQUIRE(px && wp && pos_src && pos_dst && src && dst && dZ && scale && shift && mean && rstd && partial && E > 0 &&
+                  CCN_SMALL_INT(Co) && ldpx >= Co && ldwp >= 3 && lddz >= Co,
+              "pn_edge_bwd_sums: bad arguments");
+  const dim3 grid((unsigned)ccn_pn_edge_stats_rows(E, Co), (unsigned)((Co + 63) / 64));
+  if (dz16)
+    hipLaunchKernelGGL(pn_edge_sums_kernel<1>, grid, dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp, bias, pos_src, pos_dst,
+                       src, dst, E, (int)Co, radius, dZ, lddz, scale, shift, mean, rstd, act, slope, pn_per_wave(E, Co), partial);
+  else
+    hipLaunchKernelGGL(pn_edge_sums_kernel<0>, grid, dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp, bias, pos_src, pos_dst,
+                       src, dst, E, (int)Co, radius, dZ, lddz, scale, shift, mean, rstd, act, slope, pn_per_wave(E, Co), partial);
+  CCN_LAUNCH_OK("pn_edge_bwd_sums");
+  return CCN_OK;
+}
+
+int ccn_pn_edge_bwd_gather(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias, const float* pos_src,
+                           const float* pos_dst, const int64_t* dst, const int32_t* inv_ptr, const int32_t* inv_edge,
+                           int64_t Nsrc, int64_t Co, float radius, const void* dZ, int dz16, int64_t lddz, const float* scale,
+                           const float* shift, const float* mean, const float* rstd, int act, float slope, float* pp,
+                           int64_t ldpp, void* stream) {
+  CCN_REQUIRE(px && wp && pos_src && pos_dst && dst && inv_ptr && inv_edge && dZ && scale && shift && mean && rstd && pp &&
+                  Nsrc > 0 && CCN_SMALL_INT(Co) && ldpx >= Co && ldwp >= 3 && lddz >= Co && ldpp >= 2 * Co,
+              "pn_edge_bwd_gather: bad arguments");
+  if (dz16)
+    hipLaunchKernelGGL(pn_edge_gather_kernel<1>, dim3(row_blocks(Nsrc)), dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp,
+                       bias, pos_src, pos_dst, dst, inv_ptr, inv_edge, Nsrc, (int)Co, radius, dZ, lddz, scale, shift, mean, rstd,
+                       act, slope, pp, ldpp);
+  else
+    hipLaunchKernelGGL(pn_edge_gather_kernel<0>, dim3(row_blocks(Nsrc)), dim3(TPB), 0, (hipStream_t)stream, px, ldpx, wp, ldwp,
+                       bias, pos_src, pos_dst, dst, inv_ptr, inv_edge, Nsrc, (int)Co, radius, dZ, lddz, scale, shift, mean, rstd,
+                       act, slope, pp, ldpp);
+  CCN_LAUNCH_OK("pn_edge_bwd_gather");
+  return CCN_OK;
+}
+
+int ccn_pn_edge_bwd_finish(const float* pp, int64_t ldpp, const int32_t* inv_ptr, int64_t Nsrc, int64_t E, int64_t Co,
+                           const float* scale, const double* sums, int training, float* dpx, int64_t lddpx, float* dw4,
+                           void* stream) {
+  CCN_REQUIRE(pp && inv_ptr && scale && sums && dpx && dw4 && Nsrc > 0 && E > 0 && CCN_SMALL_INT(Co) && ldpp >= 2 * Co &&
+                  lddpx >= Co,
+              "pn_edge_bwd_finish: bad arguments");
+  hipLaunchKernelGGL(pn_edge_finish_kernel, dim3(row_blocks(Nsrc)), dim3(TPB), 0, (hipStream_t)stream, pp, ldpp, inv_ptr, Nsrc, E,
+                     (int)Co, scale, sums, training, dpx, lddpx, dw4);
+  CCN_LAUNCH_OK("pn_edge_bwd_finish");
+  return CCN_OK;
 }
 
 int ccn_msg_build_fwd(const float* x_src, int64_t ldx, const float* pos_src, const float* pos_dst, const int64_t* src,

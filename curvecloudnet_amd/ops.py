@@ -1445,13 +1445,24 @@ def curve_fps(pos, topo, spacing, u):
 # A8: radius grouping along curves -> CSR edge list
 # --------------------------------------------------------------------------------------
 
+PN_BWD_GATHER = os.environ.get("CCN_PN_BWD_GATHER", "1") != "0"     # A/B: 0 = the round-1..4 backward with fp32 atomics
+
+
 class EdgeList:
     """Edges grouped by destination: ``row`` (destination / query number, non-decreasing),
     ``col`` (source point), ``offsets`` int32 (num_dst + 1)."""
 
-    def __init__(self, row, col, offsets, num_dst):
+    def __init__(self, row, col, offsets, num_dst, num_src=None):
         self.row, self.col, self.offsets, self.num_dst = row, col, offsets, num_dst
         self.num_edges = row.numel()
+        # the inverse of `col` (edges sorted by SOURCE point, ascending edge numbers): what the atomics-free backward of
+        # PointNetConv2's first layer gathers through (ccn_pn_edge_bwd_gather).  Index-only, built with the geometry.
+        self.inv_src = None
+        if (PN_BWD_GATHER and num_src is not None and self.num_edges > 0 and torch.is_grad_enabled() and not bounded()):
+            order = torch.sort(col, stable=True)[1].to(torch.int32)
+            inv_ptr = torch.zeros(num_src + 1, dtype=torch.int32, device=col.device)
+            inv_ptr[1:] = torch.cumsum(torch.bincount(col, minlength=num_src)[:num_src], 0).to(torch.int32)
+            self.inv_src = (inv_ptr, order)
 
 
 def radius_1d_group_subset(pos, idx, topo, radius):
@@ -1472,7 +1483,7 @@ def radius_1d_group_subset(pos, idx, topo, radius):
     col = torch.zeros(e, dtype=torch.int64, device=dev) if bounded() else torch.empty(e, dtype=torch.int64, device=dev)
     call("curve_group_subset_fill_cap", ptr(topo.cid), ptr(topo.curve_ptr), ptr(topo.p2c), n, q, ptr(idx), m, ptr(budget),
          ptr(offsets), ptr(row), ptr(col), e)
-    return EdgeList(row, col, offsets, m)
+    return EdgeList(row, col, offsets, m, num_src=n)
 
 
 # --------------------------------------------------------------------------------------
@@ -1656,7 +1667,7 @@ def frnn_edges(pos_q, topo_q, pos_s, topo_s, k, radius, operation="knn", accel_k
     col = (torch.zeros if bounded() else torch.empty)(e, dtype=torch.int64, device=dev)
     call("dense_to_csr_fill", ptr(nbr), ptr(topo_q.cloud_ptr), ptr(topo_s.cloud_ptr), b, p1, k, ptr(offsets), ptr(row),
          ptr(col))
-    return EdgeList(row, col, offsets, m)
+    return EdgeList(row, col, offsets, m, num_src=topo_s.n)
 
 
 # --------------------------------------------------------------------------------------
@@ -2126,7 +2137,8 @@ class PNEdgeLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, px, wp, bias, pos_src, pos_dst, src, dst, radius, gamma, beta, running_mean, running_var, training,
-                act, eps, momentum, out16=False):
+                act, eps, momentum, out16=False, inv=None):
+        ctx.inv = inv
         px, wp = _mat(px), _mat(wp.contiguous())
         e, co, dev = src.numel(), px.size(1), px.device
         has_bn = gamma is not None
@@ -2169,6 +2181,38 @@ class PNEdgeLayer(torch.autograd.Function):
         geo = (ptr(pos_src), ptr(pos_dst), ptr(src), ptr(dst), e, co, ctx.radius)
         sums = dgamma = dbeta = None
         pp = [None] * 4
+        if ctx.inv is not None:
+            # round 5: no atomics, one pass over dZ per index order (ccn_pn_edge_bwd_sums / _gather / _finish)
+            inv_ptr, inv_edge = ctx.inv
+            nsrc = px.size(0)
+            if ctx.has_bn:
+                tab = par
+            else:
+                tab = torch.zeros((4, co), dtype=torch.float32, device=dev)
+                tab[0].fill_(1.0)
+            pp = [ptr(tab[0]), ptr(tab[1]), ptr(tab[2]), ptr(tab[3])]
+            dz16 = 1 if h else 0
+            nparts = lib().ccn_pn_edge_stats_rows(e, co)
+            width = 9 * co + 4
+            partial = torch.empty((nparts + 1) * width, dtype=torch.float64, device=dev)
+            call("pn_edge_bwd_sums", ptr(px), _ld(px), ptr(wp), _ld(wp), bias_p, *geo, ptr(g), dz16, _ld(g), *pp, ctx.act,
+                 LEAKY_SLOPE, ptr(partial))
+            pq = _rows(nsrc, 2 * co, dev)
+            call("pn_edge_bwd_gather", ptr(px), _ld(px), ptr(wp), _ld(wp), bias_p, ptr(pos_src), ptr(pos_dst), ptr(dst),
+                 ptr(inv_ptr), ptr(inv_edge), nsrc, co, ctx.radius, ptr(g), dz16, _ld(g), *pp, ctx.act, LEAKY_SLOPE, ptr(pq),
+                 _ld(pq), work_rows=e)
+            sums = partial[nparts * width:]
+            call("reduce_partials", ptr(partial), nparts, width, ptr(sums))
+            if ctx.has_bn:
+                dgb = sums[:2 * co].float()
+                dbeta, dgamma = dgb[:co], dgb[co:]
+            dpx = _rows(nsrc, co, dev)
+            dw4 = torch.empty((4, co), dtype=torch.float32, device=dev)
+            call("pn_edge_bwd_finish", ptr(pq), _ld(pq), ptr(inv_ptr), nsrc, e, co, pp[0], ptr(sums),
+                 1 if (ctx.training and ctx.has_bn) else 0, ptr(dpx), _ld(dpx), ptr(dw4))
+            dwp = dw4[:3].t().contiguous()
+            dbias = dw4[3].contiguous() if ctx.has_bias else None
+            return (dpx, dwp, dbias) + (None,) * 5 + (dgamma, dbeta) + (None,) * 8
         if ctx.has_bn:
             pp = [ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3])]
             nparts = lib().ccn_pn_edge_stats_rows(e, co)
@@ -2190,7 +2234,7 @@ class PNEdgeLayer(torch.autograd.Function):
         tot = tot.view(4, co).float()
         dwp = tot[:3].t().contiguous()
         dbias = tot[3].contiguous() if ctx.has_bias else None
-        return dpx, dwp, dbias, None, None, None, None, None, dgamma, dbeta, None, None, None, None, None, None, None
+        return (dpx, dwp, dbias) + (None,) * 5 + (dgamma, dbeta) + (None,) * 8
 
 
 EDGE_OUT16 = os.environ.get("CCN_EDGE_OUT16", "1") != "0"      # (A/B and tests: 0 = fp32 rows + ccn_cast_rows_h as before)
@@ -2214,16 +2258,19 @@ def _mark16(z, out16):
 
 def pn_edge_layer(px, wp, bias, pos_src, pos_dst, edges, radius, bn, training, act, out16=False):
     pos_src, pos_dst = _pos(pos_src), _pos(pos_dst)
+    inv = getattr(edges, "inv_src", None)
+    if inv is not None and inv[0].numel() != px.size(0) + 1:
+        inv = None                      # (an edge list whose sources are not the rows of px: the atomic form)
     if bn is None:
         return PNEdgeLayer.apply(px, wp, bias, pos_src, pos_dst, edges.col, edges.row, radius, None, None, None, None,
-                                 False, None, 0.0, 0.0)
+                                 False, None, 0.0, 0.0, False, inv)
     if training and bn.track_running_stats:
         bn.num_batches_tracked += 1
     use_batch_stats = training or not bn.track_running_stats
     out16 = bool(out16 and edges.num_edges > 0)
     return _mark16(PNEdgeLayer.apply(px, wp, bias, pos_src, pos_dst, edges.col, edges.row, radius, bn.weight, bn.bias,
                                      bn.running_mean, bn.running_var, use_batch_stats, act, bn.eps,
-                                     bn.momentum if bn.momentum is not None else 0.1, out16), out16)
+                                     bn.momentum if bn.momentum is not None else 0.1, out16, inv), out16)
 
 
 # --------------------------------------------------------------------------------------

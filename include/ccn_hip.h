@@ -553,6 +553,24 @@ int ccn_cg_edge_bwd_finish(const float* pt, int64_t ldpt, const float* pp, int64
                            const int32_t* rep_row, const float* row_w, const int32_t* inv_ptr, int64_t N, int64_t E, int64_t Co,
                            const float* scale, const double* sums, double count, int training, float* dps, int64_t lddps,
                            void* stream);
+/* ... and of PointNetConv2's algebraic first layer (autograd of src/models/modules/point_conv.py:60-69): _sums = the column sums
+ * over the E edges in ONE pass over dZ -- partial: [ccn_pn_edge_stats_rows(E, Co)][9 Co + 4] doubles per row [g | g xhat | g rel_0..2 |
+ * xhat | xhat rel_0..2 | rel_0..2 -]; _gather = per SOURCE point pp = [sum g | sum xhat] over the edges that read it, through the
+ * inverse of `src` (inv_ptr int32 (Nsrc+1), inv_edge int32 (E): edges sorted by source, ascending); _finish = dPX (Nsrc x Co) and
+ * dw4 = [dWp[:, 0] | dWp[:, 1] | dWp[:, 2] | dbias] (4 x Co floats) from pp and the reduced sums (9 Co + 4 totals).  Deterministic;
+ * replaces ccn_pn_edge_bwd_stats + ccn_pn_edge_bwd (kept). */
+int ccn_pn_edge_bwd_sums(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias, const float* pos_src,
+                         const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E, int64_t Co, float radius,
+                         const void* dZ, int dz16, int64_t lddz, const float* scale, const float* shift, const float* mean,
+                         const float* rstd, int act, float slope, double* partial, void* stream);
+int ccn_pn_edge_bwd_gather(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias, const float* pos_src,
+                           const float* pos_dst, const int64_t* dst, const int32_t* inv_ptr, const int32_t* inv_edge,
+                           int64_t Nsrc, int64_t Co, float radius, const void* dZ, int dz16, int64_t lddz, const float* scale,
+                           const float* shift, const float* mean, const float* rstd, int act, float slope, float* pp,
+                           int64_t ldpp, void* stream);
+int ccn_pn_edge_bwd_finish(const float* pp, int64_t ldpp, const int32_t* inv_ptr, int64_t Nsrc, int64_t E, int64_t Co,
+                           const float* scale, const double* sums, int training, float* dpx, int64_t lddpx, float* dw4,
+                           void* stream);
 int ccn_pn_edge_apply_h(const float* px, int64_t ldpx, const float* wp, int64_t ldwp, const float* bias,
                         const float* pos_src, const float* pos_dst, const int64_t* src, const int64_t* dst, int64_t E,
                         int64_t Co, float radius, const float* scale, const float* shift, int act, float slope, void* Z,

@@ -836,7 +836,10 @@ def test_edge_layers_write_16bit_rows_directly(bf16_mode, which):
         assert not any(n.startswith("im2col") for n in calls[0]) and "im2col_fwd" in calls[1]
     elif which != "sgcnn-sparse-attend":
         kind = "cg" if which == "sgcnn" else "pn"
-        if kind == "cg" and ops.CG_BWD_GATHER:
+        if kind == "pn" and ops.PN_BWD_GATHER:
+            assert "pn_edge_apply_h" in calls[0] and "pn_edge_bwd_sums" in calls[0] and "pn_edge_bwd_gather" in calls[0]
+            assert "pn_edge_apply" in calls[1] and "pn_edge_bwd_finish" in calls[1]
+        elif kind == "cg" and ops.CG_BWD_GATHER:
             # (round 5: the compact SGCNN layer's backward is the atomics-free triple, whatever the storage mode; the 16-bit
             # gradient is read in place -- dz16 -- by _sums and _gather)
             assert kind + "_edge_apply_h" in calls[0] and "cg_edge_bwd_sums" in calls[0] and "cg_edge_bwd_gather" in calls[0]
@@ -1210,4 +1213,41 @@ def test_sgcnn_first_layer_backward_without_atomics(dtype):
             _close(a, b, tol, "gather backward vs atomic backward")
     finally:
         ops.CG_BWD_GATHER = True
+        ops.set_mlp_dtype("fp32")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_pointnetconv_first_layer_backward_without_atomics(dtype):
+    """Round 5: the backward of PointNetConv2's algebraic first layer through column sums and the inverse edge list
+    (ccn_pn_edge_bwd_sums / _gather / _finish; autograd of point_conv.py:60-69) against the round-1..4 form with fp32 atomics:
+    the same gradients (features, weights incl. the 3 position columns, bias, BatchNorm) and the SAME bits in every run."""
+    from curvecloudnet_amd import ops, steps
+    from curvecloudnet_amd.nn import MLP
+    from curvecloudnet_amd.synth import make_batch
+    d = make_batch([0, 1, 2], n_curves=120)
+    c = 45          # (> 32 input columns: the per-point product's weight gradient takes the deterministic slab kernel, not the split-K atomics)
+    ops.set_mlp_dtype(dtype)
+    try:
+        torch.manual_seed(0)
+        mod = steps.CurveSAModule(None, 0.02, MLP([c + 3 + 3, 64, 32], act="leaky_relu", bias=True), curve_fps_arclen=0.007,
+                                  use_curve_fps=True, with_xyz=True, aggr_type="max", normalize_radius=True).to(DEV).train()
+        x = torch.randn(d.pos.size(0), c, generator=torch.Generator().manual_seed(4)).to(DEV)
+        runs = []
+        for gather in (True, True, False):
+            ops.PN_BWD_GATHER = gather
+            for bn in mod.conv.local_nn.norms:
+                bn.module.reset_running_stats()
+            xi = x.clone().requires_grad_(True)
+            torch.manual_seed(3)
+            out = mod(xi, d.pos.to(DEV), d.batch.to(DEV), d.curve_idxs.to(DEV))[0]
+            cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).to(DEV)
+            runs.append([out.detach()] + [g.detach().clone() for g in
+                                          torch.autograd.grad((out * cot).sum(), [xi] + list(mod.parameters()))])
+        for a, b in zip(runs[0], runs[1]):
+            assert torch.equal(a, b), "two runs of the atomics-free backward differ in bits"
+        tol = 1e-4 if dtype == "fp32" else 2e-2
+        for a, b in zip(runs[0], runs[2]):
+            _close(a, b, tol, "gather backward vs atomic backward")
+    finally:
+        ops.PN_BWD_GATHER = True
         ops.set_mlp_dtype("fp32")
