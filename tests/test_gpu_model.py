@@ -288,13 +288,17 @@ def test_deferred_activations_give_the_same_bits():
     assert torch.equal(o0, o1) and torch.equal(l0, l1) and torch.equal(e0, e1)
     for n in b0:
         assert torch.equal(b0[n], b1[n]), "buffer %s differs" % n
+    gscale = max(float(g.abs().max()) for g in g0.values())
     for n in g0:
         scale = float(g0[n].abs().max())
         same_mode = float((g0[n] - ga[n]).abs().max())
         across = float((g0[n] - g1[n]).abs().max())
-        # (same_mode is ONE sample of the atomic-order noise and can come out as zero for a tensor: the floor is five times the
-        # typical noise, 1e-5 of the tensor's scale; a wrong transform moves gradients by 1e-2 and more)
-        assert across <= 3.0 * same_mode + 5e-5 * scale + 1e-12, (n, across, same_mode, scale)
+        # (same_mode is ONE sample of the atomic-order noise and can come out as zero for a tensor -- since round 5, with the
+        # first edge layers' backward free of atomics, it is zero for most: the floor is five times the typical noise, 1e-5 of
+        # the tensor's scale, plus 1e-5 of the largest gradient for the tensors whose gradient is zero in exact arithmetic --
+        # a bias ahead of a BatchNorm: max |g| ~ 1e-7, rounding residue of a cancelling sum that the two modes' weight-
+        # gradient kernels add up in different orders; a wrong transform moves gradients by 1e-2 of their scale and more)
+        assert across <= 3.0 * same_mode + 5e-5 * scale + 1e-5 * gscale, (n, across, same_mode, scale, gscale)
 
 
 def test_full_kitti_config_matches_oracle():
