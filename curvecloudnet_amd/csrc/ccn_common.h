@@ -67,6 +67,25 @@ int ccn_scan_i32(const int32_t* in, int32_t* out, int64_t n, bool inclusive, int
 int ccn_scan_f64(const double* in, double* out, int64_t n, bool inclusive, void* scratch, hipStream_t s);
 
 // exact distance arithmetic shared by every index kernel and by oracle/frnn_bruteforce.c
+// XCD-aware work order for one-dimensional grids of row-gathering kernels (round 5).  Workgroup ids are dealt round-robin over
+// the eight XCDs (ids b and b + 8 share an XCD and its 4 MiB L2 -- observed placement, used for speed only: any placement
+// gives the same result): with the work taken in id order, eight consecutive pieces -- 32 neighbouring points whose
+// neighbour lists overlap almost completely -- go to eight different L2s and every gathered row is fetched eight times.
+// ccn_xcd_block() renumbers the ids so that the workgroups with id % 8 == x take ONE contiguous eighth of the work: the
+// workgroups in flight on an XCD then sit next to each other in the point order and share their gathered rows in its L2.
+// A bijection of [0, gridDim.x) for any grid size.  -DCCN_XCD_ORDER=0 builds the id-order form (A/B).
+#ifndef CCN_XCD_ORDER
+#define CCN_XCD_ORDER 1
+#endif
+__device__ __forceinline__ unsigned ccn_xcd_block() {
+#if CCN_XCD_ORDER
+  const unsigned n = gridDim.x, b = blockIdx.x, x = b & 7u, k = b >> 3, per = n >> 3, rem = n & 7u;
+  return x * per + (x < rem ? x : rem) + k;
+#else
+  return blockIdx.x;
+#endif
+}
+
 __device__ __forceinline__ float ccn_sqdist3(float dx, float dy, float dz) {
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }

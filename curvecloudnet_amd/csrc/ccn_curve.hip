@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void shift_add_bwd_kernel(const float* __restr
 
 __global__ void gather_rows_kernel(const float* __restrict__ src, int64_t lds_, const int64_t* __restrict__ index,
                                    int64_t m, int64_t C, float* __restrict__ dst, int64_t ldd) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = (int64_t)ccn_xcd_block() * blockDim.x + threadIdx.x;
   if (t >= m * C) return;
   const int64_t r = m * C < 0xffffffffLL ? (int64_t)((uint32_t)t / (uint32_t)C) : t / C, c = t - r * C;
   dst[r * ldd + c] = src[index[r] * lds_ + c];
@@ -497,7 +497,7 @@ __global__ void group_superset_kernel(const float* __restrict__ pos, const int32
 __global__ void interp_fwd_kernel(const float* __restrict__ x, int64_t ldx, const int64_t* __restrict__ nbr,
                                   const float* __restrict__ weight, int64_t n, int k, int64_t C,
                                   float* __restrict__ y, int64_t ldy) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = (int64_t)ccn_xcd_block() * blockDim.x + threadIdx.x;
   if (t >= n * C) return;
   const int64_t i = n * C < 0xffffffffLL ? (int64_t)((uint32_t)t / (uint32_t)C) : t / C, c = t - i * C;
   float num = 0.0f, den = 0.0f;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void interp_bwd_gather_kernel(const float* __r
                                                                 float* __restrict__ dx, int64_t lddx) {
   constexpr int W = VEC ? 4 : 1;
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int64_t m = (int64_t)blockIdx.x * 4 + ry;
+  const int64_t m = (int64_t)ccn_xcd_block() * 4 + ry;
   if (m >= M) return;
   const int32_t lo = inv_ptr[m], hi = inv_ptr[m + 1];
   for (int64_t c0 = 0; c0 < C; c0 += 64 * W) {

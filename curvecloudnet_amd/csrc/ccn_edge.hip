@@ -47,7 +47,7 @@ __global__ __launch_bounds__(TPB) void sg_gather_fwd_kernel(const float* __restr
                                                             int64_t Nmax, int K, int C, float* __restrict__ feat,
                                                             int64_t ldf) {
   CCN_LANES;
-  const int64_t bi = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t bi = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (bi >= B * Nmax) return;
   const int64_t b = bi / Nmax, i = bi - b * Nmax;
   const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(TPB) void sg_gather_bwd_kernel(const float* __restr
                                                             int64_t Nmax, int K, int C, float* __restrict__ dx,
                                                             int64_t lddx) {
   CCN_LANES;
-  const int64_t bi = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t bi = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (bi >= B * Nmax) return;
   const int64_t b = bi / Nmax, i = bi - b * Nmax;
   const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(TPB) void sg_max_fwd_kernel(const float* __restrict
                                                          int64_t Nmax, int K, int C, float* __restrict__ out,
                                                          int64_t ldo, int32_t* __restrict__ arg) {
   CCN_LANES;
-  const int64_t bi = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t bi = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (bi >= B * Nmax) return;
   const int64_t b = bi / Nmax, i = bi - b * Nmax;
   const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(TPB) void sg_max_bwd_kernel(const float* __restrict
                                                          int64_t Nmax, int K, int C, float* __restrict__ df,
                                                          int64_t lddf) {
   CCN_LANES;
-  const int64_t bi = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t bi = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (bi >= B * Nmax) return;
   const int64_t b = bi / Nmax, i = bi - b * Nmax;
   const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(TPB) void sg_edge_stats_kernel(
     const float* __restrict__ rstd, int act, float slope, int pts, double* __restrict__ partial) {
   __shared__ double red[4][64][2];
   CCN_LANES;
-  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * pts;
+  const int64_t first = ((int64_t)ccn_xcd_block() * 4 + ry) * pts;
   {
     const int c = blockIdx.y * 64 + cx;  // one 64-channel chunk per workgroup
     double s1 = 0.0, s2 = 0.0;
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(TPB) void sg_edge_stats_kernel(
         a += red[w][cx][0];
         b2 += red[w][cx][1];
       }
-      partial[(int64_t)blockIdx.x * 2 * Co + c] = a;
-      partial[(int64_t)blockIdx.x * 2 * Co + Co + c] = b2;
+      partial[(int64_t)ccn_xcd_block() * 2 * Co + c] = a;
+      partial[(int64_t)ccn_xcd_block() * 2 * Co + Co + c] = b2;
     }
   }
 }
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(TPB) void sg_edge_apply_kernel(const float* __restr
                                                             const float* __restrict__ shift, int act, float slope,
                                                             float* __restrict__ Z, int64_t ldz) {
   CCN_LANES;
-  const int64_t bi = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t bi = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (bi >= B * Nmax) return;
   const int64_t b = bi / Nmax, i = bi - b * Nmax;
   const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(TPB) void sg_edge_bwd_kernel(
     const float* __restrict__ rstd, int act, float slope, const double* __restrict__ sums, int64_t rows_total,
     int training, float* __restrict__ dps, int64_t lddps) {
   CCN_LANES;
-  const int64_t bi = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t bi = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (bi >= B * Nmax) return;
   const int64_t b = bi / Nmax, i = bi - b * Nmax;
   const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(TPB) void cg_edge_stats_kernel(
   // -- what dS[p] is made of once the column sums are known (cg_edge_finish_kernel), so that no second pass over dZ is needed
   __shared__ double red[4][64][2];
   CCN_LANES;
-  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * pts;
+  const int64_t first = ((int64_t)ccn_xcd_block() * 4 + ry) * pts;
   const int c = blockIdx.y * 64 + cx, cc = c < Co ? c : Co - 1;
   double s1 = 0.0, s2 = 0.0;
   float sc = 0.f, sh = 0.f, mu = 0.f, rs = 0.f;
@@ -491,8 +491,8 @@ __global__ __launch_bounds__(TPB) void cg_edge_stats_kernel(
       a += red[w][cx][0];
       b2 += red[w][cx][1];
     }
-    partial[(int64_t)blockIdx.x * 2 * Co + c] = a;
-    partial[(int64_t)blockIdx.x * 2 * Co + Co + c] = b2;
+    partial[(int64_t)ccn_xcd_block() * 2 * Co + c] = a;
+    partial[(int64_t)ccn_xcd_block() * 2 * Co + Co + c] = b2;
   }
 }
 
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(TPB) void cg_edge_apply_kernel(
     const int32_t* __restrict__ rep_row, int64_t N, int64_t E, int64_t Ne, int Co, const float* __restrict__ scale,
     const float* __restrict__ shift, int act, float slope, void* __restrict__ Z, int64_t ldz) {
   CCN_LANES;
-  const int64_t p = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t p = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (p > N) return;
   const bool pad = p == N;
   const int32_t g0 = pad ? 0 : grp_ptr[p], cnt = pad ? 0 : grp_ptr[p + 1] - g0;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(TPB) void cg_edge_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope,
     const double* __restrict__ sums, double count, int training, float* __restrict__ dps, int64_t lddps) {
   CCN_LANES;
-  const int64_t p = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t p = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (p >= N) return;  // the padding row feeds nothing upstream
   const int32_t g0 = grp_ptr[p], cnt = grp_ptr[p + 1] - g0;
   const int32_t rrow = rep_row[p];
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(TPB) void cg_edge_gather_kernel(
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ rstd, int act, float slope, float* __restrict__ pp, int64_t ldpp) {
   CCN_LANES;
-  const int64_t j = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t j = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (j >= N) return;
   const int32_t t0 = inv_ptr[j], t1 = inv_ptr[j + 1];
   for (int c0 = 0; c0 < Co; c0 += 64) {
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(TPB) void cg_edge_finish_kernel(
     int64_t E, int Co, const float* __restrict__ scale, const double* __restrict__ sums, double count, int training,
     float* __restrict__ dps, int64_t lddps) {
   CCN_LANES;
-  const int64_t j = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t j = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (j >= N) return;
   const float inv_n = (float)(1.0 / count);
   const int32_t rrow = rep_row[j];
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(TPB) void cg_max_fwd_kernel(const float* __restrict
                                                          const int32_t* __restrict__ rep_row, int64_t N, int C,
                                                          float* __restrict__ out, int64_t ldo, int32_t* __restrict__ arg) {
   CCN_LANES;
-  const int64_t p = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t p = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (p >= N) return;
   const int32_t g0 = grp_ptr[p], cnt = grp_ptr[p + 1] - g0;
   const bool has_empty = rep_row[p] >= 0;
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(TPB) void cg_max_bwd_kernel(const float* __restrict
                                                          const int32_t* __restrict__ rep_row, int64_t N, int64_t R, int C,
                                                          void* __restrict__ df, int64_t lddf) {
   CCN_LANES;
-  const int64_t p = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t p = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (p > N) return;
   if (p == N) {
     for (int c = cx; c < C; c += 64) st_el<T>(df, (R - 1) * lddf + c, 0.f);
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(TPB) void pn_edge_stats_kernel(
     double* __restrict__ partial) {
   __shared__ double red[4][64][2];
   CCN_LANES;
-  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * per_wave;  // per_wave <= 64
+  const int64_t first = ((int64_t)ccn_xcd_block() * 4 + ry) * per_wave;  // per_wave <= 64
   const int64_t last = first + per_wave < E ? first + per_wave : E;
   const int c = blockIdx.y * 64 + cx, cc = c < Co ? c : Co - 1;
   double s1 = 0.0, s2 = 0.0;
@@ -821,8 +821,8 @@ __global__ __launch_bounds__(TPB) void pn_edge_stats_kernel(
       a += red[w][cx][0];
       b2 += red[w][cx][1];
     }
-    partial[(int64_t)blockIdx.x * 2 * Co + c] = a;
-    partial[(int64_t)blockIdx.x * 2 * Co + Co + c] = b2;
+    partial[(int64_t)ccn_xcd_block() * 2 * Co + c] = a;
+    partial[(int64_t)ccn_xcd_block() * 2 * Co + Co + c] = b2;
   }
 }
 
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(TPB) void pn_edge_apply_kernel(
     const float* __restrict__ scale, const float* __restrict__ shift, int act, float slope, void* __restrict__ Z,
     int64_t ldz) {
   CCN_LANES;
-  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * PN_APPLY_EDGES;
+  const int64_t first = ((int64_t)ccn_xcd_block() * 4 + ry) * PN_APPLY_EDGES;
   if (first >= E) return;
   const int64_t last = first + PN_APPLY_EDGES < E ? first + PN_APPLY_EDGES : E;
   const int cnt = (int)(last - first);
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(TPB) void pn_edge_bwd_kernel(
     const double* __restrict__ sums, int training, int per_wave, float* __restrict__ dpx, int64_t lddpx,
     double* __restrict__ wpart) {
   CCN_LANES;
-  const int64_t wave_id = (int64_t)blockIdx.x * 4 + ry;
+  const int64_t wave_id = (int64_t)ccn_xcd_block() * 4 + ry;
   const int64_t first = wave_id * per_wave;
   if (first >= E) {  // a wave without edges still owns a row of partial sums
     for (int c = cx; c < 4 * Co; c += 64) wpart[wave_id * 4 * Co + c] = 0.0;
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(TPB) void pn_edge_sums_kernel(
   __shared__ double red[4][64][9];
   __shared__ double redr[4][3];
   CCN_LANES;
-  const int64_t first = ((int64_t)blockIdx.x * 4 + ry) * per_wave;  // per_wave <= 64
+  const int64_t first = ((int64_t)ccn_xcd_block() * 4 + ry) * per_wave;  // per_wave <= 64
   const int64_t last = first + per_wave < E ? first + per_wave : E;
   const int c = blockIdx.y * 64 + cx, cc = c < Co ? c : Co - 1;
   double a[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, rr[3] = {0.0, 0.0, 0.0};
@@ -998,7 +998,7 @@ __global__ __launch_bounds__(TPB) void pn_edge_sums_kernel(
     redr[ry][2] = rr[2];
   }
   __syncthreads();
-  double* const o = partial + (int64_t)blockIdx.x * (9 * Co + 4);
+  double* const o = partial + (int64_t)ccn_xcd_block() * (9 * Co + 4);
   if (ry == 0 && c < Co) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) o[k * Co + c] = red[0][cx][k] + red[1][cx][k] + red[2][cx][k] + red[3][cx][k];
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(TPB) void pn_edge_gather_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd, int act, float slope, float* __restrict__ pp,
     int64_t ldpp) {
   CCN_LANES;
-  const int64_t j = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t j = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (j >= Nsrc) return;
   const int32_t t0 = inv_ptr[j], t1 = inv_ptr[j + 1];
   const float sx = pos_src[3 * j], sy = pos_src[3 * j + 1], sz = pos_src[3 * j + 2];
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(TPB) void pn_edge_finish_kernel(const float* __rest
                                                              float* __restrict__ dpx, int64_t lddpx, float* __restrict__ dw4) {
   CCN_LANES;
   const double inv_e = 1.0 / (double)E;
-  if (blockIdx.x == 0) {
+  if (ccn_xcd_block() == 0) {
     for (int c = threadIdx.x; c < Co; c += TPB) {
       const double sc = (double)scale[c];
       const double m1 = training ? sums[c] * inv_e : 0.0, m2 = training ? sums[Co + c] * inv_e : 0.0;
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(TPB) void pn_edge_finish_kernel(const float* __rest
       dw4[3 * Co + c] = (float)(sc * (sums[c] - (double)E * m1 - m2 * sums[5 * Co + c]));
     }
   }
-  const int64_t j = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t j = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (j >= Nsrc) return;
   const float nj = (float)(inv_ptr[j + 1] - inv_ptr[j]);
   for (int c = cx; c < Co; c += 64) {
@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(TPB) void msg_build_fwd_kernel(const float* __restr
                                                             const int64_t* __restrict__ dst, int64_t E, int C,
                                                             float radius, float* __restrict__ msg, int64_t ldm) {
   CCN_LANES;
-  const int64_t e = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t e = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (e >= E) return;
   const int64_t j = src[e], q = dst[e];
   const int W = C + 3;
@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(TPB) void msg_build_bwd_kernel(const float* __restr
                                                             const int64_t* __restrict__ src, int64_t E, int C,
                                                             float* __restrict__ dx, int64_t lddx) {
   CCN_LANES;
-  const int64_t e = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t e = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (e >= E) return;
   const int64_t j = src[e];
   for (int c = cx; c < C; c += 64) atomicAdd(&dx[j * lddx + c], dmsg[e * lddm + c]);
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(TPB) void edge_feat_fwd_kernel(const float* __restr
                                                             const int64_t* __restrict__ dst, int64_t E, int C,
                                                             void* __restrict__ msg, int64_t ldm) {
   CCN_LANES;
-  const int64_t e = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t e = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (e >= E) return;
   const int64_t j = src[e], i = dst[e];
   for (int c = cx; c < C; c += 64) {
@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(TPB) void edge_feat_bwd_csr_kernel(const void* __re
                                                                 const int32_t* __restrict__ offsets, int64_t num_dst, int C,
                                                                 float* __restrict__ dx, int64_t lddx) {
   CCN_LANES;
-  const int64_t i = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t i = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (i >= num_dst) return;
   const int32_t lo = offsets[i], hi = offsets[i + 1];
   if (lo >= hi) return;
@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(TPB) void edge_feat_bwd_kernel(const float* __restr
                                                             const int64_t* __restrict__ dst, int64_t E, int C,
                                                             float* __restrict__ dx, int64_t lddx) {
   CCN_LANES;
-  const int64_t e = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t e = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (e >= E) return;
   const int64_t j = src[e], i = dst[e];
   for (int c = cx; c < C; c += 64) {
@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(TPB) void seg_softmax_agg_fwd_kernel(const float* _
                                                                   const int32_t* __restrict__ offsets, int64_t M,
                                                                   int C, float* __restrict__ out, int64_t ldo) {
   CCN_LANES;
-  const int64_t i = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t i = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (i >= M) return;
   const int32_t lo = offsets[i], hi = offsets[i + 1];
   for (int c = cx; c < C; c += 64) {
@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(TPB) void seg_softmax_agg_bwd_kernel(const float* _
                                                                   int64_t lddm, void* __restrict__ datt,
                                                                   int64_t ldda) {
   CCN_LANES;
-  const int64_t i = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t i = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (i >= M) return;
   const int32_t lo = offsets[i], hi = offsets[i + 1];
   for (int c = cx; c < C; c += 64) {
@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(TPB) void seg_max_fwd_kernel(const float* __restric
                                                           float* __restrict__ out, int64_t ldo,
                                                           int32_t* __restrict__ arg) {
   CCN_LANES;
-  const int64_t i = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t i = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (i >= M) return;
   const int32_t lo = offsets[i], hi = offsets[i + 1];
   for (int c = cx; c < C; c += 64) {
@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(TPB) void seg_max_bwd_kernel(const float* __restric
                                                           const int32_t* __restrict__ offsets, int64_t M, int C,
                                                           float* __restrict__ dmsg, int64_t lddm) {
   CCN_LANES;
-  const int64_t i = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t i = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (i >= M) return;
   const int32_t lo = offsets[i], hi = offsets[i + 1];
   for (int c = cx; c < C; c += 64) {
@@ -1358,7 +1358,7 @@ __global__ __launch_bounds__(TPB) void seg_wsum_fwd_kernel(const float* __restri
                                                            const int32_t* __restrict__ offsets, int64_t M, int C, int mode,
                                                            float* __restrict__ out, int64_t ldo) {
   CCN_LANES;
-  const int64_t i = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t i = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (i >= M) return;
   const int32_t lo = offsets[i], hi = offsets[i + 1];
   const float inv = 1.0f / (float)(hi - lo > 1 ? hi - lo : 1);
@@ -1379,7 +1379,7 @@ __global__ __launch_bounds__(TPB) void seg_wsum_bwd_kernel(const float* __restri
                                                            float* __restrict__ dmsg, int64_t lddm, float* __restrict__ datt,
                                                            int64_t ldda) {
   CCN_LANES;
-  const int64_t i = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t i = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (i >= M) return;
   const int32_t lo = offsets[i], hi = offsets[i + 1];
   const float inv = 1.0f / (float)(hi - lo > 1 ? hi - lo : 1);
@@ -1407,7 +1407,7 @@ __global__ __launch_bounds__(TPB) void sg_reduce_fwd_kernel(const float* __restr
                                                             const int64_t* __restrict__ cloud_ptr, int64_t B, int64_t Nmax,
                                                             int K, int C, int mode, float* __restrict__ out, int64_t ldo) {
   CCN_LANES;
-  const int64_t bi = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t bi = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (bi >= B * Nmax) return;
   const int64_t b = bi / Nmax, i = bi - b * Nmax;
   const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
@@ -1457,7 +1457,7 @@ __global__ __launch_bounds__(TPB) void sg_reduce_bwd_kernel(const float* __restr
                                                             int64_t lddo, float* __restrict__ df, int64_t lddf,
                                                             float* __restrict__ datt, int64_t ldda) {
   CCN_LANES;
-  const int64_t bi = (int64_t)blockIdx.x * ROWS_PER_WG + ry;
+  const int64_t bi = (int64_t)ccn_xcd_block() * ROWS_PER_WG + ry;
   if (bi >= B * Nmax) return;
   const int64_t b = bi / Nmax, i = bi - b * Nmax;
   const int64_t base = cloud_ptr[b], len = cloud_ptr[b + 1] - base;
