@@ -68,8 +68,8 @@ def lib():
                 continue                     # (an OLDER build of the library in a tools/ A/B run: entries added since are absent)
             fn = getattr(handle, name)       # AttributeError if the header declares a missing symbol
             fn.restype, fn.argtypes = restype, argtypes
-        if handle.ccn_abi_version() != 2:
-            raise RuntimeError("libccn_hip.so ABI version mismatch")
+        if handle.ccn_abi_version() != 3 and not os.environ.get("CCN_LIB_PATH"):
+            raise RuntimeError("libccn_hip.so ABI version mismatch (header: 3, library: %d)" % handle.ccn_abi_version())
         if os.environ.get("CCN_GEMM_DMA"):       # A/B hook of the GEMM dispatch (include/ccn_hip.h: ccn_gemm_use_dma)
             handle.ccn_gemm_use_dma(int(os.environ["CCN_GEMM_DMA"]))
         if os.environ.get("CCN_GEMM_PAIR_OPT"):  # A/B hook (ccn_gemm_pair_opt)

@@ -171,7 +171,7 @@ _TABLE = {
 
 _GEOMETRY_PREFIXES = ("frnn_", "fps", "curve_fps", "curve_group", "curve_topology", "curve_split", "segment_ptr", "knn_",
                       "ball_query", "voxel_", "rank_keys", "sort_keys", "key_spread", "dense_to_csr", "cg_count", "cg_fill",
-                      "interp_inverse", "exclusive_scan", "scatter_flagged")
+                      "interp_inverse", "exclusive_scan", "scatter_flagged", "inverse_lists", "group_owner")
 
 
 def family_of(name):

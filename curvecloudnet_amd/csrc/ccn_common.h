@@ -66,6 +66,12 @@ int ccn_scan_i32(const int32_t* in, int32_t* out, int64_t n, bool inclusive, int
                  hipStream_t s);
 int ccn_scan_f64(const double* in, double* out, int64_t n, bool inclusive, void* scratch, hipStream_t s);
 
+// ---- stable LSD radix sort with payload (ccn_sort.hip) ----
+// n non-negative int64 keys sorted on the 8-bit digits named by digit_mask (bit b = digit b); *vout = the original positions
+// in sorted order, equal keys in ascending position (it points into `ws`, ccn_rank_keys_workspace_bytes(n) bytes).
+int ccn_sort_payload(const int64_t* key, int64_t n, int digit_mask, void* ws, size_t ws_bytes, hipStream_t s,
+                     const int32_t** vout);
+
 // exact distance arithmetic shared by every index kernel and by oracle/frnn_bruteforce.c
 // XCD-aware work order for one-dimensional grids of row-gathering kernels (round 5).  Workgroup ids are dealt round-robin over
 // the eight XCDs (ids b and b + 8 share an XCD and its 4 MiB L2 -- observed placement, used for speed only: any placement

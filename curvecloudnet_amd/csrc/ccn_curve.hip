@@ -534,52 +534,43 @@ __global__ void interp_bwd_kernel(const float* __restrict__ dy, int64_t lddy, co
 // Every coarse row m gets the list of (fine row, weight) pairs that interpolate from it, sorted by fine row, so the
 // backward pass is a gather with a fixed summation order: deterministic, and 4 C (k + 1) bytes per fine row read at the
 // gather rate instead of k row-wide fp32 atomic adds per fine row (r02b: interp_bwd 424 us per launch at 0.85 TB/s).
-__global__ void interp_inv_count_kernel(const int64_t* __restrict__ nbr, const float* __restrict__ weight, int64_t n, int k,
-                                        int32_t* __restrict__ counts, float* __restrict__ den) {
+__global__ void interp_inv_pack_kernel(const int64_t* __restrict__ nbr, const float* __restrict__ weight, int64_t n, int k,
+                                       int64_t M, int64_t* __restrict__ key, int32_t* __restrict__ counts,
+                                       float* __restrict__ den) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float d = 0.0f;
+  bool live = true;
   for (int s = 0; s < k; ++s) {
     const int64_t m = nbr[i * k + s];
-    if (m < 0) break;
-    d += weight[i * k + s];
-    atomicAdd(&counts[m], 1);
+    live = live && m >= 0 && m < M;             // (the slots behind the first -1 are unused, as in the forward pass)
+    key[i * k + s] = live ? m : M;
+    if (live) {
+      d += weight[i * k + s];
+      atomicAdd(&counts[m], 1);
+    }
   }
   den[i] = d;
 }
 
-__global__ void interp_inv_fill_kernel(const int64_t* __restrict__ nbr, const float* __restrict__ weight, int64_t n, int k,
-                                       const int32_t* __restrict__ inv_ptr, int32_t* __restrict__ cursor,
+// entry j of the sorted order = flat slot e = i * k + s: the fine row and its weight (slots of one coarse row arrive in ascending e,
+// i.e. ascending fine row: the stable sort's order)
+__global__ void interp_inv_fill_kernel(const int32_t* __restrict__ order, const float* __restrict__ weight,
+                                       const int32_t* __restrict__ inv_ptr, int64_t M, int k, int64_t slots,
                                        int32_t* __restrict__ inv_src, float* __restrict__ inv_w) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  for (int s = 0; s < k; ++s) {
-    const int64_t m = nbr[i * k + s];
-    if (m < 0) break;
-    const int32_t at = inv_ptr[m] + atomicAdd(&cursor[m], 1);
-    inv_src[at] = (int32_t)i;
-    inv_w[at] = weight[i * k + s];
-  }
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= slots || j >= inv_ptr[M]) return;
+  const int32_t e = order[j];
+  inv_src[j] = (int32_t)((uint32_t)e / (uint32_t)k);
+  inv_w[j] = weight[e];
 }
 
-// the lists are short (a coarse point serves the fine points around it): insertion sort by fine row, one thread per list
-__global__ void interp_inv_sort_kernel(const int32_t* __restrict__ inv_ptr, int64_t M, int32_t* __restrict__ inv_src,
-                                       float* __restrict__ inv_w) {
-  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
-  const int32_t lo = inv_ptr[m], hi = inv_ptr[m + 1];
-  for (int32_t a = lo + 1; a < hi; ++a) {
-    const int32_t sv = inv_src[a];
-    const float wv = inv_w[a];
-    int32_t b = a - 1;
-    while (b >= lo && inv_src[b] > sv) {
-      inv_src[b + 1] = inv_src[b];
-      inv_w[b + 1] = inv_w[b];
-      --b;
-    }
-    inv_src[b + 1] = sv;
-    inv_w[b + 1] = wv;
-  }
+// owner of every row of a grouped row list: owner[r] = p for grp_ptr[p] <= r < grp_ptr[p + 1] (groups of at most a few dozen rows)
+__global__ void group_owner_kernel(const int32_t* __restrict__ grp_ptr, int64_t N, int64_t E, int32_t* __restrict__ owner) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= N) return;
+  const int32_t lo = grp_ptr[p], hi = grp_ptr[p + 1];
+  for (int32_t r = lo; r < hi && r < E; ++r) owner[r] = (int32_t)p;
 }
 
 // one coarse row per wave.  The list entries (fine row, weight, weight sum) are loaded once, one per lane, and handed round
@@ -1023,8 +1014,10 @@ int ccn_interp_bwd(const float* dy, int64_t lddy, const int64_t* nbr, const floa
   return CCN_OK;
 }
 
-size_t ccn_interp_inverse_workspace_bytes(int64_t M) {
-  return 2 * ccn_align256((size_t)(M + 1) * 4) + ccn_scan_scratch_bytes(M + 1) + 512;
+size_t ccn_interp_inverse_workspace_bytes(int64_t n, int64_t k, int64_t M) {
+  const int64_t slots = n * k > 0 ? n * k : 1;
+  return ccn_align256((size_t)slots * 8) + ccn_align256((size_t)(M + 1) * 4) + ccn_align256(ccn_scan_scratch_bytes(M + 1)) +
+         ccn_rank_keys_workspace_bytes(slots) + 1024;
 }
 
 int ccn_interp_inverse(const int64_t* nbr, const float* weight, int64_t n, int64_t k, int64_t M, int32_t* inv_ptr,
@@ -1032,23 +1025,40 @@ int ccn_interp_inverse(const int64_t* nbr, const float* weight, int64_t n, int64
   hipStream_t s = (hipStream_t)stream;
   CCN_REQUIRE(nbr && weight && inv_ptr && inv_src && inv_w && den && n >= 0 && k >= 1 && M > 0, "interp_inverse: bad arguments");
   CCN_REQUIRE(n * k < (int64_t)1 << 31 && M < (int64_t)1 << 31, "interp_inverse: more than 2^31 entries");
-  CCN_REQUIRE(ws_bytes >= ccn_interp_inverse_workspace_bytes(M), "interp_inverse: workspace too small");
+  CCN_REQUIRE(ws_bytes >= ccn_interp_inverse_workspace_bytes(n, k, M), "interp_inverse: workspace too small");
+  const int64_t slots = n * k;
   CcnArena a(ws, ws_bytes);
+  int64_t* key = a.take<int64_t>(slots > 0 ? slots : 1);
   int32_t* counts = a.take<int32_t>(M + 1);
-  int32_t* cursor = a.take<int32_t>(M + 1);
   void* scratch = a.take<char>(ccn_scan_scratch_bytes(M + 1));
+  const size_t sort_bytes = ccn_rank_keys_workspace_bytes(slots > 0 ? slots : 1);
+  void* sort_ws = a.take<char>(sort_bytes);
   CCN_REQUIRE(a.ok(), "interp_inverse: workspace carve failed");
   CCN_HIP(hipMemsetAsync(counts, 0, (size_t)(M + 1) * 4, s), "interp_inverse");
-  CCN_HIP(hipMemsetAsync(cursor, 0, (size_t)(M + 1) * 4, s), "interp_inverse");
   if (n > 0)
-    hipLaunchKernelGGL(interp_inv_count_kernel, dim3(ccn_blocks(n, TPB)), dim3(TPB), 0, s, nbr, weight, n, (int)k, counts, den);
+    hipLaunchKernelGGL(interp_inv_pack_kernel, dim3(ccn_blocks(n, TPB)), dim3(TPB), 0, s, nbr, weight, n, (int)k, M, key, counts, den);
   int rc = ccn_scan_i32(counts, inv_ptr, M + 1, false, nullptr, scratch, s);       // inv_ptr[M] = total
   if (rc) return rc;
-  if (n > 0)
-    hipLaunchKernelGGL(interp_inv_fill_kernel, dim3(ccn_blocks(n, TPB)), dim3(TPB), 0, s, nbr, weight, n, (int)k, inv_ptr,
-                       cursor, inv_src, inv_w);
-  hipLaunchKernelGGL(interp_inv_sort_kernel, dim3(ccn_blocks(M, TPB)), dim3(TPB), 0, s, inv_ptr, M, inv_src, inv_w);
+  if (slots > 0) {
+    // the lists by a stable sort of the slots by coarse row (round 5; rounds 2-4: fill at an atomic cursor + one thread's
+    // insertion sort per list -- quadratic in the list length, minutes for a coarse row that thousands of fine rows read)
+    int mask = 0;
+    for (int b = 0; b < 4; ++b)
+      if (b == 0 || ((uint64_t)M >> (8 * b)) != 0) mask |= 1 << b;
+    const int32_t* order;
+    rc = ccn_sort_payload(key, slots, mask, sort_ws, sort_bytes, s, &order);
+    if (rc) return rc;
+    hipLaunchKernelGGL(interp_inv_fill_kernel, dim3(ccn_blocks(slots, TPB)), dim3(TPB), 0, s, order, weight, inv_ptr, M, (int)k, slots,
+                       inv_src, inv_w);
+  }
   CCN_LAUNCH_OK("interp_inverse");
+  return CCN_OK;
+}
+
+int ccn_group_owner(const int32_t* grp_ptr, int64_t N, int64_t E, int32_t* owner, void* stream) {
+  CCN_REQUIRE(grp_ptr && owner && N > 0 && E >= 0 && E < (int64_t)1 << 31, "group_owner: bad arguments");
+  hipLaunchKernelGGL(group_owner_kernel, dim3(ccn_blocks(N, TPB)), dim3(TPB), 0, (hipStream_t)stream, grp_ptr, N, E, owner);
+  CCN_LAUNCH_OK("group_owner");
   return CCN_OK;
 }
 

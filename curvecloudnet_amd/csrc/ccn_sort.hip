@@ -98,6 +98,20 @@ inline int64_t rs_tiles(int64_t n) { return (n + RS_TILE - 1) / RS_TILE; }
 
 }  // namespace
 
+namespace {
+// key = the source number (M for a row that names none: behind every list); counts = rows per source
+template <typename IT>
+__global__ void inv_pack_kernel(const IT* __restrict__ src, int64_t n, int64_t M, int64_t* __restrict__ key,
+                                int32_t* __restrict__ counts) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t m = (int64_t)src[r];
+  const bool ok = m >= 0 && m < M;
+  key[r] = ok ? m : M;
+  if (ok) atomicAdd(&counts[m], 1);
+}
+}  // namespace
+
 extern "C" {
 
 // spread: one device uint64 (zeroed here): OR over (key[i] ^ key[0])
@@ -204,4 +218,63 @@ int ccn_sort_keys(const int64_t* key, int64_t n, int digit_mask, int64_t* sorted
   return CCN_OK;
 }
 
+
+// ---- inverse of a flat index list (round 5): rows r = 0 .. n-1 name a source src[r] in [0, M); for every source the rows that
+// name it, ascending (what the atomics-free backward of the first edge layers gathers through: ccn_cg_edge_bwd_gather,
+// ccn_pn_edge_bwd_gather).  The stable LSD sort above over the source numbers, payload = row number: rows of one source keep
+// their ascending order, whatever the list lengths (a first form -- fill at an atomic cursor, insertion sort per list -- took
+// minutes on five lists of 60 000 rows).  Replaces torch.sort + bincount + cumsum on the geometry stream (rocprim merge-sort
+// and look-back-scan launches inside the step).  Rows naming no source (src < 0 or >= M) sort behind the last list.
+size_t ccn_inverse_lists_workspace_bytes(int64_t n, int64_t M) {
+  return ccn_align256((size_t)(n > 0 ? n : 1) * 8) + ccn_align256((size_t)(M + 1) * 4) + ccn_align256(ccn_scan_scratch_bytes(M + 1)) +
+         ccn_rank_keys_workspace_bytes(n) + 1024;
+}
+
+int ccn_inverse_lists(const void* src, int src_is_i64, int64_t n, int64_t M, int32_t* inv_ptr, int32_t* inv_row, void* ws,
+                      size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  CCN_REQUIRE(src && inv_ptr && inv_row && n >= 0 && M > 0, "inverse_lists: bad arguments");
+  CCN_REQUIRE(n < (int64_t)1 << 31 && M < (int64_t)1 << 31, "inverse_lists: more than 2^31 entries");
+  CCN_REQUIRE(ws && ws_bytes >= ccn_inverse_lists_workspace_bytes(n, M), "inverse_lists: workspace too small");
+  CcnArena a(ws, ws_bytes);
+  int64_t* key = a.take<int64_t>(n > 0 ? n : 1);
+  int32_t* counts = a.take<int32_t>(M + 1);
+  void* scratch = a.take<char>(ccn_scan_scratch_bytes(M + 1));
+  const size_t sort_bytes = ccn_rank_keys_workspace_bytes(n);
+  void* sort_ws = a.take<char>(sort_bytes);
+  CCN_REQUIRE(a.ok(), "inverse_lists: workspace carve failed");
+  CCN_HIP(hipMemsetAsync(counts, 0, (size_t)(M + 1) * 4, s), "inverse_lists");
+  if (n > 0) {
+    if (src_is_i64)
+      hipLaunchKernelGGL(inv_pack_kernel<int64_t>, dim3(ccn_blocks(n, 256)), dim3(256), 0, s, (const int64_t*)src, n, M, key, counts);
+    else
+      hipLaunchKernelGGL(inv_pack_kernel<int32_t>, dim3(ccn_blocks(n, 256)), dim3(256), 0, s, (const int32_t*)src, n, M, key, counts);
+  }
+  int rc = ccn_scan_i32(counts, inv_ptr, M + 1, false, nullptr, scratch, s);       // inv_ptr[M] = number of rows listed
+  if (rc) return rc;
+  if (n > 0) {
+    int mask = 0;
+    for (int b = 0; b < 4; ++b)
+      if (b == 0 || ((uint64_t)M >> (8 * b)) != 0) mask |= 1 << b;                  // the digits in which keys 0 .. M can differ
+    const uint64_t* kin;
+    const int32_t* vin;
+    int32_t *flag, *incl;
+    void* scan_ws;
+    rc = rs_sort(key, n, mask, sort_ws, sort_bytes, s, &kin, &vin, &flag, &incl, &scan_ws);
+    if (rc) return rc;
+    CCN_HIP(hipMemcpyAsync(inv_row, vin, (size_t)n * 4, hipMemcpyDeviceToDevice, s), "inverse_lists");
+  }
+  CCN_LAUNCH_OK("inverse_lists");
+  return CCN_OK;
+}
+
 }  // extern "C"
+
+int ccn_sort_payload(const int64_t* key, int64_t n, int digit_mask, void* ws, size_t ws_bytes, hipStream_t s,
+                     const int32_t** vout) {
+  const uint64_t* kin;
+  int32_t *flag, *incl;
+  void* scan_ws;
+  return rs_sort(key, n, digit_mask, ws, ws_bytes, s, &kin, vout, &flag, &incl, &scan_ws);
+}
+

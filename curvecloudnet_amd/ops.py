@@ -1448,6 +1448,25 @@ def curve_fps(pos, topo, spacing, u):
 PN_BWD_GATHER = os.environ.get("CCN_PN_BWD_GATHER", "1") != "0"     # A/B: 0 = the round-1..4 backward with fp32 atomics
 
 
+INV_TORCH = os.environ.get("CCN_INV_TORCH", "0") == "1"
+
+
+def inverse_lists(src, m):
+    """For every one of ``m`` sources the rows r with ``src[r] == source``, ascending: (inv_ptr int32 (m + 1), inv_row int32
+    (len(src))).  ``src``: int32 or int64, one-dimensional.  Index-only (ccn_inverse_lists: the library's stable radix sort by source with the
+    row number as payload -- no torch.sort / bincount on the geometry stream)."""
+    n, dev = src.numel(), src.device
+    if INV_TORCH:           # A/B: the round-5 first form (rocprim merge sort + histogram + scan through torch)
+        inv_ptr = torch.zeros(m + 1, dtype=torch.int32, device=dev)
+        inv_ptr[1:] = torch.cumsum(torch.bincount(src, minlength=m)[:m], 0).to(torch.int32)
+        return inv_ptr, torch.sort(src, stable=True)[1].to(torch.int32)
+    inv_ptr = torch.empty(m + 1, dtype=torch.int32, device=dev)
+    inv_row = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    ws = workspace(lib().ccn_inverse_lists_workspace_bytes(n, m), dev)
+    call("inverse_lists", ptr(src), 1 if src.dtype == torch.int64 else 0, n, m, ptr(inv_ptr), ptr(inv_row), ptr(ws), ws.numel())
+    return inv_ptr, inv_row[:n]
+
+
 class EdgeList:
     """Edges grouped by destination: ``row`` (destination / query number, non-decreasing),
     ``col`` (source point), ``offsets`` int32 (num_dst + 1)."""
@@ -1459,10 +1478,7 @@ class EdgeList:
         # PointNetConv2's first layer gathers through (ccn_pn_edge_bwd_gather).  Index-only, built with the geometry.
         self.inv_src = None
         if (PN_BWD_GATHER and num_src is not None and self.num_edges > 0 and torch.is_grad_enabled() and not bounded()):
-            order = torch.sort(col, stable=True)[1].to(torch.int32)
-            inv_ptr = torch.zeros(num_src + 1, dtype=torch.int32, device=col.device)
-            inv_ptr[1:] = torch.cumsum(torch.bincount(col, minlength=num_src)[:num_src], 0).to(torch.int32)
-            self.inv_src = (inv_ptr, order)
+            self.inv_src = inverse_lists(col, num_src)
 
 
 def radius_1d_group_subset(pos, idx, topo, radius):
@@ -1526,7 +1542,7 @@ def interp_inverse(nbr, w, m):
     inv_src = torch.empty(max(n * k, 1), dtype=torch.int32, device=dev)
     inv_w = torch.empty(max(n * k, 1), dtype=torch.float32, device=dev)
     den = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
-    ws = workspace(lib().ccn_interp_inverse_workspace_bytes(m), dev)
+    ws = workspace(lib().ccn_interp_inverse_workspace_bytes(n, k, m), dev)
     call("interp_inverse", ptr(nbr), ptr(w), n, k, m, ptr(inv_ptr), ptr(inv_src), ptr(inv_w), ptr(den), ptr(ws),
          ws.numel())
     return inv_ptr, inv_src, inv_w, den
@@ -2318,12 +2334,9 @@ class SGCompact:
         # geometry; not needed when no gradient is being recorded.
         self.inv = None
         if CG_BWD_GATHER and torch.is_grad_enabled() and not bounded():
-            order = torch.sort(self.row_src, stable=True)[1].to(torch.int32)
-            counts = torch.bincount(self.row_src, minlength=n)[:n]
-            inv_ptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
-            inv_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
-            sizes = (self.grp_ptr[1:] - self.grp_ptr[:-1]).long()
-            row_dst = torch.repeat_interleave(torch.arange(n, dtype=torch.int32, device=dev), sizes, output_size=e)
+            inv_ptr, order = inverse_lists(self.row_src, n)
+            row_dst = torch.empty(e, dtype=torch.int32, device=dev)
+            call("group_owner", ptr(self.grp_ptr), n, e, ptr(row_dst))
             self.inv = (inv_ptr, order, row_dst)
 
     def tensors(self):

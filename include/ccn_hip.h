@@ -27,8 +27,10 @@ extern "C" {
 #endif
 
 /* ABI version: bumped when the prototype of an EXISTING entry changes (additions do not bump it).
- *   1 -> 2 (round 4, recorded in round 5 / ADVICE r4): ccn_edge_feat_bwd_csr gained `int64_t N` in front of `int64_t E`. */
-#define CCN_ABI_VERSION 2
+ *   1 -> 2 (round 4, recorded in round 5 / ADVICE r4): ccn_edge_feat_bwd_csr gained `int64_t N` in front of `int64_t E`.
+ *   2 -> 3 (round 5): ccn_interp_inverse_workspace_bytes(M) became (n, k, M) -- the lists are made by a stable radix sort of the
+ *                     n * k slots, whose buffers live in the workspace. */
+#define CCN_ABI_VERSION 3
 
 #define CCN_OK 0
 #define CCN_ERR_ARG (-1)
@@ -136,10 +138,21 @@ int ccn_interp_bwd(const float* dy, int64_t lddy, const int64_t* nbr, const floa
  * src/models/utils/point_ops.py:344-355, 293-341: the autograd of their scatter_add over (y_idx, x_idx)): ccn_interp_inverse
  * turns the (n, k) neighbour table into per-coarse-row lists (inv_ptr int32[M+1], inv_src int32[n*k], inv_w float[n*k], sorted by
  * fine row; den float[n] = the weight sum of every fine row), ccn_interp_bwd_gather sums dX[m] = sum_e dY[src_e] / den[src_e] *
- * w_e in list order: deterministic.  Workspace: ccn_interp_inverse_workspace_bytes(M). */
-size_t ccn_interp_inverse_workspace_bytes(int64_t M);
+ * w_e in list order: deterministic.  Workspace: ccn_interp_inverse_workspace_bytes(n, k, M). */
+size_t ccn_interp_inverse_workspace_bytes(int64_t n, int64_t k, int64_t M);
 int ccn_interp_inverse(const int64_t* nbr, const float* weight, int64_t n, int64_t k, int64_t M, int32_t* inv_ptr,
                        int32_t* inv_src, float* inv_w, float* den, void* ws, size_t ws_bytes, void* stream);
+
+/* Inverse of a flat index list (round 5): rows r = 0 .. n-1 name a source src[r] in [0, M) (int32, or int64 when src_is_i64);
+ * inv_ptr (M + 1) / inv_row (n): for every source the rows naming it, ascending -- the lists the atomics-free backward of the first
+ * edge layers gathers through (ccn_cg_edge_bwd_gather, ccn_pn_edge_bwd_gather; reference: the autograd of x[src] in
+ * src/models/modules/dgcnn.py:172-177 and point_conv.py:60-69, an index_add over the same lists in arbitrary order).
+ * Deterministic (stable radix sort by source, payload = row).  Workspace: ccn_inverse_lists_workspace_bytes(n, M).  ccn_group_owner: owner[r] = p for the rows
+ * grp_ptr[p] <= r < grp_ptr[p + 1] of a grouped row list (r < E). */
+size_t ccn_inverse_lists_workspace_bytes(int64_t n, int64_t M);
+int ccn_inverse_lists(const void* src, int src_is_i64, int64_t n, int64_t M, int32_t* inv_ptr, int32_t* inv_row, void* ws,
+                      size_t ws_bytes, void* stream);
+int ccn_group_owner(const int32_t* grp_ptr, int64_t N, int64_t E, int32_t* owner, void* stream);
 int ccn_interp_bwd_gather(const float* dy, int64_t lddy, const int32_t* inv_ptr, const int32_t* inv_src, const float* inv_w,
                           const float* den, int64_t M, int64_t C, float* dx, int64_t lddx, void* stream);
 

@@ -433,3 +433,29 @@ def test_rank_keys_equals_torch_unique_inverse(n, hi):
         call("rank_keys", ptr(kd), n, digits, ptr(rank), ptr(meta[1:]), ptr(ws), nb)
         assert int(meta[1].item()) == uniq.numel()
         assert torch.equal(rank.cpu(), inv)
+
+
+@pytest.mark.parametrize("n,m,dtype", [(1, 1, torch.int32), (1000, 7, torch.int64), (50000, 50000, torch.int32),
+                                        (2341754, 400070, torch.int32), (300000, 5, torch.int64), (4096, 100000, torch.int32)])
+def test_inverse_lists_equal_a_stable_sort(n, m, dtype):
+    """ccn_inverse_lists (what the atomics-free backward of the first edge layers gathers through) = the stable sort of the
+    row numbers by source + a histogram, bit-exact, whatever order its atomics land in; ccn_group_owner = repeat_interleave of
+    the group numbers."""
+    from curvecloudnet_amd import ops
+    from curvecloudnet_amd._lib import call, ptr
+    gen = torch.Generator().manual_seed(n + m)
+    src = torch.randint(0, m, (n,), generator=gen).to(dtype)
+    if n > 100:
+        src[: n // 4] = src[n // 2: n // 2 + n // 4]          # long lists as well
+    inv_ptr, inv_row = ops.inverse_lists(src.to(DEV), m)
+    want_row = torch.sort(src, stable=True)[1].to(torch.int32)
+    want_ptr = torch.zeros(m + 1, dtype=torch.int32)
+    want_ptr[1:] = torch.cumsum(torch.bincount(src.long(), minlength=m), 0).to(torch.int32)
+    assert torch.equal(inv_ptr.cpu(), want_ptr) and torch.equal(inv_row.cpu(), want_row)
+    sizes = torch.randint(0, 9, (max(m, 1),), generator=gen)
+    grp = torch.zeros(sizes.numel() + 1, dtype=torch.int32)
+    grp[1:] = torch.cumsum(sizes, 0).to(torch.int32)
+    e = int(grp[-1])
+    owner = torch.full((max(e, 1),), -1, dtype=torch.int32, device=DEV)
+    call("group_owner", ptr(grp.to(DEV)), sizes.numel(), e, ptr(owner))
+    assert torch.equal(owner[:e].cpu(), torch.repeat_interleave(torch.arange(sizes.numel(), dtype=torch.int32), sizes))
