@@ -1460,11 +1460,13 @@ def inverse_lists(src, m):
         inv_ptr = torch.zeros(m + 1, dtype=torch.int32, device=dev)
         inv_ptr[1:] = torch.cumsum(torch.bincount(src, minlength=m)[:m], 0).to(torch.int32)
         return inv_ptr, torch.sort(src, stable=True)[1].to(torch.int32)
+    if n == 0:
+        return torch.zeros(m + 1, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev)
     inv_ptr = torch.empty(m + 1, dtype=torch.int32, device=dev)
-    inv_row = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    inv_row = torch.empty(n, dtype=torch.int32, device=dev)
     ws = workspace(lib().ccn_inverse_lists_workspace_bytes(n, m), dev)
     call("inverse_lists", ptr(src), 1 if src.dtype == torch.int64 else 0, n, m, ptr(inv_ptr), ptr(inv_row), ptr(ws), ws.numel())
-    return inv_ptr, inv_row[:n]
+    return inv_ptr, inv_row
 
 
 class EdgeList:

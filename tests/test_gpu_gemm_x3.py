@@ -145,7 +145,7 @@ def test_x3_full_width_kitti_cloud_forward_is_fp32_grade(x3_mode):
     """the bf16x3 mode through the same fp64 adjudication as the fp32 MFMA path, at the benchmark's own network
     and size (full-width KITTI section, 49 652 points): |gpu_x3 - fp64| <= 1.5 |cpu_fp32 - fp64| (tests.test_gpu_model
     ._check_routed)."""
-    TM.test_full_width_kitti_cloud_forward_matches_oracle()
+    TM.check_full_width_kitti_cloud_forward()
 
 
 def test_x3_mode_really_uses_the_split_kernel(x3_mode):
