@@ -76,6 +76,8 @@ def lib():
             handle.ccn_gemm_pair_opt(int(os.environ["CCN_GEMM_PAIR_OPT"]))
         if os.environ.get("CCN_FPS_CLAIM"):      # A/B hook (ccn_fps_set_lds_claim)
             handle.ccn_fps_set_lds_claim(int(os.environ["CCN_FPS_CLAIM"]))
+        if os.environ.get("CCN_FPS_CLUSTER") and hasattr(handle, "ccn_fps_use_cluster"):   # A/B hook (ccn_fps_use_cluster)
+            handle.ccn_fps_use_cluster(int(os.environ["CCN_FPS_CLUSTER"]))
         _lib = handle
     return _lib
 

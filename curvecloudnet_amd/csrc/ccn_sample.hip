@@ -347,6 +347,7 @@ __global__ void voxel_unpack_kernel(const unsigned long long* __restrict__ best,
 constexpr int FPS_TPB = 1024;
 constexpr int FPS_CLAIM_MAX = 96 * 1024;   // dynamic LDS a sampling workgroup claims to keep its CU to itself (see ccn_fps)
 static int g_fps_claim = FPS_CLAIM_MAX;    // A/B hook: ccn_fps_set_lds_claim
+static int g_fps_cluster = 1;              // A/B hook: ccn_fps_use_cluster (0 = one workgroup per cloud whatever its size, 2 = the cluster with agent-scope stores whatever the placement)
 
 __global__ __launch_bounds__(FPS_TPB) void fps_kernel(const float* __restrict__ pos,
                                                       const int64_t* __restrict__ cloud_ptr,
@@ -592,6 +593,198 @@ __global__ __launch_bounds__(FPS_TPB) void fps_hybrid_kernel(const float* __rest
   }
 }
 
+
+// ---- exact FPS over a cloud of more than 16 k points by a CLUSTER of G workgroups (round 5).
+// The hybrid form above is bound by what one CU can pull through its L1 per round (the coordinates of the points beyond its
+// registers: 400 KB per round for a 49 k-point cloud, 2.4 us per round, 12 k dependent rounds).  Here G <= 4 workgroups share the
+// cloud, every point lives in registers (16 per thread), and a round exchanges the G candidates through global memory
+// (measured: 28.7 -> 23.6 ms for the 49 k -> 12 k level of configs[4]; whole forward 54.7 -> 52.2 ms):
+//   * every workgroup finds its own best point as fps_reg_kernel does (one barrier), then lanes 0..4 of its wave 0 publish it as
+//     five 8-byte granules {field, round tag} (stored with agent scope, `sc1`, when a partner sits on another XCD, whose L2 is
+//     not coherent with this one -- MI355X_MICROARCH.md, inter-workgroup visibility) into the slot of the round's parity;
+//   * EVERY wave of every workgroup then polls the other workgroups' granules itself (agent-scope loads, tag == round + 1) and
+//     reduces the G candidates redundantly: no second barrier, nothing to broadcast inside the workgroup.
+// Two slots by round parity suffice: a workgroup publishes round r + 2 only after it has the others' round r + 1, which they publish
+// behind a barrier that all their waves reach after reading round r.  Same arithmetic, same tie rule (larger value, then smaller
+// index) as every other form: bit-identical samples.  The cluster's workgroup ids are congruent modulo 8 (one XCD under the
+// observed round-robin placement: speed only, the protocol does not depend on it).  Co-residency: G x B <= 256 workgroups of 1024
+// threads, each a whole CU; a poll that sees nothing for ~2^22 tries raises the abort word and every wave leaves.
+constexpr int FPS_CL_MAXG = 4;
+constexpr int FPS_CL_AREA = 512;                 // bytes of exchange area per cloud: 2 parities x 4 workgroups x 5 granules x 8 B, abort word, 4 XCD ids
+struct FpsGranule {
+  uint32_t value, tag;
+};
+__device__ __forceinline__ void fps_store_sc1(FpsGranule* at, uint32_t value, uint32_t tag) {
+  const uint64_t both = ((uint64_t)tag << 32) | value;          // (value in the low dword, tag in the high one: ONE 8-byte store)
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(at), "v"(both) : "memory");
+}
+__device__ __forceinline__ void fps_store_plain(FpsGranule* at, uint32_t value, uint32_t tag) {
+  const uint64_t both = ((uint64_t)tag << 32) | value;
+  asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(at), "v"(both) : "memory");
+}
+__device__ __forceinline__ uint2 fps_load_sc1(const FpsGranule* at) {
+  uint64_t both;
+  asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(both) : "v"(at) : "memory");
+  return make_uint2((uint32_t)both, (uint32_t)(both >> 32));
+}
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_TPB) void fps_cluster_kernel(const float* __restrict__ pos,
+                                                              const int64_t* __restrict__ cloud_ptr,
+                                                              const int64_t* __restrict__ start,
+                                                              const int64_t* __restrict__ out_ptr, int64_t B, int G, int force_sc1,
+                                                              char* __restrict__ xch_all, int64_t* __restrict__ out) {
+  __shared__ FpsBest red[2][FPS_TPB / 64];
+  // workgroup ids x, x + 8, x + 16, ... (x = id % 8) form the clusters x, x, ... in turn: cluster c = x + 8 * (t / G), member t % G
+  const int64_t t = blockIdx.x >> 3;
+  const int64_t b = (blockIdx.x & 7) + 8 * (t / G);
+  const int g = (int)(t % G);
+  if (b >= B) return;
+  const int64_t p0 = cloud_ptr[b];
+  const int n = (int)(cloud_ptr[b + 1] - p0);
+  const int64_t o0 = out_ptr[b];
+  const int keep = (int)(out_ptr[b + 1] - o0);
+  if (n <= 0 || keep <= 0) return;
+  const float* p = pos + 3 * p0;
+  const int S = (n + G - 1) / G;                   // points per member (<= PPT * FPS_TPB: checked by the host against max_cloud)
+  const int lo = g * S, hi = lo + S < n ? lo + S : n;
+  float px[PPT], py[PPT], pz[PPT], md[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int i = lo + threadIdx.x + k * FPS_TPB;
+    const bool in = i < hi;
+    px[k] = in ? p[3 * i] : 0.f;
+    py[k] = in ? p[3 * i + 1] : 0.f;
+    pz[k] = in ? p[3 * i + 2] : 0.f;
+    md[k] = in ? __builtin_inff() : -2.f;  // never the maximum
+  }
+  int cur = (int)start[b];
+  cur = cur < 0 ? 0 : (cur >= n ? n - 1 : cur);
+  float cx = p[3 * cur], cy = p[3 * cur + 1], cz = p[3 * cur + 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  FpsGranule* const xch = reinterpret_cast<FpsGranule*>(xch_all + b * FPS_CL_AREA);
+  uint32_t* const abort_word = reinterpret_cast<uint32_t*>(xch_all + b * FPS_CL_AREA + 2 * FPS_CL_MAXG * 5 * 8);
+  const int h_of = lane / 5, f_of = lane - 5 * h_of;      // lane = 5 * member + field (lanes 0 .. 5 G - 1 poll)
+  // Where do the members sit?  Every member publishes the id of its XCD (hardware register XCC_ID) once, with agent scope, and reads
+  // the others'.  All on one XCD (the usual case: ids congruent modulo 8): the granules of a round are written with PLAIN stores,
+  // which keep the line in that XCD's L2, where the partners' L1-bypassing loads find it a few hundred ns later.  Otherwise they are
+  // written through with `sc1` (the line leaves the L2; readers on any XCD see it, at the cross-XCD price: measured on the
+  // 49 k-point clouds of BASELINE configs[4], 12 k rounds -- one workgroup (hybrid form) 2.4 us per round, this cluster with `sc1`
+  // stores 2.4, with plain stores 1.9: a round is now the store's way into the L2 plus one L2 round trip of the poll).  Every member
+  // sees the same ids and takes the same decision; correctness never depends on the placement.
+  bool same_xcd = true;
+  {
+    FpsGranule* const where = xch + 2 * FPS_CL_MAXG * 5 + 1;          // (behind the abort word's granule)
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    if (wave == 0 && lane == 0) fps_store_sc1(where + g, xcc, 0xC0DE0001u);
+    bool done = lane >= G;
+    uint32_t theirs = xcc;
+    for (int tries = 0;; ++tries) {
+      if (!done) {
+        const uint2 r = fps_load_sc1(where + lane);
+        if (r.y == 0xC0DE0001u) {
+          theirs = r.x;
+          done = true;
+        }
+      }
+      if (__ballot(!done) == 0ull) break;
+      if (tries >= (1 << 22)) {
+        if (lane == 0) atomicExch(abort_word, 1u);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    same_xcd = !force_sc1 && __ballot(theirs != xcc) == 0ull;
+  }
+  for (int it = 0; it < keep; ++it) {
+    if (g == 0 && threadIdx.x == 0) out[o0 + it] = p0 + cur;
+    FpsBest best = {-1.f, 0x7fffffff, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const float dx = px[k] - cx, dy = py[k] - cy, dz = pz[k] - cz;
+      const float d2 = (dx * dx + dy * dy) + dz * dz;
+      const float m = md[k] < 0.f ? md[k] : fminf(md[k], d2);
+      md[k] = m;
+      if (m > best.v) {  // k (hence the point index) increases: strict > keeps the smallest index
+        best.v = m;
+        best.i = lo + threadIdx.x + k * FPS_TPB;
+        best.x = px[k];
+        best.y = py[k];
+        best.z = pz[k];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) fps_take(best, fps_shfl(best, off));
+    FpsBest* tab = red[it & 1];
+    if (lane == 0) tab[wave] = best;
+    __syncthreads();
+    FpsBest all = tab[lane & (FPS_TPB / 64 - 1)];
+#pragma unroll
+    for (int off = FPS_TPB / 128; off > 0; off >>= 1) fps_take(all, fps_shfl(all, off));
+    // ---- the cluster's exchange
+    FpsGranule* const slot = xch + (it & 1) * (FPS_CL_MAXG * 5);
+    const uint32_t tag = (uint32_t)it + 1u;
+    if (wave == 0 && lane < 5) {
+      const uint32_t field = lane == 0 ? __float_as_uint(all.v) : lane == 1 ? (uint32_t)all.i : lane == 2 ? __float_as_uint(all.x)
+                             : lane == 3 ? __float_as_uint(all.y) : __float_as_uint(all.z);
+      if (same_xcd)
+        fps_store_plain(slot + g * 5 + lane, field, tag);
+      else
+        fps_store_sc1(slot + g * 5 + lane, field, tag);
+    }
+    uint32_t got = 0;
+    const bool polls = lane < 5 * G && h_of != g;
+    bool done = !polls;
+    // Four agent-scope loads of the granule in flight, re-issued as each returns (they return in order): a poll leaves every
+    // quarter of a round trip, so the partner's store is seen one round trip after it lands instead of up to two.
+    const unsigned long long* const at = reinterpret_cast<const unsigned long long*>(slot + (polls ? h_of * 5 + f_of : g * 5));
+    unsigned long long r0 = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long r1 = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long r2 = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long r3 = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int tries = 0;; ++tries) {
+#define CCN_FPS_POLL(R_)                                                                   \
+      if (!done && (uint32_t)(R_ >> 32) == tag) {                                          \
+        got = (uint32_t)R_;                                                                \
+        done = true;                                                                       \
+      }                                                                                    \
+      if (__ballot(!done) == 0ull) break;                                                  \
+      R_ = __hip_atomic_load(at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      CCN_FPS_POLL(r0)
+      CCN_FPS_POLL(r1)
+      CCN_FPS_POLL(r2)
+      CCN_FPS_POLL(r3)
+#undef CCN_FPS_POLL
+      if ((tries & 255) == 255) {                        // a partner that never arrives: leave instead of hanging the queue
+        uint32_t ab = 0;
+        if (lane == 0) ab = fps_load_sc1(reinterpret_cast<const FpsGranule*>(abort_word)).x;
+        ab = __builtin_amdgcn_readfirstlane(ab);
+        if (tries >= (1 << 20)) {
+          if (lane == 0) atomicExch(abort_word, 1u);
+          ab = 1;
+        }
+        if (ab) return;
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < FPS_CL_MAXG; ++h) {
+      if (h >= G || h == g) continue;
+      FpsBest o;
+      o.v = __uint_as_float(__builtin_amdgcn_readlane(got, 5 * h));
+      o.i = (int)__builtin_amdgcn_readlane(got, 5 * h + 1);
+      o.x = __uint_as_float(__builtin_amdgcn_readlane(got, 5 * h + 2));
+      o.y = __uint_as_float(__builtin_amdgcn_readlane(got, 5 * h + 3));
+      o.z = __uint_as_float(__builtin_amdgcn_readlane(got, 5 * h + 4));
+      fps_take(all, o);
+    }
+    cur = all.i;
+    cx = all.x;
+    cy = all.y;
+    cz = all.z;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -696,6 +889,11 @@ int ccn_voxel_argmin(const float* score, const int64_t* voxel_of, int64_t n, int
   return CCN_OK;
 }
 
+int ccn_fps_use_cluster(int on) {
+  g_fps_cluster = on < 0 ? 0 : (on > 2 ? 2 : on);
+  return CCN_OK;
+}
+
 int ccn_fps_set_lds_claim(int bytes) {
   g_fps_claim = bytes < 0 ? 0 : (bytes > FPS_CLAIM_MAX ? FPS_CLAIM_MAX : bytes);
   return CCN_OK;
@@ -715,6 +913,7 @@ int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, co
     ok = ok && hipFuncSetAttribute((const void*)fps_reg_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void*)fps_reg_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void*)fps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
+    ok = ok && hipFuncSetAttribute((const void*)fps_cluster_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void*)fps_hybrid_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    FPS_HYB_LDS * 4) == hipSuccess;
     CCN_REQUIRE(ok, "fps: cannot raise the dynamic LDS limit");
@@ -726,7 +925,15 @@ int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, co
     hipLaunchKernelGGL(fps_reg_kernel<8>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, out);
   else if (max_cloud > 0 && max_cloud <= 16 * FPS_TPB)
     hipLaunchKernelGGL(fps_reg_kernel<16>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, out);
-  else if (max_cloud > 0 && max_cloud <= 16 * FPS_TPB + FPS_HYB_LDS && g_fps_claim > 0)      // (claim 0 = A/B: the streaming form)
+  else if (g_fps_cluster && g_fps_claim > 0 && max_cloud > 16 * FPS_TPB && max_cloud <= FPS_CL_MAXG * 16 * FPS_TPB && B * (FPS_CL_AREA / 4) <= max_cloud &&
+           8 * ((max_cloud + 16 * FPS_TPB - 1) / (16 * FPS_TPB)) * ((B + 7) / 8) <= 256) {
+    // more than 16 k points: G workgroups per cloud, every point in registers, one exchange per round (fps_cluster_kernel).
+    // The exchange areas (512 B per cloud, tags zeroed here) live at the start of the `mind` scratch: 4 max_cloud bytes at least.
+    const int G = (int)((max_cloud + 16 * FPS_TPB - 1) / (16 * FPS_TPB));
+    CCN_HIP(hipMemsetAsync(mind, 0, (size_t)B * FPS_CL_AREA, s), "fps");
+    hipLaunchKernelGGL(fps_cluster_kernel<16>, dim3((unsigned)(8 * G * ((B + 7) / 8))), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos,
+                       cloud_ptr, start, out_ptr, B, G, g_fps_cluster == 2 ? 1 : 0, reinterpret_cast<char*>(mind), out);
+  } else if (max_cloud > 0 && max_cloud <= 16 * FPS_TPB + FPS_HYB_LDS && g_fps_claim > 0)      // (claim 0 = A/B: the streaming form)
     hipLaunchKernelGGL(fps_hybrid_kernel<16>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)FPS_HYB_LDS * 4, s, pos, cloud_ptr, start,
                        out_ptr, out);
   else

@@ -20,6 +20,7 @@ int ccn_gemm_x3_use_persistent(int on); /* A/B hook: 0 = the register-staged ker
 int ccn_gemm_x3_debug(void* buf);       /* diagnostic: a device buffer of 512 x 4 x 16 uint64 words switches ccn_gemm_nt_x3's software-pipelined kernel to a build that stamps (s_memtime) where every wave's cycles go; NULL = off (tools/x3_stamps.py) */
 int ccn_gemm_tn_use_dma(int on);    /* A/B hook: 0 = always the register-staged split-K kernel of ccn_gemm_tn */
 int ccn_fps_set_lds_claim(int bytes); /* A/B hook: dynamic LDS a sampling workgroup claims to keep its CU free of GEMM workgroups (default and maximum 98304, 0 = none) */
+int ccn_fps_use_cluster(int on);      /* A/B hook (round 5): 0 = exact FPS with ONE workgroup per cloud whatever its size (the hybrid / streaming forms); default 1 = clouds of more than 16384 points by a cluster of up to four workgroups; 2 = the cluster with agent-scope (sc1) stores even when its members share an XCD */
 
 #ifdef __cplusplus
 }

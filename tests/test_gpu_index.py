@@ -288,6 +288,41 @@ def test_fps_lds_claim_does_not_change_the_samples():
         assert outs[0].numel() == int(torch.ceil(topo.lengths.cpu() * ratio).sum())
 
 
+def test_fps_by_a_cluster_of_workgroups_gives_the_same_samples():
+    """Clouds of more than 16 384 points are sampled by a cluster of 2-4 workgroups (every point in registers, the candidates of a
+    round exchanged through agent-scope granules): the same samples, bit for bit, as ONE workgroup per cloud (hybrid kernel) and
+    as the streaming kernel -- mixed batches (a large and a small cloud), duplicate points (ties go to the smaller index), a cloud
+    count that leaves clusters of the last group of eight empty."""
+    ops = _ops()
+    from curvecloudnet_amd import _lib
+    lib = _lib.lib()
+    cases = [([1, 2], 1500, 0.05, None), ([3], 2150, 0.02, None), ([1, 2, 3], 900, 0.1, None), ([4, 5], 2100, 0.01, "dup"),
+             ([6, 7, 8, 9, 10, 11, 12, 13, 14], 800, 0.01, "small")]
+    for ids, n_curves, ratio, twist in cases:
+        d = _synth(ids, n_curves=n_curves)
+        pos = d.pos.clone()
+        if twist == "dup":
+            pos[1::2] = pos[0::2][: pos[1::2].size(0)]              # every point twice: every maximum is a tie
+        batch, curves = d.batch, d.curve_idxs
+        if twist == "small":                                         # the last cloud cut to a few points
+            keep = (batch < batch.max()) | (torch.arange(batch.numel()) >= batch.numel() - 37)
+            pos, batch, curves = pos[keep], batch[keep], curves[keep]
+        topo = ops.CurveTopology(batch.to(DEV), curves.to(DEV))
+        assert int(topo.lengths.max()) > 16384
+        start = torch.arange(len(ids)) * 7 + 3
+        outs = []
+        try:
+            for cluster, claim in ((1, 98304), (0, 98304), (0, 0), (2, 98304)):     # (2: the cross-XCD protocol forced)
+                lib.ccn_fps_use_cluster(cluster)
+                lib.ccn_fps_set_lds_claim(claim)
+                outs.append(ops.fps(pos.to(DEV), topo, ratio, start=start).cpu())
+        finally:
+            lib.ccn_fps_use_cluster(1)
+            lib.ccn_fps_set_lds_claim(98304)
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), (ids, n_curves, twist)
+        assert outs[0].numel() == int(torch.ceil(topo.lengths.cpu() * ratio).sum())
+
+
 def test_knn_points_matches_bruteforce():
     ops = _ops()
     from oracle import torch_ref as R
