@@ -435,6 +435,53 @@ __device__ __forceinline__ FpsBest fps_shfl(const FpsBest& a, int off) {
   return o;
 }
 
+// The arg-max of a wave (round 5).  Rounds 1-4 ran a 6-step butterfly of five __shfl_xor each (ds_bpermute_b32: ~30 dependent
+// trips through the LDS crossbar per round, and 20 more for the 16 per-wave entries) -- a third of a round of the
+// register-resident forms.  Here: the maximum by four DPP steps inside each row of 16 lanes (quad permutes, row_half_mirror,
+// row_mirror: VALU speed) and three scalar maxima over the rows; the smallest index among the lanes that hold it the same way;
+// the winner's coordinates by v_readlane from the one lane that has that index.  Same rule (larger value, then smaller index).
+template <int CTRL>
+__device__ __forceinline__ float fps_dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int fps_dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float fps_wave_max(float v) {
+  v = fmaxf(v, fps_dpp_f<0xB1>(v));     // quad_perm [1,0,3,2]
+  v = fmaxf(v, fps_dpp_f<0x4E>(v));     // quad_perm [2,3,0,1]
+  v = fmaxf(v, fps_dpp_f<0x141>(v));    // row_half_mirror
+  v = fmaxf(v, fps_dpp_f<0x140>(v));    // row_mirror: every lane of a row holds the row's maximum
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+__device__ __forceinline__ int fps_wave_min(int v) {
+  int o;
+  o = fps_dpp_i<0xB1>(v);  v = o < v ? o : v;
+  o = fps_dpp_i<0x4E>(v);  v = o < v ? o : v;
+  o = fps_dpp_i<0x141>(v); v = o < v ? o : v;
+  o = fps_dpp_i<0x140>(v); v = o < v ? o : v;
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  const int ab = a < b ? a : b, cd = c < d ? c : d;
+  return ab < cd ? ab : cd;
+}
+__device__ __forceinline__ FpsBest fps_wave_best(const FpsBest& mine) {
+  FpsBest out;
+  out.v = fps_wave_max(mine.v);
+  out.i = fps_wave_min(mine.v == out.v ? mine.i : 0x7fffffff);
+  const unsigned long long who = __ballot(mine.v == out.v && mine.i == out.i);
+  const int src = who ? __builtin_ctzll(who) : 0;
+  out.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.x), src));
+  out.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.y), src));
+  out.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine.z), src));
+  return out;
+}
+
 template <int PPT>
 __global__ __launch_bounds__(FPS_TPB) void fps_reg_kernel(const float* __restrict__ pos,
                                                           const int64_t* __restrict__ cloud_ptr,
@@ -480,14 +527,11 @@ __global__ __launch_bounds__(FPS_TPB) void fps_reg_kernel(const float* __restric
         best.z = pz[k];
       }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) fps_take(best, fps_shfl(best, off));
+    best = fps_wave_best(best);
     FpsBest* tab = red[it & 1];
     if (lane == 0) tab[wave] = best;
     __syncthreads();
-    FpsBest all = tab[lane & (FPS_TPB / 64 - 1)];
-#pragma unroll
-    for (int off = FPS_TPB / 128; off > 0; off >>= 1) fps_take(all, fps_shfl(all, off));
+    FpsBest all = fps_wave_best(tab[lane & (FPS_TPB / 64 - 1)]);     // (the 16 entries, four times over: maxima and minima do not mind)
     cur = all.i;
     cx = all.x;
     cy = all.y;
@@ -578,14 +622,11 @@ __global__ __launch_bounds__(FPS_TPB) void fps_hybrid_kernel(const float* __rest
         }
       }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) fps_take(best, fps_shfl(best, off));
+    best = fps_wave_best(best);
     FpsBest* tab = red[it & 1];
     if (lane == 0) tab[wave] = best;
     __syncthreads();
-    FpsBest all = tab[lane & (FPS_TPB / 64 - 1)];
-#pragma unroll
-    for (int off = FPS_TPB / 128; off > 0; off >>= 1) fps_take(all, fps_shfl(all, off));
+    FpsBest all = fps_wave_best(tab[lane & (FPS_TPB / 64 - 1)]);     // (the 16 entries, four times over: maxima and minima do not mind)
     cur = all.i;
     cx = all.x;
     cy = all.y;
@@ -714,14 +755,11 @@ __global__ __launch_bounds__(FPS_TPB) void fps_cluster_kernel(const float* __res
         best.z = pz[k];
       }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) fps_take(best, fps_shfl(best, off));
+    best = fps_wave_best(best);
     FpsBest* tab = red[it & 1];
     if (lane == 0) tab[wave] = best;
     __syncthreads();
-    FpsBest all = tab[lane & (FPS_TPB / 64 - 1)];
-#pragma unroll
-    for (int off = FPS_TPB / 128; off > 0; off >>= 1) fps_take(all, fps_shfl(all, off));
+    FpsBest all = fps_wave_best(tab[lane & (FPS_TPB / 64 - 1)]);     // (the 16 entries, four times over: maxima and minima do not mind)
     // ---- the cluster's exchange
     FpsGranule* const slot = xch + (it & 1) * (FPS_CL_MAXG * 5);
     const uint32_t tag = (uint32_t)it + 1u;
