@@ -648,7 +648,7 @@ __global__ __launch_bounds__(FPS_TPB) void fps_hybrid_kernel(const float* __rest
 // Two slots by round parity suffice: a workgroup publishes round r + 2 only after it has the others' round r + 1, which they publish
 // behind a barrier that all their waves reach after reading round r.  Same arithmetic, same tie rule (larger value, then smaller
 // index) as every other form: bit-identical samples.  The cluster's workgroup ids are congruent modulo 8 (one XCD under the
-// observed round-robin placement: speed only, the protocol does not depend on it).  Co-residency: G x B <= 256 workgroups of 1024
+// observed round-robin placement: speed only, the protocol does not depend on it).  Co-residency: G x B <= 128 workgroups of 1024
 // threads, each a whole CU; a poll that sees nothing for ~2^22 tries raises the abort word and every wave leaves.
 constexpr int FPS_CL_MAXG = 4;
 constexpr int FPS_CL_AREA = 512;                 // bytes of exchange area per cloud: 2 parities x 4 workgroups x 5 granules x 8 B, abort word, 4 XCD ids
@@ -964,7 +964,7 @@ int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, co
   else if (max_cloud > 0 && max_cloud <= 16 * FPS_TPB)
     hipLaunchKernelGGL(fps_reg_kernel<16>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, out);
   else if (g_fps_cluster && g_fps_claim > 0 && max_cloud > 16 * FPS_TPB && max_cloud <= FPS_CL_MAXG * 16 * FPS_TPB && B * (FPS_CL_AREA / 4) <= max_cloud &&
-           8 * ((max_cloud + 16 * FPS_TPB - 1) / (16 * FPS_TPB)) * ((B + 7) / 8) <= 256) {
+           8 * ((max_cloud + 16 * FPS_TPB - 1) / (16 * FPS_TPB)) * ((B + 7) / 8) <= 128) {   // (at most half of the CUs spin on one another)
     // more than 16 k points: G workgroups per cloud, every point in registers, one exchange per round (fps_cluster_kernel).
     // The exchange areas (512 B per cloud, tags zeroed here) live at the start of the `mind` scratch: 4 max_cloud bytes at least.
     const int G = (int)((max_cloud + 16 * FPS_TPB - 1) / (16 * FPS_TPB));
