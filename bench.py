@@ -336,6 +336,35 @@ def cpu_baseline(cfg, in_dim, n_classes, args, seed, points_per_cloud):
                          time.perf_counter() - t_all)}
 
 
+def knn_bit_match(model, plan):
+    """The metric's boolean ("kNN idx bit-match", BASELINE.json / SURVEY section 8d), outside the timed region: the FRNN neighbour
+    table of the first SGCNN level (ref src/models/utils/point_ops.py:459 fast_knn as dgcnn.py:163 calls it) of ONE cloud of the
+    batch the last step prepared, against the exhaustive CPU search (oracle/frnn_bruteforce.c through oracle.torch_ref -- the
+    checker; FRNN's own source is absent from the reference tree, so this is a match against its published semantics: strict
+    d2 < r^2, ascending (d2, index), -1 padding)."""
+    from curvecloudnet_amd.steps import SGCNNLayer
+    from oracle import torch_ref as R
+    _, tables, _ = plan
+    torch.cuda.synchronize()
+    for step, st in zip(model.steps, tables):
+        if isinstance(step, SGCNNLayer) and st is not None and hasattr(st[0], "nbr"):
+            g = st[0]
+            n0 = int(g.topo.lengths[0])
+            pos0 = g.out[0][:n0].detach().float().cpu().contiguous()
+            got = g.nbr[0, :n0].cpu()
+            radius = 0.25 if step.r is None else float(step.r)
+            ln = torch.tensor([n0], dtype=torch.int64)
+            t0 = time.perf_counter()
+            want = R.frnn_bruteforce(pos0[None], pos0[None], ln, ln, step.k, radius)[0]
+            return {"knn_idx_bit_match": bool(torch.equal(got, want)),
+                    "knn_checked": {"P": n0, "K": int(step.k), "r": radius, "cloud": "first cloud of the last prepared batch",
+                                    "level": "first sgcnn step (points after the sa-geo sampling)",
+                                    "neighbours_found": int((want >= 0).sum()), "cpu_search_s": round(time.perf_counter() - t0, 2),
+                                    "against": "oracle/frnn_bruteforce.c (exhaustive; FRNN itself is not vendored in the reference: "
+                                               "parity with its published semantics, unpinned)"}}
+    return {"knn_idx_bit_match": None, "knn_checked": None}
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -386,6 +415,12 @@ def parse_args():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="compute each step's sampling / neighbour search inside its own forward instead of during the "
                          "previous step's backward pass")
+    ap.add_argument("--vary-batch", type=int, default=4,
+                    help="number of DIFFERENT batches rotated through the steps (default 4: every step sees other clouds, i.e. "
+                         "another point count, other sample / edge counts and other allocation sizes, as a training loop does -- "
+                         "ref src/run/kitti_seg.py:30-38); 1 = one batch reused for every step (the rounds 1-5 line)")
+    ap.add_argument("--no-knn-check", action="store_true",
+                    help="skip the metric's boolean: the first SGCNN level's FRNN table of one cloud against the exhaustive CPU search")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-curves", type=int, default=None,
                     help="curves of the CPU baseline's sample cloud (default: a quarter of --curves)")
@@ -476,10 +511,18 @@ def run(args, rank, world, local_rank, dev, quiet=False):
     opt = FlatAdam(sync, lr=1e-3)                            # torch.optim.Adam arithmetic, one launch per bucket
 
     b = args.clouds_per_gpu
-    cloud_ids = list(range(rank * b, rank * b + b))          # weak scaling: a fixed number of whole clouds per GPU
-    data = to_device(make_input(cloud_ids, in_dim, args), dev)   # inputs resident in HBM before the timed region
+    # weak scaling: a fixed number of whole clouds per GPU.  --vary-batch V: V different batches (batch v of rank r = clouds
+    # (v * world + r) * b ...), all resident in HBM before the timed region, taken in turn by the steps
+    n_batches = 1 if args.graph else max(1, args.vary_batch)
+    batches = []
+    for v in range(n_batches):
+        cloud_ids = list(range((v * world + rank) * b, (v * world + rank) * b + b))
+        d = to_device(make_input(cloud_ids, in_dim, args), dev)
+        lab = torch.randint(0, n_classes, (d.pos.size(0),), generator=torch.Generator().manual_seed(rank + 1000 * v)).to(dev)
+        batches.append((d, lab))
+    data, labels = batches[0]
     n_points = data.pos.size(0)
-    labels = torch.randint(0, n_classes, (n_points,), generator=torch.Generator().manual_seed(rank)).to(dev)
+    points_by_batch = [d.pos.size(0) for d, _ in batches]
 
     if args.graph:
         # BASELINE configs[4] leg: forward (inference) over a prepared plan, launched kernel by kernel vs replayed from ONE
@@ -546,10 +589,15 @@ def run(args, rank, world, local_rank, dev, quiet=False):
     debug = os.environ.get("CCN_BENCH_DEBUG") == "1"
 
     site = [0, 0]          # [launch sites of the dominant kernel seen in this step, steps started]
+    timing = [False]       # inside the timed region
 
     threaded = not args.no_pipeline and os.environ.get("CCN_BENCH_PREPARE_THREAD", "1") != "0"
 
+    step_ends = []          # (batch index, event at the end of the step) of the timed steps: per-step spread without a host sync
+
     def step():
+        data, labels = batches[site[1] % n_batches]            # this step's batch ...
+        data_next = batches[(site[1] + 1) % n_batches][0]      # ... and the one whose geometry is prepared meanwhile
         site[0], site[1] = 0, site[1] + 1
         marks = [time.perf_counter()]
         sync.zero_grad()
@@ -561,7 +609,7 @@ def run(args, rank, world, local_rank, dev, quiet=False):
             # the next batch's sampling / neighbour search: on the side stream, driven by a worker thread whose waits for
             # the element counts overlap this thread's queueing of forward and backward (ModelBase.prepare_async) -- what
             # a training loop does with the loader's next batch
-            pending = model.prepare_async(data, seed=7)
+            pending = model.prepare_async(data_next, seed=7)
         loss = segmentation_loss(model(data, plan=plan), labels)
         marks.append(time.perf_counter())
         loss.backward()
@@ -571,10 +619,14 @@ def run(args, rank, world, local_rank, dev, quiet=False):
         elif not args.no_pipeline:
             # (first step, or CCN_BENCH_PREPARE_THREAD=0: queued from this thread while the backward pass, already queued, runs)
             torch.manual_seed(7)
-            staged["plan"] = model.prepare(data)
+            staged["plan"] = model.prepare(data_next)
         marks.append(time.perf_counter())
         sync.finish()
         opt.step()
+        if timing[0]:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            step_ends.append(((site[1] - 1) % n_batches, ev))
         if debug:
             torch.cuda.synchronize()
             marks.append(time.perf_counter())
@@ -593,7 +645,7 @@ def run(args, rank, world, local_rank, dev, quiet=False):
 
     # setup, outside warm-up and timing: the first steps grow the caching allocator's pools (hipMalloc is synchronous and
     # slow); two priming steps keep device allocations out of the timed region whatever --warmup is
-    for _ in range(2):
+    for _ in range(max(2, n_batches + 1 - args.warmup)):     # (every batch at least once before the timed region)
         step()
     for _ in range(args.warmup):
         step()
@@ -653,11 +705,13 @@ def run(args, rank, world, local_rank, dev, quiet=False):
     ref_event.record()
     mallocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     seg0 = {k: torch.cuda.memory_stats(dev).get("segment.%s_pool.allocated" % k, 0) for k in ("large", "small")}
+    timing[0] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    timing[0] = False
     device_mallocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - mallocs0
     if os.environ.get("CCN_BENCH_DEBUG") == "1":
         print("segments allocated in the timed region:",
@@ -676,6 +730,7 @@ def run(args, rank, world, local_rank, dev, quiet=False):
     # each rank processed per step (step time = the slowest rank's: load imbalance = max / mean), the bytes handed to
     # all_reduce per step and the host time finish() waited for the collectives
     dp_stats = dict(sync.stats)
+    n_points = sum(points_by_batch) // n_batches           # from here on: the mean over the rotated batches
     points_per_rank = [n_points]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -730,6 +785,22 @@ def run(args, rank, world, local_rank, dev, quiet=False):
                    "loss": float(loss.detach())},
         "multi_gpu": multi_gpu,
     }
+    # --vary-batch: what the rotation looked like -- points of each batch, and the time between the ends of consecutive timed steps
+    # (events on the feature stream: no host synchronisation inside the timed region) by the batch the step ran on
+    gaps = {}
+    for (_, e0), (v1, e1) in zip(step_ends[:-1], step_ends[1:]):
+        gaps.setdefault(v1, []).append(e0.elapsed_time(e1))
+    all_gaps = sorted(g for v in gaps.values() for g in v)
+    result["config"]["batches"] = {
+        "different_batches": n_batches, "points_on_rank0": points_by_batch,
+        "step_ms_by_batch": {str(v): round(sum(g) / len(g), 2) for v, g in sorted(gaps.items())},
+        "step_ms_min_median_max": ([round(all_gaps[0], 2), round(all_gaps[len(all_gaps) // 2], 2), round(all_gaps[-1], 2)]
+                                   if all_gaps else None),
+        "note": "steps take the batches in turn; the geometry of the NEXT step's batch is prepared during this step's backward"}
+    result["config"]["fps_cluster_fallbacks"] = int(ops.fps_fallbacks(dev).item())
+    if not args.no_knn_check and not quiet:
+        torch.manual_seed(7)
+        result.update(knn_bit_match(model, staged["plan"] or model.prepare(batches[0][0])))
     if records:
         bracket = empty_bracket_ms()
         rows, _ = summarise_profile(records, args.steps, write_shapes=not full_records and not quiet, bracket_ms=bracket)

@@ -52,6 +52,13 @@ def parse_header(path=None):
     return protos
 
 
+def _header_abi_version():
+    m = re.search(r"^#define\s+CCN_ABI_VERSION\s+(\d+)", open(HEADER_PATH).read(), flags=re.M)
+    return int(m.group(1))
+
+
+ABI_VERSION = _header_abi_version()
+
 _lib = None
 
 
@@ -68,8 +75,10 @@ def lib():
                 continue                     # (an OLDER build of the library in a tools/ A/B run: entries added since are absent)
             fn = getattr(handle, name)       # AttributeError if the header declares a missing symbol
             fn.restype, fn.argtypes = restype, argtypes
-        if handle.ccn_abi_version() != 3 and not os.environ.get("CCN_LIB_PATH"):
-            raise RuntimeError("libccn_hip.so ABI version mismatch (header: 3, library: %d)" % handle.ccn_abi_version())
+        # (also under CCN_LIB_PATH: an A/B library of another ABI would be called with this header's argument lists -- ADVICE r5)
+        if handle.ccn_abi_version() != ABI_VERSION:
+            raise RuntimeError("libccn_hip.so ABI version mismatch (header: %d, library %s: %d)"
+                               % (ABI_VERSION, LIB_PATH, handle.ccn_abi_version()))
         if os.environ.get("CCN_GEMM_DMA"):       # A/B hook of the GEMM dispatch (include/ccn_hip.h: ccn_gemm_use_dma)
             handle.ccn_gemm_use_dma(int(os.environ["CCN_GEMM_DMA"]))
         if os.environ.get("CCN_GEMM_PAIR_OPT"):  # A/B hook (ccn_gemm_pair_opt)

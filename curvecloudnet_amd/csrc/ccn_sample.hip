@@ -4,6 +4,9 @@
 // (pytorch3d.ops.sample_farthest_points, point_ops.py:57-70).  Built with -ffp-contract=off.
 #include "ccn_common.h"
 
+#include <atomic>
+#include <mutex>
+
 namespace {
 
 constexpr int KNN_TPB = 256;
@@ -346,18 +349,33 @@ __global__ void voxel_unpack_kernel(const unsigned long long* __restrict__ best,
 // arg max (ties: smallest index).  d2 = (dx*dx + dy*dy) + dz*dz, matching the oracle.
 constexpr int FPS_TPB = 1024;
 constexpr int FPS_CLAIM_MAX = 96 * 1024;   // dynamic LDS a sampling workgroup claims to keep its CU to itself (see ccn_fps)
-static int g_fps_claim = FPS_CLAIM_MAX;    // A/B hook: ccn_fps_set_lds_claim
-static int g_fps_cluster = 1;              // A/B hook: ccn_fps_use_cluster (0 = one workgroup per cloud whatever its size, 2 = the cluster with agent-scope stores whatever the placement)
+static std::atomic<int> g_fps_claim{FPS_CLAIM_MAX};    // A/B hook: ccn_fps_set_lds_claim
+static std::atomic<int> g_fps_fault{0};                // test hook: ccn_fps_debug_fault
+static std::atomic<int> g_fps_cluster{1};              // A/B hook: ccn_fps_use_cluster (0 = one workgroup per cloud whatever its size, 2 = the cluster with agent-scope stores whatever the placement)
+
+// The cluster form (fps_cluster_kernel, below) gives a cloud up when a member never hears from a partner: it raises the cloud's
+// abort word.  The launch behind it on the same stream -- this kernel or fps_hybrid_kernel with `gate` = the exchange areas --
+// re-samples exactly those clouds with one workgroup each (same samples: every form is bit-identical), so the result of ccn_fps
+// never depends on the co-residency of a cluster's members; `fallbacks` (optional) counts the clouds that took this way.
+constexpr int FPS_CL_AREA = 512;                 // bytes of exchange area per cloud: 2 parities x 4 workgroups x 5 granules x 8 B, abort word, 4 XCD ids
+constexpr int FPS_CL_ABORT_AT = 2 * 4 * 5 * 8;   // byte offset of the abort word in a cloud's area
+__device__ __forceinline__ bool fps_gate_open(const char* gate, int64_t b, int32_t* fallbacks) {
+  const uint32_t ab = *reinterpret_cast<const uint32_t*>(gate + b * FPS_CL_AREA + FPS_CL_ABORT_AT);
+  if (ab && fallbacks && threadIdx.x == 0) atomicAdd(fallbacks, 1);
+  return ab != 0;
+}
 
 __global__ __launch_bounds__(FPS_TPB) void fps_kernel(const float* __restrict__ pos,
                                                       const int64_t* __restrict__ cloud_ptr,
                                                       const int64_t* __restrict__ start,
                                                       const int64_t* __restrict__ out_ptr, float* __restrict__ mind,
-                                                      int64_t* __restrict__ out) {
+                                                      int64_t* __restrict__ out, const char* __restrict__ gate,
+                                                      int32_t* __restrict__ fallbacks) {
   __shared__ float red_v[FPS_TPB / 64];
   __shared__ int red_i[FPS_TPB / 64];
   __shared__ int chosen;
   const int64_t b = blockIdx.x;
+  if (gate && !fps_gate_open(gate, b, fallbacks)) return;    // (the cluster's fallback: only the clouds whose cluster gave up)
   const int64_t p0 = cloud_ptr[b];
   const int n = (int)(cloud_ptr[b + 1] - p0);
   const int64_t o0 = out_ptr[b];
@@ -551,10 +569,12 @@ __global__ __launch_bounds__(FPS_TPB) void fps_hybrid_kernel(const float* __rest
                                                              const int64_t* __restrict__ cloud_ptr,
                                                              const int64_t* __restrict__ start,
                                                              const int64_t* __restrict__ out_ptr,
-                                                             int64_t* __restrict__ out) {
+                                                             int64_t* __restrict__ out, const char* __restrict__ gate,
+                                                             int32_t* __restrict__ fallbacks) {
   extern __shared__ float md_l[];                       // [n - PR * FPS_TPB] running minima of the points beyond the registers
   __shared__ FpsBest red[2][FPS_TPB / 64];
   const int64_t b = blockIdx.x;
+  if (gate && !fps_gate_open(gate, b, fallbacks)) return;    // (the cluster's fallback, see fps_gate_open)
   const int64_t p0 = cloud_ptr[b];
   const int n = (int)(cloud_ptr[b + 1] - p0);
   const int64_t o0 = out_ptr[b];
@@ -648,10 +668,14 @@ __global__ __launch_bounds__(FPS_TPB) void fps_hybrid_kernel(const float* __rest
 // Two slots by round parity suffice: a workgroup publishes round r + 2 only after it has the others' round r + 1, which they publish
 // behind a barrier that all their waves reach after reading round r.  Same arithmetic, same tie rule (larger value, then smaller
 // index) as every other form: bit-identical samples.  The cluster's workgroup ids are congruent modulo 8 (one XCD under the
-// observed round-robin placement: speed only, the protocol does not depend on it).  Co-residency: G x B <= 128 workgroups of 1024
-// threads, each a whole CU; a poll that sees nothing for ~2^22 tries raises the abort word and every wave leaves.
+// observed round-robin placement: speed only, the protocol does not depend on it).  Co-residency is NOT guaranteed by an ordinary
+// launch (G x B is held to half of the device's CUs, each workgroup a whole CU, but a busy device may still start one member long
+// after the other): a poll that sees nothing for ~2^18 tries (~0.5 s; a round is 2 us) raises the cloud's abort word, every wave of
+// every member leaves, and the gated one-workgroup launch behind this kernel re-samples that cloud (fps_gate_open): the samples
+// ccn_fps returns never depend on the placement.  `fault` (test hook ccn_fps_debug_fault): 1 = member 1 silently leaves before
+// round 1 (its partners run into the timeout), 2 = member 1 raises the abort word itself and leaves (the fast way out).
 constexpr int FPS_CL_MAXG = 4;
-constexpr int FPS_CL_AREA = 512;                 // bytes of exchange area per cloud: 2 parities x 4 workgroups x 5 granules x 8 B, abort word, 4 XCD ids
+static_assert(FPS_CL_ABORT_AT == 2 * FPS_CL_MAXG * 5 * 8, "abort word sits behind the two parities' granules");
 struct FpsGranule {
   uint32_t value, tag;
 };
@@ -674,7 +698,7 @@ __global__ __launch_bounds__(FPS_TPB) void fps_cluster_kernel(const float* __res
                                                               const int64_t* __restrict__ cloud_ptr,
                                                               const int64_t* __restrict__ start,
                                                               const int64_t* __restrict__ out_ptr, int64_t B, int G, int force_sc1,
-                                                              char* __restrict__ xch_all, int64_t* __restrict__ out) {
+                                                              int fault, char* __restrict__ xch_all, int64_t* __restrict__ out) {
   __shared__ FpsBest red[2][FPS_TPB / 64];
   // workgroup ids x, x + 8, x + 16, ... (x = id % 8) form the clusters x, x, ... in turn: cluster c = x + 8 * (t / G), member t % G
   const int64_t t = blockIdx.x >> 3;
@@ -704,7 +728,7 @@ __global__ __launch_bounds__(FPS_TPB) void fps_cluster_kernel(const float* __res
   float cx = p[3 * cur], cy = p[3 * cur + 1], cz = p[3 * cur + 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   FpsGranule* const xch = reinterpret_cast<FpsGranule*>(xch_all + b * FPS_CL_AREA);
-  uint32_t* const abort_word = reinterpret_cast<uint32_t*>(xch_all + b * FPS_CL_AREA + 2 * FPS_CL_MAXG * 5 * 8);
+  uint32_t* const abort_word = reinterpret_cast<uint32_t*>(xch_all + b * FPS_CL_AREA + FPS_CL_ABORT_AT);
   const int h_of = lane / 5, f_of = lane - 5 * h_of;      // lane = 5 * member + field (lanes 0 .. 5 G - 1 poll)
   // Where do the members sit?  Every member publishes the id of its XCD (hardware register XCC_ID) once, with agent scope, and reads
   // the others'.  All on one XCD (the usual case: ids congruent modulo 8): the granules of a round are written with PLAIN stores,
@@ -730,7 +754,7 @@ __global__ __launch_bounds__(FPS_TPB) void fps_cluster_kernel(const float* __res
         }
       }
       if (__ballot(!done) == 0ull) break;
-      if (tries >= (1 << 22)) {
+      if (tries >= (1 << 19)) {
         if (lane == 0) atomicExch(abort_word, 1u);
         return;
       }
@@ -739,6 +763,10 @@ __global__ __launch_bounds__(FPS_TPB) void fps_cluster_kernel(const float* __res
     same_xcd = !force_sc1 && __ballot(theirs != xcc) == 0ull;
   }
   for (int it = 0; it < keep; ++it) {
+    if (fault && g == 1 && it == 1) {                    // test hook: this member is gone (scalar condition, never taken in production)
+      if (fault == 2 && threadIdx.x == 0) atomicExch(abort_word, 1u);
+      return;
+    }
     if (g == 0 && threadIdx.x == 0) out[o0 + it] = p0 + cur;
     FpsBest best = {-1.f, 0x7fffffff, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -798,7 +826,7 @@ __global__ __launch_bounds__(FPS_TPB) void fps_cluster_kernel(const float* __res
         uint32_t ab = 0;
         if (lane == 0) ab = fps_load_sc1(reinterpret_cast<const FpsGranule*>(abort_word)).x;
         ab = __builtin_amdgcn_readfirstlane(ab);
-        if (tries >= (1 << 20)) {
+        if (tries >= (1 << 18)) {
           if (lane == 0) atomicExch(abort_word, 1u);
           ab = 1;
         }
@@ -928,25 +956,35 @@ int ccn_voxel_argmin(const float* score, const int64_t* voxel_of, int64_t n, int
 }
 
 int ccn_fps_use_cluster(int on) {
-  g_fps_cluster = on < 0 ? 0 : (on > 2 ? 2 : on);
+  g_fps_cluster.store(on < 0 ? 0 : (on > 2 ? 2 : on), std::memory_order_relaxed);
   return CCN_OK;
 }
 
 int ccn_fps_set_lds_claim(int bytes) {
-  g_fps_claim = bytes < 0 ? 0 : (bytes > FPS_CLAIM_MAX ? FPS_CLAIM_MAX : bytes);
+  g_fps_claim.store(bytes < 0 ? 0 : (bytes > FPS_CLAIM_MAX ? FPS_CLAIM_MAX : bytes), std::memory_order_relaxed);
   return CCN_OK;
 }
 
-int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, const int64_t* out_ptr, int64_t B,
-            int64_t max_cloud, float* mind, int64_t* out, void* stream) {
-  CCN_REQUIRE(pos && cloud_ptr && start && out_ptr && mind && out && B > 0, "fps: bad arguments");
-  hipStream_t s = (hipStream_t)stream;
-  // One workgroup per cloud runs K dependent rounds: its speed is its latency.  It asks for 96 KB of (unused) dynamic LDS
-  // so that no GEMM workgroup of the feature stream is co-scheduled on its CU -- next to two 4-wave GEMM workgroups a
-  // 40 ms sampling pass of the A2D2 model took 60 % longer and the whole step followed it (the geometry of the next batch
-  // is the critical path there); a handful of the 256 CUs is all it takes.
-  static bool claimed = false;
-  if (!claimed) {
+int ccn_fps_debug_fault(int mode) {
+  g_fps_fault.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode), std::memory_order_relaxed);
+  return CCN_OK;
+}
+
+size_t ccn_fps_workspace_bytes(int64_t n, int64_t B) {
+  if (n < 0 || B < 0) return 0;
+  return ccn_align256((size_t)n * 4) + (size_t)B * FPS_CL_AREA;
+}
+
+// Per device, once: the kernels' dynamic-LDS limits and the number of CUs (a cluster's members spin on one another, so a launch
+// of clusters is held to half of them).  Returns the CU count, 0 on failure.
+static int fps_device_setup() {
+  constexpr int MAX_DEV = 64;
+  static std::mutex mu;
+  static int cus[MAX_DEV] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cus[dev] == 0) {
     bool ok = hipFuncSetAttribute((const void*)fps_reg_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void*)fps_reg_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void*)fps_reg_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
@@ -954,28 +992,57 @@ int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, co
     ok = ok && hipFuncSetAttribute((const void*)fps_cluster_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, FPS_CLAIM_MAX) == hipSuccess;
     ok = ok && hipFuncSetAttribute((const void*)fps_hybrid_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    FPS_HYB_LDS * 4) == hipSuccess;
-    CCN_REQUIRE(ok, "fps: cannot raise the dynamic LDS limit");
-    claimed = true;
+    int n = 0;
+    ok = ok && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0;
+    if (!ok) return 0;
+    cus[dev] = n;
   }
+  return cus[dev];
+}
+
+int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, const int64_t* out_ptr, int64_t B,
+            int64_t max_cloud, int64_t n, void* workspace, size_t workspace_bytes, int32_t* fallbacks, int64_t* out,
+            void* stream) {
+  CCN_REQUIRE(pos && cloud_ptr && start && out_ptr && workspace && out && B > 0 && n >= 0, "fps: bad arguments");
+  CCN_REQUIRE(workspace_bytes >= ccn_fps_workspace_bytes(n, B), "fps: workspace of %zu bytes, %zu needed", workspace_bytes,
+              ccn_fps_workspace_bytes(n, B));
+  hipStream_t s = (hipStream_t)stream;
+  float* const mind = reinterpret_cast<float*>(workspace);                                    // running minima of the streaming form: n floats
+  char* const xch = reinterpret_cast<char*>(workspace) + ccn_align256((size_t)n * 4);         // the clusters' exchange areas: 512 B per cloud
+  // One workgroup per cloud runs K dependent rounds: its speed is its latency.  It asks for 96 KB of (unused) dynamic LDS
+  // so that no GEMM workgroup of the feature stream is co-scheduled on its CU -- next to two 4-wave GEMM workgroups a
+  // 40 ms sampling pass of the A2D2 model took 60 % longer and the whole step followed it (the geometry of the next batch
+  // is the critical path there); a handful of the 256 CUs is all it takes.
+  const int cus = fps_device_setup();
+  CCN_REQUIRE(cus > 0, "fps: cannot raise the dynamic LDS limit / read the device's CU count");
+  const int claim = g_fps_claim.load(std::memory_order_relaxed), cluster = g_fps_cluster.load(std::memory_order_relaxed);
+  const int64_t G = (max_cloud + 16 * FPS_TPB - 1) / (16 * FPS_TPB);
   if (max_cloud > 0 && max_cloud <= 4 * FPS_TPB)
-    hipLaunchKernelGGL(fps_reg_kernel<4>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, out);
+    hipLaunchKernelGGL(fps_reg_kernel<4>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)claim, s, pos, cloud_ptr, start, out_ptr, out);
   else if (max_cloud > 0 && max_cloud <= 8 * FPS_TPB)
-    hipLaunchKernelGGL(fps_reg_kernel<8>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, out);
+    hipLaunchKernelGGL(fps_reg_kernel<8>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)claim, s, pos, cloud_ptr, start, out_ptr, out);
   else if (max_cloud > 0 && max_cloud <= 16 * FPS_TPB)
-    hipLaunchKernelGGL(fps_reg_kernel<16>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, out);
-  else if (g_fps_cluster && g_fps_claim > 0 && max_cloud > 16 * FPS_TPB && max_cloud <= FPS_CL_MAXG * 16 * FPS_TPB && B * (FPS_CL_AREA / 4) <= max_cloud &&
-           8 * ((max_cloud + 16 * FPS_TPB - 1) / (16 * FPS_TPB)) * ((B + 7) / 8) <= 128) {   // (at most half of the CUs spin on one another)
-    // more than 16 k points: G workgroups per cloud, every point in registers, one exchange per round (fps_cluster_kernel).
-    // The exchange areas (512 B per cloud, tags zeroed here) live at the start of the `mind` scratch: 4 max_cloud bytes at least.
-    const int G = (int)((max_cloud + 16 * FPS_TPB - 1) / (16 * FPS_TPB));
-    CCN_HIP(hipMemsetAsync(mind, 0, (size_t)B * FPS_CL_AREA, s), "fps");
-    hipLaunchKernelGGL(fps_cluster_kernel<16>, dim3((unsigned)(8 * G * ((B + 7) / 8))), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos,
-                       cloud_ptr, start, out_ptr, B, G, g_fps_cluster == 2 ? 1 : 0, reinterpret_cast<char*>(mind), out);
-  } else if (max_cloud > 0 && max_cloud <= 16 * FPS_TPB + FPS_HYB_LDS && g_fps_claim > 0)      // (claim 0 = A/B: the streaming form)
+    hipLaunchKernelGGL(fps_reg_kernel<16>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)claim, s, pos, cloud_ptr, start, out_ptr, out);
+  else if (cluster && claim > 0 && max_cloud > 16 * FPS_TPB && max_cloud <= FPS_CL_MAXG * 16 * FPS_TPB &&
+           8 * G * ((B + 7) / 8) <= cus / 2) {   // (at most half of the CUs spin on one another)
+    // more than 16 k points: G workgroups per cloud, every point in registers, one exchange per round (fps_cluster_kernel);
+    // then the gated one-workgroup form for the clouds whose cluster gave up (none, normally: B workgroups that leave at once).
+    CCN_HIP(hipMemsetAsync(xch, 0, (size_t)B * FPS_CL_AREA, s), "fps");
+    hipLaunchKernelGGL(fps_cluster_kernel<16>, dim3((unsigned)(8 * G * ((B + 7) / 8))), dim3(FPS_TPB), (size_t)claim, s, pos,
+                       cloud_ptr, start, out_ptr, B, (int)G, cluster == 2 ? 1 : 0, g_fps_fault.load(std::memory_order_relaxed), xch,
+                       out);
+    if (max_cloud <= 16 * FPS_TPB + FPS_HYB_LDS)
+      hipLaunchKernelGGL(fps_hybrid_kernel<16>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)FPS_HYB_LDS * 4, s, pos, cloud_ptr, start,
+                         out_ptr, out, xch, fallbacks);
+    else
+      hipLaunchKernelGGL(fps_kernel, dim3((unsigned)B), dim3(FPS_TPB), (size_t)claim, s, pos, cloud_ptr, start, out_ptr, mind, out,
+                         xch, fallbacks);
+  } else if (max_cloud > 0 && max_cloud <= 16 * FPS_TPB + FPS_HYB_LDS && claim > 0)      // (claim 0 = A/B: the streaming form)
     hipLaunchKernelGGL(fps_hybrid_kernel<16>, dim3((unsigned)B), dim3(FPS_TPB), (size_t)FPS_HYB_LDS * 4, s, pos, cloud_ptr, start,
-                       out_ptr, out);
+                       out_ptr, out, (const char*)nullptr, (int32_t*)nullptr);
   else
-    hipLaunchKernelGGL(fps_kernel, dim3((unsigned)B), dim3(FPS_TPB), (size_t)g_fps_claim, s, pos, cloud_ptr, start, out_ptr, mind, out);
+    hipLaunchKernelGGL(fps_kernel, dim3((unsigned)B), dim3(FPS_TPB), (size_t)claim, s, pos, cloud_ptr, start, out_ptr, mind, out,
+                       (const char*)nullptr, (int32_t*)nullptr);
   CCN_LAUNCH_OK("fps");
   return CCN_OK;
 }

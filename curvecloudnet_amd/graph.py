@@ -12,7 +12,22 @@ Use: inference over a batch whose geometry is prepared (the same clouds evaluate
 features, ensembles of weights -- or a fixed-topology stream).  The logits of a replay are bit-identical to the eager
 pass (tests/test_gpu_graph.py).
 """
+import contextlib
+
 import torch
+
+
+@contextlib.contextmanager
+def _generator_state(state):
+    """Run the enclosed pass from the CPU generator state ``state`` and put the caller's state back afterwards: the samplers' draws
+    of a captured forward are those of construction time, but the caller's own stream of random numbers (augmentation, shuffling,
+    dropout seeding) must not be rewound by it."""
+    saved = torch.get_rng_state()
+    torch.set_rng_state(state)
+    try:
+        yield
+    finally:
+        torch.set_rng_state(saved)
 
 
 class CapturedForward:
@@ -40,8 +55,13 @@ class CapturedForward:
             cur.wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = model(data, plan=self.plan, **forward_kwargs)
+            from . import ops
+            ops.NT_CAPTURE = self._scratch = {}            # (one tail-split scratch per capture, alive as long as the graph)
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.out = model(data, plan=self.plan, **forward_kwargs)
+            finally:
+                ops.NT_CAPTURE = None
         self.launches = None
 
     def eager(self):
@@ -93,24 +113,14 @@ class CapturedWholeForward:
         # ARGUMENTS, i.e. inside the graph: every pass of this object starts from the generator state of construction time
         self._rng = torch.get_rng_state()
         # 1. the ordinary forward (reference value for the tests); its counts and its samplers' random draws are logged
-        rec = ops.COUNTS = ops.CountRecorder()
-        try:
-            with torch.no_grad():
-                torch.set_rng_state(self._rng)
-                self.reference = model(self.data, **forward_kwargs)[: self.n].clone()
-        finally:
-            ops.COUNTS = None
+        with ops.counts_scope(ops.CountRecorder()) as rec, torch.no_grad(), _generator_state(self._rng):
+            self.reference = model(self.data, **forward_kwargs)[: self.n].clone()
         self.draws = rec.draws
         # 2. calibration: one eager pass in which every count is read back, turned into a capacity and used as such at
         # once (ops.CountBounds); afterwards the same pass without any read-back, off the default stream (allocator warm-up)
         self.bounds = ops.CountBounds(None, dev, headroom, draws=self.draws)
-        ops.COUNTS = self.bounds
-        try:
-            with torch.no_grad():
-                torch.set_rng_state(self._rng)
-                model(self.data, **forward_kwargs)
-        finally:
-            ops.COUNTS = None
+        with ops.counts_scope(self.bounds), torch.no_grad(), _generator_state(self._rng):
+            model(self.data, **forward_kwargs)
         self.counts, self.caps = list(self.bounds.counts), list(self.bounds.caps)
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev)
@@ -121,14 +131,14 @@ class CapturedWholeForward:
         torch.cuda.synchronize(dev)
         # 3. capture
         self.graph = torch.cuda.CUDAGraph()
-        ops.COUNTS = self.bounds
+        ops.NT_CAPTURE = self._scratch = {}                # (one tail-split scratch per capture, alive as long as the graph)
         try:
-            torch.set_rng_state(self._rng)
-            with torch.no_grad(), torch.cuda.graph(self.graph):
-                self.bounds.rewind()
-                self.out = model(self.data, **forward_kwargs)
+            with ops.counts_scope(self.bounds), _generator_state(self._rng):
+                with torch.no_grad(), torch.cuda.graph(self.graph):
+                    self.bounds.rewind()
+                    self.out = model(self.data, **forward_kwargs)
         finally:
-            ops.COUNTS = None
+            ops.NT_CAPTURE = None
 
     @staticmethod
     def _with_phantom(data):
@@ -168,34 +178,25 @@ class CapturedWholeForward:
         if getattr(data, "x", None) is not None:
             self.data.x[: self.n].copy_(data.x)
         if verify:
-            ops.COUNTS = self.bounds
             try:
-                self.bounds.rewind(verifying=True)
-                torch.set_rng_state(self._rng)
-                with torch.no_grad():
+                with ops.counts_scope(self.bounds), torch.no_grad(), _generator_state(self._rng):
+                    self.bounds.rewind(verifying=True)
                     self.model(self.data, **self.kwargs)
             except ops.CountBounds.Exceeded as e:
                 raise self.CapacityExceeded(str(e)) from None
             finally:
                 self.bounds.rewind()
-                ops.COUNTS = None
 
     def bounded_eager(self):
         """The captured computation launched kernel by kernel (bounded counts, no read-back)."""
         from . import ops
-        ops.COUNTS = self.bounds
-        try:
+        with ops.counts_scope(self.bounds), torch.no_grad(), _generator_state(self._rng):
             self.bounds.rewind()
-            torch.set_rng_state(self._rng)
-            with torch.no_grad():
-                return self.model(self.data, **self.kwargs)[: self.n]
-        finally:
-            ops.COUNTS = None
+            return self.model(self.data, **self.kwargs)[: self.n]
 
     def eager(self):
         """The ordinary forward over the same batch (host read-back per count), for A/B timing."""
-        torch.set_rng_state(self._rng)
-        with torch.no_grad():
+        with torch.no_grad(), _generator_state(self._rng):
             return self.model(self.data, **self.kwargs)[: self.n]
 
     def replay(self, check=True):

@@ -5,6 +5,7 @@ the hot path is a ``ccn_*`` kernel launch.  Reference call sites are cited per o
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -152,6 +153,35 @@ def _i64(t):
 #     its capacity (or a sortedness check fails).  One read-back of that flag per forward replaces all the others, and the
 #     whole forward, geometry included, is hipGraph-capturable ("device-side counts").
 COUNTS = None
+_COUNTS_THREAD = None       # the thread a counts_scope() was entered on: other threads (ModelBase.prepare_async's worker) see None
+
+
+def counts():
+    """The count resolver in force FOR THE CALLING THREAD.  A resolver installed by ``counts_scope`` belongs to the thread that
+    entered the scope -- a geometry worker (``ModelBase.prepare_async``) running meanwhile keeps reading its counts back and never
+    consumes the scope's capacities out of step.  A resolver assigned to ``ops.COUNTS`` directly is process-wide."""
+    if COUNTS is None or _COUNTS_THREAD is None or _COUNTS_THREAD == threading.get_ident():
+        return COUNTS
+    return None
+
+
+class counts_scope:
+    """``with counts_scope(resolver):`` -- install a CountRecorder / CountBounds for the enclosed passes of THIS thread."""
+
+    def __init__(self, resolver):
+        self.resolver = resolver
+
+    def __enter__(self):
+        global COUNTS, _COUNTS_THREAD
+        if COUNTS is not None:
+            raise RuntimeError("a count resolver is already installed (counts_scope does not nest)")
+        COUNTS, _COUNTS_THREAD = self.resolver, threading.get_ident()
+        return self.resolver
+
+    def __exit__(self, et, ev, tb):
+        global COUNTS, _COUNTS_THREAD
+        COUNTS = _COUNTS_THREAD = None
+        return False
 
 
 class CountRecorder:
@@ -250,16 +280,17 @@ class CountBounds:
 
 
 def bounded():
-    return isinstance(COUNTS, CountBounds)
+    return isinstance(counts(), CountBounds)
 
 
 def draw(make, fit=None, device=None):
     """A host-side random draw of a sampler, through the count resolver when there is one (recorded / replayed / kept as a
     device constant: see CountRecorder.draw, CountBounds.draw)."""
-    if COUNTS is None:
+    res = counts()
+    if res is None:
         t = make()
         return t if device is None else t.to(device)
-    return COUNTS.draw(make, fit, device)
+    return res.draw(make, fit, device)
 
 
 def spread_phantoms(pos_q, idx, n_src):
@@ -286,11 +317,12 @@ def _fit_rows(n, fill):
 
 def _count(dev, whats):
     """Host integers for the device-side counts ``dev`` (a 1-D int tensor, one entry per name in ``whats``)."""
-    if bounded():
-        return COUNTS.take(dev, whats)
+    res = counts()
+    if isinstance(res, CountBounds):
+        return res.take(dev, whats)
     vals = dev.tolist()                                   # host sync, as torch.where / nonzero in the reference
-    if COUNTS is not None:
-        return COUNTS.resolve(vals, whats)
+    if res is not None:
+        return res.resolve(vals, whats)
     return [int(v) for v in vals]
 
 
@@ -339,13 +371,13 @@ class CurveTopology:
         call("curve_topology", ptr(batch), ptr(p2c), n, num_clouds, ptr(self.glob), ptr(self.cid), ptr(curve_ptr),
              ptr(self.cloud_ptr), ptr(meta), ptr(ws), ws.numel())
         if bounded():
-            COUNTS.flag(meta[1])
+            counts().flag(meta[1])
             q, longest = _count(meta[0:3:2], ("curves", "longest cloud"))
             q, longest = min(q, n), min(longest, n)
         else:
             q, bad, longest, _ = (int(v) for v in meta.tolist())
-            if COUNTS is not None:
-                COUNTS.resolve((q, longest), ("curves", "longest cloud"))
+            if counts() is not None:
+                counts().resolve((q, longest), ("curves", "longest cloud"))
             if bad:
                 raise AssertionError("batch / curve ids are not sorted (or cloud ids are not 0..B-1)")
         self.num_curves, self.max_cloud = q, longest
@@ -565,24 +597,40 @@ def _nt_name():
 
 
 _NT_SCRATCH = {}
-NT_SPLIT = os.environ.get("CCN_NT_SPLIT", "1") != "0"      # A/B: the paired kernel's tail split (ccn_gemm_nt_ws)
+# The paired kernel's tail split (ccn_gemm_nt_ws): OFF by default since round 6.  It regroups the K chains of the tiles it splits;
+# measured back to back on the full-width KITTI network, 49 652 points (profiles/r06_parity_split_ab.txt): max-norm distance to the
+# fp64 value 8.16e-4 with it against 6.14e-4 without (1.53 x / 1.13 x the CPU oracle's own distance; rms unchanged), for +-0 ms on
+# the step (profiles/r05_split_tails.txt: 104.08 vs 104.12 ms).  A change that costs parity margin and buys no time stays an
+# option: CCN_NT_SPLIT=1 enables it, the entry points and their tests (tests/test_gpu_gemm_split.py) stay.
+NT_SPLIT = os.environ.get("CCN_NT_SPLIT", "0") != "0"
 _WS, _WS_ARGS = ("_ws", 2) if NT_SPLIT else ("", 0)       # off: the entries without scratch (what an older library build has)
+
+
+NT_CAPTURE = None            # graph.py: {} while ONE capture is being recorded -> that capture's scratch buffers by device
 
 
 def _nt_scratch(device):
     """Scratch of the paired fp32 kernel's tail split (``ccn_gemm_nt_ws`` and its siblings): ONE buffer per (device,
     stream) -- launches on a stream run in order -- whose leading counters start at zero and are left at zero by every
-    launch.  -> (pointer, bytes), (None, 0) when the split is switched off."""
+    launch.  -> (pointer, bytes), (None, 0) when the split is switched off.  Under a graph capture the buffer comes from the
+    capture's private pool: one per capture when graph.py announced it (``NT_CAPTURE``), else one per call; only the 4 KiB of
+    counters are cleared (a 32 MiB fill node per product otherwise)."""
     if not NT_SPLIT:
         return None, 0
     key = (device.index if device.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(device).cuda_stream)
+    if torch.cuda.is_current_stream_capturing():
+        nbytes = int(lib().ccn_gemm_nt_split_workspace_bytes())
+        buf = NT_CAPTURE.get(key[0]) if NT_CAPTURE is not None else None
+        if buf is None:
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            buf[:4096].zero_()
+            if NT_CAPTURE is not None:
+                NT_CAPTURE[key[0]] = buf
+        return ptr(buf), nbytes
     buf = _NT_SCRATCH.get(key)
     if buf is None:
         nbytes = int(lib().ccn_gemm_nt_split_workspace_bytes())
-        if torch.cuda.is_current_stream_capturing():
-            buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)     # the capture's private pool (zeroed per replay)
-            return ptr(buf), nbytes
         buf = _NT_SCRATCH[key] = torch.zeros(nbytes, dtype=torch.uint8, device=device)
     return ptr(buf), buf.numel()
 
@@ -2011,8 +2059,8 @@ def voxel_fps(pos, batch, voxel_size, rnd=None):
     # ccn_rank_keys (radix sort on the digits in which the keys differ at all)
     meta = torch.empty(2, dtype=torch.int64, device=dev)              # [spread of the keys, number of distinct keys]
     call("key_spread", ptr(key), n, ptr(meta))
-    if bounded() and not COUNTS.calibrating and not COUNTS.verifying:
-        COUNTS.flag(bad[0])
+    if bounded() and not counts().calibrating and not counts().verifying:
+        counts().flag(bad[0])
         digits = 255                    # (no read-back of the key spread: sort on all eight digits)
     else:
         spread, n_bad = int(meta[0].item()), int(bad.item())
@@ -2032,6 +2080,19 @@ def voxel_fps(pos, batch, voxel_size, rnd=None):
         # the tail of every other bounded sample list
         idx = torch.where(idx >= n, torch.full_like(idx, n - 1), idx)
     return idx
+
+
+_FPS_FALLBACKS = {}
+
+
+def fps_fallbacks(device):
+    """Per device: an int32 counter the library increments once per cloud whose CLUSTER of sampling workgroups gave up (its members
+    were not running at the same time) and that the gated one-workgroup launch re-sampled (include/ccn_hip.h: ccn_fps).  The
+    samples are the same either way; the counter is there to be looked at (bench.py prints it), never read on the hot path."""
+    key = torch.device(device).index or 0
+    if key not in _FPS_FALLBACKS:
+        _FPS_FALLBACKS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _FPS_FALLBACKS[key]
 
 
 def fps(pos, topo, ratio, start=None):
@@ -2059,13 +2120,14 @@ def fps(pos, topo, ratio, start=None):
         if start is None:
             start = draw(lambda: torch.tensor([int(torch.randint(int(l), (1,))) for l in lengths.tolist()], dtype=torch.int64))
         total = int(out_ptr[-1])
-        if COUNTS is not None:
-            COUNTS.resolve((total,), ("FPS samples",))
+        if counts() is not None:
+            counts().resolve((total,), ("FPS samples",))
         out = torch.empty(total, dtype=torch.int64, device=dev)
         start_d, out_ptr_d = start.to(dev), out_ptr.to(dev)     # named: must outlive the asynchronous launch
-    mind = torch.empty(topo.n, dtype=torch.float32, device=dev)
-    call("fps", ptr(pos), ptr(topo.cloud_ptr), ptr(start_d), ptr(out_ptr_d), topo.num_clouds, topo.max_cloud, ptr(mind),
-         ptr(out))
+    nb = lib().ccn_fps_workspace_bytes(topo.n, topo.num_clouds)
+    ws = workspace(nb, dev)
+    call("fps", ptr(pos), ptr(topo.cloud_ptr), ptr(start_d), ptr(out_ptr_d), topo.num_clouds, topo.max_cloud, topo.n, ptr(ws),
+         nb, ptr(fps_fallbacks(dev)), ptr(out))
     # ascending packed indices (the reference sorts them too): ccn_sort_keys on the digits an index < n can differ in
     digits = (1 << max(1, (max(int(topo.n) - 1, 1).bit_length() + 7) // 8)) - 1
     nb = lib().ccn_rank_keys_workspace_bytes(total)

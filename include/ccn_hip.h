@@ -29,8 +29,11 @@ extern "C" {
 /* ABI version: bumped when the prototype of an EXISTING entry changes (additions do not bump it).
  *   1 -> 2 (round 4, recorded in round 5 / ADVICE r4): ccn_edge_feat_bwd_csr gained `int64_t N` in front of `int64_t E`.
  *   2 -> 3 (round 5): ccn_interp_inverse_workspace_bytes(M) became (n, k, M) -- the lists are made by a stable radix sort of the
- *                     n * k slots, whose buffers live in the workspace. */
-#define CCN_ABI_VERSION 3
+ *                     n * k slots, whose buffers live in the workspace.
+ *   3 -> 4 (round 6): ccn_fps takes (n, workspace, workspace_bytes, fallbacks) instead of a float scratch of n entries: the
+ *                     exchange areas of the clustered form no longer alias the streaming form's running minima, which the
+ *                     gated one-workgroup fallback of a cluster that gave up needs (ccn_fps_workspace_bytes). */
+#define CCN_ABI_VERSION 4
 
 #define CCN_OK 0
 #define CCN_ERR_ARG (-1)
@@ -636,10 +639,17 @@ int ccn_rank_keys(const int64_t* key, int64_t n, int digit_mask, int64_t* rank, 
 int ccn_sort_keys(const int64_t* key, int64_t n, int digit_mask, int64_t* sorted, void* workspace, size_t workspace_bytes,
                   void* stream);
 /* sample_farthest_points (point_ops.py:57-70): per cloud out_ptr[b+1]-out_ptr[b] samples starting at start[b];
- * out = packed point indices in selection order; mind: float scratch (n); max_cloud: largest cloud size (clouds of up
- * to 16384 points are processed register-resident, 0 = unknown). */
+ * out = packed point indices in selection order; n = cloud_ptr[B] (all points); max_cloud: largest cloud size (clouds of up
+ * to 16384 points are processed register-resident, 0 = unknown); workspace: ccn_fps_workspace_bytes(n, B), caller-owned.
+ * Clouds of 16 k - 64 k points are sampled by a cluster of up to four workgroups that exchange their candidates every round;
+ * an ordinary launch cannot promise that the members run at the same time, so a member that hears nothing from a partner for
+ * ~0.5 s gives the cloud up and a second, gated launch on the same stream re-samples that cloud with one workgroup: the
+ * samples are the same on every path.  fallbacks (nullable, device int32, NOT cleared here): incremented once per cloud that
+ * took the second way -- a counter for monitoring, never needed for correctness. */
+size_t ccn_fps_workspace_bytes(int64_t n, int64_t B);
 int ccn_fps(const float* pos, const int64_t* cloud_ptr, const int64_t* start, const int64_t* out_ptr, int64_t B,
-            int64_t max_cloud, float* mind, int64_t* out, void* stream);
+            int64_t max_cloud, int64_t n, void* workspace, size_t workspace_bytes, int32_t* fallbacks, int64_t* out,
+            void* stream);
 
 /* Dataset-side curve splitter (src/data/kitti_dataset.py:73-92 with beam == NULL,
  * src/data/nuscenes_dataset.py:101-118 on the beam-sorted sweep): curve_idx[0] = 0, a new curve starts at i where

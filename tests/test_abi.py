@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in protos:
         assert hasattr(handle, name), name
     lib = _lib.lib()
-    assert lib.ccn_abi_version() == 3
+    assert lib.ccn_abi_version() == 4
     assert lib.ccn_stats_rows(129) == 2
     assert lib.ccn_frnn_grid_bytes(2, 1000) > 0 and lib.ccn_curve_fps_workspace_bytes(1000) > 0
 

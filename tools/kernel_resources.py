@@ -15,12 +15,28 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "curvecloudnet_amd", "csrc")
-LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _llvm_bin():
+    """The ROCm LLVM tool directory: $ROCM_PATH, `hipconfig --rocmpath`, then /opt/rocm (not one hard-coded path)."""
+    roots = [os.environ.get("ROCM_PATH")]
+    try:
+        roots.append(subprocess.run(["hipconfig", "--rocmpath"], capture_output=True, text=True).stdout.strip())
+    except OSError:
+        pass
+    roots.append("/opt/rocm")
+    for r in roots:
+        if r and os.path.exists(os.path.join(r, "lib", "llvm", "bin", "llvm-objdump")):
+            return os.path.join(r, "lib", "llvm", "bin")
+    raise SystemExit("kernel_resources: no llvm-objdump under $ROCM_PATH / `hipconfig --rocmpath` / /opt/rocm")
+
+
+LLVM = _llvm_bin()
 # kernels whose correctness depends on nothing unseen entering the VMEM queue: no scratch, no spills
 # (the weight-gradient kernels gemm_tn_glds_kernel<64, 64> / gemm_h_tn_kernel hold ~250 B of scratch since round 2 / 3; they
 # wait vmcnt(0) only, which a spill cannot defeat)
 NO_SCRATCH = ("gemm_glds_pair_kernel", "gemm_glds_persistent_kernel", "gemm_glds_kernel", "gemm_x3_lean_kernel",
-              "gemm_x3_pair_kernel", "gemm_x3_persistent_kernel", "gemm_h_pair_kernel")
+              "gemm_x3_persistent_kernel", "gemm_h_pair_kernel")     # (gemm_x3_pair_kernel: replaced by the lean kernel in round 4)
 
 
 def kernels_of(obj):
@@ -30,11 +46,12 @@ def kernels_of(obj):
         os.symlink(obj, local)
         subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], cwd=tmp, check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        cos = [f for f in os.listdir(tmp) if "amdgcn" in f]
+        cos = sorted(f for f in os.listdir(tmp) if "amdgcn" in f)
         if not cos:
-            return []
-        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, cos[0])],
-                               check=True, capture_output=True, text=True).stdout
+            return None                                    # (no device code object extracted: the caller decides what that means)
+        # every extracted code object (one per offload architecture)
+        notes = "".join(subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, co)],
+                                       check=True, capture_output=True, text=True).stdout for co in cos)
     out = []
     for blk in re.split(r"\n  - \.agpr_count:", notes)[1:]:
         blk = ".agpr_count:" + blk
@@ -64,16 +81,24 @@ def demangle(names):
 def main(argv):
     check = "--check" in argv
     pat = next((a for a in argv if not a.startswith("--")), "")
-    bad = []
-    for fn in sorted(os.listdir(CSRC)):
-        if not fn.endswith(".o"):
-            continue
+    bad, blind = [], []
+    seen = {k: 0 for k in NO_SCRATCH}
+    objs = [fn for fn in sorted(os.listdir(CSRC)) if fn.endswith(".o")]
+    if check and not objs:
+        blind.append("no object files under %s" % CSRC)
+    for fn in objs:
         ks = kernels_of(os.path.join(CSRC, fn))
+        if ks is None:
+            blind.append("no device code object extracted from %s" % fn)
+            continue
         names = demangle([k for k, _ in ks])
         for (_, f), name in zip(ks, names):
             short = re.sub(r"\(anonymous namespace\)::", "", name).split("(")[0].replace("void ", "")
             held = f["private_segment_fixed_size"] > 0 or f["vgpr_spill_count"] > 0
             if check:
+                for k in NO_SCRATCH:
+                    if k in short:
+                        seen[k] += 1
                 if held and any(k in short for k in NO_SCRATCH):
                     bad.append((fn, short, f))
                 continue
@@ -85,7 +110,11 @@ def main(argv):
         for fn, short, f in bad:
             print("SCRATCH in a counted-wait kernel: %s %s: %d B scratch, %d spilled VGPRs" % (
                 fn, short, f["private_segment_fixed_size"], f["vgpr_spill_count"]))
-        return 1 if bad else 0
+        # a check that looked at nothing must not pass: a renamed kernel or a changed toolchain layout fails here
+        blind += ["no built kernel matches the guarded name %r" % k for k, n in seen.items() if n == 0]
+        for msg in blind:
+            print("kernel_resources --check cannot vouch for the build: " + msg)
+        return 1 if bad or blind else 0
     return 0
 
 
