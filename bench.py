@@ -467,6 +467,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if os.environ.get("CCN_BENCH_MAIN_PRIORITY"):           # experiment: the whole step on a stream of this priority (torch: lower = first)
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["CCN_BENCH_MAIN_PRIORITY"])))
     result = run(args, rank, world, local_rank, dev)
     if result is None:
         return

@@ -83,6 +83,8 @@ def lib():
             handle.ccn_gemm_use_dma(int(os.environ["CCN_GEMM_DMA"]))
         if os.environ.get("CCN_GEMM_PAIR_OPT"):  # A/B hook (ccn_gemm_pair_opt)
             handle.ccn_gemm_pair_opt(int(os.environ["CCN_GEMM_PAIR_OPT"]))
+        if os.environ.get("CCN_WGRAD_BG"):       # experiment (ccn_gemm_tn_background): bytes of LDS per weight-gradient workgroup
+            handle.ccn_gemm_tn_background(int(os.environ["CCN_WGRAD_BG"]))
         if os.environ.get("CCN_FPS_CLAIM"):      # A/B hook (ccn_fps_set_lds_claim)
             handle.ccn_fps_set_lds_claim(int(os.environ["CCN_FPS_CLAIM"]))
         if os.environ.get("CCN_FPS_CLUSTER") and hasattr(handle, "ccn_fps_use_cluster"):   # A/B hook (ccn_fps_use_cluster)

@@ -23,6 +23,7 @@
 //     back), so the chunk's rows are fetched from HBM once and re-read from that XCD's L2 by the other tiles.
 // Rows beyond M in the last slice: source rows are clamped (in bounds) and the dY fragment is zeroed for them.
 // Columns beyond N / K: source columns are clamped into the row; they only feed accumulator elements that are never stored.
+#include <atomic>
 #include <type_traits>
 
 #include "ccn_common.h"
@@ -419,6 +420,38 @@ struct TnXf {
   float neg;      // multiplier of non-positive values: 0 (ReLU), slope (LeakyReLU), 1 (none)
 };
 
+// Background mode (round 6 experiment, ccn_gemm_tn_background): a weight-gradient product has no consumer before the optimiser, so
+// it can run on a side stream BESIDE the backward pass.  Two of these workgroups fill a CU's register file (216 + 216 VGPRs of the
+// 512 per SIMD lane) and, next to the paired NT kernel, leave no room for anybody: a streaming kernel of the other stream then
+// crawls at one wave per SIMD.  With `g_tn_bg_lds` > 0 every workgroup claims that many bytes of LDS in all (static + unused
+// dynamic): 84 KiB -> ONE of them per CU (2 x 84 > 160 KiB) beside ONE workgroup of the paired NT kernel (84 + 66 / 74 KiB fit)
+// or 4 waves per SIMD of a streaming kernel.  Same arithmetic, same results.
+static std::atomic<int> g_tn_bg_lds{0};
+
+template <int TN, int TK>
+constexpr int tn_static_lds_bytes() {
+  constexpr int QN = TN / 64, QK = TK / 64, WC = 4 / (QN * QK);
+  constexpr int STAGE = TN_SLICE * TN + TN_SLICE * TK, RED = QN * QK * (WC - 1) * 64 * 64;
+  return 4 * (2 * STAGE > RED ? 2 * STAGE : RED);
+}
+
+template <int TN, int TK, int EPI, bool XF>
+static size_t tn_bg_dyn_lds() {
+  const int want = g_tn_bg_lds.load(std::memory_order_relaxed);
+  if (want <= tn_static_lds_bytes<TN, TK>()) return 0;
+  const int dyn = want - tn_static_lds_bytes<TN, TK>();
+  static std::atomic<int> raised{0};            // (per instantiation: the dynamic bytes allowed so far; a race only repeats the call)
+  if (raised.load(std::memory_order_relaxed) < dyn) {
+    if (hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<TN, TK, EPI, XF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            dyn) != hipSuccess) {
+      (void)hipGetLastError();                  // (not this launch's error)
+      return 0;
+    }
+    raised.store(dyn, std::memory_order_relaxed);
+  }
+  return (size_t)dyn;
+}
+
 template <int TN, int TK>
 int launch_tn(const TnPlan& p, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw,
               int64_t M, int64_t N, int64_t K, float* slabs, hipStream_t s, int64_t a_extent, int64_t b_extent,
@@ -428,7 +461,8 @@ int launch_tn(const TnPlan& p, const float* dY, int64_t lddy, const float* X, in
   const float* xh = xf ? xf->shift : nullptr;
   const float xn = xf ? xf->neg : 1.f;
 #define CCN_TN_LAUNCH(EPI_, XF_, SLABS_)                                                                                       \
-  hipLaunchKernelGGL((gemm_tn_glds_kernel<TN, TK, EPI_, XF_>), dim3((unsigned)grid), dim3(TN_TPB), 0, s, dY, lddy, X, ldx, dW,   \
+  hipLaunchKernelGGL((gemm_tn_glds_kernel<TN, TK, EPI_, XF_>), dim3((unsigned)grid), dim3(TN_TPB),                               \
+                     (tn_bg_dyn_lds<TN, TK, EPI_, XF_>()), s, dY, lddy, X, ldx, dW,                                              \
                      lddw, M, N, K, p.tiles_k, p.tiles, p.split, p.slices_per_chunk, p.n_ids, p.xcd ? 1 : 0, SLABS_, a_extent, \
                      b_extent, xs, xh, xn)
   if (p.split == 1) {
@@ -453,6 +487,11 @@ static bool g_tn_dma = true;   // A/B hook (ccn_gemm_tn_use_dma)
 }  // namespace
 
 extern "C" {
+
+int ccn_gemm_tn_background(int lds_bytes) {   // 0 = off; e.g. 86016: one weight-gradient workgroup per CU (see g_tn_bg_lds)
+  g_tn_bg_lds.store(lds_bytes < 0 ? 0 : (lds_bytes > 160 * 1024 ? 160 * 1024 : lds_bytes), std::memory_order_relaxed);
+  return CCN_OK;
+}
 
 int ccn_gemm_tn_use_dma(int on) {   // 0 / 1: the register-staged / LDS-DMA kernels; 2 + mode: tile choice A/B (pick_tile)
   if (on >= 2) g_tn_pick = on - 2;

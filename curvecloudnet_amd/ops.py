@@ -687,7 +687,8 @@ def _wgrad_stream(device):
         return None
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _WGRAD_STREAMS:
-        _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
+        # (CCN_WGRAD_PRIORITY: the side stream's priority, torch convention -- lower number = served first; the default stream is 0)
+        _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("CCN_WGRAD_PRIORITY", "0")))
     return _WGRAD_STREAMS[key]
 
 

@@ -19,6 +19,7 @@ int ccn_frnn_query_mode(int mode); /* A/B hook: 0 = automatic, 1 = one thread pe
 int ccn_gemm_x3_use_persistent(int on); /* A/B hook: 0 = the register-staged kernel for every shape, 2 = no paired 4-wave workgroups (8-wave persistent kernel for every N), 1 = default */
 int ccn_gemm_x3_debug(void* buf);       /* diagnostic: a device buffer of 512 x 4 x 16 uint64 words switches ccn_gemm_nt_x3's software-pipelined kernel to a build that stamps (s_memtime) where every wave's cycles go; NULL = off (tools/x3_stamps.py) */
 int ccn_gemm_tn_use_dma(int on);    /* A/B hook: 0 = always the register-staged split-K kernel of ccn_gemm_tn */
+int ccn_gemm_tn_background(int lds_bytes); /* experiment (round 6): total LDS a weight-gradient workgroup claims (static + unused dynamic); 86016 = ONE per CU, leaving half of the register file and 74 KiB of LDS to the other stream's kernels; 0 = off (default). Same results. */
 int ccn_fps_set_lds_claim(int bytes); /* A/B hook: dynamic LDS a sampling workgroup claims to keep its CU free of GEMM workgroups (default and maximum 98304, 0 = none) */
 int ccn_fps_use_cluster(int on);      /* A/B hook (round 5): 0 = exact FPS with ONE workgroup per cloud whatever its size (the hybrid / streaming forms); default 1 = clouds of more than 16384 points by a cluster of up to four workgroups; 2 = the cluster with agent-scope (sc1) stores even when its members share an XCD */
 int ccn_fps_debug_fault(int mode);    /* test hook (round 6): 1 = member 1 of every cluster of ccn_fps silently leaves before round 1 (its partners run into the poll timeout, ~0.5 s), 2 = it raises the abort word itself and leaves; either way the gated one-workgroup launch re-samples the cloud; 0 = off */
