@@ -15,6 +15,8 @@
 // Built with -ffp-contract=off.
 #include "ccn_common.h"
 
+#include <atomic>
+
 namespace {
 
 constexpr int BUILD_TPB = 256;
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(TEAM_TPB) void grid_query_team_kernel(
   if (count_out && tl == 0) count_out[b * P1 + i] = total < K ? total : K;
 }
 
-static int g_query_mode = 0;   // A/B hook (ccn_frnn_query_mode): 0 auto, 1 thread per query, 2 / 3 teams of 32 / 64 lanes
+static std::atomic<int> g_query_mode{0};   // A/B hook (ccn_frnn_query_mode): 0 auto, 1 thread per query, 2 / 3 teams of 32 / 64 lanes
 
 // ------------------------------------------------------------------ dense idx -> CSR edge list
 __global__ void dense_count_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ cloud_ptr1, int64_t P1,

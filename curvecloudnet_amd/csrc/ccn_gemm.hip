@@ -13,6 +13,8 @@
 // Workgroup = 4 waves; WM waves along M (32 rows each), 4/WM along N.
 #include "ccn_common.h"
 
+#include <atomic>
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -1061,9 +1063,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 1 : 2) void gemm_glds_pers
   }
 }
 
-static bool g_xcd_map = true;  // A-B hook (ccn_gemm_use_dma(3) = persistent kernel with round-robin tiles)
+static std::atomic<bool> g_xcd_map{true};  // A-B hook (ccn_gemm_use_dma(3) = persistent kernel with round-robin tiles)
 
-static int g_pair_opt = 0;      // A-B hook (ccn_gemm_pair_opt)
+static std::atomic<int> g_pair_opt{0};      // A-B hook (ccn_gemm_pair_opt)
 
 __device__ __forceinline__ float act_fwd(float z, int act, float slope) {
   if (act == CCN_ACT_RELU) return z > 0.f ? z : 0.f;
@@ -1677,8 +1679,8 @@ __global__ __launch_bounds__(PR_TPB, 2) void gemm_glds_pair_kernel(const float* 
   }
 }
 
-static void* g_pair_dbg_host = nullptr;
-static bool g_use_pair = true;  // A-B hook (ccn_gemm_use_dma(4) = the 8-wave persistent kernel for N > 64 as well)
+static std::atomic<void*> g_pair_dbg_host{nullptr};
+static std::atomic<bool> g_use_pair{true};  // A-B hook (ccn_gemm_use_dma(4) = the 8-wave persistent kernel for N > 64 as well)
 // from this many 128 x 128 tiles on (measured at 128 / 256 / 512 / 1024: 3168 x 2048 -> 1024 (200 tiles) 87 vs 80 TFLOP/s on
 // the register-staged kernel, 10550 x 1024 -> 1024 (664 tiles) 99 vs 84, 35151 x 512 -> 512 107 vs 88 on the 8-wave kernel)
 constexpr int64_t PAIR_MIN_TILES = 128;
@@ -1773,10 +1775,10 @@ int launch_glds_persistent(const float* A, int64_t lda, const float* W, int64_t 
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-static bool g_force_generic = false;  // test hook (ccn_gemm_force_generic)
-static bool g_use_glds = true;        // test / A-B hook (ccn_gemm_use_dma)
-static bool g_use_persistent = true;  // A-B hook (ccn_gemm_use_dma(2) = DMA without the persistent tile loop)
-static int64_t g_dma_min_k = 64;      // DMA kernels from this K on (A-B hook: ccn_gemm_use_dma(k >= 32) sets it)
+static std::atomic<bool> g_force_generic{false};  // test hook (ccn_gemm_force_generic)
+static std::atomic<bool> g_use_glds{true};        // test / A-B hook (ccn_gemm_use_dma)
+static std::atomic<bool> g_use_persistent{true};  // A-B hook (ccn_gemm_use_dma(2) = DMA without the persistent tile loop)
+static std::atomic<int64_t> g_dma_min_k{64};      // DMA kernels from this K on (A-B hook: ccn_gemm_use_dma(k >= 32) sets it)
 
 template <int BM, int BN, int WM, int ALAY, int BLAY, int EPI>
 int launch_gemm(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,

@@ -17,6 +17,8 @@
 // 2 s + h of its row -- one ds_read_b128, no permutation.
 #include "ccn_common.h"
 
+#include <atomic>
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -954,7 +956,7 @@ inline HtPlan ht_plan(int64_t M, int64_t N, int64_t K) {
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-static int g_h_opt = 0;      // diagnostics (ccn_gemm_h_opt)
+static std::atomic<int> g_h_opt{0};      // diagnostics (ccn_gemm_h_opt)
 
 template <bool F16, bool OUT16>
 int launch_nt_h(const u16* A, int64_t lda, const u16* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,

@@ -377,7 +377,7 @@ struct TnPlan {
 // remainder launch only costs another pass over the operands (measured, M = 1.34 M: 256 x 192 67 -> 99 TFLOP/s, 192 x 128
 // 69 -> 90; 208 k x 256 x 259: 58 -> 94).  mode 0: 64-wide tiles over the whole dimension in that case (the r2a rule);
 // mode 1: 128-wide tiles whenever d > 64.
-static int g_tn_pick = 2;
+static std::atomic<int> g_tn_pick{2};
 
 inline int pick_tile(int64_t d) {
   if (d <= 64) return 64;
@@ -440,14 +440,16 @@ static size_t tn_bg_dyn_lds() {
   const int want = g_tn_bg_lds.load(std::memory_order_relaxed);
   if (want <= tn_static_lds_bytes<TN, TK>()) return 0;
   const int dyn = want - tn_static_lds_bytes<TN, TK>();
-  static std::atomic<int> raised{0};            // (per instantiation: the dynamic bytes allowed so far; a race only repeats the call)
-  if (raised.load(std::memory_order_relaxed) < dyn) {
+  static std::atomic<int> raised_on[CCN_MAX_DEVICES];   // (per instantiation and device: the dynamic bytes allowed so far)
+  std::atomic<int>* const raised = ccn_device_slot(raised_on);
+  if (raised == nullptr) return 0;
+  if (raised->load(std::memory_order_relaxed) < dyn) {
     if (hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<TN, TK, EPI, XF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             dyn) != hipSuccess) {
       (void)hipGetLastError();                  // (not this launch's error)
       return 0;
     }
-    raised.store(dyn, std::memory_order_relaxed);
+    raised->store(dyn, std::memory_order_relaxed);
   }
   return (size_t)dyn;
 }
@@ -482,7 +484,7 @@ int launch_tn(const TnPlan& p, const float* dY, int64_t lddy, const float* X, in
   return CCN_OK;
 }
 
-static bool g_tn_dma = true;   // A/B hook (ccn_gemm_tn_use_dma)
+static std::atomic<bool> g_tn_dma{true};   // A/B hook (ccn_gemm_tn_use_dma)
 
 }  // namespace
 

@@ -20,6 +20,8 @@
 // read from HBM once and from that XCD's L2 afterwards.
 #include "ccn_common.h"
 
+#include <atomic>
+
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(X_TPB, 2) void gemm_x3_kernel(const float* __restri
 // vmcnt retires in issue order, so each iteration issues W(g+1) BEFORE A(g+2): waiting for slice g then leaves exactly
 // the four A copies of slice g+1 in flight.  The epilogue (stores issued and forgotten, BatchNorm partial sums parked in
 // an LDS table that is read out after the next tile's first barrier) is the one of gemm_glds_persistent_kernel.
-static bool g_use_persistent = true;   // A/B hook (ccn_gemm_x3_use_persistent)
+static std::atomic<bool> g_use_persistent{true};   // A/B hook (ccn_gemm_x3_use_persistent)
 constexpr int P_TPB = 512;
 constexpr int P_BM = 256;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -1016,8 +1018,8 @@ __global__ __launch_bounds__(L_TPB, 2) void gemm_x3_lean_kernel(const float* __r
   }
 }
 
-static void* g_x3_dbg_host = nullptr;
-static bool g_use_pair = true;   // A/B hook (ccn_gemm_x3_use_persistent(2) = no paired kernel)
+static std::atomic<void*> g_x3_dbg_host{nullptr};
+static std::atomic<bool> g_use_pair{true};   // A/B hook (ccn_gemm_x3_use_persistent(2) = no paired kernel)
 
 void launch_x3_lean(const float* A, int64_t lda, const __bf16* img, const float* bias, float* Y, int64_t ldy, int64_t M,
                     int64_t N, int64_t K, double* colstats, hipStream_t s) {

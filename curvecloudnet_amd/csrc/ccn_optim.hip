@@ -162,12 +162,14 @@ extern "C" int ccn_nll_loss_fwd(const float* logits, int64_t ld, const int64_t* 
   if (C <= 63) {     // 256 rows x (C + 1) floats of dynamic LDS: 64 KB at C = 63, plus the static reduction scratch
     const size_t dyn = (size_t)NLL_TPB * (C + 1) * sizeof(float);
     if (dyn > 48 * 1024) {   // above the default dynamic-LDS limit: opt in explicitly (as ccn_fps does), not by runtime leniency
-      static bool raised = false;
-      if (!raised) {
+      static std::atomic<int> raised_on[CCN_MAX_DEVICES];
+      std::atomic<int>* const raised = ccn_device_slot(raised_on);
+      CCN_REQUIRE(raised != nullptr, "nll_loss_fwd: cannot name the current device");
+      if (!raised->load(std::memory_order_relaxed)) {
         CCN_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(nll_fwd_kernel<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, NLL_TPB * 64 * (int)sizeof(float)) == hipSuccess,
                     "nll_loss_fwd: cannot raise the dynamic LDS limit");
-        raised = true;
+        raised->store(1, std::memory_order_relaxed);
       }
     }
     hipLaunchKernelGGL(nll_fwd_kernel<true>, dim3((unsigned)nb), dim3(NLL_TPB), (size_t)NLL_TPB * (C + 1) * sizeof(float),

@@ -3,6 +3,9 @@
 // the float64 arclength running sum (A7) and the hash-grid cell offsets (A11).
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
+
+#include <mutex>
 
 #include "ccn_common.h"
 
@@ -17,6 +20,32 @@ void ccn_set_error(const char* fmt, ...) {
 
 extern "C" const char* ccn_last_error(void) { return g_err; }
 extern "C" int ccn_abi_version(void) { return CCN_ABI_VERSION; }
+
+// ONE door for every diagnostics / A-B / test hook (include/ccn_hip_debug.h): serialised by a mutex, so that a hook flipped from
+// one thread never interleaves with another flip; the state behind the hooks is std::atomic, so the launch paths of other threads
+// (the geometry worker of ModelBase.prepare_async beside the main thread) read it without a data race.
+extern "C" int ccn_debug_set(const char* key, int64_t value) {
+  static std::mutex mu;
+  struct Hook {
+    const char* key;
+    int (*fn)(int);
+  };
+  static const Hook hooks[] = {
+      {"gemm_use_dma", ccn_gemm_use_dma},         {"gemm_pair_opt", ccn_gemm_pair_opt},
+      {"gemm_force_generic", ccn_gemm_force_generic}, {"gemm_h_opt", ccn_gemm_h_opt},
+      {"frnn_query_mode", ccn_frnn_query_mode},   {"gemm_x3_use_persistent", ccn_gemm_x3_use_persistent},
+      {"gemm_tn_use_dma", ccn_gemm_tn_use_dma},   {"gemm_tn_background", ccn_gemm_tn_background},
+      {"fps_set_lds_claim", ccn_fps_set_lds_claim}, {"fps_use_cluster", ccn_fps_use_cluster},
+      {"fps_debug_fault", ccn_fps_debug_fault},
+  };
+  CCN_REQUIRE(key != nullptr, "debug_set: null key");
+  CCN_REQUIRE(value >= INT32_MIN && value <= INT32_MAX, "debug_set: %s: value out of range", key);
+  std::lock_guard<std::mutex> lock(mu);
+  for (const Hook& h : hooks)
+    if (strcmp(h.key, key) == 0) return h.fn((int)value);
+  ccn_set_error("debug_set: unknown key '%s'", key);
+  return CCN_ERR_ARG;
+}
 
 namespace {
 

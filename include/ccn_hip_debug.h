@@ -9,6 +9,11 @@
 extern "C" {
 #endif
 
+/* ONE door for the integer hooks below: ccn_debug_set("<name without ccn_>", value), e.g. ccn_debug_set("fps_use_cluster", 0).
+ * Serialised by a mutex; the state behind every hook is std::atomic (the geometry worker thread and the main thread both launch
+ * kernels).  Unknown key: CCN_ERR_ARG.  The individual functions stay for the tests and tools that call them directly. */
+int ccn_debug_set(const char* key, int64_t value);
+
 int ccn_gemm_use_dma(int on);       /* A/B hook: 0 = register-staged kernels only, 2 = LDS-DMA without the persistent tile loop, 3 = persistent with round-robin tiles, 4 = the 8-wave persistent kernel for every N (no paired 4-wave workgroups), 1 = default */
 int ccn_gemm_pair_debug(void* buf);  /* diagnostic: a device buffer of 512 x 4 x 16 uint64 words switches ccn_gemm_nt's paired kernel to a build that stamps (s_memtime) where every wave's cycles go; NULL = off (tools/pair_stamps.py) */
 int ccn_gemm_pair_opt(int bits);    /* A/B hook of the paired kernel's LAUNCHER: bit 2 = one workgroup per CU, bit 6 = no split of a wide product into a 128-wide and a 64-wide launch, bit 8 = the 8-wave kernel for N <= 64, bit 9 = no tail split even with scratch (the in-kernel experiments of rounds 2-3 are no longer compiled) */

@@ -95,3 +95,15 @@ def test_frnn_compat_offers_the_third_party_signatures():
             sys.modules.pop("frnn", None)
         else:
             sys.modules["frnn"] = saved
+
+
+def test_debug_hooks_go_through_one_door():
+    """include/ccn_hip_debug.h: ccn_debug_set(key, value) serialises every A/B / test hook (VERDICT r5 Next 9); unknown keys and
+    out-of-range values are refused with a message."""
+    from curvecloudnet_amd import _lib
+    lib = _lib.lib()
+    for key in (b"gemm_use_dma", b"gemm_pair_opt", b"frnn_query_mode", b"fps_use_cluster", b"fps_debug_fault", b"gemm_tn_background"):
+        assert lib.ccn_debug_set(key, 1 if key in (b"gemm_use_dma", b"fps_use_cluster") else 0) == 0, key
+    assert lib.ccn_debug_set(b"no_such_hook", 1) < 0 and b"unknown key" in lib.ccn_last_error()
+    assert lib.ccn_debug_set(b"gemm_pair_opt", 1 << 40) < 0 and b"out of range" in lib.ccn_last_error()
+    assert lib.ccn_debug_set(None, 0) < 0
