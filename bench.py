@@ -42,12 +42,15 @@ def gemm_label(name, ints, nulls=()):
     if name in ("gemm_nt_xf", "gemm_tn_ws_xf", "gemm_nt_acc", "gemm_nt_red", "conv_rows_nt", "conv_rows_tn", "conv_rows_nt_h", "conv_rows_tn_h"):
         return name, flops
     ld_a, ld_b = ints[0], ints[1]
-    if name == "gemm_nt_h":       # (16-bit rows: the LDS-DMA kernels of csrc/ccn_gemm_h.hip; <F16, OUT16, DIAG, BN> as launch_nt_h
-        # picks them: 128 x 64 tiles for an fp32 result of width <= 64 or with a last 128-wide tile at most half used)
-        narrow = not ints[7] and (n <= 64 or (n % 128 != 0 and n % 128 <= 64))
-        return "gemm_h_pair_kernel<%s, %s, false, %d>" % ("true" if ints[6] else "false",
-                                                          "false" if narrow else ("true" if ints[7] else "false"),
-                                                          64 if narrow else 128), flops
+    if name in ("gemm_nt_h", "gemm_nt_h_stats", "gemm_nt_h_bnact"):
+        # (16-bit rows: the LDS-DMA kernels of csrc/ccn_gemm_h.hip; <F16, OUT16, DIAG, BN, FUSE> as launch_nt_h / launch_nt_h_fused
+        # pick them: 128 x 64 tiles for an fp32 result of width <= 64 or with a last 128-wide tile at most half used; FUSE 1 = the
+        # statistics pass, 2 = BatchNorm + activation in the epilogue)
+        f16, out16, fuse = ((ints[6], ints[7], 0) if name == "gemm_nt_h" else (ints[5], 0, 1) if name == "gemm_nt_h_stats"
+                            else (ints[8], ints[9], 2))
+        narrow = not out16 and (n <= 64 or (n % 128 != 0 and n % 128 <= 64))
+        return "gemm_h_pair_kernel<%s, %s, false, %d, %d>" % ("true" if f16 else "false", "true" if out16 and not narrow else "false",
+                                                              64 if narrow else 128, fuse), flops
     if name in ("gemm_tn_h", "gemm_tn_h_xf16"):
         return "gemm_h_tn_kernel", flops
     if name == "gemm_tn_ws":
@@ -98,6 +101,12 @@ def gemm_bytes(name, ints):
     if name == "gemm_nt_h":
         _, _, _, m, n, k, _, out16 = ints[:8]
         return m * (2.0 * k + (2.0 if out16 else 4.0) * n) + 2.0 * n * k
+    if name == "gemm_nt_h_stats":          # (lda, ldw, M, N, K, f16): operands read, nothing written
+        m, n, k = ints[2:5]
+        return 2.0 * (m * k + n * k)
+    if name == "gemm_nt_h_bnact":          # (lda, ldw, act, ldz, ldt, M, N, K, f16, out16): + the 16-bit pre-activation when ldt
+        m, n, k = ints[5:8]
+        return m * (2.0 * k + ((2.0 if ints[9] else 4.0) + (2.0 if ints[4] else 0.0)) * n) + 2.0 * n * k
     if name in ("gemm_tn_h", "gemm_tn_h_xf16"):
         _, _, _, m, n, k = ints[:6]
         return 2.0 * m * (n + k) + 8.0 * n * k
@@ -428,7 +437,11 @@ def parse_args():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-second-line", action="store_true",
                     help="skip the bf16x3 second line the default (fp32 headline, 1 GPU) run appends as `second_line`")
+    ap.add_argument("--no-third-line", action="store_true",
+                    help="skip BASELINE configs[2] (nuScenes section, bf16 storage path) appended as `third_line` by the default run")
     args = ap.parse_args()
+    if args.no_second_line:
+        args.no_third_line = True           # (the A/B scripts pass --no-second-line to time the headline alone)
     preset = BASELINE_PRESETS.get(args.baseline_config, {})
     defaults = dict(config="kitti", clouds_per_gpu=8, curves=2048, mixed_lengths=False, mlp_dtype="fp32")
     for k, dflt in defaults.items():
@@ -492,6 +505,21 @@ def main():
                                      loss=second["config"]["loss"],
                                      device_mallocs_in_timed_region=second["config"]["device_mallocs_in_timed_region"])
         ops.set_mlp_dtype(args.mlp_dtype)
+        # The THIRD LINE (VERDICT r5 Next 4): BASELINE configs[2] -- the nuScenes model section, 16 x ~35 k-point clouds, bf16 MLP
+        # MFMA path (16-bit storage, BatchNorm layers without their fp32 intermediate) -- so that the driver's record carries it.
+        if not args.no_third_line:
+            gc.collect()
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats(dev)
+            args3 = copy.copy(args)
+            for k, v in BASELINE_PRESETS[2].items():
+                setattr(args3, k, v)
+            args3.no_cpu_baseline, args3.steps, args3.warmup = True, min(args.steps, 12), min(args.warmup, 3)
+            third = run(args3, rank, world, local_rank, dev, quiet=True)
+            result["third_line"] = dict({k: third[k] for k in keep if k in third},
+                                        workload=third["config"]["workload"], loss=third["config"]["loss"],
+                                        device_mallocs_in_timed_region=third["config"]["device_mallocs_in_timed_region"])
+            ops.set_mlp_dtype(args.mlp_dtype)
     print(json.dumps(result))
 
 
@@ -678,8 +706,9 @@ def run(args, rank, world, local_rank, dev, quiet=False):
         # run on): an event pair costs ~3 us of GPU time -- over all ~2300 launches of a step 4 % of the step, over every
         # GEMM launch of both streams, or over all ~130 launches of the dominant kernel, still ~1 % (70.8 vs 71.5 clouds/s)
         dominant = {"fp32": "gemm_glds_pair_kernel",
-                    "bf16": "gemm_h_pair_kernel<false, false, false, 128>" if ops.STORE16 else "gemm_bf16_kernel<128, 128",
-                    "fp16": "gemm_h_pair_kernel<true, false, false, 128>" if ops.STORE16 else "gemm_bf16_kernel<128, 128",
+                    # (16-bit storage: every instantiation of the one NT kernel -- plain, statistics pass, fused epilogue, 16-bit result)
+                    "bf16": "gemm_h_pair_kernel<false" if ops.STORE16 else "gemm_bf16_kernel<128, 128",
+                    "fp16": "gemm_h_pair_kernel<" if ops.STORE16 else "gemm_bf16_kernel<128, 128",
                     "bf16x3": "gemm_x3_lean_kernel"}[args.mlp_dtype]
 
         def only_dominant(name, cargs):
@@ -842,8 +871,11 @@ def run(args, rank, world, local_rank, dev, quiet=False):
                                   "unit": "TFLOP/s", "frac": achieved / peak,
                                   "traffic": tr["bytes_per_launch"] if tr else None, "traffic_source": tr,
                                   "flops_per_launch": top.get("flops_per_launch", top["flops"] / top["launches"]),
-                                  "kernel": name, "avg_launch_ms": top.get("avg_launch_ms", top["ms"] / top["launches"]),
-                                  "launches": top["launches"], "launch_sites": top.get("sites"),
+                                  "kernel": (name if not dominant.endswith(("<", "<false")) else
+                                             "gemm_h_pair_kernel (every instantiation the step launches: plain, statistics pass, "
+                                             "fused BatchNorm epilogue, 16-bit result; the most expensive: %s)" % name),
+                                  "avg_launch_ms": top.get("avg_launch_ms", top["ms"] / top["launches"]),
+                                  "launches": len(records), "launch_sites": top.get("sites"),
                                   "share_of_kernel_time": full_share,
                                   "empty_bracket_us": round(1e3 * bracket, 2),
                                   "launches_note": "every %d-th launch of this kernel inside the timed region is bracketed by "

@@ -31,6 +31,8 @@ GEMM_MNK = {
     "gemm_tn_ws": lambda i: i[3:6], "gemm_nt_bf16": lambda i: i[3:6], "gemm_nt_f16": lambda i: i[3:6],
     "gemm_tn_bf16": lambda i: i[3:6], "gemm_nt_x3": lambda i: i[3:6],
     "gemm_nt_h": lambda i: i[3:6], "gemm_tn_h": lambda i: i[3:6], "gemm_tn_h_xf16": lambda i: i[3:6],
+    "gemm_nt_h_stats": lambda i: i[2:5],       # (lda, ldw, M, N, K, f16): the statistics pass, nothing written
+    "gemm_nt_h_bnact": lambda i: i[5:8],       # (lda, ldw, act, ldz, ldt, M, N, K, f16, out16): product + BatchNorm + activation
     "gemm_nt_xf": lambda i: i[4:7],            # (lda, a_act, ldw, ldy, M, N, K)
     "gemm_nt_red": lambda i: i[3:6],           # (lda, ldw, ldy, M, N, K, ldyp, act): + the y tile of the previous layer
     "gemm_tn_ws_xf": lambda i: i[4:7],         # (lddy, ldx, x_act, lddw, M, N, K, workspace_bytes)
@@ -50,6 +52,10 @@ def _gemm_cost(name, ints):
     m, n, k = gemm_shape(name, ints)
     if name == "gemm_nt_h":                    # 16-bit A and W; Y fp32, or 16-bit when out16 (ints[7])
         return _gemm(m, n, k, el_a=2.0, el_w=2.0, el_y=2.0 if len(ints) > 7 and ints[7] else F32)
+    if name == "gemm_nt_h_stats":              # A and W read, column sums out
+        return 2.0 * m * n * k, 2.0 * (m * k + n * k)
+    if name == "gemm_nt_h_bnact":              # A and W read, z written as fp32 or 16-bit rows (out16: ints[9]), + t (16-bit) when ldt
+        return _gemm(m, n, k, el_a=2.0, el_w=2.0, el_y=(2.0 if len(ints) > 9 and ints[9] else F32) + (2.0 if ints[4] else 0.0))
     if name in ("gemm_tn_h", "gemm_tn_h_xf16"):  # dW (fp32, read + written) += dY^T X on 16-bit rows: M = rows
         return 2.0 * m * n * k, 2.0 * m * (n + k) + 2 * F32 * n * k
     if name == "conv_rows_nt_h":               # rows overlap: M x lda distinct 16-bit elements of A
@@ -87,6 +93,10 @@ _TABLE = {
     "bn_act_bwd_apply_ex": ("batchnorm", lambda i, r: 3 * F32 * _rc(i, 2, 3)),
     "bn_act_bwd_apply_count": ("batchnorm", lambda i, r: 3 * F32 * _rc(i, 2, 3)),
     "bn_act_bwd_apply_h": ("batchnorm", lambda i, r: (F32 + 2.0 + 2.0) * _rc(i, 3, 4)),   # (dz16, lddz, ldy, rows, C, …)
+    # round 6, from the layer's OUTPUT z (or its 16-bit pre-activation): (dz16, lddz, zt, z_pre, ldz, rows, C, act, …): dz (2 / 4 B),
+    # z (2 B, 4 when zt == 3) [-> dy (2 B)]
+    "bn_act_bwd_reduce_hz": ("batchnorm", lambda i, r: ((2.0 if i[0] else F32) + (F32 if i[2] == 3 else 2.0)) * _rc(i, 5, 6)),
+    "bn_act_bwd_apply_hz": ("batchnorm", lambda i, r: ((2.0 if i[0] else F32) + (F32 if i[2] == 3 else 2.0) + 2.0) * _rc(i, 5, 6)),
     "colsum": ("batchnorm", lambda i, r: F32 * _rc(i, 1, 2)),                            # (ldx, rows, C)
     "colstats_weighted": ("batchnorm", lambda i, r: F32 * _rc(i, 1, 2)),
     "bn_finalize": ("batchnorm", lambda i, r: 16.0 * (i[0] / 128.0 + 1) * i[1]),         # (rows, C): partial rows of doubles

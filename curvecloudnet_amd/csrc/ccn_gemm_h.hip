@@ -59,6 +59,17 @@ __device__ __forceinline__ float from_h(u16 v) {
   return __builtin_bit_cast(float, (uint32_t)v << 16);
 }
 
+__device__ __forceinline__ float act_fwd_h(float z, int act, float slope) {
+  if (act == CCN_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (act == CCN_ACT_LEAKY) return z > 0.f ? z : z * slope;
+  return z;
+}
+__device__ __forceinline__ float act_grad_h(float z, int act, float slope) {
+  if (act == CCN_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == CCN_ACT_LEAKY) return z > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
 // OUT16: the result is written as 16-bit (a data gradient): the MFMA operands are SWAPPED, so that a lane holds one output
 // ROW and four consecutive COLUMNS per register quad -- 16 eight-byte stores per lane and tile instead of 64 two-byte ones
 // (the sums per output element are the same fma chains in the same k order: a*b commutes).  No statistics in that form.
@@ -69,13 +80,30 @@ __device__ __forceinline__ float from_h(u16 v) {
 // cannot have copies land past its own pending stores (vmcnt retires in order), so the store burst of one tile only
 // overlaps OTHER workgroups' loads: more, smaller workgroups per CU keep more of both in flight.  The A tile is then read
 // by N / 64 column tiles instead of N / 128: they sit on one XCD in the same step (tile_of) and share it through that L2.
-template <bool F16, bool OUT16, bool DIAG = false, int BN = HB_BN>
+// FUSE (round 6: the forward of a BatchNorm layer WITHOUT its fp32 intermediate -- VERDICT r3-r5).  The kernel is HBM-bound at the
+// network's widths (MFMA pipes 17 % busy, 63 % of its bytes the fp32 result the BatchNorm pass re-reads), so the product is
+// computed twice instead of stored once:  FUSE 1 = statistics only -- the fp32-result form with its stores compiled out (2 K bytes
+// per row read, nothing written);  FUSE 2 = z = act(acc * ep_scale[n] + ep_shift[n]) in the epilogue (the expression of
+// ccn_bn_act_fwd_h on the same fp32 sums: the same bits as product + BatchNorm pass), written as fp32 rows (!OUT16: a lane holds
+// a column, its two constants are registers) or as 16-bit rows (OUT16: a lane holds a row, the constants of the tile's columns
+// sit in LDS -- the statistics table, unused in this form -- and are read four at a time, one broadcast ds_read_b128 each).
+// Per row: 4 K + 2 N bytes instead of 2 K + 10 N.
+template <bool F16, bool OUT16, bool DIAG = false, int BN = HB_BN, int FUSE = 0>
 __global__ __launch_bounds__(HB_TPB, BN == 128 ? 2 : 3) void gemm_h_pair_kernel(const u16* __restrict__ A, int64_t lda,
                                                                 const u16* __restrict__ B, int64_t ldb,
                                                                 const float* __restrict__ bias, void* __restrict__ Cv,
                                                                 int64_t ldc, int64_t M, int64_t N, int64_t K, int64_t tiles,
                                                                 int64_t gn, int xcd_order, double* __restrict__ colstats,
-                                                                int opt_rt, int64_t a_extent) {
+                                                                int opt_rt, int64_t a_extent,
+                                                                const float* __restrict__ ep_scale,
+                                                                const float* __restrict__ ep_shift, int ep_act, float ep_slope,
+                                                                void* __restrict__ Tv, int64_t ldt) {
+  // Tv (FUSE 3 = FUSE 2 with two results, OUT16 only): a second 16-bit result, the PRE-activation t = acc * scale + shift.  A ReLU layer needs it for its
+  // backward pass -- xhat of a clipped element is not recoverable from z = 0, and BatchNorm's backward needs xhat of EVERY row --
+  // a LeakyReLU layer does not (z is invertible).  2 N more bytes per row, still 6 N - 2 K fewer than the three-kernel form.
+  static_assert(FUSE == 0 || !DIAG, "the fused forms have no diagnostics build");
+  static_assert(FUSE != 1 || !OUT16, "statistics come from the fp32-result layout");
+  static_assert(FUSE != 3 || OUT16, "the pre-activation output exists in the 16-bit form only");
   // a_extent: 16-bit elements readable from the start of an A row (= lda, or K when rows overlap: ccn_conv_rows_nt_h)
   // opt (diagnostics, ccn_gemm_h_opt; results WRONG when set): bit 0 = no epilogue stores, bit 1 = no wait for the LDS-DMA
   const int opt = DIAG ? opt_rt : 0;
@@ -263,12 +291,48 @@ __global__ __launch_bounds__(HB_TPB, BN == 128 ? 2 : 3) void gemm_h_pair_kernel(
       if (acc[0][0][0] == 1.2345e30f) reinterpret_cast<float*>(Cv)[0] = acc[1][NTW - 1][3] + acc[0][NTW - 1][5] + acc[1][0][7];   // (keeps the MFMAs alive)
       continue;
     }
-    if (OUT16 && (N & 7) == 0 && (ldc & 7) == 0 && ((uintptr_t)Cv & 15) == 0) {
+    if (FUSE >= 2 && OUT16) {
+      // the tile's BatchNorm constants: [scale | shift][BN] in the (otherwise unused) statistics table; the previous tile's readers
+      // are at least one slice barrier behind, this tile's readers wait at the barrier below
+      for (int c = threadIdx.x; c < BN; c += HB_TPB) {
+        const int64_t n = n0 + c;
+        stat_part[c] = n < N ? ep_scale[n] : 0.f;
+        stat_part[BN + c] = n < N ? ep_shift[n] : 0.f;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int col = wn * 64 + t * 32 + 8 * q4 + 4 * h;
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(&stat_part[col]);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(&stat_part[BN + col]);
+#pragma unroll
+          for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[ab][t][4 * q4 + e] = acc[ab][t][4 * q4 + e] * sc[e] + sh[e];
+        }
+    }
+    // (FUSE 2 with a pre-activation output: the store code below runs twice -- t into Tv, then z = act(t) into Cv)
+#pragma unroll
+    for (int pass = (FUSE == 3) ? 0 : 1; pass < 2; ++pass) {
+    void* const Ov = pass == 0 ? Tv : Cv;
+    const int64_t ldo = pass == 0 ? ldt : ldc;
+    if (FUSE >= 2 && OUT16 && pass == 1) {
+#pragma unroll
+      for (int ab = 0; ab < 2; ++ab)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[ab][t][r] = act_fwd_h(acc[ab][t][r], ep_act, ep_slope);
+    }
+    if (OUT16 && (N & 7) == 0 && (ldo & 7) == 0 && ((uintptr_t)Ov & 15) == 0) {
       // Through LDS, so that the tile leaves in whole 256-byte rows (the direct form below writes 8 bytes into each of 32
       // rows per instruction: the store phase ran at 3.3 TB/s against 5.7 for full lines, tools/bench_gemm_h_opt.py).  The
       // stage the last slice was read from is free until the next iteration's copies (issued behind that iteration's
       // barrier): [128 rows][256 bytes], 16-byte chunk c of row r at chunk c ^ (r & 15).
-      u16* const C = reinterpret_cast<u16*>(Cv);
+      u16* const C = reinterpret_cast<u16*>(Ov);
       const uint32_t tbase = lds_base + (uint32_t)(((g - 1) & 1) * STAGE * 2);
       __builtin_amdgcn_s_barrier();            // every wave has read its last fragments of that stage
 #pragma unroll
@@ -295,13 +359,13 @@ __global__ __launch_bounds__(HB_TPB, BN == 128 ? 2 : 3) void gemm_h_pair_kernel(
         asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(tbase + (uint32_t)(r * 256 + ((c ^ (r & 15)) << 4))) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int64_t m = m0 + r, n = n0 + 8 * c;
-        if (m < M && n < N) *reinterpret_cast<uint4*>(C + m * ldc + n) = v;
+        if (m < M && n < N) *reinterpret_cast<uint4*>(C + m * ldo + n) = v;
       }
       continue;      // (the next iteration's barrier sits between these reads and the copies that reuse the stage)
     }
     if (OUT16) {
       // D[p][q] of mfma(B-fragment, A-fragment): p = column n (registers: (r&3) + 8*(r>>2) + 4*h), q = row m (lane i)
-      u16* const C = reinterpret_cast<u16*>(Cv);
+      u16* const C = reinterpret_cast<u16*>(Ov);
 #pragma unroll
       for (int ab = 0; ab < 2; ++ab) {
         const int64_t m = m0 + wm * 64 + ab * 32 + i;
@@ -311,7 +375,7 @@ __global__ __launch_bounds__(HB_TPB, BN == 128 ? 2 : 3) void gemm_h_pair_kernel(
           for (int q4 = 0; q4 < 4; ++q4) {
             const int64_t n = n0 + wn * 64 + t * 32 + 8 * q4 + 4 * h;
             if (m < M) {
-              u16* const dst = C + m * ldc + n;
+              u16* const dst = C + m * ldo + n;
               const u16 v0 = to_h<F16>(acc[ab][t][4 * q4 + 0]), v1 = to_h<F16>(acc[ab][t][4 * q4 + 1]);
               const u16 v2 = to_h<F16>(acc[ab][t][4 * q4 + 2]), v3 = to_h<F16>(acc[ab][t][4 * q4 + 3]);
               if (n + 3 < N) {
@@ -326,33 +390,48 @@ __global__ __launch_bounds__(HB_TPB, BN == 128 ? 2 : 3) void gemm_h_pair_kernel(
       }
       continue;
     }
+    break;
+    }      // (passes)
+    if (OUT16) continue;
     float* const C = reinterpret_cast<float*>(Cv);
     const bool interior = m0 + HB_BM <= M && n0 + BN <= N;
+    // The statistics table is read out by waves 0-1 behind the FIRST slice barrier of the next tile and rewritten in that tile's
+    // epilogue: with one slice per tile (K <= 64) nothing but the readers' own speed lies between the two.  The storing forms are
+    // thousands of cycles of store issue away from the rewrite; the statistics-only form is not (found as a forward that was not
+    // repeatable on the 64 -> 64 head of the nuScenes section): it takes a barrier here.
+    if (TT == 1 && colstats != nullptr) __builtin_amdgcn_s_barrier();      // (every form: a barrier per tile at K <= 64 only)
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int ncol = wn * (BN / 2) + t * 32 + i;
       const int64_t n = n0 + ncol;
       float s1 = 0.f, s2 = 0.f;
+      float esc = 0.f, esh = 0.f;
+      if (FUSE == 2) {
+        esc = n < N ? ep_scale[n] : 0.f;
+        esh = n < N ? ep_shift[n] : 0.f;
+      }
 #pragma unroll
       for (int ab = 0; ab < 2; ++ab) {
         float* const crow = C + (m0 + wm * 64 + ab * 32 + 4 * h) * ldc + n;
         if (interior) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const float v = acc[ab][t][r];
-            crow[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;
+            float v = acc[ab][t][r];
+            if (FUSE == 2) v = act_fwd_h(v * esc + esh, ep_act, ep_slope);
+            if (FUSE != 1) crow[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;
             s1 += v;
-            s2 += v * v;
+            s2 = __builtin_fmaf(v, v, s2);      // (explicitly fused: the storing and the statistics-only build must agree to the bit)
           }
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int64_t m = m0 + wm * 64 + ab * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             if (m < M && n < N) {
-              const float v = acc[ab][t][r];
-              C[m * ldc + n] = v;
+              float v = acc[ab][t][r];
+              if (FUSE == 2) v = act_fwd_h(v * esc + esh, ep_act, ep_slope);
+              if (FUSE != 1) C[m * ldc + n] = v;
               s1 += v;
-              s2 += v * v;
+              s2 = __builtin_fmaf(v, v, s2);      // (explicitly fused: the storing and the statistics-only build must agree to the bit)
             }
           }
         }
@@ -422,6 +501,40 @@ __device__ __forceinline__ void load8h(const u16* __restrict__ p, bool vec, int6
     for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? from_h<false>(p[e]) : 0.f;
   }
 }
+__device__ __forceinline__ void load8f16(const u16* __restrict__ p, bool vec, int64_t c0, int64_t C, float (&v)[8]) {   // fp16
+  if (vec) {
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+    const uint32_t qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[2 * e] = from_h<true>((u16)(qq[e] & 0xffffu));
+      v[2 * e + 1] = from_h<true>((u16)(qq[e] >> 16));
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? from_h<true>(p[e]) : 0.f;
+  }
+}
+// The second operand of the BatchNorm-backward passes.  YT 0: the fp32 PRE-normalisation product y (rounds 3-5).  YT 1 / 2 / 3
+// (round 6, layers whose forward ran ccn_gemm_nt_h_bnact and never wrote y): the layer's OUTPUT z = act(t), t = y scale + shift,
+// as bf16 / fp16 / fp32 rows -- t = act^-1(z) (ReLU: z where z > 0, and act'(t) = 0 elsewhere, so nothing else is needed;
+// LeakyReLU: z / slope where z <= 0), xhat = (t - beta) / gamma = t * xa + xb with xa = rstd / scale, xb = -(shift / scale + mean) rstd
+// (gamma = 0 makes xhat unrecoverable AND dy = 0: xa = xb = 0 there).  ld in elements of the operand's own type.
+template <int YT>
+__device__ __forceinline__ void load_y8(const void* __restrict__ Yv, int64_t row_off, bool vec, int64_t c0, int64_t C, float (&v)[8]) {
+  if (YT == 0 || YT == 3) load8(reinterpret_cast<const float*>(Yv) + row_off, vec, c0, C, v);
+  else if (YT == 1) load8h(reinterpret_cast<const u16*>(Yv) + row_off, vec, c0, C, v);
+  else load8f16(reinterpret_cast<const u16*>(Yv) + row_off, vec, c0, C, v);
+}
+template <int YT>
+__device__ __forceinline__ bool y8_vec_ok(const void* Yv, int64_t ldy, bool full) {
+  return full && ((YT == 0 || YT == 3) ? (ldy & 3) == 0 : (ldy & 7) == 0) && ((uintptr_t)Yv & 15) == 0;
+}
+__device__ __forceinline__ float act_inv_h(float z, int act, float slope) {
+  if (act == CCN_ACT_LEAKY) return z > 0.f ? z : z / slope;
+  return z;          // (ReLU: z = 0 stands for every t <= 0; act'(0) = 0 makes the choice irrelevant)
+}
+
 template <bool F16>
 __device__ __forceinline__ void store8h(u16* __restrict__ p, const float (&v)[8]) {
   uint32_t w[4];
@@ -521,16 +634,6 @@ __global__ __launch_bounds__(256) void transpose_cast_h_kernel(const float* __re
   }
 }
 
-__device__ __forceinline__ float act_fwd_h(float z, int act, float slope) {
-  if (act == CCN_ACT_RELU) return z > 0.f ? z : 0.f;
-  if (act == CCN_ACT_LEAKY) return z > 0.f ? z : z * slope;
-  return z;
-}
-__device__ __forceinline__ float act_grad_h(float z, int act, float slope) {
-  if (act == CCN_ACT_RELU) return z > 0.f ? 1.f : 0.f;
-  if (act == CCN_ACT_LEAKY) return z > 0.f ? 1.f : slope;
-  return 1.f;
-}
 
 // z = act(y * scale + shift) written as 16-bit rows (the expression of ccn_bn_act_fwd, then ONE rounding); padding columns
 // [C, ldz) zeroed
@@ -563,12 +666,13 @@ __global__ __launch_bounds__(EW_TPB) void bn_act_fwd_h_kernel(const float* __res
 // BatchNorm + activation backward, second pass: dY (bf16 rows) from dZ (fp32 or bf16), y and the column sums of the first
 // pass -- the expression of bn_act_bwd_apply_kernel, then ONE rounding (both consumers of dY, the data- and the weight-
 // gradient product, round it to bf16 anyway in the 16-bit modes).  DZ16: dZ is bf16 (a 16-bit activation's gradient).
-template <bool F16, bool DZ16>
+template <bool F16, bool DZ16, int YT = 0>
 __global__ __launch_bounds__(EW_TPB) void bn_act_bwd_apply_h_kernel(
-    const void* __restrict__ dZv, int64_t lddz, const float* __restrict__ Y, int64_t ldy, int64_t rows, int64_t C,
+    const void* __restrict__ dZv, int64_t lddz, const void* __restrict__ Y, int64_t ldy, int64_t rows, int64_t C,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ rstd, int act, float slope, const double* __restrict__ sums, int training, float inv_n,
-    u16* __restrict__ dY, int64_t lddy, float* __restrict__ dgamma, float* __restrict__ dbeta, int acc_params, int cpb, int rpp) {
+    u16* __restrict__ dY, int64_t lddy, float* __restrict__ dgamma, float* __restrict__ dbeta, int acc_params, int cpb, int rpp,
+    int pre = 0) {
   const int ch = threadIdx.x % cpb, rr = threadIdx.x / cpb;
   const int64_t c0 = ((int64_t)blockIdx.y * cpb + ch) * 8;
   if (rr >= rpp || c0 >= lddy) return;
@@ -577,6 +681,12 @@ __global__ __launch_bounds__(EW_TPB) void bn_act_bwd_apply_h_kernel(
   for (int e = 0; e < 8; ++e) {
     const int64_t c = c0 + e < C ? c0 + e : C - 1;
     sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; rs[e] = rstd[c];
+    if (YT != 0) {      // (sh, mu reused as xa, xb: xhat = t * xa + xb)
+      const float isc = sc[e] != 0.f ? 1.f / sc[e] : 0.f;
+      const float xa = rs[e] * isc, xb = sc[e] != 0.f ? -(sh[e] * isc + mu[e]) * rs[e] : 0.f;
+      sh[e] = xa;
+      mu[e] = xb;
+    }
     m1[e] = (float)sums[c] * inv_n;
     m2[e] = (float)sums[C + c] * inv_n;
     if (blockIdx.x == 0 && rr == 0 && c0 + e < C) {   // parameter gradients (acc_params: add into gradient-bucket views)
@@ -585,19 +695,27 @@ __global__ __launch_bounds__(EW_TPB) void bn_act_bwd_apply_h_kernel(
     }
   }
   const bool full = c0 + 8 <= C;
-  const bool yvec = full && (ldy & 3) == 0 && ((uintptr_t)Y & 15) == 0;
+  const bool yvec = y8_vec_ok<YT>(Y, ldy, full);
   const bool gvec = full && (DZ16 ? ((lddz & 7) == 0) : ((lddz & 3) == 0)) && ((uintptr_t)dZv & 15) == 0;
   const int64_t r0 = (int64_t)blockIdx.x * EW_ROWS;
   const int64_t r1 = r0 + EW_ROWS < rows ? r0 + EW_ROWS : rows;
   for (int64_t r = r0 + rr; r < r1; r += rpp) {
     float y[8], gz[8], o[8];
-    load8(Y + r * ldy + c0, yvec, c0, C, y);
+    load_y8<YT>(Y, r * ldy + c0, yvec, c0, C, y);
     if (DZ16) load8h(reinterpret_cast<const u16*>(dZv) + r * lddz + c0, gvec, c0, C, gz);
     else load8(reinterpret_cast<const float*>(dZv) + r * lddz + c0, gvec, c0, C, gz);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float g = gz[e] * act_grad_h(y[e] * sc[e] + sh[e], act, slope);
-      const float v = training ? sc[e] * (g - m1[e] - (y[e] - mu[e]) * rs[e] * m2[e]) : sc[e] * g;
+      float g, xhat;
+      if (YT == 0) {
+        g = gz[e] * act_grad_h(y[e] * sc[e] + sh[e], act, slope);
+        xhat = (y[e] - mu[e]) * rs[e];
+      } else {
+        const float t = pre ? y[e] : act_inv_h(y[e], act, slope);
+        g = gz[e] * act_grad_h(t, act, slope);
+        xhat = t * sh[e] + mu[e];
+      }
+      const float v = training ? sc[e] * (g - m1[e] - xhat * m2[e]) : sc[e] * g;
       o[e] = c0 + e < C ? v : 0.f;
     }
     store8h<F16>(dY + r * lddy + c0, o);
@@ -605,13 +723,14 @@ __global__ __launch_bounds__(EW_TPB) void bn_act_bwd_apply_h_kernel(
 }
 
 // first pass with a bf16 dZ: column sums of g = dZ * act'(u) and of g * xhat; one fp64 partial row per 128-row workgroup
-__global__ __launch_bounds__(EW_TPB) void bn_act_bwd_reduce_h_kernel(const u16* __restrict__ dZ, int64_t lddz,
-                                                                     const float* __restrict__ Y, int64_t ldy, int64_t rows,
+template <bool DZ16 = true, int YT = 0>
+__global__ __launch_bounds__(EW_TPB) void bn_act_bwd_reduce_h_kernel(const void* __restrict__ dZ, int64_t lddz,
+                                                                     const void* __restrict__ Y, int64_t ldy, int64_t rows,
                                                                      int64_t C, const float* __restrict__ scale,
                                                                      const float* __restrict__ shift,
                                                                      const float* __restrict__ mean,
                                                                      const float* __restrict__ rstd, int act, float slope,
-                                                                     double* __restrict__ partial, int cpb, int rpp) {
+                                                                     double* __restrict__ partial, int cpb, int rpp, int pre = 0) {
   __shared__ float red[2][EW_TPB * 8];          // [sum | sum * xhat][row group rr][chunk ch][8]
   const int ch = threadIdx.x % cpb, rr = threadIdx.x / cpb;
   const int64_t c0 = ((int64_t)blockIdx.y * cpb + ch) * 8;
@@ -625,21 +744,35 @@ __global__ __launch_bounds__(EW_TPB) void bn_act_bwd_reduce_h_kernel(const u16* 
     for (int e = 0; e < 8; ++e) {
       const int64_t c = c0 + e < C ? c0 + e : C - 1;
       sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; rs[e] = rstd[c];
+      if (YT != 0) {      // (sh, mu reused as xa, xb: xhat = t * xa + xb, see load_y8)
+        const float isc = sc[e] != 0.f ? 1.f / sc[e] : 0.f;
+        const float xa = rs[e] * isc, xb = sc[e] != 0.f ? -(sh[e] * isc + mu[e]) * rs[e] : 0.f;
+        sh[e] = xa;
+        mu[e] = xb;
+      }
     }
     const bool full = c0 + 8 <= C;
-    const bool yvec = full && (ldy & 3) == 0 && ((uintptr_t)Y & 15) == 0;
-    const bool gvec = full && (lddz & 7) == 0 && ((uintptr_t)dZ & 15) == 0;
+    const bool yvec = y8_vec_ok<YT>(Y, ldy, full);
+    const bool gvec = full && (DZ16 ? (lddz & 7) == 0 : (lddz & 3) == 0) && ((uintptr_t)dZ & 15) == 0;
     const int64_t r0 = (int64_t)blockIdx.x * EW_ROWS;
     const int64_t r1 = r0 + EW_ROWS < rows ? r0 + EW_ROWS : rows;
     for (int64_t r = r0 + rr; r < r1; r += rpp) {
       float y[8], gz[8];
-      load8(Y + r * ldy + c0, yvec, c0, C, y);
-      load8h(dZ + r * lddz + c0, gvec, c0, C, gz);
+      load_y8<YT>(Y, r * ldy + c0, yvec, c0, C, y);
+      if (DZ16) load8h(reinterpret_cast<const u16*>(dZ) + r * lddz + c0, gvec, c0, C, gz);
+      else load8(reinterpret_cast<const float*>(dZ) + r * lddz + c0, gvec, c0, C, gz);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float g = gz[e] * act_grad_h(y[e] * sc[e] + sh[e], act, slope);
-        a1[e] += g;
-        a2[e] += g * ((y[e] - mu[e]) * rs[e]);
+        if (YT == 0) {
+          const float g = gz[e] * act_grad_h(y[e] * sc[e] + sh[e], act, slope);
+          a1[e] += g;
+          a2[e] += g * ((y[e] - mu[e]) * rs[e]);
+        } else {
+          const float t = pre ? y[e] : act_inv_h(y[e], act, slope);
+          const float g = gz[e] * act_grad_h(t, act, slope);
+          a1[e] += g;
+          a2[e] += g * (t * sh[e] + mu[e]);
+        }
       }
     }
   }
@@ -974,7 +1107,8 @@ int launch_nt_h(const u16* A, int64_t lda, const u16* W, int64_t ldw, const floa
       if (tiles6 < ((int64_t)1 << 31)) {
         const int64_t grid6 = tiles6 < 768 ? tiles6 : 768;
         hipLaunchKernelGGL((gemm_h_pair_kernel<F16, false, false, 64>), dim3((unsigned)grid6), dim3(HB_TPB), 0, s, A, lda, W, ldw,
-                           bias, Y, ldy, M, N, K, tiles6, gn6, 1, colstats, 0, a_extent);
+                           bias, Y, ldy, M, N, K, tiles6, gn6, 1, colstats, 0, a_extent, (const float*)nullptr, (const float*)nullptr, 0,
+                           0.f, (void*)nullptr, (int64_t)0);
         return CCN_OK;
       }
     }
@@ -988,10 +1122,47 @@ int launch_nt_h(const u16* A, int64_t lda, const u16* W, int64_t ldw, const floa
   const int64_t grid = tiles < 512 ? tiles : 512;  // two workgroups per CU
   if (g_h_opt != 0)
     hipLaunchKernelGGL((gemm_h_pair_kernel<F16, OUT16, true>), dim3((unsigned)grid), dim3(HB_TPB), 0, s, A, lda, W, ldw, bias, Y,
-                       ldy, M, N, K, tiles, gn, 1, colstats, g_h_opt, a_extent);
+                       ldy, M, N, K, tiles, gn, 1, colstats, g_h_opt, a_extent, (const float*)nullptr, (const float*)nullptr, 0, 0.f, (void*)nullptr, (int64_t)0);
   else
     hipLaunchKernelGGL((gemm_h_pair_kernel<F16, OUT16>), dim3((unsigned)grid), dim3(HB_TPB), 0, s, A, lda, W, ldw, bias, Y, ldy,
-                       M, N, K, tiles, gn, 1, colstats, 0, a_extent);
+                       M, N, K, tiles, gn, 1, colstats, 0, a_extent, (const float*)nullptr, (const float*)nullptr, 0, 0.f, (void*)nullptr, (int64_t)0);
+  return CCN_OK;
+}
+
+// the fused forms (FUSE 1: statistics only, FUSE 2: BatchNorm + activation in the epilogue); tile choice as launch_nt_h
+template <bool F16, bool OUT16, int FUSE>
+int launch_nt_h_fused(const u16* A, int64_t lda, const u16* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
+                      int64_t N, int64_t K, double* colstats, hipStream_t s, const float* scale, const float* shift, int act,
+                      float slope, void* T = nullptr, int64_t ldt = 0) {
+  if constexpr (!OUT16) {
+    const bool narrow = N <= 64 || (N % HB_BN != 0 && N % HB_BN <= 64);
+    if (narrow) {
+      const int64_t gm6 = (M + HB_BM - 1) / HB_BM, gn6 = (N + 63) / 64;
+      const int64_t tiles6 = gm6 * gn6;
+      if (tiles6 < ((int64_t)1 << 31)) {
+        const int64_t grid6 = tiles6 < 768 ? tiles6 : 768;
+        hipLaunchKernelGGL((gemm_h_pair_kernel<F16, false, false, 64, FUSE>), dim3((unsigned)grid6), dim3(HB_TPB), 0, s, A, lda, W,
+                           ldw, bias, Y, ldy, M, N, K, tiles6, gn6, 1, colstats, 0, lda, scale, shift, act, slope, (void*)nullptr, (int64_t)0);
+        return CCN_OK;
+      }
+    }
+  }
+  const int64_t gm = (M + HB_BM - 1) / HB_BM, gn = (N + HB_BN - 1) / HB_BN;
+  const int64_t tiles = gm * gn;
+  if (tiles >= ((int64_t)1 << 31)) {
+    ccn_set_error("gemm_nt_h: more than 2^31 output tiles");
+    return CCN_ERR_ARG;
+  }
+  const int64_t grid = tiles < 512 ? tiles : 512;
+  if constexpr (OUT16 && FUSE == 2) {
+    if (T != nullptr) {
+      hipLaunchKernelGGL((gemm_h_pair_kernel<F16, true, false, HB_BN, 3>), dim3((unsigned)grid), dim3(HB_TPB), 0, s, A, lda, W, ldw,
+                         bias, Y, ldy, M, N, K, tiles, gn, 1, colstats, 0, lda, scale, shift, act, slope, T, ldt);
+      return CCN_OK;
+    }
+  }
+  hipLaunchKernelGGL((gemm_h_pair_kernel<F16, OUT16, false, HB_BN, FUSE>), dim3((unsigned)grid), dim3(HB_TPB), 0, s, A, lda, W, ldw,
+                     bias, Y, ldy, M, N, K, tiles, gn, 1, colstats, 0, lda, scale, shift, act, slope, (void*)nullptr, (int64_t)0);
   return CCN_OK;
 }
 
@@ -1030,6 +1201,47 @@ int ccn_gemm_nt_h(const void* A, int64_t lda, const void* W, int64_t ldw, const 
                   int64_t N, int64_t K, double* colstats, int f16, int out16, void* stream) {
   CCN_REQUIRE(lda >= K, "gemm_nt_h: bad sizes (lda < K)");
   return gemm_nt_h_impl(A, lda, W, ldw, bias, Y, ldy, M, N, K, colstats, f16, out16, stream, lda);
+}
+
+int ccn_gemm_nt_h_stats(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int64_t M, int64_t N, int64_t K,
+                        double* colstats, int f16, void* stream) {
+  CCN_REQUIRE(A && W && colstats, "gemm_nt_h_stats: null pointer");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lda >= K && lda >= 8 && ldw >= K, "gemm_nt_h_stats: bad sizes");
+  CCN_REQUIRE(aligned16(A) && aligned16(W) && lda % 8 == 0 && ldw % 8 == 0,
+              "gemm_nt_h_stats: 16-bit operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+  if (M == 0) return CCN_OK;
+  const u16* a = (const u16*)A;
+  const u16* w = (const u16*)W;
+  const int rc = f16 ? launch_nt_h_fused<true, false, 1>(a, lda, w, ldw, bias, nullptr, N, M, N, K, colstats, (hipStream_t)stream, nullptr, nullptr, 0, 0.f)
+                     : launch_nt_h_fused<false, false, 1>(a, lda, w, ldw, bias, nullptr, N, M, N, K, colstats, (hipStream_t)stream, nullptr, nullptr, 0, 0.f);
+  if (rc) return rc;
+  CCN_LAUNCH_OK("gemm_nt_h_stats");
+  return CCN_OK;
+}
+
+int ccn_gemm_nt_h_bnact(const void* A, int64_t lda, const void* W, int64_t ldw, const float* scale, const float* shift, int act,
+                        float slope, void* Z, int64_t ldz, void* T, int64_t ldt, int64_t M, int64_t N, int64_t K, int f16, int out16,
+                        void* stream) {
+  CCN_REQUIRE(A && W && Z && scale && shift, "gemm_nt_h_bnact: null pointer");
+  CCN_REQUIRE(T == nullptr || (out16 && ldt >= N && ldt % 4 == 0 && ((uintptr_t)T & 7) == 0),
+              "gemm_nt_h_bnact: the pre-activation output exists in the 16-bit form only (8-byte aligned rows)");
+  CCN_REQUIRE(M >= 0 && N > 0 && K > 0 && lda >= K && lda >= 8 && ldw >= K && ldz >= N, "gemm_nt_h_bnact: bad sizes");
+  CCN_REQUIRE(aligned16(A) && aligned16(W) && lda % 8 == 0 && ldw % 8 == 0,
+              "gemm_nt_h_bnact: 16-bit operands must be 16-byte aligned with leading dimensions that are multiples of 8");
+  CCN_REQUIRE(!out16 || (((uintptr_t)Z & 7) == 0 && ldz % 4 == 0), "gemm_nt_h_bnact: a 16-bit result needs 8-byte aligned rows");
+  CCN_REQUIRE(act == CCN_ACT_NONE || act == CCN_ACT_RELU || act == CCN_ACT_LEAKY, "gemm_nt_h_bnact: unknown activation");
+  if (M == 0) return CCN_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const u16* a = (const u16*)A;
+  const u16* w = (const u16*)W;
+  int rc;
+  if (f16) rc = out16 ? launch_nt_h_fused<true, true, 2>(a, lda, w, ldw, nullptr, Z, ldz, M, N, K, nullptr, s, scale, shift, act, slope, T, ldt)
+                      : launch_nt_h_fused<true, false, 2>(a, lda, w, ldw, nullptr, Z, ldz, M, N, K, nullptr, s, scale, shift, act, slope);
+  else rc = out16 ? launch_nt_h_fused<false, true, 2>(a, lda, w, ldw, nullptr, Z, ldz, M, N, K, nullptr, s, scale, shift, act, slope, T, ldt)
+                  : launch_nt_h_fused<false, false, 2>(a, lda, w, ldw, nullptr, Z, ldz, M, N, K, nullptr, s, scale, shift, act, slope);
+  if (rc) return rc;
+  CCN_LAUNCH_OK("gemm_nt_h_bnact");
+  return CCN_OK;
 }
 
 // Implicit-GEMM curve convolution on a 16-bit row sequence (the 16-bit form of ccn_conv_rows_nt): row i of the shifted-row
@@ -1168,8 +1380,8 @@ int ccn_bn_act_bwd_reduce_h(const void* dZ, int64_t lddz, const float* Y, int64_
   const int64_t nparts = ccn_stats_rows(rows);
   double* partial = sums + 2 * C;
   const EwGeom g = ew_geom((C + 7) / 8 * 8);
-  hipLaunchKernelGGL(bn_act_bwd_reduce_h_kernel, dim3((unsigned)nparts, g.gy), dim3(EW_TPB), 0, (hipStream_t)stream,
-                     (const u16*)dZ, lddz, Y, ldy, rows, C, scale, shift, mean, rstd, act, slope, partial, g.cpb, g.rpp);
+  hipLaunchKernelGGL((bn_act_bwd_reduce_h_kernel<true, 0>), dim3((unsigned)nparts, g.gy), dim3(EW_TPB), 0, (hipStream_t)stream,
+                     dZ, lddz, (const void*)Y, ldy, rows, C, scale, shift, mean, rstd, act, slope, partial, g.cpb, g.rpp);
   CCN_LAUNCH_OK("bn_act_bwd_reduce_h");
   return ccn_reduce_partials(partial, nparts, 2 * C, sums, stream);
 }
@@ -1185,12 +1397,55 @@ int ccn_bn_act_bwd_apply_h(const void* dZ, int dz16, int64_t lddz, const float* 
   const float inv_n = 1.f / count;
 #define CCN_APPLY_H(F16_, DZ16_)                                                                                              \
   hipLaunchKernelGGL((bn_act_bwd_apply_h_kernel<F16_, DZ16_>), grid, dim3(EW_TPB), 0, (hipStream_t)stream,                    \
-                     dZ, lddz, Y, ldy, rows, C, scale, shift, mean, rstd, act, slope, sums, training, inv_n, (u16*)dY, lddy,  \
+                     dZ, lddz, (const void*)Y, ldy, rows, C, scale, shift, mean, rstd, act, slope, sums, training, inv_n, (u16*)dY, lddy,  \
                      dgamma, dbeta, acc_params, g.cpb, g.rpp)
   if (f16) { if (dz16) CCN_APPLY_H(true, true); else CCN_APPLY_H(true, false); }
   else { if (dz16) CCN_APPLY_H(false, true); else CCN_APPLY_H(false, false); }
 #undef CCN_APPLY_H
   CCN_LAUNCH_OK("bn_act_bwd_apply_h");
+  return CCN_OK;
+}
+
+// ---- the same two passes for a layer that kept only its OUTPUT z (ccn_gemm_nt_h_bnact): zt 1 = bf16 rows, 2 = fp16 rows, 3 = fp32 rows
+static bool hz_args_ok(const void* Z, int zt, int64_t ldz, int64_t C) {
+  return Z != nullptr && zt >= 1 && zt <= 3 && ldz >= C;
+}
+
+int ccn_bn_act_bwd_reduce_hz(const void* dZ, int dz16, int64_t lddz, const void* Z, int zt, int z_pre, int64_t ldz, int64_t rows, int64_t C,
+                             const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                             double* sums, void* stream) {
+  CCN_REQUIRE(dZ && sums && rows > 0 && C > 0 && lddz >= C && hz_args_ok(Z, zt, ldz, C), "bn_act_bwd_reduce_hz: bad arguments");
+  const int64_t nparts = ccn_stats_rows(rows);
+  double* partial = sums + 2 * C;
+  const EwGeom g = ew_geom((C + 7) / 8 * 8);
+#define CCN_REDUCE_HZ(DZ16_, YT_)                                                                                                \
+  hipLaunchKernelGGL((bn_act_bwd_reduce_h_kernel<DZ16_, YT_>), dim3((unsigned)nparts, g.gy), dim3(EW_TPB), 0, (hipStream_t)stream, \
+                     dZ, lddz, Z, ldz, rows, C, scale, shift, mean, rstd, act, slope, partial, g.cpb, g.rpp, z_pre)
+  if (dz16) { if (zt == 1) CCN_REDUCE_HZ(true, 1); else if (zt == 2) CCN_REDUCE_HZ(true, 2); else CCN_REDUCE_HZ(true, 3); }
+  else { if (zt == 1) CCN_REDUCE_HZ(false, 1); else if (zt == 2) CCN_REDUCE_HZ(false, 2); else CCN_REDUCE_HZ(false, 3); }
+#undef CCN_REDUCE_HZ
+  CCN_LAUNCH_OK("bn_act_bwd_reduce_hz");
+  return ccn_reduce_partials(partial, nparts, 2 * C, sums, stream);
+}
+
+int ccn_bn_act_bwd_apply_hz(const void* dZ, int dz16, int64_t lddz, const void* Z, int zt, int z_pre, int64_t ldz, int64_t rows, int64_t C,
+                            const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                            const double* sums, float count, int training, int acc_params, void* dY, int64_t lddy, float* dgamma,
+                            float* dbeta, void* stream) {
+  CCN_REQUIRE(dZ && dY && sums && rows > 0 && C > 0 && lddz >= C && lddy >= C && lddy % 8 == 0 && aligned16(dY) &&
+                  hz_args_ok(Z, zt, ldz, C),
+              "bn_act_bwd_apply_hz: bad arguments");
+  const EwGeom g = ew_geom(lddy);
+  const dim3 grid((unsigned)ccn_blocks(rows, EW_ROWS), g.gy);
+  const float inv_n = 1.f / count;
+#define CCN_APPLY_HZ(DZ16_, YT_)                                                                                              \
+  hipLaunchKernelGGL((bn_act_bwd_apply_h_kernel<false, DZ16_, YT_>), grid, dim3(EW_TPB), 0, (hipStream_t)stream,               \
+                     dZ, lddz, Z, ldz, rows, C, scale, shift, mean, rstd, act, slope, sums, training, inv_n, (u16*)dY, lddy,   \
+                     dgamma, dbeta, acc_params, g.cpb, g.rpp, z_pre)
+  if (dz16) { if (zt == 1) CCN_APPLY_HZ(true, 1); else if (zt == 2) CCN_APPLY_HZ(true, 2); else CCN_APPLY_HZ(true, 3); }
+  else { if (zt == 1) CCN_APPLY_HZ(false, 1); else if (zt == 2) CCN_APPLY_HZ(false, 2); else CCN_APPLY_HZ(false, 3); }
+#undef CCN_APPLY_HZ
+  CCN_LAUNCH_OK("bn_act_bwd_apply_hz");
   return CCN_OK;
 }
 

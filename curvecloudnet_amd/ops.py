@@ -1100,6 +1100,13 @@ class LinearBNAct(torch.autograd.Function):
 # same fp32 number, earlier); the gradient of a 16-bit hidden activation is rounded to bf16 once more than there
 # (oracle.torch_ref mirrors it).  CCN_STORE16=0 keeps the fp32-storage kernels (A/B).
 STORE16 = os.environ.get("CCN_STORE16", "1") != "0"
+# Round 6: a BatchNorm layer of the 16-bit storage path without its fp32 intermediate -- statistics pass without
+# stores (ccn_gemm_nt_h_stats), then product + BatchNorm + activation in one kernel (ccn_gemm_nt_h_bnact): 4 K + 2 N bytes per row
+# instead of 2 K + 10 N, the same forward bits; backward reads the layer's output (2 N) instead of the product (4 N) and recovers
+# xhat from it (ccn_bn_act_bwd_*_hz).  For layers up to FUSE16_MAX wide / deep: beyond it the product is MFMA-bound and computing
+# it twice costs more than its bytes.  CCN_FUSE16=0: the three-kernel form of rounds 3-5 (A/B).
+FUSE16 = os.environ.get("CCN_FUSE16", "1") != "0"
+FUSE16_MAX = int(os.environ.get("CCN_FUSE16_MAX", "512"))
 
 
 def _fwd16():
@@ -1181,11 +1188,16 @@ class LinearBNActH(torch.autograd.Function):
         ctx.x16_in = bool(x_f16_bits) or (x.dtype == torch.bfloat16 and fdt == torch.bfloat16)
         x16 = _cast16(x, fdt)
         w16 = _cast16(weight.detach(), fdt)
-        y = _rows(m, n, dev)
         has_bn = gamma is not None
+        # (a 16-bit result whose width is not a multiple of 8 would leave its padding columns unwritten: the three-kernel form)
+        # ... and a ReLU layer needs its 16-bit PRE-activation as a second result for the backward pass (xhat of a clipped element
+        # cannot be read off z = 0): the kernel writes it in the 16-bit form only)
+        fuse = (has_bn and FUSE16 and m > 0 and max(n, k) <= FUSE16_MAX and post is None and not dual
+                and not (out16 and n % 8 != 0) and (out16 or ACT[act] != 1))
+        y = None if fuse else _rows(m, n, dev)
         ctx.has_bn, ctx.act, ctx.training, ctx.has_bias = has_bn, ACT[act], bool(training), bias is not None
         ctx.out16 = bool(out16 and has_bn)
-        none = y.new_empty(0)
+        none = x16.new_empty(0)          # (unused placeholder kept from the fp32 form)
         ctx.main_grad_of = weight if (grad_on and ctx.needs_input_grad[1] and _main_grad(weight, n, k) is not None) else None
         ctx.bn_refs = ((gamma, beta) if has_bn and grad_on and ctx.needs_input_grad[3] and ctx.needs_input_grad[4]
                        and _main_grad_vec(gamma, n) is not None and _main_grad_vec(beta, n) is not None else None)
@@ -1226,9 +1238,34 @@ class LinearBNActH(torch.autograd.Function):
         if post is not None or dual:
             raise ValueError("LinearBNActH: a fused reduction / a dual output follows plain layers only")
         par = torch.empty((4, n), dtype=torch.float32, device=dev)      # scale, shift, mean, rstd
+        if training and m < 2:
+            raise ValueError("Expected more than 1 value per channel when training")
+        # Round 6: the product is computed TWICE instead of stored once (FUSE16, see above): a statistics pass that writes
+        # nothing, then product + BatchNorm + activation in one kernel -- the fp32 intermediate y is never written, and backward
+        # recovers what it needs from the layer's output z (ccn_bn_act_bwd_*_hz).  Same forward bits as the three-kernel form.
+        ctx.from_z = 0
+        if fuse:
+            if training:
+                stats = _stats_buffer(m, n, dev)
+                call("gemm_nt_h_stats", ptr(x16), _ld(x16), ptr(w16), _ld(w16), ptr(bias), m, n, k, ptr(stats), f16)
+                call("bn_finalize", ptr(stats), m, n, ptr(gamma), ptr(beta), float(eps), float(momentum),
+                     ptr(running_mean), ptr(running_var), ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+            else:
+                call("bn_eval_params", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps), n,
+                     ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]))
+            shift = par[1] if bias is None else torch.addcmul(par[1], bias.detach(), par[0])     # (the bias folded into the shift)
+            z = _rows16(m, n, dev, fdt) if ctx.out16 else _rows(m, n, dev)
+            t16 = _rows16(m, n, dev, fdt) if ctx.act == 1 else None          # (ReLU: the pre-activation, for backward)
+            call("gemm_nt_h_bnact", ptr(x16), _ld(x16), ptr(w16), _ld(w16), ptr(par[0]), ptr(shift), ctx.act, LEAKY_SLOPE,
+                 ptr(z), _ld(z), ptr(t16), _ld(t16) if t16 is not None else 0, m, n, k, f16, 1 if ctx.out16 else 0)
+            ctx.from_z = (2 if f16 else 1) if ctx.out16 else 3
+            ctx.z_pre = 1 if t16 is not None else 0
+            ctx.save_for_backward(x16, weight, t16 if t16 is not None else z, par)
+            if ctx.out16:
+                return z.view(torch.bfloat16) if f16 else z
+            _trace_act(z, ctx.act)
+            return z
         if training:
-            if m < 2:
-                raise ValueError("Expected more than 1 value per channel when training")
             stats = _stats_buffer(m, n, dev)
             product(stats)
             call("bn_finalize", ptr(stats), m, n, ptr(gamma), ptr(beta), float(eps), float(momentum),
@@ -1259,7 +1296,10 @@ class LinearBNActH(torch.autograd.Function):
                 g, g16 = g.float(), False
             g = g if g16 else _mat(g)
             sums = _stats_buffer(m, n, dev)
-            if g16:
+            if ctx.from_z:
+                call("bn_act_bwd_reduce_hz", ptr(g), 1 if g16 else 0, _ld(g), ptr(y), ctx.from_z, ctx.z_pre, _ld(y), m, n, ptr(par[0]),
+                     ptr(par[1]), ptr(par[2]), ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums))
+            elif g16:
                 call("bn_act_bwd_reduce_h", ptr(g), _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]), ptr(par[2]),
                      ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums))
             else:
@@ -1276,9 +1316,14 @@ class LinearBNActH(torch.autograd.Function):
             if not fused:
                 dgb = torch.empty((2, n), dtype=torch.float32, device=dev)
                 gview, bview = dgb[0], dgb[1]
-            call("bn_act_bwd_apply_h", ptr(g), 1 if g16 else 0, _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]),
-                 ptr(par[2]), ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums), float(m), 1 if ctx.training else 0,
-                 1 if fused else 0, ptr(dy16), _ld(dy16), ptr(gview), ptr(bview), 0)
+            if ctx.from_z:
+                call("bn_act_bwd_apply_hz", ptr(g), 1 if g16 else 0, _ld(g), ptr(y), ctx.from_z, ctx.z_pre, _ld(y), m, n, ptr(par[0]),
+                     ptr(par[1]), ptr(par[2]), ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums), float(m), 1 if ctx.training else 0,
+                     1 if fused else 0, ptr(dy16), _ld(dy16), ptr(gview), ptr(bview))
+            else:
+                call("bn_act_bwd_apply_h", ptr(g), 1 if g16 else 0, _ld(g), ptr(y), _ld(y), m, n, ptr(par[0]), ptr(par[1]),
+                     ptr(par[2]), ptr(par[3]), ctx.act, LEAKY_SLOPE, ptr(sums), float(m), 1 if ctx.training else 0,
+                     1 if fused else 0, ptr(dy16), _ld(dy16), ptr(gview), ptr(bview), 0)
             if fused:
                 dgamma, dbeta = _main_grad_done(refs[0]), _main_grad_done(refs[1])
             else:

@@ -306,6 +306,32 @@ int ccn_gemm_tn_bf16(const float* dY, int64_t lddy, const float* X, int64_t ldx,
  *                  (ccn_gemm_tn_h_workspace_bytes), summed in chunk order (deterministic). */
 int ccn_gemm_nt_h(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* Y, int64_t ldy, int64_t M,
                   int64_t N, int64_t K, double* colstats, int f16, int out16, void* stream);
+/* round 6: the forward of a BatchNorm layer of the 16-bit modes WITHOUT its fp32 intermediate (PyG MLP hidden layers, reference
+ * base.py:90-125: Linear -> BatchNorm1d -> activation).  The product kernel is HBM-bound at the network's widths, so it runs twice:
+ *   ccn_gemm_nt_h_stats: the column statistics of A W^T (+ bias) as ccn_gemm_nt_h(out16 = 0) takes them -- the same fp32 sums --
+ *                        and NOTHING written (2 K bytes per row read);
+ *   ccn_gemm_nt_h_bnact: Z = act((A W^T) * scale[n] + shift[n]) (a bias is folded into shift by the caller), fp32 rows
+ *                        (out16 = 0) or 16-bit rows (out16 != 0): the bits of ccn_gemm_nt_h followed by ccn_bn_act_fwd(_h).
+ * 4 K + 2 N bytes per row instead of 2 K + 10 N.  The backward passes of such a layer recover what they need from Z itself:
+ *   ccn_bn_act_bwd_reduce_hz / _apply_hz = ccn_bn_act_bwd_reduce(_h) / ccn_bn_act_bwd_apply_h with the layer's OUTPUT in place of
+ *   its pre-normalisation product (zt 1 = bf16 rows, 2 = fp16 rows, 3 = fp32 rows; ldz in elements): t = act^-1(z),
+ *   xhat = (t - beta) / gamma.  That needs an INVERTIBLE activation (LeakyReLU, none): BatchNorm's backward uses xhat of every row,
+ *   also of the rows a ReLU clipped to 0.  For a ReLU layer ccn_gemm_nt_h_bnact therefore writes a second 16-bit result T = the
+ *   pre-activation t (nullable; 16-bit form only), which these passes take in place of Z with z_pre != 0 (no inversion).
+ *   A column with gamma = 0 has dy = 0 and xhat = 0 (its dgamma is then 0 instead of sum(g xhat): unrecoverable, measure zero in
+ *   training).  dZ: bf16 rows (dz16 != 0) or fp32 rows. */
+int ccn_gemm_nt_h_stats(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int64_t M, int64_t N, int64_t K,
+                        double* colstats, int f16, void* stream);
+int ccn_gemm_nt_h_bnact(const void* A, int64_t lda, const void* W, int64_t ldw, const float* scale, const float* shift, int act,
+                        float slope, void* Z, int64_t ldz, void* T, int64_t ldt, int64_t M, int64_t N, int64_t K, int f16, int out16,
+                        void* stream);
+int ccn_bn_act_bwd_reduce_hz(const void* dZ, int dz16, int64_t lddz, const void* Z, int zt, int z_pre, int64_t ldz, int64_t rows, int64_t C,
+                             const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                             double* sums, void* stream);
+int ccn_bn_act_bwd_apply_hz(const void* dZ, int dz16, int64_t lddz, const void* Z, int zt, int z_pre, int64_t ldz, int64_t rows, int64_t C,
+                            const float* scale, const float* shift, const float* mean, const float* rstd, int act, float slope,
+                            const double* sums, float count, int training, int acc_params, void* dY, int64_t lddy, float* dgamma,
+                            float* dbeta, void* stream);
 /* round 4: the implicit-GEMM curve convolution of ccn_conv_rows_nt / _tn (fast_conv1d.py:173-184 over the zero-separated
  * sequence of :48-61 / :115-126) on 16-BIT row sequences: row i of the shifted-row matrix is the span of K = taps * lda
  * elements starting at A + i * lda, read in place (lda % 8 == 0, taps / 2 zero halo rows at both ends of the allocation).

@@ -81,6 +81,140 @@ def test_gemm_nt_h_exact_integers_and_statistics(M, N, K, dtype):
     assert bool((y16[:, N:] == -1.0).all())
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 192, 128), (1000, 259, 72), (129, 64, 200), (5000, 256, 256),
+                                   (70000, 128, 320), (40000, 40, 72)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("act", [1, 2])
+def test_batchnorm_layer_forward_without_its_fp32_intermediate(M, N, K, dtype, act):
+    """Round 6: ccn_gemm_nt_h_stats = the statistics of ccn_gemm_nt_h with nothing stored (the same fp32 sums: bit-identical
+    partial rows); ccn_gemm_nt_h_bnact = ccn_gemm_nt_h followed by ccn_bn_act_fwd / ccn_bn_act_fwd_h, as fp32 rows and as 16-bit
+    rows -- the same bits (one fused multiply-add on the same fp32 sum), for shapes that are not multiples of the tile / slice,
+    with a bias (folded into the shift by the caller)."""
+    call, lib, ptr, _ = _api()
+    f16 = 1 if dtype == torch.float16 else 0
+    gen = torch.Generator().manual_seed(M + N + K + act)
+    a16, lda = _to16(torch.randn(M, K, generator=gen), dtype)
+    w16, ldw = _to16(torch.randn(N, K, generator=gen) / K ** 0.5, dtype)
+    bias = (torch.randn(N, generator=gen) * 0.2).to(DEV)
+    scale, shift = (torch.rand(N, generator=gen) + 0.5).to(DEV), (torch.randn(N, generator=gen) * 0.3).to(DEV)
+    nparts = lib().ccn_stats_rows(M)
+    for b in (bias, None):
+        y = torch.empty(M, N, device=DEV)
+        stats = torch.zeros((nparts + 1) * 2 * N, dtype=torch.float64, device=DEV)
+        call("gemm_nt_h", ptr(a16), lda, ptr(w16), ldw, ptr(b), ptr(y), N, M, N, K, ptr(stats), f16, 0)
+        stats2 = torch.zeros_like(stats)
+        call("gemm_nt_h_stats", ptr(a16), lda, ptr(w16), ldw, ptr(b), M, N, K, ptr(stats2), f16)
+        assert torch.equal(stats2, stats), "statistics-only pass"
+        shift_eff = shift if b is None else torch.addcmul(shift, b, scale)
+        # reference: the three-kernel form on the product WITHOUT the bias + the folded shift (the fused kernel's own definition),
+        # which equals BatchNorm of (product + bias) up to one fp32 rounding of the folded constant
+        y0 = torch.empty(M, N, device=DEV)
+        call("gemm_nt_h", ptr(a16), lda, ptr(w16), ldw, None, ptr(y0), N, M, N, K, None, f16, 0)
+        z32 = torch.empty(M, N, device=DEV)
+        call("bn_act_fwd", ptr(y0), N, M, N, ptr(scale), ptr(shift_eff), act, 0.01, ptr(z32), N)
+        got32 = torch.full((M, N + 3), -7.0, device=DEV)
+        call("gemm_nt_h_bnact", ptr(a16), lda, ptr(w16), ldw, ptr(scale), ptr(shift_eff), act, 0.01, ptr(got32), N + 3, None, 0, M, N, K, f16, 0)
+        assert torch.equal(got32[:, :N], z32), float((got32[:, :N] - z32).abs().max())
+        assert bool((got32[:, N:] == -7.0).all())
+        z16, ldz = _rows16(M, N, dtype)
+        call("bn_act_fwd_h", ptr(y0), N, M, N, ptr(scale), ptr(shift_eff), act, 0.01, ptr(z16), ldz, f16)
+        got16, ldg = _rows16(M, N, dtype)
+        got16.fill_(3.0)
+        call("gemm_nt_h_bnact", ptr(a16), lda, ptr(w16), ldw, ptr(scale), ptr(shift_eff), act, 0.01, ptr(got16), ldg, None, 0, M, N, K, f16, 1)
+        assert torch.equal(got16[:, :N], z16[:, :N]), "16-bit rows"
+        # ... and with the pre-activation as a second 16-bit result (what a ReLU layer keeps for its backward pass)
+        t32 = torch.empty(M, N, device=DEV)
+        call("bn_act_fwd", ptr(y0), N, M, N, ptr(scale), ptr(shift_eff), 0, 0.01, ptr(t32), N)
+        got16.fill_(3.0)
+        t16, ldt = _rows16(M, N, dtype)
+        t16.fill_(3.0)
+        call("gemm_nt_h_bnact", ptr(a16), lda, ptr(w16), ldw, ptr(scale), ptr(shift_eff), act, 0.01, ptr(got16), ldg, ptr(t16), ldt, M, N, K, f16, 1)
+        assert torch.equal(got16[:, :N], z16[:, :N]) and torch.equal(t16[:, :N], t32.to(dtype)), "two 16-bit results"
+        if b is not None:      # against BatchNorm of the biased product: the folding is one rounding of a constant away
+            zb = torch.empty(M, N, device=DEV)
+            call("bn_act_fwd", ptr(y), N, M, N, ptr(scale), ptr(shift), act, 0.01, ptr(zb), N)
+            assert float((got32[:, :N] - zb).abs().max()) <= 4e-6 * max(1.0, float(zb.abs().max()))
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 64), (4099, 259), (300, 8), (70000, 128)])
+@pytest.mark.parametrize("act", [1, 2])
+def test_batchnorm_backward_from_the_layer_output(rows, C, act):
+    """ccn_bn_act_bwd_reduce_hz / _apply_hz take the layer's OUTPUT z in place of its pre-normalisation product y.  With z held in
+    fp32 they reproduce the y-passes to fp32 rounding (t = act^-1(z), xhat = (t - beta) / gamma); with z rounded to bf16 / fp16 they
+    equal the y-passes evaluated on the y that this rounded z stands for."""
+    call, lib, ptr, _ = _api()
+    gen = torch.Generator().manual_seed(rows + C + act)
+    y = torch.randn(rows, C, generator=gen).to(DEV)
+    par = torch.stack([torch.rand(C, generator=gen) + 0.5, torch.randn(C, generator=gen) * 0.3,
+                       torch.randn(C, generator=gen) * 0.1, torch.rand(C, generator=gen) + 0.5]).to(DEV)   # scale shift mean rstd
+    nparts = lib().ccn_stats_rows(rows)
+    g32 = torch.randn(rows, C, generator=gen).to(DEV)
+    g16, ldg = _to16(g32.cpu())
+    g16f = g16[:, :C].float().contiguous()
+    z32 = torch.empty(rows, C, device=DEV)
+    call("bn_act_fwd", ptr(y), C, rows, C, ptr(par[0]), ptr(par[1]), act, 0.01, ptr(z32), C)
+
+    def y_passes(yy, gg):
+        s = torch.zeros((nparts + 1) * 2 * C, dtype=torch.float64, device=DEV)
+        call("bn_act_bwd_reduce", ptr(gg), C, ptr(yy), C, rows, C, ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]), act, 0.01, ptr(s))
+        dy = torch.empty(rows, C, device=DEV)
+        dgb = torch.zeros(2, C, device=DEV)
+        call("bn_act_bwd_apply_ex", ptr(gg), C, ptr(yy), C, rows, C, ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]), act, 0.01,
+             ptr(s), float(rows), 1, 0, ptr(dy), C, ptr(dgb[0]), ptr(dgb[1]))
+        return s[: 2 * C].clone(), dy, dgb
+
+    # LeakyReLU (act 2): the output z is invertible -- z rows, z_pre = 0.  ReLU (act 1): xhat of a clipped element is gone from z,
+    # and BatchNorm's backward needs it for EVERY row: such a layer hands over its 16-bit PRE-activation t -- t rows, z_pre = 1.
+    pre = 1 if act == 1 else 0
+    t32 = torch.empty(rows, C, device=DEV)
+    call("bn_act_fwd", ptr(y), C, rows, C, ptr(par[0]), ptr(par[1]), 0, 0.01, ptr(t32), C)
+    src32 = t32 if pre else z32
+    for zt, zdt in ((3, torch.float32), (1, torch.bfloat16), (2, torch.float16)):
+        if zt == 3:
+            z, ldz = src32, C
+            zval = src32
+        else:
+            z, ldz = _rows16(rows, C, zdt)
+            z[:, :C] = src32.to(zdt)
+            zval = z[:, :C].float()
+        # the y this operand stands for: t = the operand itself (pre-activation) or act^-1(z); y = (t - shift) / scale
+        t = zval if pre else torch.where(zval > 0, zval, zval / 0.01)
+        y_of_z = ((t - par[1]) / par[0]).contiguous()
+        for dz16, gsrc, ldsrc, gval in ((1, g16, ldg, g16f), (0, g32, C, g32)):
+            want_s, want_dy, want_dgb = y_passes(y_of_z, gval)
+            s = torch.zeros((nparts + 1) * 2 * C, dtype=torch.float64, device=DEV)
+            call("bn_act_bwd_reduce_hz", ptr(gsrc), dz16, ldsrc, ptr(z), zt, pre, ldz, rows, C, ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                 ptr(par[3]), act, 0.01, ptr(s))
+            scale_s = float(want_s.abs().max()) + rows ** 0.5
+            # (an element whose t is within rounding of 0 may take the other slope on one side: its g is one term of rows)
+            assert float((s[: 2 * C] - want_s).abs().max()) <= 2e-5 * scale_s + 4.0, (zt, dz16, float((s[: 2 * C] - want_s).abs().max()))
+            dy16, lddy = _rows16(rows, C)
+            dgb = torch.full((2, C), 9.0, device=DEV)
+            call("bn_act_bwd_apply_hz", ptr(gsrc), dz16, ldsrc, ptr(z), zt, pre, ldz, rows, C, ptr(par[0]), ptr(par[1]), ptr(par[2]),
+                 ptr(par[3]), act, 0.01, ptr(_sums_like(want_s, nparts, C)), float(rows), 1, 0,
+                 ptr(dy16), lddy, ptr(dgb[0]), ptr(dgb[1]))
+            diff = (dy16[:, :C].float() - want_dy).abs()
+            tol = want_dy.abs() * 2 ** -7 + 2e-5
+            # (y_of_z * scale + shift reproduces t only to rounding: where |t| < 1e-6 the reference may sit on the other slope)
+            kink = (t.abs() < 1e-6)
+            assert bool(((diff <= tol) | kink).all()), (zt, dz16, float(diff.max()))
+            assert torch.allclose(dgb, want_dgb, rtol=1e-6, atol=1e-6)
+            assert bool((dy16[:, C:] == 0).all())
+        if zt == 3:      # fp32 operand: the y-passes on the TRUE y, to fp32 rounding of the inversion
+            true_s, true_dy, _ = y_passes(y, g32)
+            s = torch.zeros((nparts + 1) * 2 * C, dtype=torch.float64, device=DEV)
+            call("bn_act_bwd_reduce_hz", ptr(g32), 0, C, ptr(src32), 3, pre, C, rows, C, ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]),
+                 act, 0.01, ptr(s))
+            assert float((s[: 2 * C] - true_s).abs().max()) <= 1e-4 * (float(true_s.abs().max()) + rows ** 0.5)
+
+
+def _sums_like(totals, nparts, C):
+    """a sums buffer (2 C totals + scratch) holding ``totals``"""
+    s = torch.zeros((nparts + 1) * 2 * C, dtype=torch.float64, device=totals.device)
+    s[: 2 * C] = totals
+    return s
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 256, 256), (100000, 128, 192), (3000, 1024, 1024), (50000, 64, 64)])
 def test_gemm_nt_h_random_against_fp64(M, N, K):
     call, lib, ptr, _ = _api()
