@@ -530,9 +530,9 @@ template <int YT>
 __device__ __forceinline__ bool y8_vec_ok(const void* Yv, int64_t ldy, bool full) {
   return full && ((YT == 0 || YT == 3) ? (ldy & 3) == 0 : (ldy & 7) == 0) && ((uintptr_t)Yv & 15) == 0;
 }
-__device__ __forceinline__ float act_inv_h(float z, int act, float slope) {
-  if (act == CCN_ACT_LEAKY) return z > 0.f ? z : z / slope;
-  return z;          // (ReLU: z = 0 stands for every t <= 0; act'(0) = 0 makes the choice irrelevant)
+__device__ __forceinline__ float act_inv_h(float z, int act, float inv_slope) {
+  if (act == CCN_ACT_LEAKY) return z > 0.f ? z : z * inv_slope;      // (a multiplication: a division per element made the pass instruction-bound)
+  return z;          // (ReLU is NOT invertible: such layers hand over their pre-activation, z_pre)
 }
 
 template <bool F16>
@@ -695,6 +695,7 @@ __global__ __launch_bounds__(EW_TPB) void bn_act_bwd_apply_h_kernel(
     }
   }
   const bool full = c0 + 8 <= C;
+  const float inv_slope = slope != 0.f ? 1.f / slope : 0.f;
   const bool yvec = y8_vec_ok<YT>(Y, ldy, full);
   const bool gvec = full && (DZ16 ? ((lddz & 7) == 0) : ((lddz & 3) == 0)) && ((uintptr_t)dZv & 15) == 0;
   const int64_t r0 = (int64_t)blockIdx.x * EW_ROWS;
@@ -711,7 +712,7 @@ __global__ __launch_bounds__(EW_TPB) void bn_act_bwd_apply_h_kernel(
         g = gz[e] * act_grad_h(y[e] * sc[e] + sh[e], act, slope);
         xhat = (y[e] - mu[e]) * rs[e];
       } else {
-        const float t = pre ? y[e] : act_inv_h(y[e], act, slope);
+        const float t = pre ? y[e] : act_inv_h(y[e], act, inv_slope);
         g = gz[e] * act_grad_h(t, act, slope);
         xhat = t * sh[e] + mu[e];
       }
@@ -752,6 +753,7 @@ __global__ __launch_bounds__(EW_TPB) void bn_act_bwd_reduce_h_kernel(const void*
       }
     }
     const bool full = c0 + 8 <= C;
+    const float inv_slope = slope != 0.f ? 1.f / slope : 0.f;
     const bool yvec = y8_vec_ok<YT>(Y, ldy, full);
     const bool gvec = full && (DZ16 ? (lddz & 7) == 0 : (lddz & 3) == 0) && ((uintptr_t)dZ & 15) == 0;
     const int64_t r0 = (int64_t)blockIdx.x * EW_ROWS;
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(EW_TPB) void bn_act_bwd_reduce_h_kernel(const void*
           a1[e] += g;
           a2[e] += g * ((y[e] - mu[e]) * rs[e]);
         } else {
-          const float t = pre ? y[e] : act_inv_h(y[e], act, slope);
+          const float t = pre ? y[e] : act_inv_h(y[e], act, inv_slope);
           const float g = gz[e] * act_grad_h(t, act, slope);
           a1[e] += g;
           a2[e] += g * (t * sh[e] + mu[e]);

@@ -2053,8 +2053,11 @@ def knn_points_packed(pos_q, topo_q, pos_s, topo_s, k):
     """pytorch3d.ops.knn_points semantics on packed clouds: (nbr (Nq,k) packed source index, weight)."""
     pos_q, pos_s = _pos(pos_q), _pos(pos_s)
     nq, dev = pos_q.size(0), pos_q.device
-    nbr = torch.empty((nq, k), dtype=torch.int64, device=dev)
-    w = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    # (bounded counts: the launch covers `longest cloud` CAPACITY queries per cloud; a cloud past it -- the overflow flag is up --
+    # leaves rows of the table unwritten, which must still be valid gather indices for the replay to stay inside its buffers)
+    alloc = torch.zeros if bounded() else torch.empty
+    nbr = alloc((nq, k), dtype=torch.int64, device=dev)
+    w = alloc((nq, k), dtype=torch.float32, device=dev)
     b = topo_q.num_clouds
     if topo_s.max_cloud < KNN_GRID_MIN_POINTS or KNN_GRID_SCALE <= 0:
         call("knn_points", ptr(pos_q), ptr(topo_q.cloud_ptr), ptr(pos_s), ptr(topo_s.cloud_ptr), b, topo_q.max_cloud, k,

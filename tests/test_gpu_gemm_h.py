@@ -178,7 +178,7 @@ def test_batchnorm_backward_from_the_layer_output(rows, C, act):
             z[:, :C] = src32.to(zdt)
             zval = z[:, :C].float()
         # the y this operand stands for: t = the operand itself (pre-activation) or act^-1(z); y = (t - shift) / scale
-        t = zval if pre else torch.where(zval > 0, zval, zval / 0.01)
+        t = zval if pre else torch.where(zval > 0, zval, zval * (1.0 / torch.tensor(0.01, dtype=torch.float32)).item())
         y_of_z = ((t - par[1]) / par[0]).contiguous()
         for dz16, gsrc, ldsrc, gval in ((1, g16, ldg, g16f), (0, g32, C, g32)):
             want_s, want_dy, want_dgb = y_passes(y_of_z, gval)
