@@ -3,6 +3,8 @@
 Two kinds of checks: the raw C-ABI entry against an fp64 product next to the fp32 MFMA entry (its error must be of the
 same size), and the SAME fp32 parity tests the fp32 mode passes (layer against torch, assembled network against the
 oracle), re-run with the mode switched on and unchanged tolerances."""
+import os
+
 import pytest
 import torch
 
@@ -180,24 +182,35 @@ def test_x3_step_modules_against_reference_vectors(x3_mode, name):
     TG.test_step_modules_against_reference_vectors(name)
 
 
-@pytest.mark.parametrize("name", _model_names())
+# The re-runs below that add no kernel of their own to what the kept ones exercise (reduced-width sections other than KITTI and the
+# hot path, the 2048-point object networks, the full-width hot path = a subset of the full-width KITTI network) run only with
+# CCN_X3_FULL=1: the suite has to stay inside the driver's time budget (VERDICT r5 Next 9: 476 s of 900).  They were all green at the
+# end of round 6 (profiles/r06_parity_margins.txt carries their `[bf16x3]` lines from a CCN_X3_FULL=1 run).
+x3_full = pytest.mark.skipif(os.environ.get("CCN_X3_FULL") != "1", reason="bf16x3 re-run of a reduced-width / duplicate case: CCN_X3_FULL=1")
+
+
+@pytest.mark.parametrize("name", [pytest.param(n, marks=() if n in ("kitti", "hotpath") else x3_full) for n in _model_names()])
 def test_x3_model_sections_against_reference_vectors(x3_mode, name):
     TG.test_model_sections_against_reference_vectors(name)
 
 
+@x3_full
 def test_x3_shapenet_seg_config_matches_oracle(x3_mode):
     TM.test_shapenet_seg_config_matches_oracle()
 
 
+@x3_full
 @pytest.mark.parametrize("which", ["a2d2", "shapenet-cls", "kortx"])
 def test_x3_remaining_reference_configs_match_oracle(x3_mode, which):
     TM.test_remaining_reference_configs_match_oracle(which)
 
 
+@x3_full
 def test_x3_a2d2_section_mixed_curve_lengths_matches_oracle(x3_mode):
     TM.test_a2d2_section_mixed_curve_lengths_matches_oracle()
 
 
+@x3_full
 def test_x3_full_width_hotpath_cloud_matches_oracle(x3_mode):
     TM.test_full_width_hotpath_cloud_matches_oracle()
 
@@ -206,6 +219,7 @@ def test_x3_full_width_kitti_backward_matches_oracle(x3_mode):
     TM.test_full_width_kitti_backward_matches_oracle()
 
 
+@x3_full
 @pytest.mark.parametrize("kortx", [False, True])
 def test_x3_full_width_shapenet_seg_and_kortx_on_2048_point_clouds(x3_mode, kortx):
     TM.test_full_width_shapenet_seg_and_kortx_on_2048_point_clouds(kortx)
