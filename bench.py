@@ -457,7 +457,8 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(self_launch(args))
 
-    # Streams in play per rank: backward (default), geometry, weight-gradient, RCCL's own.  The ROCm runtime maps streams
+    # Streams in play per rank: the feature stream (default), the geometry stream, RCCL's own (the weight-gradient side stream is
+    # retired since round 3: CCN_WGRAD_STREAM=1 brings it back for A/B runs only).  The ROCm runtime maps streams
     # onto GPU_MAX_HW_QUEUES hardware queues (default 4): with a fifth stream two of them share a queue and serialise --
     # measured with a one-rank RCCL group: the geometry stream of the NEXT batch waited behind the whole backward pass
     # (prepare() 18 -> 105 ms of host time, 66.4 -> 61.3 clouds/s).  Must be set before the runtime initialises.
@@ -890,7 +891,7 @@ def run(args, rank, world, local_rank, dev, quiet=False):
                 result["roofline"].update({"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                            "frac": gbs / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": site_bytes / len(per_site),
                                            "mfma": {"achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak}})
-            # The GEMM launches run on two streams (weight-gradient products overlap the rest of the backward pass), so a
+            # With CCN_WGRAD_STREAM=1 (A/B runs) the GEMM launches run on two streams and a
             # launch's own duration includes the time it shares the chip.  All GEMM launches together: flops over the
             # UNION of their execution intervals = the MFMA throughput the step actually gets out of the chip.
             fam_records, fam_steps = (full_records, 2) if full_records else (records, args.steps)
