@@ -213,6 +213,8 @@ class CapturedWholeForward:
         if getattr(data, "x", None) is not None:
             self.data.x[:n].copy_(data.x)
             self.data.x[n:].zero_()
+        if hasattr(data, "labels") and hasattr(self.data, "labels"):      # (per-cloud category ids of the object sets; the phantom cloud keeps its own)
+            self.data.labels[:b].copy_(data.labels)
         if verify:
             try:
                 with ops.counts_scope(self.bounds), torch.no_grad(), _generator_state(self._rng):
