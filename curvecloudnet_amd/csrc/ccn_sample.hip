@@ -332,11 +332,15 @@ __global__ void voxel_keys_kernel(const float* __restrict__ pos, const int64_t* 
 // per voxel the point with the smallest score (ties: smallest index), as one 64-bit atomicMin on
 // (score bits, index): scores are >= 0 so their bit patterns order like the values
 __global__ void voxel_argmin_kernel(const float* __restrict__ score, const int64_t* __restrict__ voxel_of, int64_t n,
-                                    unsigned long long* __restrict__ best) {
+                                    int64_t num_voxels, unsigned long long* __restrict__ best) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  const int64_t v = voxel_of[i];
+  // (num_voxels may be a CAPACITY -- a caller that keeps the counts on the device: a voxel past it has no slot and is dropped;
+  // round 6: this was an unguarded write, found by replaying a deliberately overflowing batch)
+  if (v < 0 || v >= num_voxels) return;
   const unsigned long long packed = ((unsigned long long)__float_as_uint(score[i]) << 32) | (unsigned long long)i;
-  atomicMin(&best[voxel_of[i]], packed);
+  atomicMin(&best[v], packed);
 }
 
 __global__ void voxel_unpack_kernel(const unsigned long long* __restrict__ best, int64_t m, int64_t* __restrict__ idx) {
@@ -947,7 +951,7 @@ int ccn_voxel_argmin(const float* score, const int64_t* voxel_of, int64_t n, int
   CCN_REQUIRE(score && voxel_of && scratch && idx && n > 0 && num_voxels > 0, "voxel_argmin: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   CCN_HIP(hipMemsetAsync(scratch, 0xff, (size_t)num_voxels * 8, s), "voxel_argmin");
-  hipLaunchKernelGGL(voxel_argmin_kernel, dim3(ccn_blocks(n, 256)), dim3(256), 0, s, score, voxel_of, n,
+  hipLaunchKernelGGL(voxel_argmin_kernel, dim3(ccn_blocks(n, 256)), dim3(256), 0, s, score, voxel_of, n, num_voxels,
                      (unsigned long long*)scratch);
   hipLaunchKernelGGL(voxel_unpack_kernel, dim3(ccn_blocks(num_voxels, 256)), dim3(256), 0, s,
                      (const unsigned long long*)scratch, num_voxels, idx);

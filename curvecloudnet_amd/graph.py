@@ -187,12 +187,12 @@ class CapturedWholeForward:
         no capacity was given), the same number of clouds; the rows behind it become phantom points.  New positions mean new counts.
         ``verify=True`` runs ONE eager pass that reads every count back and raises ``CapacityExceeded`` before a count that does not
         fit is used (ops.CountBounds, verifying) -- after a successful check every replay over this batch is safe.
-        ``verify=False`` skips that pass: for a batch whose counts are KNOWN to fit (the head-room was sized for the stream, or the
-        batch was verified before).  ``replay()`` still reads the device flag and raises ``CapacityExceeded`` when a count did not fit
-        -- but only afterwards, and a replay past a capacity is NOT memory-safe in general: the fill kernels stop at the capacities
-        and the offsets are clamped, yet round 6 found gathers downstream that trust per-cloud tables the overflow leaves
-        inconsistent (tools/dbg_overflow.py: kNN tables past `longest cloud` -- now zero-filled --, the compact-row first layer of the
-        next SGCNN level -- open).  A stream of unknown clouds verifies, or sizes ``headroom`` so that the flag never rises."""
+        ``verify=False`` skips that pass (a stream of clouds: no extra pass, no read-back).  A count past its capacity then raises
+        the device flag and ``replay()`` raises ``CapacityExceeded`` -- afterwards; the replay itself stays inside its buffers: fill
+        kernels stop at the capacities, offsets / group pointers / per-cloud lengths are clamped to them, tables the bounded
+        launches do not cover are initialised (round 6 replayed a deliberately overflowing batch, found four places where that
+        did not hold and fixed them: tools/dbg_overflow.py, tests/test_gpu_graph.py).  The logits of such a replay are garbage
+        by construction: the caller runs the eager forward for that batch (or sizes ``headroom`` so that the flag never rises)."""
         from . import ops
         n = data.pos.size(0)
         if n + 1 > self.capacity:

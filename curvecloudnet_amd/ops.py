@@ -383,6 +383,10 @@ class CurveTopology:
         self.num_curves, self.max_cloud = q, longest
         self.curve_ptr = curve_ptr[: q + 1]
         self.lengths = self.cloud_ptr[1:] - self.cloud_ptr[:-1]
+        if bounded():
+            # (a cloud longer than the `longest cloud` CAPACITY -- the overflow flag is up -- must not hand the padded (B, Nmax)
+            # layouts more points than they hold: the neighbour searches build their grids from these lengths)
+            self.lengths = self.lengths.clamp(max=longest)
         if num_clouds == 1:
             self.glob = p2c                                   # quirk Q8: identity for one cloud
 
@@ -2416,8 +2420,12 @@ class SGCompact:
     def __init__(self, nbr, topo):
         b, nmax, k = nbr.shape
         n, dev = topo.n, nbr.device
-        cnt = torch.empty(n + 1, dtype=torch.int32, device=dev)
-        has = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        # (bounded counts: the launches cover `longest cloud` CAPACITY points per cloud; the points of a cloud past it -- the overflow
+        # flag is up -- must read as "no rows, no representative", not as whatever the allocation held: found by replaying a
+        # deliberately overflowing batch, tools/dbg_overflow.py)
+        alloc = torch.zeros if bounded() else torch.empty
+        cnt = alloc(n + 1, dtype=torch.int32, device=dev)
+        has = alloc(n + 1, dtype=torch.int32, device=dev)
         call("cg_count", ptr(nbr), ptr(topo.cloud_ptr), b, nmax, k, ptr(cnt), ptr(has))
         self.grp_ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         rep_off = torch.empty(n + 1, dtype=torch.int32, device=dev)
@@ -2437,8 +2445,9 @@ class SGCompact:
         self.count = float(b * nmax * (k + 1))                    # rows of the dense layout = sum of all weights
         self.row_src = (torch.zeros(e, dtype=torch.int32, device=dev) if bounded()
                         else torch.empty(e, dtype=torch.int32, device=dev))
-        self.rep_row = torch.empty(n, dtype=torch.int32, device=dev)
-        self.row_w = torch.empty(ne + 1, dtype=torch.float32, device=dev)
+        self.rep_row = (torch.full((n,), -1, dtype=torch.int32, device=dev) if bounded()
+                        else torch.empty(n, dtype=torch.int32, device=dev))
+        self.row_w = alloc(ne + 1, dtype=torch.float32, device=dev)
         call("cg_fill", ptr(nbr), ptr(topo.cloud_ptr), b, nmax, k, ptr(self.grp_ptr), ptr(rep_off), e, ptr(self.row_src),
              ptr(self.rep_row), ptr(self.row_w))
         self.row_w[ne:].fill_(float((b * nmax - n) * (k + 1)))    # the padding row stands for all padding rows

@@ -169,8 +169,9 @@ def test_whole_forward_graph_serves_a_stream_of_different_clouds():
     isolated phantom points; ``load(batch, verify=False)`` writes any batch of at most that many points into the graph's inputs -- no
     eager pass, no read-back -- and the replay equals the bounded eager pass bit for bit and the ordinary forward over the same
     (padded) batch to fp32 rounding.  A batch whose counts do NOT fit (captured with no head-room, then fed clouds twice as dense) is
-    refused by the verifying load before anything past a capacity is touched; the eager forward answers instead, and the graph
-    serves the next fitting batch as before."""
+    refused by the verifying load before anything past a capacity is touched -- and, loaded WITHOUT verification, its replay stays
+    memory-safe: the device flag raises ``CapacityExceeded`` afterwards, the device is healthy, the eager forward answers instead,
+    and the graph serves the next fitting batch as before."""
     from curvecloudnet_amd import configs, ops
     from curvecloudnet_amd.graph import CapturedWholeForward
     from curvecloudnet_amd.model import build_model
@@ -201,14 +202,22 @@ def test_whole_forward_graph_serves_a_stream_of_different_clouds():
         cap.load(batch_to(make_batch([0, 1, 2, 3], n_curves=200), DEV), verify=False)       # another number of clouds
     with pytest.raises(ValueError):
         cap.load(batch_to(make_batch([0, 1, 2], n_curves=260), DEV), verify=False)          # more points than the capacity
-    # ---- a batch that does NOT fit: the verifying load refuses it BEFORE a count past its capacity is used (an unverified replay of
-    # such a batch is NOT memory-safe -- see CapturedWholeForward.load -- so a stream either verifies or sizes its head-room)
+    # ---- a batch that does NOT fit.  The verifying load refuses it BEFORE a count past its capacity is used ...
     tight = CapturedWholeForward(model, batches[0], headroom=1.0, point_capacity=max(sizes) + 65)
     dense = batch_to(make_batch([0, 1, 2], n_curves=200), DEV)
     dense.pos = dense.pos * 0.5                              # half the spacing: more samples kept per voxel level, more neighbours per radius
     with pytest.raises(CapturedWholeForward.CapacityExceeded):
         tight.load(dense)
+    # ... and WITHOUT the verifying pass the replay itself stays inside its buffers (VERDICT r5 Next 7): the device flag makes it
+    # raise afterwards, the device takes no harm, the ordinary forward answers, the graph serves the next fitting batch.  (Round 6
+    # found four places that did not hold under an overflow -- tools/dbg_overflow.py -- and fixed them: neighbour tables left
+    # unwritten past `longest cloud`, per-cloud lengths past the padded layouts, an unguarded voxel slot, compact-row tables of
+    # points past the capacity.)
+    tight.load(dense, verify=False)
+    with pytest.raises(CapturedWholeForward.CapacityExceeded):
+        tight.replay()
     torch.cuda.synchronize()
+    assert int(tight.bounds.overflow.item()) != 0
     with torch.no_grad():
         fallback = model(dense)                              # the caller's way out: the ordinary forward
     assert fallback.shape[0] == sizes[0] and bool(torch.isfinite(fallback).all())
